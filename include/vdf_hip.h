@@ -1,0 +1,153 @@
+/* vdf_hip.h -- C ABI of the MI355X-native Nova/MinRoot hot path (libvdf_hip.so).
+ *
+ * This is the drop-in boundary (seam B2).  Each entry point
+ * names the reference interface it replaces.  The reference is Rust; the third-party
+ * crates it calls through (pasta-msm 0.1.1, nova-snark 0.8.0, pasta_curves 0.4.0,
+ * Cargo.toml:15-18) are where these operations live today, reached from
+ * `RecursiveSNARK::prove_step` at /root/reference/src/nova/proof.rs:342-349.
+ *
+ * Conventions
+ *   - All integers little-endian.  A field element is 4 x u64 limbs of x*2^256 mod m
+ *     (Montgomery form), the in-memory form of pasta_curves with `repr-c`
+ *     (Cargo.toml:17).  Inputs must be canonical (< m); VDF_ERR_NONCANONICAL otherwise
+ *     where the entry point says it checks.
+ *   - affine = {x, y}, identity = (0, 0).  jac = {x, y, z} Jacobian, identity z = 0.
+ *     Jacobian outputs are not unique; parity is defined on the affine normalisation.
+ *   - Every data pointer may be a HOST pointer or a DEVICE (hipMalloc / torch) pointer;
+ *     the library classifies each one with hipPointerGetAttributes.  Host buffers are
+ *     staged through device memory (PCIe-inclusive); device buffers are used in place.
+ *   - Caller owns every buffer.  The library keeps no caller pointer past a call; only the
+ *     opaque handles (vdf_ctx, vdf_bases, vdf_shape) own device memory.
+ *   - Calls are blocking unless the context is in async mode AND every buffer of the call
+ *     is device-resident; then work is enqueued on the context's HIP stream.
+ *   - Re-entrant across threads on one context (per-context mutex); no global mutable state
+ *     except the lazily created default context of the two `mult_pippenger_*` shims.
+ *   - No C++ exception or abort crosses this boundary: int status + vdf_last_error().
+ *   - There is NO CPU back-end: vdf_ctx_create fails with VDF_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef VDF_HIP_H
+#define VDF_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } vdf_fe;            /* pasta_curves Fp / Fq, repr-c */
+typedef struct { vdf_fe x, y; } vdf_affine;          /* pallas::Affine / vesta::Affine */
+typedef struct { vdf_fe x, y, z; } vdf_jac;          /* pallas::Point / vesta::Point */
+
+typedef struct vdf_ctx vdf_ctx;
+typedef struct vdf_bases vdf_bases;
+typedef struct vdf_shape vdf_shape;
+
+enum {
+  VDF_OK = 0,
+  VDF_ERR_BAD_ARG = 1,
+  VDF_ERR_BAD_LENGTH = 2,
+  VDF_ERR_NONCANONICAL = 3,
+  VDF_ERR_DEVICE = 4,
+  VDF_ERR_OOM = 5,
+  VDF_ERR_NO_DEVICE = 6
+};
+
+enum { VDF_CURVE_PALLAS = 0, VDF_CURVE_VESTA = 1 };   /* G1 / G2, src/nova/proof.rs:26-27 */
+enum { VDF_FIELD_FP = 0, VDF_FIELD_FQ = 1 };          /* S2 = Fp, S1 = Fq, src/nova/proof.rs:29-30 */
+
+/* ---- context ------------------------------------------------------------------------ */
+/* One context drives one GPU.  device_ids/n_devices: n_devices must be 1 (one process per
+ * GPU; multi-GPU jobs create one context per rank).  No reference counterpart (the
+ * reference is CPU-only); this is the handle the FFI shim would keep in a OnceCell. */
+int  vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out);
+void vdf_ctx_destroy(vdf_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int  vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream);
+void* vdf_ctx_get_stream(vdf_ctx* ctx);
+/* async != 0: calls whose buffers are all device-resident return after enqueueing. */
+int  vdf_ctx_set_async(vdf_ctx* ctx, int async);
+int  vdf_ctx_sync(vdf_ctx* ctx);
+const char* vdf_last_error(vdf_ctx* ctx);              /* ctx may be NULL: last create error */
+
+/* ---- commitment generators (Pedersen bases) ------------------------------------------ */
+/* Replaces nova-snark's CommitGens (built in PublicParams::setup, src/nova/proof.rs:236):
+ * the generator table lives in HBM for the life of the public parameters. */
+int  vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n, vdf_bases** out);
+/* Synthetic generators P_i = [k_i]G, G = (-1, 2), k_i = splitmix64-derived 64-bit (see
+ * oracle/pasta.py base_dlog); stands in for nova-snark's label -> hash-to-curve derivation,
+ * which is implementation-defined and unpinned. */
+int  vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out);
+/* Build the fixed-base table  2^(window_bits*sets*j) * P_i, j = 0..tables-1, so that an MSM
+ * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table). */
+int  vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets);
+int  vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out);
+size_t vdf_bases_len(const vdf_bases* bases);
+const void* vdf_bases_device_ptr(const vdf_bases* bases);
+void vdf_bases_free(vdf_bases* bases);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------ */
+/* out = sum_{i<n} scalars[i] * bases[offset + i].
+ * Replaces nova-snark `Group::vartime_multiscalar_mul` -> pasta_msm::pallas/vesta
+ * (the Pedersen commit of W and T inside prove_step, src/nova/proof.rs:342-349; K1/K2).
+ * is_mont: scalars are in Montgomery form (as pasta-msm's `is_mont = true`). */
+int  vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n,
+             int is_mont, vdf_jac* out);
+/* Window size override for tuning (0 = automatic). */
+int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
+
+/* Drop-in shims with the upstream pasta-msm 0.1.1 shape (upload-on-call, default context
+ * on device 0, abort-free: on failure `out` is set to the identity and the error is
+ * readable through vdf_last_error(NULL)). */
+void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
+void mult_pippenger_vesta(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
+
+/* ---- R1CS shape + sparse mat-vec ------------------------------------------------------- */
+/* Replaces nova-snark R1CSShape{A,B,C} (COO triples over z = (W, u, X)) and
+ * `R1CSShape::multiply_vec` (K4).  rows/cols/vals[k] describe matrix k = A, B, C; values in
+ * Montgomery form.  The shape is converted to CSR with a coefficient dictionary and kept in HBM. */
+int  vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols,
+                      const uint32_t* const rows[3], const uint32_t* const cols[3],
+                      const vdf_fe* const vals[3], const size_t nnz[3], vdf_shape** out);
+void vdf_shape_free(vdf_shape* shape);
+int  vdf_spmv3(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z, vdf_fe* Az, vdf_fe* Bz, vdf_fe* Cz);
+
+/* ---- folding vector ops ---------------------------------------------------------------- */
+/* T = Az1 o Bz2 + Az2 o Bz1 - u1*Cz2 - Cz1   (nova-snark `commit_T`, K5; u2 = 1). */
+int  vdf_cross_term(vdf_ctx* ctx, int field, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1,
+                    const vdf_fe* Az2, const vdf_fe* Bz2, const vdf_fe* Cz2, const vdf_fe* u1,
+                    size_t n, vdf_fe* T);
+/* out = a + r*b   (nova-snark RelaxedR1CSWitness::fold: W1 + r*W2, E1 + r*T; K6).
+ * `r` is one field element (host or device).  out may alias a. */
+int  vdf_axpy(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* r, const vdf_fe* b, size_t n, vdf_fe* out);
+
+/* ---- MinRoot step-circuit witness ------------------------------------------------------- */
+/* Fills the 4t+1 auxiliary values `InverseMinRootCircuit::synthesize` allocates
+ * (src/nova/proof.rs:107-126), in allocation order per round new_x, tmp1, tmp2, new_y
+ * (src/nova/proof.rs:167, 176, 178, 181) then final_i (:122), from the forward trace
+ * trace_xy[k] = (x_k, y_k), k = 0..t (trace_xy[t] is the step's `result`, trace_xy[0] its
+ * `input`); i0 = the `i` of trace_xy[0].  Round-parallel. */
+int  vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const vdf_fe* i0, uint64_t t,
+                         vdf_fe* W_segment);
+
+/* ---- utilities the host layer and the tests need ---------------------------------------- */
+/* Element-wise Montgomery product / conversions, n elements (test + host plumbing). */
+int  vdf_fe_mul(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* b, size_t n, vdf_fe* out);
+int  vdf_fe_to_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe* out);
+int  vdf_fe_from_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe* out);
+/* Throughput probe: each of n lanes runs `iters` dependent Montgomery multiplications
+ * (roofline / issue-rate calibration for DESIGN.md; not on the prove path). */
+int  vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int iters, vdf_fe* out);
+/* Device memory helpers so a non-torch host (the C++ Nova layer) can keep state resident. */
+int  vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out);
+int  vdf_dev_free(vdf_ctx* ctx, void* p);
+int  vdf_dev_memcpy(vdf_ctx* ctx, void* dst, const void* src, size_t bytes);   /* any direction */
+int  vdf_dev_memset(vdf_ctx* ctx, void* dst, int value, size_t bytes);
+/* Library build identification ("vdf_hip gfx950 <date>"). */
+const char* vdf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDF_HIP_H */

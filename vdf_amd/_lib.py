@@ -1,0 +1,71 @@
+"""ctypes binding of libvdf_hip.so (include/vdf_hip.h).
+
+The HIP library is the product; this module only loads it and declares prototypes.  There is no
+Python or CPU fallback: if the library is missing the import raises, and without a GPU
+`vdf_ctx_create` fails with VDF_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdf_hip.so")
+
+VDF_OK, VDF_ERR_BAD_ARG, VDF_ERR_BAD_LENGTH, VDF_ERR_NONCANONICAL, VDF_ERR_DEVICE, VDF_ERR_OOM, VDF_ERR_NO_DEVICE = range(7)
+CURVE_PALLAS, CURVE_VESTA = 0, 1
+FIELD_FP, FIELD_FQ = 0, 1
+
+# every symbol include/vdf_hip.h declares: (name, restype, argtypes)
+_vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+PROTOTYPES = {
+    "vdf_ctx_create": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "vdf_ctx_destroy": (None, [_vp]),
+    "vdf_ctx_set_stream": (_i, [_vp, _vp]),
+    "vdf_ctx_get_stream": (_vp, [_vp]),
+    "vdf_ctx_set_async": (_i, [_vp, _i]),
+    "vdf_ctx_sync": (_i, [_vp]),
+    "vdf_last_error": (C.c_char_p, [_vp]),
+    "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
+    "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),
+    "vdf_bases_precompute": (_i, [_vp, _vp, _i, _i]),
+    "vdf_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "vdf_bases_len": (_sz, [_vp]),
+    "vdf_bases_device_ptr": (_vp, [_vp]),
+    "vdf_bases_free": (None, [_vp]),
+    "vdf_msm": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp]),
+    "vdf_ctx_set_msm_window": (_i, [_vp, _i]),
+    "mult_pippenger_pallas": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
+    "mult_pippenger_vesta": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
+    "vdf_shape_create": (_i, [_vp, _i, _sz, _sz, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp)]),
+    "vdf_shape_free": (None, [_vp]),
+    "vdf_spmv3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_cross_term": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vdf_axpy": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "vdf_minroot_witness": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "vdf_fe_mul": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "vdf_fe_to_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "vdf_fe_from_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "vdf_fe_mul_chain": (_i, [_vp, _i, _vp, _sz, _i, _vp]),
+    "vdf_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "vdf_dev_free": (_i, [_vp, _vp]),
+    "vdf_dev_memcpy": (_i, [_vp, _vp, _vp, _sz]),
+    "vdf_dev_memset": (_i, [_vp, _vp, _i, _sz]),
+    "vdf_version": (C.c_char_p, []),
+}
+
+
+def load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). vdf_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()

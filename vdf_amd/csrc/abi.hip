@@ -1,0 +1,562 @@
+// extern "C" boundary of libvdf_hip.so (include/vdf_hip.h).  Plain pointers and sizes only; no
+// exception leaves this file.  There is no CPU back-end: without a GPU vdf_ctx_create fails.
+#include <cstring>
+#include <map>
+#include <array>
+#include <new>
+#include "internal.h"
+#include "fe.cuh"
+
+using vdf::Status;
+
+namespace {
+
+thread_local std::string g_create_err;
+std::mutex g_default_mu;
+vdf_ctx* g_default_ctx = nullptr;
+
+bool ptr_is_device(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// Host buffers are staged through temporaries; device buffers are used in place.
+struct Staging {
+  vdf_ctx* ctx;
+  std::vector<void*> temps;
+  struct Out { void* host; void* dev; size_t bytes; };
+  std::vector<Out> outs;
+  bool any_host = false;
+  explicit Staging(vdf_ctx* c) : ctx(c) {}
+  ~Staging() { for (void* t : temps) (void)hipFree(t); }
+  Status in(const void* p, size_t bytes, const void** dev) {
+    if (bytes == 0) { *dev = p; return Status{}; }
+    if (!p) return Status{VDF_ERR_BAD_ARG, "null input pointer"};
+    if (ptr_is_device(p)) { *dev = p; return Status{}; }
+    any_host = true;
+    void* t = nullptr;
+    VDF_TRY_HIP(hipMalloc(&t, bytes));
+    temps.push_back(t);
+    VDF_TRY_HIP(hipMemcpyAsync(t, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = t;
+    return Status{};
+  }
+  Status out(void* p, size_t bytes, void** dev) {
+    if (bytes == 0) { *dev = p; return Status{}; }
+    if (!p) return Status{VDF_ERR_BAD_ARG, "null output pointer"};
+    if (ptr_is_device(p)) { *dev = p; return Status{}; }
+    any_host = true;
+    void* t = nullptr;
+    VDF_TRY_HIP(hipMalloc(&t, bytes));
+    temps.push_back(t);
+    outs.push_back({p, t, bytes});
+    *dev = t;
+    return Status{};
+  }
+  Status finish() {
+    for (auto& o : outs) VDF_TRY_HIP(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (any_host || !ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  }
+};
+
+int fail(vdf_ctx* ctx, const Status& s) {
+  if (ctx) ctx->err = s.msg; else g_create_err = s.msg;
+  return s.code;
+}
+
+template <class F>
+int guarded(vdf_ctx* ctx, F&& body) {
+  if (!ctx) { g_create_err = "null context"; return VDF_ERR_BAD_ARG; }
+  try {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, vdf::hip_status(e, "hipSetDevice"));
+    Status s = body();
+    if (!s.ok()) return fail(ctx, s);
+    return VDF_OK;
+  } catch (const std::bad_alloc&) {
+    ctx->err = "host allocation failed";
+    return VDF_ERR_OOM;
+  } catch (const std::exception& ex) {
+    ctx->err = ex.what();
+    return VDF_ERR_DEVICE;
+  } catch (...) {
+    ctx->err = "unknown failure";
+    return VDF_ERR_DEVICE;
+  }
+}
+
+Status ensure_ws(vdf_ctx* ctx, size_t bytes) {
+  if (ctx->ws_bytes >= bytes) return Status{};
+  if (ctx->ws) { VDF_TRY_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+  VDF_TRY_HIP(hipMalloc(&ctx->ws, bytes));
+  ctx->ws_bytes = bytes;
+  return Status{};
+}
+
+size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
+
+Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont,
+                vdf_jac* out) {
+  if (!bases || !out) return Status{VDF_ERR_BAD_ARG, "null bases/out"};
+  if (bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bases belong to another context"};
+  if (offset > bases->n || n > bases->n - offset) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
+  if (n >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "n too large (max 2^27 - 1 points per call)"};
+  Staging st(ctx);
+  void* d_out = nullptr;
+  VDF_TRY(st.out(out, sizeof(vdf_jac), &d_out));
+  if (n == 0) {
+    VDF_TRY_HIP(hipMemsetAsync(d_out, 0, sizeof(vdf_jac), ctx->stream));
+    return st.finish();
+  }
+  const void* d_scalars = nullptr;
+  VDF_TRY(st.in(scalars, n * sizeof(vdf_fe), &d_scalars));
+  vdf::MsmPlan plan;
+  const char* pts;
+  if (bases->d_table && (ctx->msm_window == 0 || ctx->msm_window == bases->tbl_c)) {
+    plan = vdf::msm_make_plan(n, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus);
+    plan.tstride = (uint32_t)bases->n;
+    pts = reinterpret_cast<const char*>(bases->d_table) + offset * 64;
+  } else {
+    int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(n);
+    plan = vdf::msm_make_plan(n, c, 0, 0, ctx->num_cus);
+    plan.tstride = 0;
+    pts = reinterpret_cast<const char*>(bases->d_pts) + offset * 64;
+  }
+  if ((size_t)plan.tstride * plan.tables + n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "table index exceeds 31 bits"};
+  if ((uint64_t)n * plan.windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
+  VDF_TRY(ensure_ws(ctx, plan.ws_bytes));
+  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream));
+  return st.finish();
+}
+
+vdf_ctx* default_ctx() {
+  std::lock_guard<std::mutex> lock(g_default_mu);
+  if (!g_default_ctx) {
+    int dev = 0;
+    if (vdf_ctx_create(&dev, 1, &g_default_ctx) != VDF_OK) g_default_ctx = nullptr;
+  }
+  return g_default_ctx;
+}
+
+void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf_fe* scalars, bool is_mont) {
+  if (out) std::memset(out, 0, sizeof(*out));
+  vdf_ctx* ctx = default_ctx();
+  if (!ctx || !out) return;
+  vdf_bases* b = nullptr;
+  if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
+  if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
+    g_create_err = ctx->err;
+    std::memset(out, 0, sizeof(*out));
+  }
+  vdf_bases_free(b);
+}
+
+template <class P>
+void build_dict_consts(std::array<uint32_t, 8>& one, std::array<uint32_t, 8>& minus_one) {
+  vdf::Fe<P> o = vdf::fe_one<P>();
+  vdf::Fe<P> m = vdf::fe_neg(o);
+  for (int i = 0; i < 8; ++i) { one[i] = o.v[i]; minus_one[i] = m.v[i]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vdf_version(void) { return "vdf_hip gfx950 r1 (" __DATE__ ")"; }
+
+int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
+  if (!out) { g_create_err = "null out"; return VDF_ERR_BAD_ARG; }
+  *out = nullptr;
+  if (n_devices != 1 || !device_ids) {
+    g_create_err = "vdf_ctx_create: exactly one device per context (one process per GPU); there is no CPU back-end";
+    return n_devices == 0 ? VDF_ERR_NO_DEVICE : VDF_ERR_BAD_ARG;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    g_create_err = "vdf_ctx_create: no HIP device visible (the HIP path is mandatory; no CPU fallback exists)";
+    return VDF_ERR_NO_DEVICE;
+  }
+  if (device_ids[0] < 0 || device_ids[0] >= count) { g_create_err = "device id out of range"; return VDF_ERR_BAD_ARG; }
+  vdf_ctx* c = new (std::nothrow) vdf_ctx();
+  if (!c) { g_create_err = "host allocation failed"; return VDF_ERR_OOM; }
+  c->device = device_ids[0];
+  e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->d_out, 256);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
+  if (e != hipSuccess) {
+    g_create_err = std::string("vdf_ctx_create: ") + hipGetErrorString(e);
+    delete c;
+    return VDF_ERR_DEVICE;
+  }
+  c->own_stream = true;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = c;
+  return VDF_OK;
+}
+
+void vdf_ctx_destroy(vdf_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream) {
+  return guarded(ctx, [&]() -> Status {
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return Status{};
+  });
+}
+
+void* vdf_ctx_get_stream(vdf_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int vdf_ctx_set_async(vdf_ctx* ctx, int async) {
+  return guarded(ctx, [&]() -> Status { ctx->async = async != 0; return Status{}; });
+}
+
+int vdf_ctx_sync(vdf_ctx* ctx) {
+  return guarded(ctx, [&]() -> Status { VDF_TRY_HIP(hipStreamSynchronize(ctx->stream)); return Status{}; });
+}
+
+int vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits) {
+  return guarded(ctx, [&]() -> Status {
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return Status{VDF_ERR_BAD_ARG, "window_bits must be 0 or 4..16"};
+    ctx->msm_window = window_bits;
+    return Status{};
+  });
+}
+
+const char* vdf_last_error(vdf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+// ---- bases --------------------------------------------------------------------------------
+int vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n, vdf_bases** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    if (curve != VDF_CURVE_PALLAS && curve != VDF_CURVE_VESTA) return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+    if (n && !bases) return Status{VDF_ERR_BAD_ARG, "null bases"};
+    vdf_bases* b = new vdf_bases();
+    b->ctx = ctx; b->curve = curve; b->n = n;
+    if (n) {
+      hipError_t e = hipMalloc(&b->d_pts, n * sizeof(vdf_affine));
+      if (e != hipSuccess) { delete b; return vdf::hip_status(e, "hipMalloc(bases)"); }
+      e = hipMemcpyAsync(b->d_pts, bases, n * sizeof(vdf_affine), hipMemcpyDefault, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { (void)hipFree(b->d_pts); delete b; return vdf::hip_status(e, "upload bases"); }
+    }
+    *out = b;
+    return Status{};
+  });
+}
+
+int vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    if (curve != VDF_CURVE_PALLAS && curve != VDF_CURVE_VESTA) return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+    if (n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "too many bases"};
+    vdf_bases* b = new vdf_bases();
+    b->ctx = ctx; b->curve = curve; b->n = n;
+    if (n) {
+      hipError_t e = hipMalloc(&b->d_pts, n * sizeof(vdf_affine));
+      if (e != hipSuccess) { delete b; return vdf::hip_status(e, "hipMalloc(bases)"); }
+      Status s = vdf::bases_generate(curve, seed, n, b->d_pts, ctx->stream);
+      if (s.ok()) s = vdf::hip_status(hipStreamSynchronize(ctx->stream), "bases_generate");
+      if (!s.ok()) { (void)hipFree(b->d_pts); delete b; return s; }
+    }
+    *out = b;
+    return Status{};
+  });
+}
+
+int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets) {
+  return guarded(ctx, [&]() -> Status {
+    if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
+    if (window_bits < 4 || window_bits > 16) return Status{VDF_ERR_BAD_ARG, "window_bits must be 4..16"};
+    const int windows = (256 + window_bits - 1) / window_bits;
+    if (sets <= 0) sets = 1;
+    if (sets > windows) sets = windows;
+    while (windows % sets) ++sets;                 // windows = sets * tables exactly
+    const int tables = windows / sets;
+    if (bases->d_table) { (void)hipFree(bases->d_table); bases->d_table = nullptr; }
+    bases->tbl_c = bases->tbl_sets = bases->tbl_tables = 0;
+    if (bases->n == 0 || tables == 1) return Status{};
+    VDF_TRY_HIP(hipMalloc(&bases->d_table, (size_t)tables * bases->n * sizeof(vdf_affine)));
+    Status s = vdf::bases_precompute(bases->curve, bases->d_pts, bases->n, window_bits, sets, tables, bases->d_table, ctx->stream);
+    if (s.ok()) s = vdf::hip_status(hipStreamSynchronize(ctx->stream), "bases_precompute");
+    if (!s.ok()) { (void)hipFree(bases->d_table); bases->d_table = nullptr; return s; }
+    bases->tbl_c = window_bits; bases->tbl_sets = sets; bases->tbl_tables = tables;
+    return Status{};
+  });
+}
+
+int vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!bases || bases->ctx != ctx || (n && !out)) return Status{VDF_ERR_BAD_ARG, "bad arguments"};
+    if (offset > bases->n || n > bases->n - offset) return Status{VDF_ERR_BAD_LENGTH, "range exceeds the generator table"};
+    if (n == 0) return Status{};
+    VDF_TRY_HIP(hipMemcpyAsync(out, reinterpret_cast<const char*>(bases->d_pts) + offset * 64, n * 64, hipMemcpyDefault, ctx->stream));
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+size_t vdf_bases_len(const vdf_bases* bases) { return bases ? bases->n : 0; }
+const void* vdf_bases_device_ptr(const vdf_bases* bases) { return bases ? bases->d_pts : nullptr; }
+
+void vdf_bases_free(vdf_bases* bases) {
+  if (!bases) return;
+  if (bases->ctx) {
+    std::lock_guard<std::mutex> lock(bases->ctx->mu);
+    (void)hipSetDevice(bases->ctx->device);
+    (void)hipStreamSynchronize(bases->ctx->stream);
+    if (bases->d_pts) (void)hipFree(bases->d_pts);
+    if (bases->d_table) (void)hipFree(bases->d_table);
+  }
+  delete bases;
+}
+
+// ---- MSM ------------------------------------------------------------------------------------
+int vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont, vdf_jac* out) {
+  return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, offset, scalars, n, is_mont, out); });
+}
+
+void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont) {
+  shim(VDF_CURVE_PALLAS, out, points, npoints, scalars, is_mont);
+}
+void mult_pippenger_vesta(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont) {
+  shim(VDF_CURVE_VESTA, out, points, npoints, scalars, is_mont);
+}
+
+// ---- R1CS shape -------------------------------------------------------------------------------
+int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, const uint32_t* const rows[3],
+                     const uint32_t* const cols[3], const vdf_fe* const vals[3], const size_t nnz[3], vdf_shape** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out || !rows || !cols || !vals || !nnz) return Status{VDF_ERR_BAD_ARG, "null argument"};
+    *out = nullptr;
+    if (field != VDF_FIELD_FP && field != VDF_FIELD_FQ) return Status{VDF_ERR_BAD_ARG, "unknown field"};
+    if (num_cons >= (1ull << 31) || num_cols >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "shape too large"};
+    std::array<uint32_t, 8> one, minus_one;
+    if (field == VDF_FIELD_FP) build_dict_consts<FpParams>(one, minus_one); else build_dict_consts<FqParams>(one, minus_one);
+    std::map<std::array<uint32_t, 8>, uint32_t> dict_idx;
+    std::vector<std::array<uint32_t, 8>> dict;
+    dict.push_back(one); dict_idx[one] = 0;
+    dict.push_back(minus_one); dict_idx[minus_one] = 1;
+    std::vector<uint32_t> rowptr[3], col[3], coef[3];
+    for (int k = 0; k < 3; ++k) {
+      const size_t z = nnz[k];
+      if (z && (!rows[k] || !cols[k] || !vals[k])) return Status{VDF_ERR_BAD_ARG, "null matrix arrays"};
+      if (z >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "too many non-zeros"};
+      rowptr[k].assign(num_cons + 1, 0);
+      for (size_t i = 0; i < z; ++i) {
+        if (rows[k][i] >= num_cons || cols[k][i] >= num_cols) return Status{VDF_ERR_BAD_LENGTH, "matrix entry out of range"};
+        rowptr[k][rows[k][i] + 1]++;
+      }
+      for (size_t r = 0; r < num_cons; ++r) rowptr[k][r + 1] += rowptr[k][r];
+      col[k].resize(z); coef[k].resize(z);
+      std::vector<uint32_t> fill(rowptr[k].begin(), rowptr[k].end() - 1);
+      for (size_t i = 0; i < z; ++i) {
+        std::array<uint32_t, 8> v;
+        std::memcpy(v.data(), &vals[k][i], 32);
+        auto it = dict_idx.find(v);
+        uint32_t ci;
+        if (it == dict_idx.end()) { ci = (uint32_t)dict.size(); dict.push_back(v); dict_idx[v] = ci; } else ci = it->second;
+        uint32_t p = fill[rows[k][i]]++;
+        col[k][p] = cols[k][i];
+        coef[k][p] = ci;
+      }
+    }
+    vdf_shape* s = new vdf_shape();
+    s->ctx = ctx; s->field = field; s->num_cons = num_cons; s->num_cols = num_cols; s->dict_len = dict.size();
+    auto cleanup = [&]() {
+      for (int k = 0; k < 3; ++k) { (void)hipFree(s->d_rowptr[k]); (void)hipFree(s->d_col[k]); (void)hipFree(s->d_coef[k]); }
+      (void)hipFree(s->d_dict);
+      delete s;
+    };
+    hipError_t e = hipMalloc(&s->d_dict, dict.size() * 32);
+    if (e == hipSuccess) e = hipMemcpy(s->d_dict, dict.data(), dict.size() * 32, hipMemcpyHostToDevice);
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+      s->nnz[k] = nnz[k];
+      e = hipMalloc(reinterpret_cast<void**>(&s->d_rowptr[k]), (num_cons + 1) * 4);
+      if (e == hipSuccess) e = hipMemcpy(s->d_rowptr[k], rowptr[k].data(), (num_cons + 1) * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_col[k]), (nnz[k] + 1) * 4);
+      if (e == hipSuccess && nnz[k]) e = hipMemcpy(s->d_col[k], col[k].data(), nnz[k] * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_coef[k]), (nnz[k] + 1) * 4);
+      if (e == hipSuccess && nnz[k]) e = hipMemcpy(s->d_coef[k], coef[k].data(), nnz[k] * 4, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { cleanup(); return vdf::hip_status(e, "vdf_shape_create upload"); }
+    *out = s;
+    return Status{};
+  });
+}
+
+void vdf_shape_free(vdf_shape* shape) {
+  if (!shape) return;
+  if (shape->ctx) {
+    std::lock_guard<std::mutex> lock(shape->ctx->mu);
+    (void)hipSetDevice(shape->ctx->device);
+    (void)hipStreamSynchronize(shape->ctx->stream);
+    for (int k = 0; k < 3; ++k) { (void)hipFree(shape->d_rowptr[k]); (void)hipFree(shape->d_col[k]); (void)hipFree(shape->d_coef[k]); }
+    (void)hipFree(shape->d_dict);
+  }
+  delete shape;
+}
+
+int vdf_spmv3(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z, vdf_fe* Az, vdf_fe* Bz, vdf_fe* Cz) {
+  return guarded(ctx, [&]() -> Status {
+    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+    Staging st(ctx);
+    const void* dz; void* o[3];
+    VDF_TRY(st.in(z, shape->num_cols * 32, &dz));
+    VDF_TRY(st.out(Az, shape->num_cons * 32, &o[0]));
+    VDF_TRY(st.out(Bz, shape->num_cons * 32, &o[1]));
+    VDF_TRY(st.out(Cz, shape->num_cons * 32, &o[2]));
+    for (int k = 0; k < 3; ++k)
+      VDF_TRY(vdf::vec_spmv(shape->field, shape->d_rowptr[k], shape->d_col[k], shape->d_coef[k], shape->d_dict, dz,
+                            shape->num_cons, o[k], ctx->stream));
+    return st.finish();
+  });
+}
+
+// ---- vector ops -------------------------------------------------------------------------------
+int vdf_cross_term(vdf_ctx* ctx, int field, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* Az2,
+                   const vdf_fe* Bz2, const vdf_fe* Cz2, const vdf_fe* u1, size_t n, vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void* in[7]; void* dT;
+    const vdf_fe* src[6] = {Az1, Bz1, Cz1, Az2, Bz2, Cz2};
+    for (int k = 0; k < 6; ++k) VDF_TRY(st.in(src[k], n * 32, &in[k]));
+    VDF_TRY(st.in(u1, 32, &in[6]));
+    VDF_TRY(st.out(T, n * 32, &dT));
+    VDF_TRY(vdf::vec_cross_term(field, in[0], in[1], in[2], in[3], in[4], in[5], in[6], n, dT, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_axpy(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* r, const vdf_fe* b, size_t n, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void *da, *dr, *db; void* dout;
+    VDF_TRY(st.in(a, n * 32, &da));
+    VDF_TRY(st.in(r, 32, &dr));
+    VDF_TRY(st.in(b, n * 32, &db));
+    VDF_TRY(st.out(out, n * 32, &dout));
+    VDF_TRY(vdf::vec_axpy(field, da, dr, db, n, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const vdf_fe* i0, uint64_t t, vdf_fe* W_segment) {
+  return guarded(ctx, [&]() -> Status {
+    if (t >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "t too large"};
+    Staging st(ctx);
+    const void *dt, *di; void* dw;
+    VDF_TRY(st.in(trace_xy, (t + 1) * 64, &dt));
+    VDF_TRY(st.in(i0, 32, &di));
+    VDF_TRY(st.out(W_segment, (4 * t + 1) * 32, &dw));
+    VDF_TRY(vdf::vec_minroot_witness(field, dt, di, t, dw, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_fe_mul(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* b, size_t n, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void *da, *db; void* dout;
+    VDF_TRY(st.in(a, n * 32, &da));
+    VDF_TRY(st.in(b, n * 32, &db));
+    VDF_TRY(st.out(out, n * 32, &dout));
+    VDF_TRY(vdf::vec_mul(field, da, db, n, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_fe_to_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void* da; void* dout;
+    VDF_TRY(st.in(a, n * 32, &da));
+    VDF_TRY(st.out(out, n * 32, &dout));
+    VDF_TRY(vdf::vec_to_mont(field, da, n, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_fe_from_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void* da; void* dout;
+    VDF_TRY(st.in(a, n * 32, &da));
+    VDF_TRY(st.out(out, n * 32, &dout));
+    VDF_TRY(vdf::vec_from_mont(field, da, n, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int iters, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    Staging st(ctx);
+    const void* da; void* dout;
+    VDF_TRY(st.in(a, n * 32, &da));
+    VDF_TRY(st.out(out, n * 32, &dout));
+    VDF_TRY(vdf::vec_mul_chain(field, da, n, iters, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+// ---- device memory helpers ----------------------------------------------------------------------
+int vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    VDF_TRY_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return Status{};
+  });
+}
+
+int vdf_dev_free(vdf_ctx* ctx, void* p) {
+  return guarded(ctx, [&]() -> Status {
+    if (!p) return Status{};
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    VDF_TRY_HIP(hipFree(p));
+    return Status{};
+  });
+}
+
+int vdf_dev_memcpy(vdf_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  return guarded(ctx, [&]() -> Status {
+    if (bytes == 0) return Status{};
+    if (!dst || !src) return Status{VDF_ERR_BAD_ARG, "null pointer"};
+    const bool both_dev = ptr_is_device(dst) && ptr_is_device(src);
+    VDF_TRY_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    if (!(both_dev && ctx->async)) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_dev_memset(vdf_ctx* ctx, void* dst, int value, size_t bytes) {
+  return guarded(ctx, [&]() -> Status {
+    if (bytes == 0) return Status{};
+    if (!dst) return Status{VDF_ERR_BAD_ARG, "null pointer"};
+    VDF_TRY_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+}  // extern "C"

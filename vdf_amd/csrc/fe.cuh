@@ -1,0 +1,262 @@
+// Pasta field arithmetic for gfx950: 8 x 32-bit limbs, Montgomery form (R = 2^256).
+//
+// Replaces (on the device) the field layer the reference reaches through
+// pasta_curves 0.4.0 (Cargo.toml:17): Fp/Fq `mul`, `square`, `add`, `sub`
+// (used at src/minroot.rs:74, :221, :331-333, :339-342 and by every third-party
+// call on the prove_step path, src/nova/proof.rs:342-349).  In-memory layout is
+// the same 4 x u64 little-endian Montgomery limbs pasta_curves' `repr-c` uses, so
+// buffers cross the C ABI unchanged.
+//
+// The work-horse is v_mad_u64_u32 (32x32+64 -> 64).  Both moduli are 2^254 + c,
+// c < 2^126, == 1 (mod 2^32):  -m^-1 mod 2^32 = 0xFFFFFFFF so the Montgomery
+// quotient digit is just the negated low limb, modulus limb 0 is 1 (no multiply),
+// limbs 4..6 are zero and limb 7 is 2^30 (a shift): 3 real multiplies per
+// reduction round instead of 8.
+//
+// The same code compiles for the host (the C++ Nova layer uses it for its O(1)
+// scalar work); there is no separate CPU implementation in the product.
+#pragma once
+#include <stdint.h>
+#include "pasta_constants.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define VDF_HD __host__ __device__ __forceinline__
+#else
+#define VDF_HD inline
+#endif
+
+namespace vdf {
+
+template <class P>
+struct Fe {
+  uint32_t v[8];
+};
+
+using Fp = Fe<FpParams>;
+using Fq = Fe<FqParams>;
+
+template <class P> VDF_HD Fe<P> fe_zero() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  return r;
+}
+template <class P> VDF_HD Fe<P> fe_one() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = P::ONE[i];
+  return r;
+}
+template <class P> VDF_HD bool fe_is_zero(const Fe<P>& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.v[i];
+  return o == 0;
+}
+template <class P> VDF_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+
+// r = a - m if a >= m (a < 2m assumed).
+template <class P> VDF_HD void fe_cond_sub(uint32_t t[8]) {
+  uint32_t d[8];
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t s = (uint64_t)t[i] - P::MOD[i] - borrow;
+    d[i] = (uint32_t)s;
+    borrow = (uint32_t)(s >> 63);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = borrow ? t[i] : d[i];
+}
+
+template <class P> VDF_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t s = (uint64_t)a.v[i] + b.v[i] + c;
+    r.v[i] = (uint32_t)s;
+    c = (uint32_t)(s >> 32);
+  }
+  // a, b < m < 2^255 so no carry out of limb 7.
+  fe_cond_sub<P>(r.v);
+  return r;
+}
+
+template <class P> VDF_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
+    r.v[i] = (uint32_t)s;
+    borrow = (uint32_t)(s >> 63);
+  }
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t s = (uint64_t)r.v[i] + (borrow ? P::MOD[i] : 0u) + c;
+    r.v[i] = (uint32_t)s;
+    c = (uint32_t)(s >> 32);
+  }
+  return r;
+}
+
+template <class P> VDF_HD Fe<P> fe_neg(const Fe<P>& a) {
+  return fe_is_zero(a) ? a : fe_sub(fe_zero<P>(), a);
+}
+
+template <class P> VDF_HD Fe<P> fe_dbl(const Fe<P>& a) { return fe_add(a, a); }
+
+// One Montgomery reduction round on t[0..8]: t = (t + q*m) / 2^32 with q = -t[0].
+template <class P> VDF_HD void mont_round(uint32_t t[9]) {
+  const uint32_t q = 0u - t[0];
+  uint64_t s;
+  uint32_t c = (t[0] != 0u);                       // t0 + q*1 = 0 or 2^32
+  s = (uint64_t)q * P::MOD[1] + t[1] + c; t[0] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)q * P::MOD[2] + t[2] + c; t[1] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)q * P::MOD[3] + t[3] + c; t[2] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)t[4] + c;                 t[3] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)t[5] + c;                 t[4] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)t[6] + c;                 t[5] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  // q * 2^30 split over limbs 7 and 8
+  s = (uint64_t)t[7] + (uint32_t)(q << 30) + c; t[6] = (uint32_t)s; c = (uint32_t)(s >> 32);
+  s = (uint64_t)t[8] + (q >> 2) + c;      t[7] = (uint32_t)s; t[8] = (uint32_t)(s >> 32);
+}
+
+// Montgomery product a*b/R mod m, inputs and output in [0, m).  Always-inline body; only the hot
+// mixed-add of the MSM uses it directly (a fully inlined multiply is ~350 instructions and
+// hipcc's compile time is super-linear in the size of such straight-line blocks).
+template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+      t[j] = (uint32_t)s;
+      c = (uint32_t)(s >> 32);
+    }
+    t[8] += c;                                    // t < 2m*2^32-ish: no overflow of limb 8
+    mont_round<P>(t);
+  }
+  fe_cond_sub<P>(t);
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+  return r;
+}
+
+// Out-of-line multiply (by-value arguments travel in VGPRs): one copy per field per TU.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class P> __device__ __attribute__((noinline)) Fe<P> fe_mul_call(Fe<P> a, Fe<P> b) { return fe_mul_inl(a, b); }
+template <class P> VDF_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul_call<P>(a, b); }
+#else
+template <class P> VDF_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul_inl(a, b); }
+#endif
+template <class P> VDF_HD Fe<P> fe_sqr(const Fe<P>& a) { return fe_mul(a, a); }
+template <class P> VDF_HD Fe<P> fe_sqr_inl(const Fe<P>& a) { return fe_mul_inl(a, a); }
+// compile-time choice between the two
+template <bool INL, class P> VDF_HD Fe<P> fe_mul_sel(const Fe<P>& a, const Fe<P>& b) {
+  if constexpr (INL) return fe_mul_inl(a, b); else return fe_mul(a, b);
+}
+
+// Out of Montgomery form: a/R mod m (eight reduction rounds of a alone).
+template <class P> VDF_HD Fe<P> fe_from_mont(const Fe<P>& a) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = a.v[i];
+  t[8] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mont_round<P>(t);
+  fe_cond_sub<P>(t);
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+  return r;
+}
+
+template <class P> VDF_HD Fe<P> fe_to_mont(const Fe<P>& a) {
+  Fe<P> r2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r2.v[i] = P::R2[i];
+  return fe_mul(a, r2);
+}
+
+// true iff the 256-bit value is a canonical residue (< m).
+template <class P> VDF_HD bool fe_is_canonical(const Fe<P>& a) {
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t s = (uint64_t)a.v[i] - P::MOD[i] - borrow;
+    borrow = (uint32_t)(s >> 63);
+  }
+  return borrow != 0;
+}
+
+// a^e for a 256-bit exponent given as 8 x u32 LE limbs, left-to-right square and
+// multiply (same shape as ff::Field::pow_vartime, src/minroot.rs:312-314).
+template <class P> VDF_HD Fe<P> fe_pow(const Fe<P>& a, const uint32_t e[8]) {
+  Fe<P> r = fe_one<P>();
+  bool started = false;
+  for (int i = 7; i >= 0; --i) {
+    for (int b = 31; b >= 0; --b) {
+      if (started) r = fe_sqr(r);
+      if ((e[i] >> b) & 1u) {
+        r = started ? fe_mul(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+template <class P> VDF_HD Fe<P> fe_inv(const Fe<P>& a) {   // a^(m-2); inv(0) = 0
+  uint32_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = P::MOD_MINUS_2[i];
+  return fe_pow(a, e);
+}
+
+template <class P> VDF_HD Fe<P> fe_from_u64(uint64_t x) {     // Montgomery form of a small integer
+  Fe<P> r = fe_zero<P>();
+  r.v[0] = (uint32_t)x;
+  r.v[1] = (uint32_t)(x >> 32);
+  return fe_to_mont(r);
+}
+
+// 16-byte vectorised load/store of one 32-byte element (two dwordx4 per lane).
+template <class P> VDF_HD Fe<P> fe_load(const void* p) {
+  Fe<P> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 lo = q[0], hi = q[1];
+  r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+  r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+#else
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  for (int i = 0; i < 8; ++i) r.v[i] = q[i];
+#endif
+  return r;
+}
+template <class P> VDF_HD void fe_store(void* p, const Fe<P>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+#else
+  uint32_t* q = reinterpret_cast<uint32_t*>(p);
+  for (int i = 0; i < 8; ++i) q[i] = a.v[i];
+#endif
+}
+
+}  // namespace vdf

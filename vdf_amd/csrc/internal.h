@@ -1,0 +1,112 @@
+// Internal declarations shared by the translation units of libvdf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/vdf_hip.h"
+
+struct vdf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool async = false;
+  int msm_window = 0;          // 0 = automatic
+  std::mutex mu;
+  std::string err;
+  // MSM workspace (grown on demand, reused across calls)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  void* d_out = nullptr;       // 128 B result slot
+  int num_cus = 256;
+};
+
+struct vdf_bases {
+  vdf_ctx* ctx = nullptr;
+  int curve = 0;
+  size_t n = 0;
+  void* d_pts = nullptr;       // n affine points, 64 B each
+  // fixed-base table: tables x n affine points; table j holds 2^(c*sets*j) * P_i
+  int tbl_c = 0, tbl_sets = 0, tbl_tables = 0;
+  void* d_table = nullptr;
+};
+
+struct vdf_shape {
+  vdf_ctx* ctx = nullptr;
+  int field = 0;
+  size_t num_cons = 0, num_cols = 0;
+  size_t nnz[3] = {0, 0, 0};
+  uint32_t* d_rowptr[3] = {nullptr, nullptr, nullptr};   // num_cons + 1
+  uint32_t* d_col[3] = {nullptr, nullptr, nullptr};      // nnz
+  uint32_t* d_coef[3] = {nullptr, nullptr, nullptr};     // nnz, index into dictionary
+  void* d_dict = nullptr;                                 // dictionary of field elements
+  size_t dict_len = 0;
+};
+
+namespace vdf {
+
+struct Status {
+  int code = VDF_OK;
+  std::string msg;
+  bool ok() const { return code == VDF_OK; }
+};
+
+inline Status hip_status(hipError_t e, const char* what) {
+  Status s;
+  if (e != hipSuccess) {
+    s.code = (e == hipErrorOutOfMemory) ? VDF_ERR_OOM : VDF_ERR_DEVICE;
+    s.msg = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  return s;
+}
+
+#define VDF_TRY_HIP(expr)                                   \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) return ::vdf::hip_status(e__, #expr); \
+  } while (0)
+#define VDF_TRY(expr)                 \
+  do {                                \
+    ::vdf::Status s__ = (expr);       \
+    if (!s__.ok()) return s__;        \
+  } while (0)
+
+// ---- msm.hip --------------------------------------------------------------------------
+struct MsmPlan {
+  uint32_t n = 0;        // points
+  int c = 0;             // window bits
+  int windows = 0;       // ceil(256 / c)
+  int sets = 0;          // bucket sets (Horner length); windows = sets * tables
+  int tables = 0;
+  uint32_t nbk = 0;      // buckets per set = 2^(c-1)   (digit magnitudes 1..2^(c-1))
+  uint32_t chunk = 0;    // points per sort chunk
+  uint32_t K = 0;        // chunks per window
+  uint32_t L = 0;        // sorted entries per accumulate thread
+  uint32_t nthreads = 0; // accumulate threads
+  uint32_t tstride = 0;  // points per fixed-base table (tables > 1)
+  size_t ws_bytes = 0;
+};
+MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus);
+int msm_auto_window(size_t n);
+// d_points: table (tables*n affine) or plain bases (tables == 1).  d_scalars: n x 32 B device.
+// d_out: 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
+Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* d_scalars, bool is_mont,
+               void* ws, void* d_out, hipStream_t stream);
+Status bases_generate(int curve, uint64_t seed, size_t n, void* d_pts, hipStream_t stream);
+Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,
+                        hipStream_t stream);
+
+// ---- vecops.hip ------------------------------------------------------------------------
+Status vec_axpy(int field, const void* a, const void* r, const void* b, size_t n, void* out, hipStream_t s);
+Status vec_cross_term(int field, const void* az1, const void* bz1, const void* cz1, const void* az2,
+                      const void* bz2, const void* cz2, const void* u1, size_t n, void* T, hipStream_t s);
+Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint64_t t, void* W, hipStream_t s);
+Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const uint32_t* coef, const void* dict,
+                const void* z, size_t rows, void* out, hipStream_t s);
+Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);
+Status vec_to_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
+Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
+Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, hipStream_t s);
+
+}  // namespace vdf

@@ -1,0 +1,199 @@
+"""Thin Python handle over the C ABI (include/vdf_hip.h).  Plumbing only: every arithmetic
+operation is a HIP kernel behind `libvdf_hip.so`.  Buffers may be numpy arrays (host, staged by
+the library over PCIe) or torch CUDA tensors (device, used in place)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, CURVE_PALLAS, CURVE_VESTA, FIELD_FP, FIELD_FQ  # noqa: F401
+
+
+class VdfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vdf_hip error {code}: {msg}")
+        self.code = code
+
+
+def ints_to_limbs(vals: Sequence[int]) -> np.ndarray:
+    """Python ints -> uint64[n, 4] little-endian limbs (data reshaping, no arithmetic)."""
+    buf = b"".join(int(v).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype="<u8").reshape(-1, 4).copy()
+
+
+def limbs_to_ints(arr: np.ndarray) -> list:
+    a = np.ascontiguousarray(arr, dtype="<u8").reshape(-1, 4)
+    raw = a.tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(a.shape[0])]
+
+
+def _ptr(x) -> Optional[int]:
+    """Address of a numpy array or torch tensor (None stays None)."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("numpy buffers must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensors must be contiguous")
+        return x.data_ptr()
+    if isinstance(x, int):
+        return x
+    raise TypeError(type(x))
+
+
+class Bases:
+    def __init__(self, ctx: "Context", handle: int, curve: int):
+        self.ctx, self.handle, self.curve = ctx, handle, curve
+
+    def __len__(self) -> int:
+        return lib.vdf_bases_len(self.handle)
+
+    @property
+    def device_ptr(self) -> int:
+        return lib.vdf_bases_device_ptr(self.handle)
+
+    def precompute(self, window_bits: int = 16, sets: int = 1) -> None:
+        self.ctx._check(lib.vdf_bases_precompute(self.ctx.handle, self.handle, window_bits, sets))
+
+    def download(self, offset: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = len(self) - offset if n is None else n
+        out = np.zeros((n, 8), dtype="<u8")
+        self.ctx._check(lib.vdf_bases_download(self.ctx.handle, self.handle, offset, n, _ptr(out)))
+        return out
+
+    def free(self) -> None:
+        if self.handle:
+            lib.vdf_bases_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Shape:
+    def __init__(self, ctx: "Context", handle: int, field: int, num_cons: int, num_cols: int):
+        self.ctx, self.handle, self.field, self.num_cons, self.num_cols = ctx, handle, field, num_cons, num_cols
+
+    def free(self) -> None:
+        if self.handle:
+            lib.vdf_shape_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One context per GPU (one process per GPU)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        dev = C.c_int(device)
+        rc = lib.vdf_ctx_create(C.byref(dev), 1, C.byref(h))
+        if rc != _lib.VDF_OK:
+            raise VdfError(rc, (lib.vdf_last_error(None) or b"").decode())
+        self.handle = h.value
+        self.device = device
+
+    def _check(self, rc: int) -> None:
+        if rc != _lib.VDF_OK:
+            raise VdfError(rc, (lib.vdf_last_error(self.handle) or b"").decode())
+
+    def close(self) -> None:
+        if self.handle:
+            lib.vdf_ctx_destroy(self.handle)
+            self.handle = None
+
+    def set_stream(self, stream_ptr: int) -> None:
+        self._check(lib.vdf_ctx_set_stream(self.handle, stream_ptr))
+
+    @property
+    def stream(self) -> int:
+        return lib.vdf_ctx_get_stream(self.handle)
+
+    def set_async(self, flag: bool) -> None:
+        self._check(lib.vdf_ctx_set_async(self.handle, int(flag)))
+
+    def sync(self) -> None:
+        self._check(lib.vdf_ctx_sync(self.handle))
+
+    def set_msm_window(self, c: int) -> None:
+        self._check(lib.vdf_ctx_set_msm_window(self.handle, c))
+
+    # ---- bases -------------------------------------------------------------------------
+    def bases_upload(self, curve: int, pts) -> Bases:
+        n = pts.shape[0]
+        h = C.c_void_p()
+        self._check(lib.vdf_bases_upload(self.handle, curve, _ptr(pts), n, C.byref(h)))
+        return Bases(self, h.value, curve)
+
+    def bases_generate(self, curve: int, seed: int, n: int) -> Bases:
+        h = C.c_void_p()
+        self._check(lib.vdf_bases_generate(self.handle, curve, seed, n, C.byref(h)))
+        return Bases(self, h.value, curve)
+
+    # ---- msm ---------------------------------------------------------------------------
+    def msm(self, bases: Bases, scalars, n: Optional[int] = None, offset: int = 0, is_mont: bool = False, out=None):
+        """Returns the Jacobian result as uint64[12] (numpy) unless `out` (device tensor) is given."""
+        n = scalars.shape[0] if n is None else n
+        host_out = out is None
+        if host_out:
+            out = np.zeros(12, dtype="<u8")
+        self._check(lib.vdf_msm(self.handle, bases.handle, offset, _ptr(scalars), n, int(is_mont), _ptr(out)))
+        return out
+
+    # ---- shape / spmv --------------------------------------------------------------------
+    def shape_create(self, field: int, num_cons: int, num_cols: int, mats) -> Shape:
+        """mats: three (rows uint32[nnz], cols uint32[nnz], vals uint64[nnz,4]) triples (host)."""
+        rows = (C.c_void_p * 3)(*[_ptr(m[0]) for m in mats])
+        cols = (C.c_void_p * 3)(*[_ptr(m[1]) for m in mats])
+        vals = (C.c_void_p * 3)(*[_ptr(m[2]) for m in mats])
+        nnz = (C.c_size_t * 3)(*[int(m[0].shape[0]) for m in mats])
+        h = C.c_void_p()
+        self._check(lib.vdf_shape_create(self.handle, field, num_cons, num_cols, rows, cols, vals, nnz, C.byref(h)))
+        self._keep = mats
+        return Shape(self, h.value, field, num_cons, num_cols)
+
+    def spmv3(self, shape: Shape, z, az, bz, cz) -> None:
+        self._check(lib.vdf_spmv3(self.handle, shape.handle, _ptr(z), _ptr(az), _ptr(bz), _ptr(cz)))
+
+    # ---- vector ops ------------------------------------------------------------------------
+    def cross_term(self, field, az1, bz1, cz1, az2, bz2, cz2, u1, n, out) -> None:
+        self._check(lib.vdf_cross_term(self.handle, field, _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(az2), _ptr(bz2),
+                                       _ptr(cz2), _ptr(u1), n, _ptr(out)))
+
+    def axpy(self, field, a, r, b, n, out) -> None:
+        self._check(lib.vdf_axpy(self.handle, field, _ptr(a), _ptr(r), _ptr(b), n, _ptr(out)))
+
+    def minroot_witness(self, field, trace_xy, i0, t, out) -> None:
+        self._check(lib.vdf_minroot_witness(self.handle, field, _ptr(trace_xy), _ptr(i0), t, _ptr(out)))
+
+    def fe_mul(self, field, a, b, n, out) -> None:
+        self._check(lib.vdf_fe_mul(self.handle, field, _ptr(a), _ptr(b), n, _ptr(out)))
+
+    def fe_to_mont(self, field, a, n, out) -> None:
+        self._check(lib.vdf_fe_to_mont(self.handle, field, _ptr(a), n, _ptr(out)))
+
+    def fe_from_mont(self, field, a, n, out) -> None:
+        self._check(lib.vdf_fe_from_mont(self.handle, field, _ptr(a), n, _ptr(out)))
+
+    def fe_mul_chain(self, field, a, n, iters, out) -> None:
+        self._check(lib.vdf_fe_mul_chain(self.handle, field, _ptr(a), n, iters, _ptr(out)))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
