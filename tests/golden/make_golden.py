@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/vectors.json from the Python big-integer oracle (oracle/pasta.py).
+
+These are ORACLE-derived vectors, not reference-derived ones: the Rust reference cannot be run
+here and its tests hold no known answers.  They pin the C restatement and the HIP
+path to the same canonical prime-field / prime-order-group results, and include the
+surveyor-derived MinRoot known answers of SURVEY.md Appendix B.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+from oracle import pasta as o  # noqa: E402
+
+H = lambda x: "%064x" % x
+out = {"note": "oracle-derived (Python big ints); canonical big-endian hex, NOT Montgomery form"}
+
+# --- field multiplication / edge elements ---------------------------------------------------
+fields = {}
+for f, m in ((o.FIELD_FP, o.P), (o.FIELD_FQ, o.Q)):
+    a = [0, 1, m - 1, 2, (1 << 254) % m, (m - 1) // 2] + [o.rand_fe(11, i, m) for i in range(10)]
+    b = [5, m - 1, m - 1, (m + 1) // 2, (1 << 254) % m, 3] + [o.rand_fe(12, i, m) for i in range(10)]
+    fields[str(f)] = {"a": [H(x) for x in a], "b": [H(x) for x in b], "mul": [H(x * y % m) for x, y in zip(a, b)]}
+out["field_mul"] = fields
+
+# --- MinRoot known answers (SURVEY.md Appendix B inputs: x=123, y=321, i=0) -------------------
+mr = {}
+for f in (o.FIELD_FP, o.FIELD_FQ):
+    s = o.State(123, 321, 0)
+    rows = {}
+    for t in (1, 2, 10):
+        r = o.minroot_eval(s, t, f)
+        rows[str(t)] = [H(r.x), H(r.y), H(r.i)]
+    mr[str(f)] = rows
+out["minroot_eval_123_321_0"] = mr
+r10 = o.minroot_eval(o.State(123, 321, 0), 10, o.FIELD_FQ)
+out["circuit_round0_on_pallas_t10"] = [H(v) for v in o.step_witness_segment(r10, 1, o.FIELD_FQ)[:4]]
+
+# --- step-circuit witness for t = 5 (reference test size, src/nova/proof.rs:405), i0 = 1 --------
+x0 = o.rand_fe(42, 0, o.Q)
+tr = o.minroot_eval_trace(o.State(x0, 0, 1), 5, o.FIELD_FQ)
+out["witness_t5"] = {
+    "trace_xy": [[H(s.x), H(s.y)] for s in tr], "i0": H(1),
+    "W": [H(v) for v in o.step_witness_from_trace([(s.x, s.y) for s in tr], 1, 5, o.FIELD_FQ)],
+}
+assert out["witness_t5"]["W"] == [H(v) for v in o.step_witness_segment(tr[-1], 5, o.FIELD_FQ)]
+
+# --- small MSMs on both curves (synthetic bases, seed 7) --------------------------------------
+msm = {}
+for curve in (o.CURVE_PALLAS, o.CURVE_VESTA):
+    sm = o.curve_scalar_modulus(curve)
+    cases = {}
+    for n in (1, 2, 3, 17, 64):
+        sc = [o.rand_fe(100 + n, i, sm) for i in range(n)]
+        if n >= 3:
+            sc[0], sc[1], sc[2] = 0, 1, sm - 1
+        bases = o.synthetic_bases(curve, 7, n)
+        res = o.msm_naive(sc, bases, curve)
+        assert res == o.msm_by_dlog(sc, curve, 7)
+        cases[str(n)] = {"scalars": [H(s) for s in sc], "bases": [[H(p[0]), H(p[1])] for p in bases],
+                         "result": [H(v) for v in o.point_to_affine_ints(res)]}
+    msm[str(curve)] = cases
+out["msm_seed7"] = msm
+
+# --- folding vector ops on t = 5 shape ------------------------------------------------------------
+sh = o.step_circuit_shape(5, o.FIELD_FQ)
+res = tr[-1]
+W = [res.x, res.y, res.i] + o.step_witness_segment(res, 5, o.FIELD_FQ)
+X = [res.x, res.y, res.i, tr[0].x, tr[0].y, tr[0].i]
+z = W + [1] + X
+az, bz, cz = o.multiply_vec(sh, z, o.Q)
+assert o.is_sat_relaxed(sh, W, [0] * sh.num_cons, 1, X, o.Q)
+z1 = [o.rand_fe(77, i, o.Q) for i in range(len(z))]
+az1, bz1, cz1 = o.multiply_vec(sh, z1, o.Q)
+u1 = z1[sh.num_vars]
+T = o.cross_term(az1, bz1, cz1, az, bz, cz, u1, o.Q)
+r = o.rand_fe(78, 0, o.Q) >> 126
+out["fold_t5"] = {
+    "shape": {"num_cons": sh.num_cons, "num_vars": sh.num_vars, "num_io": sh.num_io,
+              "A": [[a, b, H(c)] for a, b, c in sh.A], "B": [[a, b, H(c)] for a, b, c in sh.B],
+              "C": [[a, b, H(c)] for a, b, c in sh.C]},
+    "z2": [H(v) for v in z], "az2": [H(v) for v in az], "bz2": [H(v) for v in bz], "cz2": [H(v) for v in cz],
+    "z1": [H(v) for v in z1], "az1": [H(v) for v in az1], "bz1": [H(v) for v in bz1], "cz1": [H(v) for v in cz1],
+    "T": [H(v) for v in T], "r": H(r), "W_fold": [H(v) for v in o.axpy(z1[:sh.num_vars], r, W, o.Q)],
+}
+path = os.path.join(os.path.dirname(__file__), "vectors.json")
+json.dump(out, open(path, "w"), indent=0)
+print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,72 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/vdf_hip.h declares, and refuses to work without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "vdf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b((?:vdf_|mult_pippenger_)\w+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_header_declares_the_survey_entry_points():
+    names = set(declared_symbols())
+    for must in ("vdf_ctx_create", "vdf_ctx_destroy", "vdf_bases_upload", "vdf_bases_free", "vdf_msm",
+                 "mult_pippenger_pallas", "mult_pippenger_vesta", "vdf_spmv3", "vdf_cross_term", "vdf_axpy",
+                 "vdf_minroot_witness", "vdf_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from vdf_amd import _lib
+    for name in declared_symbols():
+        assert hasattr(_lib.lib, name), f"libvdf_hip.so does not export {name}"
+        assert name in _lib.PROTOTYPES, f"vdf_amd/_lib.py has no prototype for {name}"
+
+
+def test_no_torch_types_in_the_boundary():
+    txt = open(os.path.join(ROOT, "include", "vdf_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # comments may mention torch; signatures may not
+    assert "torch" not in code.lower() and "at::" not in code and "std::" not in code
+    assert "#include <torch" not in txt and "ATen" not in txt
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a device the product must fail loudly rather than compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from vdf_amd import _lib
+    h = C.c_void_p()
+    dev = C.c_int(0)
+    rc = _lib.lib.vdf_ctx_create(C.byref(dev), 1, C.byref(h))
+    assert rc == _lib.VDF_ERR_NO_DEVICE
+    assert b"no CPU fallback" in _lib.lib.vdf_last_error(None) or b"no HIP device" in _lib.lib.vdf_last_error(None)
+    import vdf_amd
+    with pytest.raises(vdf_amd.VdfError):
+        vdf_amd.Context(0)
+
+
+def test_cpu_backend_request_is_refused():
+    from vdf_amd import _lib
+    h = C.c_void_p()
+    rc = _lib.lib.vdf_ctx_create(None, 0, C.byref(h))     # SURVEY's "n_devices 0 -> CPU back-end" is NOT offered
+    assert rc == _lib.VDF_ERR_NO_DEVICE and not h.value
+
+
+def test_product_does_not_import_the_oracle():
+    """vdf_amd/ (the product) must never import oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "vdf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+                assert "pasta_ref" not in src and "oracle/" not in src.replace("oracle/pasta.py base_dlog", ""), fn

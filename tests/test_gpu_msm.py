@@ -1,0 +1,227 @@
+"""GPU parity: Pippenger MSM through the C ABI against the golden vectors, the C restatement
+and (at full BASELINE sizes) the discrete-log identity of the synthetic generators."""
+import numpy as np
+import pytest
+
+from oracle import pasta as o
+from util import limbs, ints, mont, unmont, hexes, jac_to_affine, affine_array, rand_limbs
+
+pytestmark = pytest.mark.gpu
+CURVES = [o.CURVE_PALLAS, o.CURVE_VESTA]
+
+
+def cpu_msm(cref, curve, pts, sc, is_mont=0):
+    out = np.zeros(12, dtype="<u8")
+    cref.lib().ref_msm(curve, cref.p(pts), cref.p(sc), len(sc), is_mont, 8, 0, cref.p(out))
+    return jac_to_affine(out, curve)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_golden_small(ctx, golden, curve):
+    sm = o.curve_scalar_modulus(curve)
+    for n, c in golden["msm_seed7"][str(curve)].items():
+        pts = affine_array([tuple(hexes(p)) for p in c["bases"]], curve)
+        bases = ctx.bases_upload(curve, pts)
+        exp = tuple(hexes(c["result"]))
+        for is_mont in (False, True):
+            sc = mont(hexes(c["scalars"]), sm) if is_mont else limbs(hexes(c["scalars"]))
+            got = jac_to_affine(ctx.msm(bases, sc, is_mont=is_mont), curve)
+            assert (got or (0, 0)) == exp, (curve, n, is_mont)
+        bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_generated_bases_match_oracle(ctx, cref, curve):
+    n = 2000
+    bases = ctx.bases_generate(curve, 7, n)
+    host = bases.download()
+    exp = np.zeros((n, 8), dtype="<u8")
+    cref.lib().ref_synthetic_bases(curve, 7, 0, n, cref.p(exp))
+    assert np.array_equal(host, exp)
+    assert cref.lib().ref_count_off_curve(curve, cref.p(host), n) == 0
+    bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [0, 1, 2, 127, 128, 129, 1 << 10, 5000, 1 << 14, (1 << 16) + 3])
+def test_sizes_vs_c(ctx, cref, curve, n):
+    bases = ctx.bases_generate(curve, 21, max(n, 1))
+    pts = bases.download()
+    sc = rand_limbs(np.random.default_rng(n), n)
+    got = jac_to_affine(ctx.msm(bases, sc, n=n), curve)
+    exp = cpu_msm(cref, curve, pts[:n], sc) if n else None
+    assert got == exp
+    bases.free()
+
+
+def _distributions(n, sm, rng):
+    full = rand_limbs(rng, n)
+    d = {}
+    d["all_zero"] = np.zeros((n, 4), dtype="<u8")
+    d["all_one"] = limbs([1] * n)
+    d["all_q_minus_1"] = limbs([sm - 1] * n)
+    d["all_equal_random"] = np.repeat(full[:1], n, axis=0).copy()
+    single = np.zeros((n, 4), dtype="<u8"); single[n // 2] = full[0]
+    d["single_nonzero"] = single
+    half = full.copy(); half[rng.random(n) < 0.5] = 0
+    d["half_zero"] = half
+    small = np.zeros((n, 4), dtype="<u8"); small[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+    d["le_16_bit"] = small
+    d["one_bit"] = limbs([1 << int(b) for b in rng.integers(0, 254, size=n)])
+    d["window_edges"] = limbs([(1 << 15) | (1 << 31) | (0x8000 << 48) | (0xFFFF << 100)] * n)
+    return d
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_scalar_distributions(ctx, cref, curve):
+    n = 6000
+    sm = o.curve_scalar_modulus(curve)
+    bases = ctx.bases_generate(curve, 33, n)
+    pts = bases.download()
+    rng = np.random.default_rng(99)
+    for name, sc in _distributions(n, sm, rng).items():
+        got = jac_to_affine(ctx.msm(bases, sc), curve)
+        assert got == cpu_msm(cref, curve, pts, sc), name
+    bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_duplicate_and_identity_bases(ctx, cref, curve):
+    """Duplicated bases force the P + P doubling branch of the mixed addition; (0, 0) bases are
+    the identity and must be skipped; P and -P in one bucket must cancel."""
+    n = 4096
+    bases0 = ctx.bases_generate(curve, 5, n)
+    pts = bases0.download()
+    pts[1::2] = pts[0::2]                      # every point twice
+    pts[10] = 0                                # identity bases
+    pts[11] = 0
+    m = o.curve_base_modulus(curve)
+    neg = unmont(pts[20].reshape(2, 4), m)
+    pts[21] = limbs([o.to_mont(neg[0], m), o.to_mont((-neg[1]) % m, m)]).reshape(8)   # -P next to P
+    bases = ctx.bases_upload(curve, pts)
+    rng = np.random.default_rng(1)
+    sc = rand_limbs(rng, n)
+    sc[1::2] = sc[0::2]                        # equal scalars on equal points: same bucket in every window
+    for arr in (sc, limbs([3] * n), limbs([1] * n)):
+        got = jac_to_affine(ctx.msm(bases, arr), curve)
+        assert got == cpu_msm(cref, curve, pts, arr)
+    bases.free(); bases0.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+def test_window_sizes(ctx, cref, curve, c):
+    n = 3000
+    bases = ctx.bases_generate(curve, 8, n)
+    pts = bases.download()
+    sc = rand_limbs(np.random.default_rng(c), n)
+    ctx.set_msm_window(c)
+    try:
+        got = jac_to_affine(ctx.msm(bases, sc), curve)
+    finally:
+        ctx.set_msm_window(0)
+    assert got == cpu_msm(cref, curve, pts, sc)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("c,sets", [(16, 1), (16, 4), (13, 1), (8, 2), (16, 16)])
+def test_fixed_base_tables(ctx, cref, curve, c, sets):
+    n = 5000
+    bases = ctx.bases_generate(curve, 13, n)
+    pts = bases.download()
+    bases.precompute(c, sets)
+    rng = np.random.default_rng(c * 100 + sets)
+    sc = rand_limbs(rng, n)
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == cpu_msm(cref, curve, pts, sc)
+    # offset + shorter length against the same table (how commit_T reuses the generator table)
+    off, k = 777, 3000
+    got = jac_to_affine(ctx.msm(bases, sc[:k].copy(), n=k, offset=off), curve)
+    assert got == cpu_msm(cref, curve, pts[off:off + k].copy(), sc[:k].copy())
+    # skewed scalars through the table path (one heavy bucket)
+    eq = np.repeat(sc[:1], n, axis=0).copy()
+    assert jac_to_affine(ctx.msm(bases, eq), curve) == cpu_msm(cref, curve, pts, eq)
+    bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_heavy_bucket_path(ctx, curve):
+    """All-equal scalars at 2^17 put every point of a window into one bucket: exercises the
+    queued wavefront reduce.  Expected value through the discrete-log identity."""
+    n = 1 << 17
+    sm = o.curve_scalar_modulus(curve)
+    bases = ctx.bases_generate(curve, 3, n)
+    s = o.rand_fe(1, 0, sm)
+    sc = limbs([s] * n)
+    exp = o.msm_by_dlog([s] * n, curve, 3)
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == exp
+    bases.precompute(16, 1)
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == exp
+    bases.free()
+
+
+@pytest.mark.parametrize("mode", ["plain", "table"])
+def test_full_size_2_20_dlog_identity(ctx, mode):
+    """BASELINE config 2 (2^20 Pallas points), device-resident scalars, checked bit-exactly
+    through sum s_i*[k_i]G = [sum s_i*k_i]G."""
+    import torch
+    n, curve = 1 << 20, o.CURVE_PALLAS
+    bases = ctx.bases_generate(curve, 7, n)
+    if mode == "table":
+        bases.precompute(16, 1)
+    sc = rand_limbs(np.random.default_rng(2020), n)
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    ctx.msm(bases, d, n=n, out=out)
+    ctx.sync()
+    got = jac_to_affine(out.cpu().numpy().view("<u8"), curve)
+    assert got == o.msm_by_dlog(ints(sc), curve, 7)
+    bases.free()
+
+
+def test_linearity_property(ctx):
+    """msm(a + r*b) == msm(a) + r*msm(b): ties the MSM and axpy kernels together at 2^16."""
+    n, curve = 1 << 16, o.CURVE_PALLAS
+    bases = ctx.bases_generate(curve, 4, n)
+    rng = np.random.default_rng(8)
+    a, b = rand_limbs(rng, n), rand_limbs(rng, n)
+    r = 0x1234567
+    am, bm, rm = (np.zeros_like(a) for _ in range(3))
+    ctx.fe_to_mont(o.FIELD_FQ, a, n, am); ctx.fe_to_mont(o.FIELD_FQ, b, n, bm)
+    rmont = mont([r], o.Q)
+    cm = np.zeros_like(a)
+    ctx.axpy(o.FIELD_FQ, am, rmont, bm, n, cm)
+    pa = jac_to_affine(ctx.msm(bases, am, is_mont=True), curve)
+    pb = jac_to_affine(ctx.msm(bases, bm, is_mont=True), curve)
+    pc = jac_to_affine(ctx.msm(bases, cm, is_mont=True), curve)
+    assert pc == o.pt_add(pa, o.pt_mul(r, pb, o.P), o.P)
+    bases.free()
+
+
+def test_pippenger_shims(cref):
+    """Drop-in shims with the upstream pasta-msm shape (host pointers, upload on call)."""
+    from vdf_amd._lib import lib
+    for curve, fn in ((o.CURVE_PALLAS, lib.mult_pippenger_pallas), (o.CURVE_VESTA, lib.mult_pippenger_vesta)):
+        n = 1500
+        pts = np.zeros((n, 8), dtype="<u8")
+        cref.lib().ref_synthetic_bases(curve, 2, 0, n, cref.p(pts))
+        sm = o.curve_scalar_modulus(curve)
+        sc = [o.rand_fe(6, i, sm) for i in range(n)]
+        scm = mont(sc, sm)
+        out = np.zeros(12, dtype="<u8")
+        fn(out.ctypes.data, pts.ctypes.data, n, scm.ctypes.data, True)
+        assert jac_to_affine(out, curve) == o.msm_by_dlog(sc, curve, 2)
+
+
+def test_error_paths(ctx):
+    import vdf_amd
+    bases = ctx.bases_generate(o.CURVE_PALLAS, 1, 16)
+    sc = np.zeros((32, 4), dtype="<u8")
+    with pytest.raises(vdf_amd.VdfError) as e:
+        ctx.msm(bases, sc, n=32)                       # more scalars than generators
+    assert e.value.code == vdf_amd._lib.VDF_ERR_BAD_LENGTH
+    with pytest.raises(vdf_amd.VdfError):
+        ctx.set_msm_window(3)
+    with pytest.raises(vdf_amd.VdfError):
+        ctx.axpy(7, sc, sc, sc, 4, sc)                 # unknown field
+    bases.free()
