@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement of the MI355X-native Nova/MinRoot hot path.
+
+Workload (BASELINE.json configs[1], weak scaling for N > 1 as configs[3]): one Pippenger MSM over
+2^20 Pallas points PER GPU.  A "step" = one pass of the hot path over one batch of synthetic input
+already resident in HBM: scalars -> signed digits -> LDS counting sort -> bucket accumulation ->
+bucket reduction -> one Jacobian point; with N GPUs the global MSM has N * 2^20 points, sharded by
+point-chunk, and each step ends with the all-gather of N 96-byte partials (RCCL over xGMI) and a
+local point-sum.  value = points processed by all ranks / max-over-ranks wall time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation) against the
+HBM roofline with its algorithmic bytes (96 B per (base, scalar) pair) over its average
+duration measured with HIP events on the library's stream.  `cpu_baseline` times the plain-C CPU
+restatement (oracle/pasta_ref.c, kind "port") on this box's host cores on the same inputs and checks
+the GPU result against it bit-for-bit (only this leg touches oracle/).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="points per GPU (2^k)")
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
+    """Rank 0, N = 1 only.  The ONLY place bench.py touches oracle/: times the C restatement on the
+    host cores and checks the GPU result against it."""
+    from oracle import cref
+    L = cref.lib()
+    # the restatement spreads its 16 windows (c = 16 at 2^20) over a thread pool: at most 16 threads work
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    pts = bases.download(0, n)
+    sc = scalars_dev.cpu().numpy().view("<u8").copy()
+    out = np.zeros(12, dtype="<u8")
+    t0 = time.perf_counter()
+    L.ref_msm(curve, cref.p(pts), cref.p(sc), n, 0, cores, 0, cref.p(out))
+    dt = time.perf_counter() - t0
+    aff_cpu = np.zeros(8, dtype="<u8")
+    aff_gpu = np.zeros(8, dtype="<u8")
+    L.ref_jac_to_affine(curve, cref.p(out), cref.p(aff_cpu))
+    g = np.ascontiguousarray(gpu_jac, dtype="<u8")
+    L.ref_jac_to_affine(curve, cref.p(g), cref.p(aff_gpu))
+    return {
+        "value": n / dt / 1e9, "unit": "GPoints/s", "cores": cores, "kind": "port",
+        "sample": f"the full 2^{n.bit_length() - 1}-point MSM of the timed workload (same bases and scalars), "
+                  f"{dt:.2f} s wall on {cores} threads, windows spread over a pthread pool",
+        "parity_bit_exact": bool(np.array_equal(aff_cpu, aff_gpu)),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the product and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import vdf_amd
+    from vdf_amd.dist import ShardedMsm
+
+    curve = vdf_amd.CURVE_PALLAS
+    n = 1 << args.log2n
+    ctx = vdf_amd.Context(local_rank)
+    sh = ShardedMsm(ctx, curve, seed=7, n_total=n * world, rank=rank, world=world, table=(args.window, args.sets))
+
+    # synthetic scalars, uniform 254-bit (< q), generated on the device
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + rank)
+    sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    partial = torch.zeros(12, dtype=torch.int64, device="cuda")
+    gathered = torch.zeros(world * 12, dtype=torch.int64, device="cuda")
+    result = torch.zeros(12, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+
+    # run the library on torch's current stream so the collective and the kernels are ordered
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_async(True)
+
+    def all_gather(dst, src):
+        dist.all_gather_into_tensor(dst, src)
+
+    def step():
+        sh.run(sc, partial, gathered, all_gather, out=result)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.set_timing(True)
+    ctx.msm_timing()                      # clear
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    sort_ms, acc_ms, tail_ms, total_ms, calls = ctx.msm_timing()
+    ctx.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = (n * world) / (elapsed / args.steps) / 1e9
+        acc_avg_ms = acc_ms / max(calls, 1)
+        alg_bytes = 96.0 * n
+        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step)",
+            "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
+            "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU, uniform 254-bit scalars resident in HBM, "
+                                   f"fixed-base table c={args.window} sets={args.sets}; N>1: point-chunk shards + all-gather of 96-B partials",
+                       "points_per_gpu": n, "window_bits": args.window, "bucket_sets": args.sets},
+            "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),
+                         "pipeline": total_ms / max(calls, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "k_accumulate", "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": acc_avg_ms,
+                         "note": "MSM is integer-ALU-bound (SURVEY.md 7.3 H5); see DESIGN.md for the v_mad_u64_u32 issue ceiling"},
+        }
+        if world == 1 and not args.no_cpu:
+            ctx.set_async(False)
+            line["cpu_baseline"] = cpu_baseline_leg(ctx, sh.bases, sc, n, curve, result.cpu().numpy().view("<u8"))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

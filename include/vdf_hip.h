@@ -79,6 +79,8 @@ int  vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n
  * oracle/pasta.py base_dlog); stands in for nova-snark's label -> hash-to-curve derivation,
  * which is implementation-defined and unpinned. */
 int  vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out);
+/* Same, for the index range [start, start + n): the shard a rank owns in a multi-GPU MSM. */
+int  vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, vdf_bases** out);
 /* Build the fixed-base table  2^(window_bits*sets*j) * P_i, j = 0..tables-1, so that an MSM
  * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table). */
 int  vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets);
@@ -96,6 +98,16 @@ int  vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* 
              int is_mont, vdf_jac* out);
 /* Window size override for tuning (0 = automatic). */
 int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
+/* out = sum of n Jacobian points (the combine step of a point-chunk-sharded MSM: each GPU
+ * contributes one 96-byte partial, exchanged with an RCCL all-gather). */
+int  vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_jac* out);
+/* Stage timing of MSM calls (HIP events on the context's stream; for bench.py's roofline leg).
+ * enable != 0 records events around the stages of every following vdf_msm.  vdf_msm_timing
+ * synchronises and returns, summed over the calls since the last query:
+ * ms[0] = sort (digits, histogram, scans, scatter), ms[1] = bucket accumulation kernel,
+ * ms[2] = tail (fix-up, bucket reduction, final), ms[3] = whole pipeline; *calls = number of MSMs. */
+int  vdf_ctx_set_timing(vdf_ctx* ctx, int enable);
+int  vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls);
 
 /* Drop-in shims with the upstream pasta-msm 0.1.1 shape (upload-on-call, default context
  * on device 0, abort-free: on failure `out` is set to the identity and the error is

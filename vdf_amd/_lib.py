@@ -28,6 +28,7 @@ PROTOTYPES = {
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),
+    "vdf_bases_generate_range": (_i, [_vp, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
     "vdf_bases_precompute": (_i, [_vp, _vp, _i, _i]),
     "vdf_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "vdf_bases_len": (_sz, [_vp]),
@@ -35,6 +36,9 @@ PROTOTYPES = {
     "vdf_bases_free": (None, [_vp]),
     "vdf_msm": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "vdf_ctx_set_msm_window": (_i, [_vp, _i]),
+    "vdf_point_sum": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "vdf_ctx_set_timing": (_i, [_vp, _i]),
+    "vdf_msm_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "mult_pippenger_pallas": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
     "mult_pippenger_vesta": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
     "vdf_shape_create": (_i, [_vp, _i, _sz, _sz, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp)]),

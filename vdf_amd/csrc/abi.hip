@@ -130,7 +130,17 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_f
   if ((size_t)plan.tstride * plan.tables + n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "table index exceeds 31 bits"};
   if ((uint64_t)n * plan.windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
   VDF_TRY(ensure_ws(ctx, plan.ws_bytes));
-  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream));
+  hipEvent_t* ev = nullptr;
+  vdf_ctx::TimedCall tc;
+  if (ctx->timing) {
+    for (int i = 0; i < 4; ++i) {
+      if (!ctx->ev_pool.empty()) { tc.ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+      else VDF_TRY_HIP(hipEventCreate(&tc.ev[i]));
+    }
+    ev = tc.ev;
+  }
+  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev));
+  if (ev) ctx->timed.push_back(tc);
   return st.finish();
 }
 
@@ -209,6 +219,8 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
+  for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -265,6 +277,10 @@ int vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n,
 }
 
 int vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out) {
+  return vdf_bases_generate_range(ctx, curve, seed, 0, n, out);
+}
+
+int vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, vdf_bases** out) {
   return guarded(ctx, [&]() -> Status {
     if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
     *out = nullptr;
@@ -275,7 +291,7 @@ int vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bas
     if (n) {
       hipError_t e = hipMalloc(&b->d_pts, n * sizeof(vdf_affine));
       if (e != hipSuccess) { delete b; return vdf::hip_status(e, "hipMalloc(bases)"); }
-      Status s = vdf::bases_generate(curve, seed, n, b->d_pts, ctx->stream);
+      Status s = vdf::bases_generate(curve, seed, start, n, b->d_pts, ctx->stream);
       if (s.ok()) s = vdf::hip_status(hipStreamSynchronize(ctx->stream), "bases_generate");
       if (!s.ok()) { (void)hipFree(b->d_pts); delete b; return s; }
     }
@@ -334,6 +350,42 @@ void vdf_bases_free(vdf_bases* bases) {
 // ---- MSM ------------------------------------------------------------------------------------
 int vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont, vdf_jac* out) {
   return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, offset, scalars, n, is_mont, out); });
+}
+
+int vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_jac* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "too many points"};
+    Staging st(ctx);
+    const void* dp; void* dout;
+    VDF_TRY(st.in(points, n * sizeof(vdf_jac), &dp));
+    VDF_TRY(st.out(out, sizeof(vdf_jac), &dout));
+    VDF_TRY(vdf::point_sum(curve, dp, n, dout, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_ctx_set_timing(vdf_ctx* ctx, int enable) {
+  return guarded(ctx, [&]() -> Status { ctx->timing = enable != 0; return Status{}; });
+}
+
+int vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls) {
+  return guarded(ctx, [&]() -> Status {
+    if (!ms || !calls) return Status{VDF_ERR_BAD_ARG, "null output"};
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) ms[i] = 0.f;
+    *calls = (int)ctx->timed.size();
+    for (auto& tc : ctx->timed) {
+      float a = 0, b = 0, c = 0, d = 0;
+      VDF_TRY_HIP(hipEventElapsedTime(&a, tc.ev[0], tc.ev[1]));
+      VDF_TRY_HIP(hipEventElapsedTime(&b, tc.ev[1], tc.ev[2]));
+      VDF_TRY_HIP(hipEventElapsedTime(&c, tc.ev[2], tc.ev[3]));
+      VDF_TRY_HIP(hipEventElapsedTime(&d, tc.ev[0], tc.ev[3]));
+      ms[0] += a; ms[1] += b; ms[2] += c; ms[3] += d;
+      for (int i = 0; i < 4; ++i) ctx->ev_pool.push_back(tc.ev[i]);
+    }
+    ctx->timed.clear();
+    return Status{};
+  });
 }
 
 void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont) {

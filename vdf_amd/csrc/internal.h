@@ -20,6 +20,11 @@ struct vdf_ctx {
   size_t ws_bytes = 0;
   void* d_out = nullptr;       // 128 B result slot
   int num_cus = 256;
+  // stage timing (bench.py roofline leg)
+  bool timing = false;
+  struct TimedCall { hipEvent_t ev[4]; };
+  std::vector<TimedCall> timed;      // events of calls not yet queried
+  std::vector<hipEvent_t> ev_pool;   // recycled events
 };
 
 struct vdf_bases {
@@ -91,9 +96,11 @@ MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus);
 int msm_auto_window(size_t n);
 // d_points: table (tables*n affine) or plain bases (tables == 1).  d_scalars: n x 32 B device.
 // d_out: 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
+// ev (optional): 4 events recorded at start / before accumulate / after accumulate / end.
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* d_scalars, bool is_mont,
-               void* ws, void* d_out, hipStream_t stream);
-Status bases_generate(int curve, uint64_t seed, size_t n, void* d_pts, hipStream_t stream);
+               void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr);
+Status bases_generate(int curve, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
+Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,
                         hipStream_t stream);
 

@@ -435,10 +435,10 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void k_bases_generate(uint64_t seed, uint32_t n, char* __restrict__ pts) {
+__global__ __launch_bounds__(256) void k_bases_generate(uint64_t seed, uint64_t start, uint32_t n, char* __restrict__ pts) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t k = splitmix64(seed * 0xD1342543DE82EF95ull + i) | 1ull;
+  const uint64_t k = splitmix64(seed * 0xD1342543DE82EF95ull + (start + i)) | 1ull;
   Affine<P> g;
 #pragma unroll
   for (int l = 0; l < 8; ++l) { g.x.v[l] = P::GEN_X[l]; g.y.v[l] = P::GEN_Y[l]; }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts
 // ------------------------------------------------------------------------------------------
 template <class P, class SP>
 static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_scalars, bool is_mont, void* ws,
-                        void* d_out, hipStream_t st) {
+                        void* d_out, hipStream_t st, hipEvent_t* ev) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* dig = reinterpret_cast<uint32_t*>(base + w.dig);
@@ -488,6 +488,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
     VDF_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
     VDF_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
   }
+  if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   VDF_TRY_HIP(hipMemsetAsync(bucket_acc, 0, (size_t)nkeys * 128, st));
   VDF_TRY_HIP(hipMemsetAsync(heavy, 0, 4, st));
   VDF_TRY_HIP(hipMemsetAsync(sorted, 0, 64, st));     // sorted[0] is read even when the list is empty
@@ -499,8 +500,10 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, bcount, nkeys, bstart);
   hipLaunchKernelGGL(k_scatter, dim3(p.windows * p.K), dim3(1024), lds_sort, st, dig, p.n, p.nbk, p.chunk, p.K, p.sets,
                      p.tstride, counts, bstart, sorted);
+  if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
+  if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
@@ -509,28 +512,63 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
                      partials);
   hipLaunchKernelGGL((k_reduce2<P>), dim3(p.sets), dim3(64), 0, st, partials, w.red_blocks_per_set, wsum);
   hipLaunchKernelGGL((k_final<P>), dim3(1), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
+  if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* d_scalars, bool is_mont, void* ws,
-               void* d_out, hipStream_t stream) {
+               void* d_out, hipStream_t stream, hipEvent_t* ev) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
   if (curve == VDF_CURVE_PALLAS)
-    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream);
+    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev);
   if (curve == VDF_CURVE_VESTA)
-    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream);
+    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 
-Status bases_generate(int curve, uint64_t seed, size_t n, void* d_pts, hipStream_t stream) {
+// sum of n Jacobian points: one wavefront, lanes stride over the inputs, butterfly reduce
+template <class P>
+__global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, uint32_t n, char* __restrict__ out) {
+  XYZZ<P> acc = xyzz_identity<P>();
+  for (uint32_t i = threadIdx.x; i < n; i += 64) {
+    Jac<P> j;
+    j.x = fe_load<P>(pts + (size_t)i * 96);
+    j.y = fe_load<P>(pts + (size_t)i * 96 + 32);
+    j.z = fe_load<P>(pts + (size_t)i * 96 + 64);
+    XYZZ<P> v = jac_to_xyzz(j);
+    xyzz_add(acc, v);
+  }
+  acc = xyzz_wave_sum(acc);
+  if (threadIdx.x == 0) {
+    Jac<P> j = xyzz_to_jac(acc);
+    fe_store<P>(out, j.x);
+    fe_store<P>(out + 32, j.y);
+    fe_store<P>(out + 64, j.z);
+  }
+}
+
+Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream) {
+  if (curve == VDF_CURVE_PALLAS)
+    hipLaunchKernelGGL((k_point_sum<FpParams>), dim3(1), dim3(64), 0, stream, reinterpret_cast<const char*>(d_jac),
+                       (uint32_t)n, reinterpret_cast<char*>(d_out));
+  else if (curve == VDF_CURVE_VESTA)
+    hipLaunchKernelGGL((k_point_sum<FqParams>), dim3(1), dim3(64), 0, stream, reinterpret_cast<const char*>(d_jac),
+                       (uint32_t)n, reinterpret_cast<char*>(d_out));
+  else
+    return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
+Status bases_generate(int curve, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream) {
   if (n == 0) return Status{};
   dim3 grid((unsigned)((n + 255) / 256));
   if (curve == VDF_CURVE_PALLAS)
-    hipLaunchKernelGGL((k_bases_generate<FpParams>), grid, dim3(256), 0, stream, seed, (uint32_t)n,
+    hipLaunchKernelGGL((k_bases_generate<FpParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
                        reinterpret_cast<char*>(d_pts));
   else if (curve == VDF_CURVE_VESTA)
-    hipLaunchKernelGGL((k_bases_generate<FqParams>), grid, dim3(256), 0, stream, seed, (uint32_t)n,
+    hipLaunchKernelGGL((k_bases_generate<FqParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
                        reinterpret_cast<char*>(d_pts));
   else
     return Status{VDF_ERR_BAD_ARG, "unknown curve"};

@@ -4,6 +4,7 @@ the library over PCIe) or torch CUDA tensors (device, used in place)."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -50,6 +51,7 @@ def _ptr(x) -> Optional[int]:
 class Bases:
     def __init__(self, ctx: "Context", handle: int, curve: int):
         self.ctx, self.handle, self.curve = ctx, handle, curve
+        ctx._children.add(self)
 
     def __len__(self) -> int:
         return lib.vdf_bases_len(self.handle)
@@ -82,6 +84,7 @@ class Bases:
 class Shape:
     def __init__(self, ctx: "Context", handle: int, field: int, num_cons: int, num_cols: int):
         self.ctx, self.handle, self.field, self.num_cons, self.num_cols = ctx, handle, field, num_cons, num_cols
+        ctx._children.add(self)
 
     def free(self) -> None:
         if self.handle:
@@ -106,6 +109,7 @@ class Context:
             raise VdfError(rc, (lib.vdf_last_error(None) or b"").decode())
         self.handle = h.value
         self.device = device
+        self._children = weakref.WeakSet()      # handles that own device memory of this context
 
     def _check(self, rc: int) -> None:
         if rc != _lib.VDF_OK:
@@ -113,6 +117,8 @@ class Context:
 
     def close(self) -> None:
         if self.handle:
+            for child in list(self._children):   # bases / shapes must go before their context
+                child.free()
             lib.vdf_ctx_destroy(self.handle)
             self.handle = None
 
@@ -139,9 +145,9 @@ class Context:
         self._check(lib.vdf_bases_upload(self.handle, curve, _ptr(pts), n, C.byref(h)))
         return Bases(self, h.value, curve)
 
-    def bases_generate(self, curve: int, seed: int, n: int) -> Bases:
+    def bases_generate(self, curve: int, seed: int, n: int, start: int = 0) -> Bases:
         h = C.c_void_p()
-        self._check(lib.vdf_bases_generate(self.handle, curve, seed, n, C.byref(h)))
+        self._check(lib.vdf_bases_generate_range(self.handle, curve, seed, start, n, C.byref(h)))
         return Bases(self, h.value, curve)
 
     # ---- msm ---------------------------------------------------------------------------
@@ -153,6 +159,23 @@ class Context:
             out = np.zeros(12, dtype="<u8")
         self._check(lib.vdf_msm(self.handle, bases.handle, offset, _ptr(scalars), n, int(is_mont), _ptr(out)))
         return out
+
+    def point_sum(self, curve: int, points, n: int, out=None):
+        host_out = out is None
+        if host_out:
+            out = np.zeros(12, dtype="<u8")
+        self._check(lib.vdf_point_sum(self.handle, curve, _ptr(points), n, _ptr(out)))
+        return out
+
+    def set_timing(self, flag: bool) -> None:
+        self._check(lib.vdf_ctx_set_timing(self.handle, int(flag)))
+
+    def msm_timing(self):
+        """(sort_ms, accumulate_ms, tail_ms, total_ms, calls) summed since the last query."""
+        ms = (C.c_float * 4)()
+        calls = C.c_int()
+        self._check(lib.vdf_msm_timing(self.handle, ms, C.byref(calls)))
+        return (*[float(x) for x in ms], calls.value)
 
     # ---- shape / spmv --------------------------------------------------------------------
     def shape_create(self, field: int, num_cons: int, num_cols: int, mats) -> Shape:
