@@ -9,7 +9,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
-constexpr int ITERS = 2048;
+constexpr int ITERS = 8192;
 constexpr int UNROLL = 16;   // independent chains per lane
 
 template <int OP>
@@ -58,6 +58,28 @@ __global__ void k_rate(uint64_t* out, uint64_t* cycles, uint32_t seed) {
         asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(db));
       } else if (OP == 10) {  // v_lshl_add_u64 (64-bit add in one op on gfx94x+)
         asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[j]) : "v"(acc[(j + 1) % UNROLL]));
+      } else if (OP == 12) {  // mad + addc pair (the 96-bit column accumulate)
+        uint32_t hi = (uint32_t)(acc[(j + 1) % UNROLL]);
+        asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(acc[j]), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+        d[j] = (double)hi;
+      } else if (OP == 13) {  // v_addc_co_u32 alone (carry chain)
+        uint32_t lo = (uint32_t)acc[j];
+        asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %1, vcc" : "+v"(lo) : "v"(a) : "vcc");
+        acc[j] = lo;
+      } else if (OP == 14) {  // mad with SGPR carry-out (not vcc)
+        asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b) : "s20", "s21");
+      } else if (OP == 15) {  // v_add_co_u32 alone
+        uint32_t lo = (uint32_t)acc[j];
+        asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1" : "+v"(lo) : "v"(a) : "vcc");
+        acc[j] = lo;
+      } else if (OP == 16) {  // v_add3_u32
+        uint32_t lo = (uint32_t)acc[j];
+        asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));
+        acc[j] = lo;
+      } else if (OP == 17) {  // v_mul_lo + v_mul_hi pair
+        uint32_t lo = (uint32_t)acc[j], h2;
+        asm volatile("v_mul_hi_u32 %1, %0, %2\n\tv_mul_lo_u32 %0, %0, %2" : "+v"(lo), "=&v"(h2) : "v"(a));
+        acc[j] = lo + h2;
       } else if (OP == 11) {  // v_cvt_f64_u32 + back
         uint32_t lo = (uint32_t)acc[j];
         double t;
@@ -77,7 +99,7 @@ __global__ void k_rate(uint64_t* out, uint64_t* cycles, uint32_t seed) {
 template <int OP>
 int run(const char* name, int ops_per_inst) {
   // (a) one wave per SIMD: 256 CUs x 4 waves; (b) 4 waves per SIMD: 256 x 16 waves.
-  for (int wpb : {4, 16}) {
+  for (int wpb : {4, 8, 16, 32}) {
     int blocks = 256, threads = wpb * 64;
     uint64_t *out, *cyc;
     CK(hipMalloc(&out, sizeof(uint64_t) * blocks * threads));
@@ -109,6 +131,12 @@ int main() {
   printf("device %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", p.gcnArchName, p.multiProcessorCount, p.clockRate, p.sharedMemPerBlock);
   run<7>("v_add_u32", 1);
   run<0>("v_mad_u64_u32", 1);
+  run<14>("v_mad_u64_u32 sgpr-cy", 1);
+  run<12>("mad+addc pair", 2);
+  run<13>("v_addc_co_u32", 1);
+  run<15>("v_add_co_u32", 1);
+  run<16>("v_add3_u32", 1);
+  run<17>("mul_hi+mul_lo", 2);
   run<1>("v_mul_lo_u32", 1);
   run<2>("v_mul_hi_u32", 1);
   run<4>("v_mad_u32_u24", 1);

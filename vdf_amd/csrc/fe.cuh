@@ -62,44 +62,118 @@ template <class P> VDF_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
 }
 
 // r = a - m if a >= m (a < 2m assumed).
+#if defined(__HIP_DEVICE_COMPILE__)
+// 8 subtract-with-borrow + 8 selects; modulus limbs 0, 4..7 are inline constants (1, 0, 0, 0, 2^30).
+template <class P> __device__ __forceinline__ void fe_cond_sub(uint32_t t[8]) {
+  uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+  asm("v_subrev_co_u32_e32 %0, vcc, 1, %8\n\t"
+      "v_subbrev_co_u32_e32 %1, vcc, %16, %9, vcc\n\t"
+      "v_subbrev_co_u32_e32 %2, vcc, %17, %10, vcc\n\t"
+      "v_subbrev_co_u32_e32 %3, vcc, %18, %11, vcc\n\t"
+      "v_subbrev_co_u32_e32 %4, vcc, 0, %12, vcc\n\t"
+      "v_subbrev_co_u32_e32 %5, vcc, 0, %13, vcc\n\t"
+      "v_subbrev_co_u32_e32 %6, vcc, 0, %14, vcc\n\t"
+      "v_subbrev_co_u32_e32 %7, vcc, 2.0, %15, vcc\n\t"
+      "v_cndmask_b32_e32 %8, %0, %8, vcc\n\t"
+      "v_cndmask_b32_e32 %9, %1, %9, vcc\n\t"
+      "v_cndmask_b32_e32 %10, %2, %10, vcc\n\t"
+      "v_cndmask_b32_e32 %11, %3, %11, vcc\n\t"
+      "v_cndmask_b32_e32 %12, %4, %12, vcc\n\t"
+      "v_cndmask_b32_e32 %13, %5, %13, vcc\n\t"
+      "v_cndmask_b32_e32 %14, %6, %14, vcc\n\t"
+      "v_cndmask_b32_e32 %15, %7, %15, vcc"
+      : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7),
+        "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+      : "v"(P::MOD[1]), "v"(P::MOD[2]), "v"(P::MOD[3])     // VGPRs: VCC carry-in already uses the constant bus
+      : "vcc");
+}
+static_assert(FpParams::MOD[0] == 1 && FpParams::MOD[4] == 0 && FpParams::MOD[5] == 0 && FpParams::MOD[6] == 0 &&
+              FpParams::MOD[7] == 0x40000000u, "fe_cond_sub hard-codes the sparse limbs");
+static_assert(FqParams::MOD[0] == 1 && FqParams::MOD[4] == 0 && FqParams::MOD[5] == 0 && FqParams::MOD[6] == 0 &&
+              FqParams::MOD[7] == 0x40000000u, "fe_cond_sub hard-codes the sparse limbs");
+
+template <class P> __device__ __forceinline__ Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r = a;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %12, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, %5, %13, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, %6, %14, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %15, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  fe_cond_sub<P>(r.v);        // a, b < m < 2^255: no carry out of limb 7
+  return r;
+}
+
+// a - b, plus m when the subtraction borrows (mask from the final borrow, then a second carry chain)
+template <class P> __device__ __forceinline__ Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r = a;
+  uint32_t mask;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "v_cndmask_b32_e64 %8, 0, -1, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+        "=&v"(mask)
+      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  const uint32_t m0 = mask & 1u, m1 = mask & P::MOD[1], m2 = mask & P::MOD[2], m3 = mask & P::MOD[3],
+                 m7 = mask & 0x40000000u;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %12, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+      : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m7)
+      : "vcc");
+  return r;
+}
+#else
 template <class P> VDF_HD void fe_cond_sub(uint32_t t[8]) {
   uint32_t d[8];
   uint32_t borrow = 0;
-#pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t s = (uint64_t)t[i] - P::MOD[i] - borrow;
     d[i] = (uint32_t)s;
     borrow = (uint32_t)(s >> 63);
   }
-#pragma unroll
   for (int i = 0; i < 8; ++i) t[i] = borrow ? t[i] : d[i];
 }
 
 template <class P> VDF_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
   uint32_t c = 0;
-#pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t s = (uint64_t)a.v[i] + b.v[i] + c;
     r.v[i] = (uint32_t)s;
     c = (uint32_t)(s >> 32);
   }
-  // a, b < m < 2^255 so no carry out of limb 7.
-  fe_cond_sub<P>(r.v);
+  fe_cond_sub<P>(r.v);        // a, b < m < 2^255 so no carry out of limb 7
   return r;
 }
 
 template <class P> VDF_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
   Fe<P> r;
   uint32_t borrow = 0;
-#pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t s = (uint64_t)a.v[i] - b.v[i] - borrow;
     r.v[i] = (uint32_t)s;
     borrow = (uint32_t)(s >> 63);
   }
   uint32_t c = 0;
-#pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint64_t s = (uint64_t)r.v[i] + (borrow ? P::MOD[i] : 0u) + c;
     r.v[i] = (uint32_t)s;
@@ -107,6 +181,7 @@ template <class P> VDF_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
   }
   return r;
 }
+#endif
 
 template <class P> VDF_HD Fe<P> fe_neg(const Fe<P>& a) {
   return fe_is_zero(a) ? a : fe_sub(fe_zero<P>(), a);
@@ -130,10 +205,9 @@ template <class P> VDF_HD void mont_round(uint32_t t[9]) {
   s = (uint64_t)t[8] + (q >> 2) + c;      t[7] = (uint32_t)s; t[8] = (uint32_t)(s >> 32);
 }
 
-// Montgomery product a*b/R mod m, inputs and output in [0, m).  Always-inline body; only the hot
-// mixed-add of the MSM uses it directly (a fully inlined multiply is ~350 instructions and
-// hipcc's compile time is super-linear in the size of such straight-line blocks).
-template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) {
+// Montgomery product a*b/R mod m, inputs and output in [0, m): portable form (host, and the
+// reference the device form is tested against).
+template <class P> VDF_HD Fe<P> fe_mul_generic(const Fe<P>& a, const Fe<P>& b) {
   uint32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) t[i] = 0;
@@ -155,6 +229,123 @@ template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) {
   for (int i = 0; i < 8; ++i) r.v[i] = t[i];
   return r;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 form: product scanning with a 96-bit column accumulator ---------------------------
+// acc = (lo, mid) in an aligned VGPR pair + hi.  One product costs v_mad_u64_u32 (64-bit
+// accumulate, carry to VCC) + v_addc_co_u32 (carry into hi): 2 instructions, no v_mov glue.
+// hipcc's own lowering of the portable form is 563 instructions for 88 multiplies; this is ~260.
+__device__ __forceinline__ void madc(uint64_t& acc, uint32_t& hi, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+}
+// same with a scalar (SGPR / inline constant) multiplier: modulus limbs are wave-uniform constants
+__device__ __forceinline__ void madc_s(uint64_t& acc, uint32_t& hi, uint32_t a, uint32_t k) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(hi) : "v"(a), "s"(k) : "vcc");
+}
+// Montgomery step of a low column: adding q*m0 (m0 = 1, q = -lo) makes the low word 0 and carries
+// (lo != 0); this also performs the one-limb shift: (lo, mid, hi) -> (mid + c, hi + c', 0).
+__device__ __forceinline__ void col_shift_q(uint64_t& acc, uint32_t& hi) {
+  uint32_t lo = (uint32_t)acc, mid = (uint32_t)(acc >> 32), nlo, nmid;
+  asm("v_cmp_ne_u32_e32 vcc, 0, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
+      : "=&v"(nlo), "=&v"(nmid) : "v"(lo), "v"(mid), "v"(hi) : "vcc");
+  acc = ((uint64_t)nmid << 32) | nlo;
+  hi = 0;
+}
+__device__ __forceinline__ void col_shift(uint64_t& acc, uint32_t& hi) {
+  acc = (acc >> 32) | ((uint64_t)hi << 32);
+  hi = 0;
+}
+
+// One column of the product scan as a single asm statement (fewer asm boundaries = fewer of the
+// s_nop hazard pads hipcc puts between consecutive asm blocks).  NP products a[i]*b[K-i] and the
+// reduction terms q[K-1]*m1, q[K-2]*m2, q[K-3]*m3, q[K-7]*m7 are accumulated into (acc, hi).
+#define VDF_MADC "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+__device__ __forceinline__ void madc2(uint64_t& acc, uint32_t& hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+}
+__device__ __forceinline__ void madc4(uint64_t& acc, uint32_t& hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1,
+                                      uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
+}
+// reduction terms of one column: up to four q*m products with scalar (wave-uniform) modulus limbs
+template <int N>
+__device__ __forceinline__ void madc_red(uint64_t& acc, uint32_t& hi, uint32_t q1, uint32_t q2, uint32_t q3, uint32_t q7,
+                                         uint32_t m1, uint32_t m2, uint32_t m3, uint32_t m7) {
+  if constexpr (N == 4)
+    asm("v_mad_u64_u32 %0, vcc, %2, %6, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %7, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %8, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %9, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(hi) : "v"(q1), "v"(q2), "v"(q3), "v"(q7), "s"(m1), "s"(m2), "s"(m3), "s"(m7) : "vcc");
+  else if constexpr (N == 3)
+    asm("v_mad_u64_u32 %0, vcc, %2, %5, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %6, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %7, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(hi) : "v"(q1), "v"(q2), "v"(q3), "s"(m1), "s"(m2), "s"(m3) : "vcc");
+}
+
+template <class P> __device__ __forceinline__ Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) {
+  constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
+  uint32_t q[8], r[8];
+  uint64_t acc = 0;
+  uint32_t hi = 0;
+  const uint32_t* A = a.v;
+  const uint32_t* B = b.v;
+  // ---- low columns: products, reduction terms, q digit, shift ----
+  madc(acc, hi, A[0], B[0]);
+  q[0] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc2(acc, hi, A[0], B[1], A[1], B[0]); madc_s(acc, hi, q[0], M1);
+  q[1] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc2(acc, hi, A[0], B[2], A[1], B[1]); madc(acc, hi, A[2], B[0]); madc_s(acc, hi, q[1], M1); madc_s(acc, hi, q[0], M2);
+  q[2] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc4(acc, hi, A[0], B[3], A[1], B[2], A[2], B[1], A[3], B[0]); madc_red<3>(acc, hi, q[2], q[1], q[0], 0, M1, M2, M3, 0);
+  q[3] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc4(acc, hi, A[0], B[4], A[1], B[3], A[2], B[2], A[3], B[1]); madc(acc, hi, A[4], B[0]); madc_red<3>(acc, hi, q[3], q[2], q[1], 0, M1, M2, M3, 0);
+  q[4] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc4(acc, hi, A[0], B[5], A[1], B[4], A[2], B[3], A[3], B[2]); madc2(acc, hi, A[4], B[1], A[5], B[0]); madc_red<3>(acc, hi, q[4], q[3], q[2], 0, M1, M2, M3, 0);
+  q[5] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc4(acc, hi, A[0], B[6], A[1], B[5], A[2], B[4], A[3], B[3]); madc2(acc, hi, A[4], B[2], A[5], B[1]); madc(acc, hi, A[6], B[0]);
+  madc_red<3>(acc, hi, q[5], q[4], q[3], 0, M1, M2, M3, 0);
+  q[6] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  madc4(acc, hi, A[0], B[7], A[1], B[6], A[2], B[5], A[3], B[4]); madc4(acc, hi, A[4], B[3], A[5], B[2], A[6], B[1], A[7], B[0]);
+  madc_red<4>(acc, hi, q[6], q[5], q[4], q[0], M1, M2, M3, M7);
+  q[7] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
+  // ---- high columns ----
+  madc4(acc, hi, A[1], B[7], A[2], B[6], A[3], B[5], A[4], B[4]); madc2(acc, hi, A[5], B[3], A[6], B[2]); madc(acc, hi, A[7], B[1]);
+  madc_red<4>(acc, hi, q[7], q[6], q[5], q[1], M1, M2, M3, M7);
+  r[0] = (uint32_t)acc; col_shift(acc, hi);
+  madc4(acc, hi, A[2], B[7], A[3], B[6], A[4], B[5], A[5], B[4]); madc2(acc, hi, A[6], B[3], A[7], B[2]);
+  madc_s(acc, hi, q[7], M2); madc_s(acc, hi, q[6], M3); madc_s(acc, hi, q[2], M7);
+  r[1] = (uint32_t)acc; col_shift(acc, hi);
+  madc4(acc, hi, A[3], B[7], A[4], B[6], A[5], B[5], A[6], B[4]); madc(acc, hi, A[7], B[3]);
+  madc_s(acc, hi, q[7], M3); madc_s(acc, hi, q[3], M7);
+  r[2] = (uint32_t)acc; col_shift(acc, hi);
+  madc4(acc, hi, A[4], B[7], A[5], B[6], A[6], B[5], A[7], B[4]); madc_s(acc, hi, q[4], M7);
+  r[3] = (uint32_t)acc; col_shift(acc, hi);
+  madc2(acc, hi, A[5], B[7], A[6], B[6]); madc(acc, hi, A[7], B[5]); madc_s(acc, hi, q[5], M7);
+  r[4] = (uint32_t)acc; col_shift(acc, hi);
+  madc2(acc, hi, A[6], B[7], A[7], B[6]); madc_s(acc, hi, q[6], M7);
+  r[5] = (uint32_t)acc; col_shift(acc, hi);
+  madc(acc, hi, A[7], B[7]); madc_s(acc, hi, q[7], M7);
+  r[6] = (uint32_t)acc; col_shift(acc, hi);
+  r[7] = (uint32_t)acc;
+  fe_cond_sub<P>(r);                      // result < 2m < 2^256: the carry word is zero
+  Fe<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = r[i];
+  return o;
+}
+#else
+template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
+#endif
 
 // Out-of-line multiply (by-value arguments travel in VGPRs): one copy per field per TU.
 #if defined(__HIP_DEVICE_COMPILE__)

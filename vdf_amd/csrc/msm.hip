@@ -49,7 +49,7 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.counts = take((size_t)p.windows * p.K * p.nbk * 4);
   w.bcount = take(nkeys * 4);
   w.bstart = take((nkeys + 1) * 4);
-  w.sorted = take((size_t)p.windows * p.n * 4 + 64);
+  w.sorted = take(((size_t)p.windows * p.n + 64 * (size_t)p.L + 64) * 4);
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
   w.heavy = take((nkeys + 4) * 4);
@@ -159,6 +159,8 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t* __restrict__ dig,
 }
 
 // one thread per bucket key (set s, bucket b): exclusive scan over its feeding chunks
+// (counts[chunk][bucket]: coalesced across the threads of a wave; eight chunks are loaded before
+// their dependent stores so the loop is not one L2 round trip per chunk)
 __global__ __launch_bounds__(256) void k_scan_chunks(uint32_t* __restrict__ counts, uint32_t nbk, uint32_t K, int sets,
                                                      int tables, uint32_t* __restrict__ bcount) {
   const uint32_t key = blockIdx.x * 256 + threadIdx.x;
@@ -167,10 +169,18 @@ __global__ __launch_bounds__(256) void k_scan_chunks(uint32_t* __restrict__ coun
   uint32_t run = 0;
   for (int j = 0; j < tables; ++j) {
     const uint32_t w = (uint32_t)j * sets + s;
-    for (uint32_t k = 0; k < K; ++k) {
-      size_t idx = ((size_t)w * K + k) * nbk + b;
-      uint32_t v = counts[idx];
-      counts[idx] = run;
+    uint32_t* base = counts + (size_t)w * K * nbk + b;
+    uint32_t k = 0;
+    for (; k + 8 <= K; k += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(k + u) * nbk];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { base[(size_t)(k + u) * nbk] = run; run += v[u]; }
+    }
+    for (; k < K; ++k) {
+      uint32_t v = base[(size_t)k * nbk];
+      base[(size_t)k * nbk] = run;
       run += v;
     }
   }
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
 }
 
 __global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ dig, uint32_t n, uint32_t nbk,
-                                                  uint32_t chunk, uint32_t K, int sets, uint32_t tstride,
+                                                  uint32_t chunk, uint32_t K, int sets, uint32_t tstride, uint32_t L,
                                                   const uint32_t* __restrict__ counts,
                                                   const uint32_t* __restrict__ bstart, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t lds[];
@@ -219,7 +229,10 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ d
     uint32_t mag = v & ~SIGN_BIT;
     if (mag) {
       uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
-      sorted[pos] = (src_base + i) | (v & SIGN_BIT);
+      // lane-interleaved layout: the slice of accumulate-thread t = pos / L lives at stride 64 inside
+      // its wave's 64*L block, so a wave reads entry k of all its lanes as one 256-byte line
+      const uint32_t wv = pos / (64u * L), within = pos % (64u * L);
+      sorted[(size_t)wv * 64u * L + (within % L) * 64u + within / L] = (src_base + i) | (v & SIGN_BIT);
     }
   }
 }
@@ -249,12 +262,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   uint32_t next = bstart[g + 1];
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
-  uint32_t e = sorted[lo];
+  const uint32_t* mine = sorted + (size_t)(t >> 6) * 64u * L + (t & 63u);   // entry k of this slice: mine[k * 64]
+  uint32_t e = mine[0];
   Affine<P> pt = affine_load<P>(points + (size_t)(e & ~SIGN_BIT) * 64);
   for (uint32_t pos = lo; pos < hi; ++pos) {
     // prefetch the next entry's point while this one is added
     const uint32_t pn = (pos + 1 < hi) ? pos + 1 : pos;
-    const uint32_t en = sorted[pn];
+    const uint32_t en = mine[(size_t)(pn - lo) * 64u];
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
       if (is_head) xyzz_store<P>(heads + (size_t)t * 128, acc);
@@ -491,7 +505,6 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   VDF_TRY_HIP(hipMemsetAsync(bucket_acc, 0, (size_t)nkeys * 128, st));
   VDF_TRY_HIP(hipMemsetAsync(heavy, 0, 4, st));
-  VDF_TRY_HIP(hipMemsetAsync(sorted, 0, 64, st));     // sorted[0] is read even when the list is empty
   hipLaunchKernelGGL((k_digits<SP>), dim3((p.n + 255) / 256), dim3(256), 0, st,
                      reinterpret_cast<const uint32_t*>(d_scalars), p.n, is_mont ? 1 : 0, p.c, p.windows, dig);
   hipLaunchKernelGGL(k_hist, dim3(p.windows * p.K), dim3(1024), lds_sort, st, dig, p.n, p.nbk, p.chunk, p.K, counts);
@@ -499,7 +512,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
                      bcount);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, bcount, nkeys, bstart);
   hipLaunchKernelGGL(k_scatter, dim3(p.windows * p.K), dim3(1024), lds_sort, st, dig, p.n, p.nbk, p.chunk, p.K, p.sets,
-                     p.tstride, counts, bstart, sorted);
+                     p.tstride, p.L, counts, bstart, sorted);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
