@@ -1,0 +1,189 @@
+"""GPU tests of the Nova proof layer (vdf_amd/nova.py over libvdf_nova.so + libvdf_hip.so):
+the reference's test_nova_proof (src/nova/proof.rs:403-451) at its own size, BASELINE config 1
+(t = 1024, 3 steps), and a full replay of the folds by the oracle (witness, error vector,
+instance, commitments through the discrete-log identity, SHAKE256 transcript)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import pasta as o
+from util import ints, unmont
+from vdf_amd.minroot import PallasVDF, State, FIELD_FQ
+from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+
+pytestmark = pytest.mark.gpu
+GENS_SEED = 0x4E6F7661
+
+
+def le32(v):
+    return int(v).to_bytes(32, "little")
+
+
+def aff_ints(arr):
+    x, y = unmont(np.asarray(arr).reshape(2, 4), o.P)
+    return (x, y)
+
+
+def shape_digest(sh, t):
+    h = hashlib.shake_256()
+    h.update(b"vdf-nova-shape-v1")
+    for v in (t, sh.num_cons, sh.num_vars, sh.num_io, GENS_SEED):
+        h.update(int(v).to_bytes(8, "little"))
+    for mat in (sh.A, sh.B, sh.C):
+        for r, c, v in mat:
+            h.update(int(r).to_bytes(4, "little") + int(c).to_bytes(4, "little") + le32(v))
+    return h.digest(32)
+
+
+def challenge(digest, cW, cE, u, X, cw2, X2, cT):
+    h = hashlib.shake_256()
+    h.update(b"vdf-nova-fold-v1" + digest)
+    for p in (cW, cE):
+        h.update(le32(p[0]) + le32(p[1]))
+    h.update(le32(u))
+    for v in X:
+        h.update(le32(v))
+    h.update(le32(cw2[0]) + le32(cw2[1]))
+    for v in X2:
+        h.update(le32(v))
+    h.update(le32(cT[0]) + le32(cT[1]))
+    return int.from_bytes(h.digest(16), "little")
+
+
+def make(ctx, t, n, seed=42, i0=1):
+    x = o.rand_fe(seed, 0, o.Q)
+    initial = State.from_ints(FIELD_FQ, x, 0, i0)             # y = 0, i = 1: src/nova/proof.rs:417-421
+    pp = public_params(ctx, t)
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    return pp, z0, circuits, initial, (x, 0, i0)
+
+
+def test_nova_proof(ctx):
+    """test_nova_proof_aux(5, 3), src/nova/proof.rs:403-451 (without the compress leg)."""
+    t, n = 5, 3
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n)
+    zi = [initial.x, initial.y, initial.i]
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.verify(pp, n, z0, zi) is True
+    # Ok(false) legs: wrong expected z_i, wrong step count
+    wrong = [initial.y, initial.x, initial.i]
+    assert proof.verify(pp, n, z0, wrong) is False
+    assert proof.verify(pp, n + 1, z0, zi) is False
+    assert proof.verify(pp, n, zi, zi) is False
+    with pytest.raises(NotImplementedError):
+        proof.compress(pp)
+
+
+def test_eval_and_make_circuits_order(ctx):
+    """Circuits come back reversed and z0 is the FINAL state (src/nova/proof.rs:278-294)."""
+    t, n = 4, 3
+    x = o.rand_fe(9, 0, o.Q)
+    initial = State.from_ints(FIELD_FQ, x, 0, 0)
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    states = [o.State(x, 0, 0)]
+    for _ in range(n):
+        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    assert State(*z0).to_ints(FIELD_FQ) == (states[-1].x, states[-1].y, states[-1].i)
+    assert len(circuits) == n
+    for k in range(n):
+        res, inp = circuits.states(k)
+        assert res.to_ints(FIELD_FQ) == (states[n - k].x, states[n - k].y, states[n - k].i)
+        assert inp.to_ints(FIELD_FQ) == (states[n - k - 1].x, states[n - k - 1].y, states[n - k - 1].i)
+    with pytest.raises(AssertionError):
+        InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, 0, initial)
+
+
+@pytest.mark.parametrize("t,n", [(5, 3), (64, 4)])
+def test_prove_steps_replayed_by_the_oracle(ctx, t, n):
+    """Every quantity of every fold, bit-exact against the Python oracle."""
+    m = o.Q
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
+    sh = o.step_circuit_shape(t, o.FIELD_FQ)
+    sizes = pp.sizes()
+    assert (sizes["num_cons"], sizes["num_vars"], sizes["num_io"]) == (sh.num_cons, sh.num_vars, 6)
+    assert sizes["nnz"] == len(sh.A) + len(sh.B) + len(sh.C)
+    digest = shape_digest(sh, t)
+    # forward states by the oracle
+    states = [o.State(*init_ints)]
+    for _ in range(n):
+        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    proof = None
+    W = E = u = X = cW = cE = None
+    for k in range(n):
+        proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+        res, inp = states[n - k], states[n - k - 1]
+        W2 = [res.x, res.y, res.i] + o.step_witness_segment(res, t, o.FIELD_FQ)
+        X2 = [res.x, res.y, res.i, inp.x, inp.y, inp.i]
+        cw2 = o.msm_by_dlog(W2, o.CURVE_PALLAS, GENS_SEED) or (0, 0)
+        rec = proof.step_record(k)
+        assert aff_ints(rec["comm_w"]) == cw2
+        assert unmont(rec["X"], m) == X2
+        if k == 0:
+            W, E, u, X, cW, cE = W2, [0] * sh.num_cons, 1, X2, cw2, (0, 0)
+        else:
+            a1, b1, c1 = o.multiply_vec(sh, W + [u] + X, m)
+            a2, b2, c2 = o.multiply_vec(sh, W2 + [1] + X2, m)
+            T = o.cross_term(a1, b1, c1, a2, b2, c2, u, m)
+            cT = o.msm_by_dlog(T, o.CURVE_PALLAS, GENS_SEED) or (0, 0)
+            assert aff_ints(rec["comm_T"]) == cT
+            r = challenge(digest, cW, cE, u, X, cw2, X2, cT)
+            assert unmont(rec["r"].reshape(1, 4), m) == [r]
+            W, E = o.axpy(W, r, W2, m), o.axpy(E, r, T, m)
+            u, X = (u + r) % m, o.axpy(X, r, X2, m)
+            cW = o.pt_add(None if cW == (0, 0) else cW, o.pt_mul(r, None if cw2 == (0, 0) else cw2, o.P), o.P) or (0, 0)
+            cE = o.pt_add(None if cE == (0, 0) else cE, o.pt_mul(r, None if cT == (0, 0) else cT, o.P), o.P) or (0, 0)
+        inst = proof.instance()
+        gW, gE = proof.witness()
+        assert unmont(gW, m) == W
+        assert unmont(gE, m) == E
+        assert unmont(inst["u"].reshape(1, 4), m) == [u]
+        assert unmont(inst["X"], m) == X
+        assert aff_ints(inst["comm_W"]) == cW and aff_ints(inst["comm_E"]) == cE
+        assert o.is_sat_relaxed(sh, W, E, u, X, m)
+    zi = [State.from_ints(FIELD_FQ, *init_ints).x, State.from_ints(FIELD_FQ, *init_ints).y, State.from_ints(FIELD_FQ, *init_ints).i]
+    assert proof.verify(pp, n, z0, zi)
+
+
+def test_tampered_witness_is_rejected(ctx):
+    """Corrupting one word of the running witness on the device must fail verification."""
+    import ctypes as C
+    from vdf_amd._lib import lib
+    from vdf_amd.nova import nova_lib
+    t, n = 8, 2
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=5)
+    zi = [initial.x, initial.y, initial.i]
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.verify(pp, n, z0, zi)
+    dW, dE = C.c_void_p(), C.c_void_p()
+    nova_lib.vdf_nova_proof_witness_ptrs(proof.handle, C.byref(dW), C.byref(dE))
+    word = np.zeros(4, dtype="<u8")
+    ctx._check(lib.vdf_dev_memcpy(ctx.handle, word.ctypes.data, dW.value + 7 * 32, 32))
+    bad = word.copy(); bad[0] ^= 1
+    ctx._check(lib.vdf_dev_memcpy(ctx.handle, dW.value + 7 * 32, bad.ctypes.data, 32))
+    assert proof.verify(pp, n, z0, zi) is False
+    ctx._check(lib.vdf_dev_memcpy(ctx.handle, dW.value + 7 * 32, word.ctypes.data, 32))
+    assert proof.verify(pp, n, z0, zi) is True
+
+
+def test_mismatched_z0_is_an_error(ctx):
+    import vdf_amd
+    t, n = 4, 2
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=6)
+    with pytest.raises(vdf_amd.VdfError):
+        NovaVDFProof.prove_recursively(pp, circuits, t, [initial.x, initial.y, initial.i])   # not the final state
+    with pytest.raises(vdf_amd.VdfError):
+        NovaVDFProof.prove_recursively(pp, circuits, t + 1, z0)
+
+
+def test_config1_t1024_three_steps(ctx):
+    """BASELINE config 1: 1024 iterations per step, 3 recursive steps; both i = 0 (benches/nova.rs:24-26)
+    and i = 1 (src/nova/proof.rs:419)."""
+    for i0 in (0, 1):
+        t, n = 1024, 3
+        pp, z0, circuits, initial, _ = make(ctx, t, n, seed=11, i0=i0)
+        proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+        assert proof.num_steps() == n
+        assert proof.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+        ms = proof.last_step_ms()
+        assert ms["total"] > 0

@@ -30,16 +30,27 @@ struct Staging {
   struct Out { void* host; void* dev; size_t bytes; };
   std::vector<Out> outs;
   bool any_host = false;
+  size_t small_used = 0;     // bytes taken from the context's small staging pool (calls hold ctx->mu)
   explicit Staging(vdf_ctx* c) : ctx(c) {}
   ~Staging() { for (void* t : temps) (void)hipFree(t); }
+  Status temp(size_t bytes, void** t) {
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (need <= 1024 && ctx->small_pool && small_used + need <= vdf_ctx::SMALL_POOL_BYTES) {
+      *t = reinterpret_cast<char*>(ctx->small_pool) + small_used;
+      small_used += need;
+      return Status{};
+    }
+    VDF_TRY_HIP(hipMalloc(t, bytes));
+    temps.push_back(*t);
+    return Status{};
+  }
   Status in(const void* p, size_t bytes, const void** dev) {
     if (bytes == 0) { *dev = p; return Status{}; }
     if (!p) return Status{VDF_ERR_BAD_ARG, "null input pointer"};
     if (ptr_is_device(p)) { *dev = p; return Status{}; }
     any_host = true;
     void* t = nullptr;
-    VDF_TRY_HIP(hipMalloc(&t, bytes));
-    temps.push_back(t);
+    VDF_TRY(temp(bytes, &t));
     VDF_TRY_HIP(hipMemcpyAsync(t, p, bytes, hipMemcpyHostToDevice, ctx->stream));
     *dev = t;
     return Status{};
@@ -50,8 +61,7 @@ struct Staging {
     if (ptr_is_device(p)) { *dev = p; return Status{}; }
     any_host = true;
     void* t = nullptr;
-    VDF_TRY_HIP(hipMalloc(&t, bytes));
-    temps.push_back(t);
+    VDF_TRY(temp(bytes, &t));
     outs.push_back({p, t, bytes});
     *dev = t;
     return Status{};
@@ -200,6 +210,7 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   e = hipSetDevice(c->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&c->d_out, 256);
+  if (e == hipSuccess) e = hipMalloc(&c->small_pool, vdf_ctx::SMALL_POOL_BYTES);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
   if (e != hipSuccess) {
@@ -219,6 +230,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->small_pool) (void)hipFree(ctx->small_pool);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -1,0 +1,146 @@
+// Host-side arithmetic of the Nova layer: what the reference also keeps on the CPU -- the sequential
+// MinRoot evaluation (src/minroot.rs:329-359), O(1) instance folds and transcript hashing.  4 x 64-bit
+// Montgomery limbs (R = 2^256), the in-memory form of pasta_curves' Fp/Fq (Cargo.toml:17), so values
+// cross the C ABI unchanged.  No kernel work lives here.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include "../../../include/vdf_hip.h"
+
+namespace vdfhost {
+
+typedef unsigned __int128 u128;
+
+struct Field {
+  uint64_t m[4], inv, one[4], r2[4];
+};
+
+inline uint64_t neg_inv64(uint64_t m0) {          // -m^-1 mod 2^64 by Newton iteration
+  uint64_t x = 1;
+  for (int i = 0; i < 6; ++i) x *= 2 - m0 * x;
+  return 0 - x;
+}
+
+inline bool geq(const uint64_t* a, const uint64_t* b) {
+  for (int i = 3; i >= 0; --i) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+inline void sub4(uint64_t* a, const uint64_t* b) {
+  u128 br = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)a[i] - b[i] - (uint64_t)br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+
+struct Fe {
+  uint64_t l[4];
+  bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+  bool operator==(const Fe& o) const { return memcmp(l, o.l, 32) == 0; }
+  bool operator!=(const Fe& o) const { return !(*this == o); }
+};
+static_assert(sizeof(Fe) == sizeof(vdf_fe), "layout");
+
+inline Fe add(const Fe& a, const Fe& b, const Field& F) {
+  Fe r;
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (geq(r.l, F.m)) sub4(r.l, F.m);
+  return r;
+}
+inline Fe sub(const Fe& a, const Fe& b, const Field& F) {
+  Fe r = a;
+  u128 br = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)r.l[i] - b.l[i] - (uint64_t)br;
+    r.l[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)r.l[i] + F.m[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  }
+  return r;
+}
+inline Fe neg(const Fe& a, const Field& F) {
+  Fe z = {{0, 0, 0, 0}};
+  return a.is_zero() ? a : sub(z, a, F);
+}
+// coarsely integrated operand scanning Montgomery product
+inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t q = t[0] * F.inv;
+    c = ((u128)q * F.m[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; ++j) { c += (u128)q * F.m[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  Fe r;
+  memcpy(r.l, t, 32);
+  if (t[4] || geq(r.l, F.m)) sub4(r.l, F.m);
+  return r;
+}
+inline Fe sqr(const Fe& a, const Field& F) { return mul(a, a, F); }
+inline Fe one(const Field& F) { Fe r; memcpy(r.l, F.one, 32); return r; }
+inline Fe zero() { Fe r = {{0, 0, 0, 0}}; return r; }
+inline Fe to_mont(const Fe& a, const Field& F) { Fe r2; memcpy(r2.l, F.r2, 32); return mul(a, r2, F); }
+inline Fe from_mont(const Fe& a, const Field& F) { Fe o = {{1, 0, 0, 0}}; return mul(a, o, F); }
+inline Fe from_u64(uint64_t v, const Field& F) { Fe t = {{v, 0, 0, 0}}; return to_mont(t, F); }
+// left-to-right square and multiply: the shape of ff::Field::pow_vartime (src/minroot.rs:312-314)
+inline Fe pow_vartime(const Fe& a, const uint64_t e[4], const Field& F) {
+  Fe acc = one(F);
+  for (int i = 3; i >= 0; --i)
+    for (int b = 63; b >= 0; --b) {
+      acc = sqr(acc, F);
+      if ((e[i] >> b) & 1) acc = mul(acc, a, F);
+    }
+  return acc;
+}
+inline Fe inverse(const Fe& a, const Field& F) {
+  uint64_t e[4] = {F.m[0] - 2, F.m[1], F.m[2], F.m[3]};
+  return pow_vartime(a, e, F);
+}
+
+const Field& field_fp();
+const Field& field_fq();
+inline const Field& field(int f) { return f == VDF_FIELD_FP ? field_fp() : field_fq(); }
+
+// ---- curve y^2 = x^3 + 5 on the host (instance folds: two 128-bit scalar multiplications per step) --
+struct Aff { Fe x, y; bool is_id() const { return x.is_zero() && y.is_zero(); } };
+struct Pt { Fe x, y, zz, zzz; bool is_id() const { return zz.is_zero(); } };   // XYZZ
+
+inline Pt pt_identity() { Pt p; p.x = p.y = p.zz = p.zzz = zero(); return p; }
+inline Pt pt_from_aff(const Aff& a, const Field& F) {
+  if (a.is_id()) return pt_identity();
+  Pt p; p.x = a.x; p.y = a.y; p.zz = one(F); p.zzz = one(F);
+  return p;
+}
+Pt pt_dbl(const Pt& a, const Field& F);
+Pt pt_add(const Pt& a, const Pt& b, const Field& F);
+Pt pt_mul(const Pt& a, const uint64_t k[4], int bits, const Field& F);
+Aff pt_to_aff(const Pt& a, const Field& F);
+Aff jac_to_aff(const vdf_jac& j, const Field& F);
+
+// ---- SHAKE256 (FIPS 202) for the transcript -----------------------------------------------------
+struct Shake256 {
+  uint64_t st[25];
+  uint8_t buf[136];
+  size_t pos;
+  bool squeezing;
+  Shake256();
+  void absorb(const void* data, size_t n);
+  void squeeze(void* out, size_t n);
+};
+
+}  // namespace vdfhost

@@ -1,0 +1,626 @@
+// libvdf_nova.so: the reference crate's MinRoot + Nova proof surface (include/vdf_nova.h) on top of
+// the kernel ABI (include/vdf_hip.h).  See the header for the stage this implements.
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../../include/vdf_nova.h"
+#include "host_math.hpp"
+
+using namespace vdfhost;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCALL(ctx, expr)                                                          \
+  do {                                                                              \
+    int rc__ = (expr);                                                              \
+    if (rc__ != VDF_OK) return fail(rc__, std::string(#expr) + ": " + vdf_last_error(ctx)); \
+  } while (0)
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MinRoot (src/minroot.rs)
+// ---------------------------------------------------------------------------------------------
+const uint64_t FP_RESCUE_INVALPHA[4] = {0xe0f0f3f0cccccccdull, 0x4e9ee0c9a10a60e2ull, 0x3333333333333333ull,
+                                        0x3333333333333333ull};   // src/minroot.rs:273-278
+const uint64_t FQ_RESCUE_INVALPHA[4] = {0xd69f2280cccccccdull, 0x4e9ee0c9a143ba4aull, 0x3333333333333333ull,
+                                        0x3333333333333333ull};   // src/minroot.rs:280-285
+
+struct Chain {   // the closures of src/minroot.rs:89-92 / :224-227
+  const Field& F;
+  Fe sq(Fe x, int n) const { for (int i = 0; i < n; ++i) x = sqr(x, F); return x; }
+  Fe sqr_mul(const Fe& x, int n, const Fe& y) const { return mul(y, sq(x, n), F); }
+};
+
+// PallasVDF::forward_step_ltr_addition_chain, src/minroot.rs:88-127
+Fe fwd_ltr_addchain_fq(const Fe& x) {
+  const Field& F = field_fq();
+  Chain c{F};
+  Fe q1 = x, q10 = c.sq(q1, 1), q11 = mul(q10, q1, F), q101 = mul(q10, q11, F), q110 = c.sq(q11, 1);
+  Fe q111 = mul(q110, q1, F), q1001 = mul(q111, q10, F), q1111 = mul(q1001, q110, F);
+  Fe qr2 = c.sqr_mul(q110, 3, q11), qr4 = c.sqr_mul(qr2, 8, qr2), qr8 = c.sqr_mul(qr4, 16, qr4);
+  Fe qr16 = c.sqr_mul(qr8, 32, qr8), qr32 = c.sqr_mul(qr16, 64, qr16);
+  Fe v = c.sqr_mul(qr32, 5, q1001);
+  struct { int n; const Fe* y; } steps[] = {{8, &q111}, {4, &q1}, {2, &qr4}, {7, &q11}, {6, &q1001}, {3, &q101},
+      {7, &q101}, {7, &q111}, {4, &q111}, {5, &q1001}, {5, &q101}, {3, &q11}, {4, &q101}, {3, &q101}, {6, &q1111},
+      {4, &q1001}, {6, &q101}, {37, &qr8}, {2, &q1}};
+  for (auto& s : steps) v = c.sqr_mul(v, s.n, *s.y);
+  return v;
+}
+// PallasVDF::forward_step_rtl_sequential, src/minroot.rs:130-151
+Fe fwd_rtl_fq(const Fe& x) {
+  const Field& F = field_fq();
+  Fe acc = one(F), s = x;
+  for (int count = 0; count < 254; ++count) {
+    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = mul(acc, s, F);
+    s = sqr(s, F);
+  }
+  return acc;
+}
+// PallasVDF::forward_step_sequential_rtl_addition_chain, src/minroot.rs:154-196
+Fe fwd_rtl_addchain_fq(const Fe& x) {
+  const Field& F = field_fq();
+  Fe acc = one(F), s = x, last = x;
+  for (int count = 0; count < 128; ++count) {
+    last = s;
+    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = mul(acc, s, F);
+    s = sqr(s, F);
+  }
+  Fe sa = last;
+  sa = mul(sa, sqr(sa, F), F);                                   // :179
+  sa = mul(sa, sqr(sqr(sqr(sqr(sa, F), F), F), F), F);           // :180
+  for (int count = 1; count <= 122; ++count) {                   // :182-195
+    sa = sqr(sa, F);
+    if (count % 8 == 1) acc = mul(acc, sa, F);
+  }
+  return acc;
+}
+// VestaVDF::forward_step, src/minroot.rs:223-261
+Fe fwd_addchain_fp(const Fe& x) {
+  const Field& F = field_fp();
+  Chain c{F};
+  Fe p1 = x, p10 = c.sq(p1, 1), p11 = mul(p10, p1, F), p101 = mul(p10, p11, F), p110 = c.sq(p11, 1);
+  Fe p111 = mul(p110, p1, F), p1001 = mul(p111, p10, F), p1111 = mul(p1001, p110, F);
+  Fe pr2 = c.sqr_mul(p110, 3, p11), pr4 = c.sqr_mul(pr2, 8, pr2), pr8 = c.sqr_mul(pr4, 16, pr4);
+  Fe pr16 = c.sqr_mul(pr8, 32, pr8), pr32 = c.sqr_mul(pr16, 64, pr16);
+  Fe v = c.sqr_mul(pr32, 5, p1001);
+  struct { int n; const Fe* y; } steps[] = {{8, &p111}, {4, &p1}, {2, &pr4}, {7, &p11}, {6, &p1001}, {3, &p101},
+      {5, &p1}, {7, &p101}, {4, &p11}, {8, &p111}, {4, &p1}, {4, &p111}, {9, &p1111}, {8, &p1111}, {6, &p1111},
+      {2, &p11}, {34, &pr8}, {2, &p1}};
+  for (auto& s : steps) v = c.sqr_mul(v, s.n, *s.y);
+  return v;
+}
+
+// dispatch of src/minroot.rs:77-84; VestaVDF ignores the mode (:203-205)
+Fe forward_step(int field_id, int mode, const Fe& x) {
+  if (field_id == VDF_FIELD_FP) return fwd_addchain_fp(x);
+  switch (mode) {
+    case VDF_MODE_LTR_SEQUENTIAL: return pow_vartime(x, FQ_RESCUE_INVALPHA, field_fq());     // :312-314
+    case VDF_MODE_LTR_ADDCHAIN_SEQUENTIAL: return fwd_ltr_addchain_fq(x);
+    case VDF_MODE_RTL_SEQUENTIAL: return fwd_rtl_fq(x);
+    default: return fwd_rtl_addchain_fq(x);
+  }
+}
+Fe inverse_step(const Fe& x, const Field& F) { return mul(x, sqr(sqr(x, F), F), F); }            // :73-75
+
+struct St { Fe x, y, i; };
+St load_state(const vdf_state* s) { St r; memcpy(&r, s, sizeof(St)); return r; }
+void store_state(vdf_state* o, const St& s) { memcpy(o, &s, sizeof(St)); }
+
+St round_fwd(int f, int mode, const St& s) {                                                     // :329-335
+  const Field& F = field(f);
+  St r;
+  r.x = forward_step(f, mode, add(s.x, s.y, F));
+  r.y = add(s.x, s.i, F);
+  r.i = add(s.i, one(F), F);
+  return r;
+}
+St round_inv(int f, const St& s) {                                                               // :338-344
+  const Field& F = field(f);
+  St r;
+  r.i = sub(s.i, one(F), F);
+  r.x = sub(s.y, r.i, F);
+  r.y = sub(inverse_step(s.x, F), r.x, F);
+  return r;
+}
+bool valid_field(int f) { return f == VDF_FIELD_FP || f == VDF_FIELD_FQ; }
+bool valid_mode(int m) { return m >= 0 && m <= 3; }
+
+// ---------------------------------------------------------------------------------------------
+// Nova (folding-only stage)
+// ---------------------------------------------------------------------------------------------
+constexpr int NUM_IO = 6;                  // X = [z_in(3), z_out(3)]
+constexpr uint64_t GENS_SEED = 0x4e6f7661; // "Nova": label of the synthetic generator family
+constexpr int PRIMARY_FIELD = VDF_FIELD_FQ;   // S1 = pallas::Scalar, src/nova/proof.rs:29
+constexpr int PRIMARY_CURVE = VDF_CURVE_PALLAS;   // G1, src/nova/proof.rs:26
+
+struct StepRecord { Aff comm_w, comm_T; Fe r; Fe X[NUM_IO]; };
+
+}  // namespace
+
+struct vdf_pp {
+  vdf_ctx* ctx = nullptr;
+  uint64_t t = 0;
+  size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
+  vdf_shape* shape = nullptr;
+  vdf_bases* gens = nullptr;
+  uint8_t digest[32];
+  void* d_zero = nullptr;   // num_cons zero elements (satisfiability residual)
+};
+
+struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-66, + the forward trace
+  uint64_t inverse_exponent = 5;
+  St result, input;
+  uint64_t t = 0;
+  std::vector<Fe> trace_xy;  // (x, y) of states 0..t: trace[0] = input, trace[t] = result
+};
+struct vdf_circuits { std::vector<Circuit> v; };
+
+struct vdf_proof {
+  vdf_pp* pp = nullptr;
+  size_t i = 0;              // steps folded so far
+  Fe zi[3];                  // current z_i (starts at z0)
+  Aff comm_W, comm_E;        // running relaxed instance
+  Fe u, X[NUM_IO];
+  void* d_z1 = nullptr;      // [W | u | X] of the running instance (W aliases the front)
+  void* d_z2 = nullptr;      // [W | 1 | X] of the fresh instance
+  void* d_E = nullptr;       // running error vector
+  void* d_T = nullptr;
+  void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
+  void* d_trace = nullptr;
+  void* d_small = nullptr;   // staging for r, u1, i0 (3 elements)
+  std::vector<StepRecord> steps;
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+void absorb_fe(Shake256& h, const Fe& a, const Field& F) { Fe c = from_mont(a, F); h.absorb(c.l, 32); }
+void absorb_aff(Shake256& h, const Aff& p) {
+  const Field& F = field_fp();    // Pallas coordinates live in Fp
+  absorb_fe(h, p.x, F);
+  absorb_fe(h, p.y, F);
+}
+// r = SHAKE256(digest | U1 | u2 | comm_T) squeezed to 128 bits
+Fe challenge(const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Aff& cw2, const Fe* X2,
+             const Aff& cT, uint64_t r_raw[4]) {
+  const Field& F = field(PRIMARY_FIELD);
+  Shake256 h;
+  h.absorb("vdf-nova-fold-v1", 16);
+  h.absorb(pp->digest, 32);
+  absorb_aff(h, cW); absorb_aff(h, cE); absorb_fe(h, u, F);
+  for (int k = 0; k < NUM_IO; ++k) absorb_fe(h, X[k], F);
+  absorb_aff(h, cw2);
+  for (int k = 0; k < NUM_IO; ++k) absorb_fe(h, X2[k], F);
+  absorb_aff(h, cT);
+  r_raw[0] = r_raw[1] = r_raw[2] = r_raw[3] = 0;
+  h.squeeze(r_raw, 16);
+  Fe r;
+  memcpy(r.l, r_raw, 32);
+  return to_mont(r, F);
+}
+
+// Builds the COO triples of the wrapped step circuit; same layout as oracle/pasta.py step_circuit_shape
+// (constraint order of src/nova/proof.rs:176-178, :219-227, :128-133, then the six IO-binding rows).
+struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
+void build_shape(uint64_t t, Coo m[3], size_t* num_cons, size_t* num_vars) {
+  const Field& F = field(PRIMARY_FIELD);
+  const Fe ONE = one(F), MINUS_ONE = neg(ONE, F);
+  const uint32_t nv = (uint32_t)(3 + 4 * t + 1), one_col = nv, io = nv + 1;
+  auto push = [](Coo& c, uint32_t r, uint32_t col, const Fe& v) { c.rows.push_back(r); c.cols.push_back(col); c.vals.push_back(v); };
+  uint32_t xv = 0, yv = 1, iv = 2, row = 0;
+  for (uint64_t j = 0; j < t; ++j) {
+    const uint32_t base = (uint32_t)(3 + 4 * j), new_x = base, tmp1 = base + 1, tmp2 = base + 2, new_y = base + 3;
+    push(m[0], row, xv, ONE); push(m[1], row, xv, ONE); push(m[2], row, tmp1, ONE); ++row;          // x*x = tmp1
+    push(m[0], row, tmp1, ONE); push(m[1], row, tmp1, ONE); push(m[2], row, tmp2, ONE); ++row;      // tmp1*tmp1 = tmp2
+    push(m[0], row, tmp2, ONE); push(m[1], row, xv, ONE);                                           // tmp2*x = new_y + y - i + 1
+    push(m[2], row, new_y, ONE); push(m[2], row, yv, ONE); push(m[2], row, iv, MINUS_ONE);
+    push(m[2], row, one_col, from_u64(j + 1, F)); ++row;                                            // i = z_in.i - j
+    xv = new_x; yv = new_y;
+  }
+  const uint32_t final_i = (uint32_t)(3 + 4 * t);
+  push(m[0], row, final_i, ONE); push(m[1], row, one_col, ONE);                                     // final_i*1 = i - t
+  push(m[2], row, iv, ONE); push(m[2], row, one_col, neg(from_u64(t, F), F)); ++row;
+  const uint32_t outs[6] = {0, 1, 2, xv, yv, final_i};
+  for (int k = 0; k < 6; ++k) {
+    push(m[0], row, outs[k], ONE); push(m[1], row, one_col, ONE); push(m[2], row, io + k, ONE); ++row;
+  }
+  *num_cons = row;
+  *num_vars = nv;
+}
+
+int alloc_proof_buffers(vdf_proof* p) {
+  vdf_pp* pp = p->pp;
+  vdf_ctx* ctx = pp->ctx;
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z1));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_E));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
+  for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, 3 * 32, &p->d_small));
+  HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
+  return VDF_OK;
+}
+
+Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b) {      // a + r*b on Pallas
+  const Field& F = field_fp();
+  Pt rb = pt_mul(pt_from_aff(b, F), r_raw, 128, F);
+  return pt_to_aff(pt_add(pt_from_aff(a, F), rb, F), F);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vdf_nova_last_error(void) { return g_err.c_str(); }
+
+// ---- MinRoot -------------------------------------------------------------------------------------
+int vdf_minroot_forward_step(int f, int mode, const vdf_fe* x, vdf_fe* out) {
+  if (!valid_field(f) || !valid_mode(mode) || !x || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  Fe a; memcpy(&a, x, 32);
+  Fe r = forward_step(f, mode, a);
+  memcpy(out, &r, 32);
+  return VDF_OK;
+}
+int vdf_minroot_inverse_step(int f, const vdf_fe* x, vdf_fe* out) {
+  if (!valid_field(f) || !x || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  Fe a; memcpy(&a, x, 32);
+  Fe r = inverse_step(a, field(f));
+  memcpy(out, &r, 32);
+  return VDF_OK;
+}
+int vdf_minroot_round(int f, int mode, const vdf_state* s, vdf_state* out) {
+  if (!valid_field(f) || !valid_mode(mode) || !s || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  store_state(out, round_fwd(f, mode, load_state(s)));
+  return VDF_OK;
+}
+int vdf_minroot_inverse_round(int f, const vdf_state* s, vdf_state* out) {
+  if (!valid_field(f) || !s || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  store_state(out, round_inv(f, load_state(s)));
+  return VDF_OK;
+}
+int vdf_minroot_eval(int f, int mode, const vdf_state* s, uint64_t t, vdf_state* out, vdf_fe* trace_xy) {
+  if (!valid_field(f) || !valid_mode(mode) || !s || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  St acc = load_state(s);
+  if (trace_xy) { memcpy(&trace_xy[0], &acc.x, 32); memcpy(&trace_xy[1], &acc.y, 32); }
+  for (uint64_t k = 0; k < t; ++k) {                               // simple_eval, :352-359
+    acc = round_fwd(f, mode, acc);
+    if (trace_xy) { memcpy(&trace_xy[2 * (k + 1)], &acc.x, 32); memcpy(&trace_xy[2 * (k + 1) + 1], &acc.y, 32); }
+  }
+  store_state(out, acc);
+  return VDF_OK;
+}
+int vdf_minroot_inverse_eval(int f, const vdf_state* s, uint64_t t, vdf_state* out) {
+  if (!valid_field(f) || !s || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  St acc = load_state(s);
+  for (uint64_t k = 0; k < t; ++k) acc = round_inv(f, acc);        // :363-365
+  store_state(out, acc);
+  return VDF_OK;
+}
+int vdf_minroot_check(int f, const vdf_state* result, uint64_t t, const vdf_state* original) {
+  vdf_state back;
+  if (vdf_minroot_inverse_eval(f, result, t, &back) != VDF_OK || !original) return 0;
+  return memcmp(&back, original, sizeof(back)) == 0;               // :369-371
+}
+int vdf_minroot_element(int f, uint64_t n, vdf_fe* out) {
+  if (!valid_field(f) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  Fe r = from_u64(n, field(f));
+  memcpy(out, &r, 32);
+  return VDF_OK;
+}
+
+// ---- public parameters -------------------------------------------------------------------------------
+int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
+  if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  *out = nullptr;
+  vdf_pp* pp = new vdf_pp();
+  pp->ctx = ctx;
+  pp->t = t;
+  Coo m[3];
+  build_shape(t, m, &pp->num_cons, &pp->num_vars);
+  pp->ncols = pp->num_vars + 1 + NUM_IO;
+  pp->nnz3 = m[0].rows.size() + m[1].rows.size() + m[2].rows.size();
+  const uint32_t* rows[3] = {m[0].rows.data(), m[1].rows.data(), m[2].rows.data()};
+  const uint32_t* cols[3] = {m[0].cols.data(), m[1].cols.data(), m[2].cols.data()};
+  const vdf_fe* vals[3] = {(const vdf_fe*)m[0].vals.data(), (const vdf_fe*)m[1].vals.data(), (const vdf_fe*)m[2].vals.data()};
+  const size_t nnz[3] = {m[0].rows.size(), m[1].rows.size(), m[2].rows.size()};
+  int rc = vdf_shape_create(ctx, PRIMARY_FIELD, pp->num_cons, pp->ncols, rows, cols, vals, nnz, &pp->shape);
+  if (rc != VDF_OK) { std::string e = vdf_last_error(ctx); delete pp; return fail(rc, "vdf_shape_create: " + e); }
+  size_t need = pp->num_vars > pp->num_cons ? pp->num_vars : pp->num_cons;
+  size_t g = 1;
+  while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
+  pp->num_gens = g;
+  rc = vdf_bases_generate(ctx, PRIMARY_CURVE, GENS_SEED, g, &pp->gens);
+  if (rc == VDF_OK) rc = vdf_bases_precompute(ctx, pp->gens, 16, 1);
+  if (rc == VDF_OK) rc = vdf_dev_alloc(ctx, pp->num_cons * 32, &pp->d_zero);
+  if (rc == VDF_OK) rc = vdf_dev_memset(ctx, pp->d_zero, 0, pp->num_cons * 32);
+  if (rc != VDF_OK) { std::string e = vdf_last_error(ctx); vdf_nova_pp_free(pp); return fail(rc, "generator setup: " + e); }
+  // shape digest: sizes, every COO triple in canonical form, generator family
+  Shake256 h;
+  h.absorb("vdf-nova-shape-v1", 17);
+  uint64_t hdr[5] = {t, (uint64_t)pp->num_cons, (uint64_t)pp->num_vars, (uint64_t)NUM_IO, GENS_SEED};
+  h.absorb(hdr, sizeof(hdr));
+  const Field& F = field(PRIMARY_FIELD);
+  for (int k = 0; k < 3; ++k)
+    for (size_t e = 0; e < m[k].rows.size(); ++e) {
+      uint32_t rc2[2] = {m[k].rows[e], m[k].cols[e]};
+      h.absorb(rc2, 8);
+      absorb_fe(h, m[k].vals[e], F);
+    }
+  h.squeeze(pp->digest, 32);
+  *out = pp;
+  return VDF_OK;
+}
+void vdf_nova_pp_free(vdf_pp* pp) {
+  if (!pp) return;
+  if (pp->d_zero) vdf_dev_free(pp->ctx, pp->d_zero);
+  if (pp->shape) vdf_shape_free(pp->shape);
+  if (pp->gens) vdf_bases_free(pp->gens);
+  delete pp;
+}
+int vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
+                      uint64_t* num_gens) {
+  if (!pp) return fail(VDF_ERR_BAD_ARG, "null pp");
+  if (num_cons) *num_cons = pp->num_cons;
+  if (num_vars) *num_vars = pp->num_vars;
+  if (num_io) *num_io = NUM_IO;
+  if (nnz3) *nnz3 = pp->nnz3;
+  if (num_gens) *num_gens = pp->num_gens;
+  return VDF_OK;
+}
+
+// ---- circuits ----------------------------------------------------------------------------------------
+int vdf_nova_eval_and_make_circuits(int mode, uint64_t t, size_t num_steps, const vdf_state* initial_state,
+                                    vdf_fe z0_primary[3], vdf_circuits** out) {
+  if (!valid_mode(mode) || !initial_state || !z0_primary || !out || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  if (num_steps == 0) return fail(VDF_ERR_BAD_ARG, "num_steps must be > 0 (assert!, src/nova/proof.rs:268)");
+  vdf_circuits* cs = new vdf_circuits();
+  St state = load_state(initial_state);
+  for (size_t s = 0; s < num_steps; ++s) {                          // :274-279
+    Circuit c;
+    c.t = t;
+    c.input = state;                                                 // previous_state, :285-291
+    c.trace_xy.resize(2 * (t + 1));
+    vdf_state res;
+    vdf_state in;
+    store_state(&in, state);
+    vdf_minroot_eval(PRIMARY_FIELD, mode, &in, t, &res, (vdf_fe*)c.trace_xy.data());
+    c.result = load_state(&res);
+    state = c.result;
+    cs->v.push_back(std::move(c));
+  }
+  memcpy(z0_primary, &state, 96);                                    // z0 = final state, :278-281
+  std::vector<Circuit> rev(cs->v.rbegin(), cs->v.rend());            // circuits.reverse(), :294
+  cs->v.swap(rev);
+  *out = cs;
+  return VDF_OK;
+}
+size_t vdf_nova_circuits_len(const vdf_circuits* c) { return c ? c->v.size() : 0; }
+int vdf_nova_circuit_states(const vdf_circuits* c, size_t k, vdf_state* result, vdf_state* input) {
+  if (!c || k >= c->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
+  if (result) store_state(result, c->v[k].result);
+  if (input) store_state(input, c->v[k].input);
+  return VDF_OK;
+}
+void vdf_nova_circuits_free(vdf_circuits* c) { delete c; }
+
+// ---- prove_step ----------------------------------------------------------------------------------------
+int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]) {
+  if (!pp || !proof || !circuits || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
+  const Circuit& c = circuits->v[k];
+  if (c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
+  vdf_ctx* ctx = pp->ctx;
+  const Field& F = field(PRIMARY_FIELD);
+  vdf_proof* p = *proof;
+  const bool first = (p == nullptr);
+  if (first) {
+    p = new vdf_proof();
+    p->pp = pp;
+    memcpy(p->zi, z0, 96);
+    int rc = alloc_proof_buffers(p);
+    if (rc != VDF_OK) { vdf_nova_proof_free(p); return rc; }
+  }
+  // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
+  if (memcmp(p->zi, &c.result, 96) != 0) {
+    if (first) vdf_nova_proof_free(p);
+    return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
+  }
+  const double t0 = now_ms();
+  const size_t nv = pp->num_vars, nc = pp->num_cons;
+  char* z2 = (char*)p->d_z2;
+  // --- fresh witness: W2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i] -------------------
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_trace, c.trace_xy.data(), (pp->t + 1) * 64));
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, z2, &c.result, 96));
+  HIPCALL(ctx, vdf_minroot_witness(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_trace, (const vdf_fe*)&c.input.i, pp->t,
+                                   (vdf_fe*)(z2 + 96)));
+  Fe X2[NUM_IO] = {c.result.x, c.result.y, c.result.i, c.input.x, c.input.y, c.input.i};
+  Fe tail[1 + NUM_IO];
+  tail[0] = one(F);
+  for (int j = 0; j < NUM_IO; ++j) tail[1 + j] = X2[j];
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, z2 + nv * 32, tail, sizeof(tail)));
+  HIPCALL(ctx, vdf_ctx_sync(ctx));
+  const double t1 = now_ms();
+  // --- commit W2 ---------------------------------------------------------------------------------------
+  vdf_jac jw;
+  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)z2, nv, 1, &jw));
+  const Aff comm_w = jac_to_aff(jw, field_fp());
+  const double t2 = now_ms();
+  StepRecord rec;
+  rec.comm_w = comm_w;
+  for (int j = 0; j < NUM_IO; ++j) rec.X[j] = X2[j];
+  double t3 = t2, t4 = t2, t5 = t2, t6 = t2;
+  if (first) {
+    // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_z1, p->d_z2, pp->ncols * 32));
+    p->comm_W = comm_w;
+    p->comm_E.x = p->comm_E.y = zero();
+    p->u = one(F);
+    for (int j = 0; j < NUM_IO; ++j) p->X[j] = X2[j];
+    rec.comm_T.x = rec.comm_T.y = zero();
+    rec.r = zero();
+    t6 = now_ms();
+  } else {
+    // --- NIFS.prove: multiply_vec x 2, cross term, commit T, challenge, fold ------
+    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
+    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z2, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4], (vdf_fe*)p->d_abc[5]));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    t3 = now_ms();
+    HIPCALL(ctx, vdf_cross_term(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1], (const vdf_fe*)p->d_abc[2],
+                                (const vdf_fe*)p->d_abc[3], (const vdf_fe*)p->d_abc[4], (const vdf_fe*)p->d_abc[5],
+                                (const vdf_fe*)&p->u, nc, (vdf_fe*)p->d_T));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    t4 = now_ms();
+    vdf_jac jt;
+    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, &jt));
+    const Aff comm_T = jac_to_aff(jt, field_fp());
+    t5 = now_ms();
+    uint64_t r_raw[4];
+    const Fe r = challenge(pp, p->comm_W, p->comm_E, p->u, p->X, comm_w, X2, comm_T, r_raw);
+    // witness fold on the device: W <- W + r*W2, E <- E + r*T
+    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_z1, (const vdf_fe*)&r, (const vdf_fe*)p->d_z2, nv, (vdf_fe*)p->d_z1));
+    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_E, (const vdf_fe*)&r, (const vdf_fe*)p->d_T, nc, (vdf_fe*)p->d_E));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    t6 = now_ms();
+    // instance fold on the host (O(1)): commitments, u, X
+    p->comm_W = fold_commitment(p->comm_W, r_raw, comm_w);
+    p->comm_E = fold_commitment(p->comm_E, r_raw, comm_T);
+    p->u = add(p->u, r, F);
+    for (int j = 0; j < NUM_IO; ++j) p->X[j] = add(p->X[j], mul(r, X2[j], F), F);
+    Fe utail[1 + NUM_IO];
+    utail[0] = p->u;
+    for (int j = 0; j < NUM_IO; ++j) utail[1 + j] = p->X[j];
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z1 + nv * 32, utail, sizeof(utail)));
+    rec.comm_T = comm_T;
+    rec.r = r;
+  }
+  p->steps.push_back(rec);
+  p->i += 1;
+  p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
+  const double t7 = now_ms();
+  p->ms[0] = t1 - t0; p->ms[1] = t2 - t1; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3; p->ms[4] = t5 - t4;
+  p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
+  *proof = p;
+  return VDF_OK;
+}
+
+int vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_t num_iters_per_step, const vdf_fe z0[3],
+                               vdf_proof** out) {
+  if (!pp || !circuits || !out || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (num_iters_per_step != pp->t) return fail(VDF_ERR_BAD_LENGTH, "num_iters_per_step differs from the public parameters");
+  if (circuits->v.empty()) return fail(VDF_ERR_BAD_LENGTH, "no circuits (recursive_snark.unwrap(), src/nova/proof.rs:357)");
+  vdf_proof* p = nullptr;
+  for (size_t k = 0; k < circuits->v.size(); ++k) {                   // :318-355
+    int rc = vdf_nova_prove_step(pp, &p, circuits, k, z0);
+    if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
+  }
+  *out = p;
+  return VDF_OK;
+}
+
+void vdf_nova_proof_free(vdf_proof* p) {
+  if (!p) return;
+  vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
+  if (ctx) {
+    void* bufs[] = {p->d_z1, p->d_z2, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4],
+                    p->d_abc[5], p->d_trace, p->d_small};
+    for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
+  }
+  delete p;
+}
+size_t vdf_nova_proof_num_steps(const vdf_proof* p) { return p ? p->i : 0; }
+
+int vdf_nova_proof_instance(const vdf_proof* p, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[6]) {
+  if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+  if (comm_W) memcpy(comm_W, &p->comm_W, 64);
+  if (comm_E) memcpy(comm_E, &p->comm_E, 64);
+  if (u) memcpy(u, &p->u, 32);
+  if (X) memcpy(X, p->X, 32 * NUM_IO);
+  return VDF_OK;
+}
+int vdf_nova_proof_witness_ptrs(const vdf_proof* p, const void** d_W, const void** d_E) {
+  if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+  if (d_W) *d_W = p->d_z1;
+  if (d_E) *d_E = p->d_E;
+  return VDF_OK;
+}
+int vdf_nova_proof_step_record(const vdf_proof* p, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]) {
+  if (!p || k >= p->steps.size()) return fail(VDF_ERR_BAD_LENGTH, "step index out of range");
+  const StepRecord& s = p->steps[k];
+  if (comm_w) memcpy(comm_w, &s.comm_w, 64);
+  if (comm_T) memcpy(comm_T, &s.comm_T, 64);
+  if (r) memcpy(r, &s.r, 32);
+  if (X) memcpy(X, s.X, 32 * NUM_IO);
+  return VDF_OK;
+}
+int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
+  if (!p || !ms) return fail(VDF_ERR_BAD_ARG, "null argument");
+  memcpy(ms, p->ms, sizeof(p->ms));
+  return VDF_OK;
+}
+
+// ---- verify --------------------------------------------------------------------------------------------
+int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
+  if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
+  *ok = 0;
+  if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+  vdf_ctx* ctx = pp->ctx;
+  const Field& F = field(PRIMARY_FIELD);
+  if (num_steps == 0 || p->steps.size() != num_steps || p->i != num_steps) return VDF_OK;   // NovaError::ProofVerifyError
+  // (1) public-IO chain: X_0.z_in = z0, X_k.z_out = X_{k+1}.z_in; the last z_out is the verified z_i
+  if (memcmp(p->steps[0].X, z0, 96) != 0) return VDF_OK;
+  for (size_t k = 0; k + 1 < num_steps; ++k)
+    if (memcmp(&p->steps[k].X[3], &p->steps[k + 1].X[0], 96) != 0) return VDF_OK;
+  // every step must move the counter by exactly t in the inverse direction
+  const Fe tfe = from_u64(pp->t, F);
+  for (size_t k = 0; k < num_steps; ++k)
+    if (sub(p->steps[k].X[2], p->steps[k].X[5], F) != tfe) return VDF_OK;
+  // (2) replay the folds of the instances
+  Aff cW = p->steps[0].comm_w, cE;
+  cE.x = cE.y = zero();
+  Fe u = one(F), X[NUM_IO];
+  for (int j = 0; j < NUM_IO; ++j) X[j] = p->steps[0].X[j];
+  for (size_t k = 1; k < num_steps; ++k) {
+    const StepRecord& s = p->steps[k];
+    uint64_t r_raw[4];
+    const Fe r = challenge(pp, cW, cE, u, X, s.comm_w, s.X, s.comm_T, r_raw);
+    if (r != s.r) return VDF_OK;
+    cW = fold_commitment(cW, r_raw, s.comm_w);
+    cE = fold_commitment(cE, r_raw, s.comm_T);
+    u = add(u, r, F);
+    for (int j = 0; j < NUM_IO; ++j) X[j] = add(X[j], mul(r, s.X[j], F), F);
+  }
+  if (memcmp(&cW, &p->comm_W, 64) || memcmp(&cE, &p->comm_E, 64) || u != p->u || memcmp(X, p->X, sizeof(X))) return VDF_OK;
+  // (3) the running witness opens the folded instance: commitments and relaxed satisfiability
+  const size_t nv = pp->num_vars, nc = pp->num_cons;
+  vdf_jac j1, j2;
+  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_z1, nv, 1, &j1));
+  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_E, nc, 1, &j2));
+  Aff a1 = jac_to_aff(j1, field_fp()), a2 = jac_to_aff(j2, field_fp());
+  if (memcmp(&a1, &p->comm_W, 64) || memcmp(&a2, &p->comm_E, 64)) return VDF_OK;
+  // z = (W, u, X) must carry the instance's u and X
+  std::vector<Fe> tail(1 + NUM_IO);
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, tail.data(), (const char*)p->d_z1 + nv * 32, tail.size() * 32));
+  if (tail[0] != p->u || memcmp(&tail[1], p->X, 32 * NUM_IO)) return VDF_OK;
+  HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
+  // residual Az*Bz - u*Cz - E through the cross-term kernel with Az2 = Bz1 = 0
+  HIPCALL(ctx, vdf_cross_term(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)pp->d_zero, (const vdf_fe*)p->d_E,
+                              (const vdf_fe*)pp->d_zero, (const vdf_fe*)p->d_abc[1], (const vdf_fe*)p->d_abc[2],
+                              (const vdf_fe*)&p->u, nc, (vdf_fe*)p->d_T));
+  std::vector<uint64_t> res(nc * 4);
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, res.data(), p->d_T, nc * 32));
+  uint64_t any = 0;
+  for (uint64_t w : res) any |= w;
+  if (any) return VDF_OK;
+  // Ok(zi_primary == zi_primary_verified), src/nova/proof.rs:386
+  *ok = memcmp(&p->steps[num_steps - 1].X[3], zi, 96) == 0 ? 1 : 0;
+  return VDF_OK;
+}
+
+}  // extern "C"

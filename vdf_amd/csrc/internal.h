@@ -19,6 +19,8 @@ struct vdf_ctx {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   void* d_out = nullptr;       // 128 B result slot
+  static constexpr size_t SMALL_POOL_BYTES = 16 * 1024;
+  void* small_pool = nullptr;  // staging for tiny host operands (challenge scalars, result points)
   int num_cus = 256;
   // stage timing (bench.py roofline leg)
   bool timing = false;

@@ -1,0 +1,185 @@
+"""Python mirror of the reference's Nova proof API (/root/reference/src/nova/proof.rs:232-392) over
+libvdf_nova.so: `public_params`, `InverseMinRootCircuit.{circuits, eval_and_make_circuits}`,
+`NovaVDFProof.{prove_recursively, verify, compress}`.  Every heavy step runs as HIP kernels through
+the C ABI of libvdf_hip.so; see include/vdf_nova.h for the stage implemented (folding-only)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from .hip import Context, VdfError
+from .minroot import State, _State, _Fe, nova_lib, EvalMode, MinRootVDF, PallasVDF  # noqa: F401
+
+_vp, _i, _u64, _sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+for _name, _res, _args in [
+    ("vdf_nova_public_params", _i, [_vp, _u64, C.POINTER(_vp)]),
+    ("vdf_nova_pp_free", None, [_vp]),
+    ("vdf_nova_pp_sizes", _i, [_vp] + [C.POINTER(_u64)] * 5),
+    ("vdf_nova_eval_and_make_circuits", _i, [_i, _u64, _sz, C.POINTER(_State), C.POINTER(_Fe * 3), C.POINTER(_vp)]),
+    ("vdf_nova_circuits_len", _sz, [_vp]),
+    ("vdf_nova_circuit_states", _i, [_vp, _sz, C.POINTER(_State), C.POINTER(_State)]),
+    ("vdf_nova_circuits_free", None, [_vp]),
+    ("vdf_nova_prove_recursively", _i, [_vp, _vp, _u64, C.POINTER(_Fe * 3), C.POINTER(_vp)]),
+    ("vdf_nova_prove_step", _i, [_vp, C.POINTER(_vp), _vp, _sz, C.POINTER(_Fe * 3)]),
+    ("vdf_nova_verify", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
+    ("vdf_nova_proof_free", None, [_vp]),
+    ("vdf_nova_proof_num_steps", _sz, [_vp]),
+    ("vdf_nova_proof_instance", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("vdf_nova_proof_witness_ptrs", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("vdf_nova_proof_step_record", _i, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    ("vdf_nova_last_step_ms", _i, [_vp, C.POINTER(C.c_double * 8)]),
+]:
+    getattr(nova_lib, _name).argtypes = _args
+    getattr(nova_lib, _name).restype = _res
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise VdfError(rc, (nova_lib.vdf_nova_last_error() or b"").decode())
+
+
+def _z(vals: Sequence[bytes]):
+    return (_Fe * 3)(*[_Fe.from_buffer_copy(v) for v in vals])
+
+
+class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
+    def __init__(self, ctx: Context, handle: int, t: int):
+        self.ctx, self.handle, self.num_iters_per_step = ctx, handle, t
+        ctx._children.add(self)
+
+    def sizes(self) -> dict:
+        v = [C.c_uint64() for _ in range(5)]
+        _check(nova_lib.vdf_nova_pp_sizes(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("num_cons", "num_vars", "num_io", "nnz", "num_gens"), [x.value for x in v]))
+
+    def free(self) -> None:
+        if self.handle:
+            nova_lib.vdf_nova_pp_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def public_params(ctx: Context, num_iters_per_step: int) -> NovaVDFPublicParams:      # :232-237
+    h = C.c_void_p()
+    _check(nova_lib.vdf_nova_public_params(ctx.handle, num_iters_per_step, C.byref(h)))
+    return NovaVDFPublicParams(ctx, h.value, num_iters_per_step)
+
+
+class Circuits:
+    """Vec<InverseMinRootCircuit<G1>> in proving order (already reversed, :294)."""
+
+    def __init__(self, handle: int, t: int):
+        self.handle, self.t = handle, t
+
+    def __len__(self) -> int:
+        return nova_lib.vdf_nova_circuits_len(self.handle)
+
+    def states(self, k: int) -> Tuple[State, State]:
+        """(result, input) of circuit k: InverseMinRootCircuit.result / .input (:63-64)."""
+        r, i = _State(), _State()
+        _check(nova_lib.vdf_nova_circuit_states(self.handle, k, C.byref(r), C.byref(i)))
+        return State._from_c(r), State._from_c(i)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                nova_lib.vdf_nova_circuits_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class InverseMinRootCircuit:      # src/nova/proof.rs:57-66, :239-299
+    arity = 3                     # :83-85
+
+    @staticmethod
+    def eval_and_make_circuits(v: MinRootVDF, num_iters_per_step: int, num_steps: int,
+                               initial_state: State) -> Tuple[List[bytes], Circuits]:   # :262-299
+        if num_steps <= 0:
+            raise AssertionError("num_steps > 0")                                       # :268
+        z0 = (_Fe * 3)()
+        h = C.c_void_p()
+        _check(nova_lib.vdf_nova_eval_and_make_circuits(int(v.eval_mode), num_iters_per_step, num_steps,
+                                                        C.byref(initial_state._c()), C.byref(z0), C.byref(h)))
+        return [bytes(z0[k]) for k in range(3)], Circuits(h.value, num_iters_per_step)
+
+
+class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed }, :51-55
+    def __init__(self, handle: int, pp: NovaVDFPublicParams):
+        self.handle, self.pp = handle, pp
+        pp.ctx._children.add(self)
+
+    @staticmethod
+    def prove_recursively(pp: NovaVDFPublicParams, circuits: Circuits, num_iters_per_step: int,
+                          z0: Sequence[bytes]) -> "NovaVDFProof":                       # :302-358
+        h = C.c_void_p()
+        _check(nova_lib.vdf_nova_prove_recursively(pp.handle, circuits.handle, num_iters_per_step, C.byref(_z(z0)), C.byref(h)))
+        return NovaVDFProof(h.value, pp)
+
+    @staticmethod
+    def prove_step(pp: NovaVDFPublicParams, proof: "NovaVDFProof | None", circuits: Circuits, k: int,
+                   z0: Sequence[bytes]) -> "NovaVDFProof":                              # RecursiveSNARK::prove_step, :342-349
+        h = C.c_void_p(proof.handle if proof is not None else None)
+        _check(nova_lib.vdf_nova_prove_step(pp.handle, C.byref(h), circuits.handle, k, C.byref(_z(z0))))
+        if proof is None:
+            return NovaVDFProof(h.value, pp)
+        return proof
+
+    def verify(self, pp: NovaVDFPublicParams, num_steps: int, z0: Sequence[bytes], zi: Sequence[bytes]) -> bool:   # :370-387
+        ok = C.c_int(0)
+        _check(nova_lib.vdf_nova_verify(self.handle, pp.handle, num_steps, C.byref(_z(z0)), C.byref(_z(zi)), C.byref(ok)))
+        return bool(ok.value)
+
+    def compress(self, pp: NovaVDFPublicParams):                                        # :360-368
+        raise NotImplementedError("CompressedSNARK (Spartan + IPA) is the next row of SURVEY.md 8f; not built in this round")
+
+    # ---- introspection used by the parity tests and the bench ----
+    def num_steps(self) -> int:
+        return nova_lib.vdf_nova_proof_num_steps(self.handle)
+
+    def instance(self) -> dict:
+        cw, ce = np.zeros(8, dtype="<u8"), np.zeros(8, dtype="<u8")
+        u, X = np.zeros(4, dtype="<u8"), np.zeros((6, 4), dtype="<u8")
+        _check(nova_lib.vdf_nova_proof_instance(self.handle, cw.ctypes.data, ce.ctypes.data, u.ctypes.data, X.ctypes.data))
+        return {"comm_W": cw, "comm_E": ce, "u": u, "X": X}
+
+    def witness(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Downloads the running (W, E) for parity checks."""
+        from ._lib import lib
+        s = self.pp.sizes()
+        dW, dE = C.c_void_p(), C.c_void_p()
+        _check(nova_lib.vdf_nova_proof_witness_ptrs(self.handle, C.byref(dW), C.byref(dE)))
+        W = np.zeros((s["num_vars"], 4), dtype="<u8")
+        E = np.zeros((s["num_cons"], 4), dtype="<u8")
+        self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, W.ctypes.data, dW.value, W.nbytes))
+        self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, E.ctypes.data, dE.value, E.nbytes))
+        return W, E
+
+    def step_record(self, k: int) -> dict:
+        cw, ct = np.zeros(8, dtype="<u8"), np.zeros(8, dtype="<u8")
+        r, X = np.zeros(4, dtype="<u8"), np.zeros((6, 4), dtype="<u8")
+        _check(nova_lib.vdf_nova_proof_step_record(self.handle, k, cw.ctypes.data, ct.ctypes.data, r.ctypes.data, X.ctypes.data))
+        return {"comm_w": cw, "comm_T": ct, "r": r, "X": X}
+
+    def last_step_ms(self) -> dict:
+        ms = (C.c_double * 8)()
+        _check(nova_lib.vdf_nova_last_step_ms(self.handle, C.byref(ms)))
+        return dict(zip(("witness", "commit_W", "spmv", "cross_term", "commit_T", "fold", "host", "total"), list(ms)))
+
+    def free(self) -> None:
+        if self.handle:
+            nova_lib.vdf_nova_proof_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
