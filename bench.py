@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-prove", action="store_true", help="skip the prove_step leg (BASELINE config 3)")
+    ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
+    ap.add_argument("--prove-steps", type=int, default=6)
     return ap.parse_args()
 
 
@@ -67,6 +70,41 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
                   f"{dt:.2f} s wall on {cores} threads, windows spread over a pthread pool",
         "parity_bit_exact": bool(np.array_equal(aff_cpu, aff_gpu)),
     }
+
+
+def prove_step_leg(ctx, log2t, nsteps):
+    """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU (folding-only
+    stage, see include/vdf_nova.h).  Forward evaluation and public parameters are outside the timed region
+    (benches/nova.rs:28-59); step 0 (base case) is reported apart from the steady-state steps."""
+    from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode
+    from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+    t = 1 << log2t
+    pp = public_params(ctx, t)
+    initial = State.from_ints(FIELD_FQ, 0x1234567890ABCDEF1234567890ABCDEF, 0, 0)   # y = 0, i = 0: benches/nova.rs:24-26
+    t0 = time.perf_counter()
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(
+        PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, nsteps, initial)
+    eval_s = time.perf_counter() - t0
+    proof, per_step, stages = None, [], []
+    for k in range(nsteps):
+        a = time.perf_counter()
+        proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+        per_step.append(time.perf_counter() - a)
+        stages.append(proof.last_step_ms())
+    ok = proof.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
+    steady = per_step[1:] if nsteps > 1 else per_step
+    avg = sum(steady) / len(steady)
+    keys = list(stages[-1].keys())
+    stage_avg = {k: sum(s[k] for s in stages[1:]) / max(len(stages) - 1, 1) for k in keys} if nsteps > 1 else stages[0]
+    sizes = pp.sizes()
+    out = {"metric": "Nova prove_step/sec (MinRoot, 2^%d iters/step)" % log2t, "value": 1.0 / avg, "unit": "prove_step/s",
+           "ms_per_step": avg * 1e3, "base_case_ms": per_step[0] * 1e3, "steady_state_steps": len(steady),
+           "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes,
+           "forward_eval_s_per_step_host": eval_s / nsteps,
+           "stage": "folding-only (step circuit + NIFS on the primary curve; no augmented circuit / secondary curve)"}
+    proof.free()
+    pp.free()
+    return out
 
 
 def main():
@@ -150,7 +188,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step)",
+            "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step); prove_step/s in `prove_step`",
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
@@ -165,6 +203,9 @@ def main():
                          "avg_launch_ms": acc_avg_ms,
                          "note": "MSM is integer-ALU-bound (SURVEY.md 7.3 H5); see DESIGN.md for the v_mad_u64_u32 issue ceiling"},
         }
+        if world == 1 and not args.no_prove:
+            ctx.set_async(False)
+            line["prove_step"] = prove_step_leg(ctx, args.prove_log2t, args.prove_steps)
         if world == 1 and not args.no_cpu:
             ctx.set_async(False)
             line["cpu_baseline"] = cpu_baseline_leg(ctx, sh.bases, sc, n, curve, result.cpu().numpy().view("<u8"))

@@ -1,0 +1,20 @@
+"""prove_step timing at t = 2^k (BASELINE config 3): per-stage breakdown."""
+import sys, time
+sys.path.insert(0, ".")
+from oracle import pasta as o
+import vdf_amd
+from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode
+from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+t = 1 << lg
+ctx = vdf_amd.Context(0)
+t0 = time.time(); pp = public_params(ctx, t); print("public_params %.2f s" % (time.time() - t0), pp.sizes())
+initial = State.from_ints(FIELD_FQ, o.rand_fe(1, 0, o.Q), 0, 0)
+t0 = time.time(); z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, n, initial)
+print("forward evaluation of %d x 2^%d rounds: %.2f s (host, sequential)" % (n, lg, time.time() - t0))
+proof = None
+for k in range(n):
+    t0 = time.perf_counter(); proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0); dt = time.perf_counter() - t0
+    print("step %d: %.2f ms " % (k, dt * 1e3), {a: round(b, 3) for a, b in proof.last_step_ms().items()})
+t0 = time.time(); ok = proof.verify(pp, n, z0, [initial.x, initial.y, initial.i]); print("verify", ok, "%.1f ms" % ((time.time() - t0) * 1e3))
