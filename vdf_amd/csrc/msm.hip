@@ -31,7 +31,7 @@ namespace vdf {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
-static constexpr int RED_SEG = 8;           // buckets per thread in k_reduce1
+static constexpr int RED_SEG = 2;           // buckets per thread in k_reduce1 (serial depth 2*RED_SEG)
 
 struct WsLayout {
   size_t dig, counts, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void k_scan_chunks(uint32_t* __restrict__ coun
   bcount[key] = run;
 }
 
-// single workgroup exclusive scan: bstart[0..nkeys], bstart[nkeys] = total entries
+// single workgroup exclusive scan: bstart[0..nkeys], bstart[nkeys] = total entries.
+// Each thread owns a contiguous run of keys; loads are issued eight at a time so the run is a few
+// L2 round trips instead of one per key.
 __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__ bcount, uint32_t nkeys,
                                                     uint32_t* __restrict__ bstart) {
   __shared__ uint32_t part[1024];
@@ -195,7 +197,15 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
   const uint32_t lo = threadIdx.x * per;
   const uint32_t hi = (lo + per < nkeys) ? lo + per : nkeys;
   uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; ++i) sum += bcount[i];
+  uint32_t i = lo;
+  for (; i + 8 <= hi; i += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = bcount[i + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; i < hi; ++i) sum += bcount[i];
   part[threadIdx.x] = sum;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -205,7 +215,15 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
     __syncthreads();
   }
   uint32_t run = part[threadIdx.x] - sum;
-  for (uint32_t i = lo; i < hi; ++i) { bstart[i] = run; run += bcount[i]; }
+  i = lo;
+  for (; i + 8 <= hi; i += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = bcount[i + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { bstart[i + u] = run; run += v[u]; }
+  }
+  for (; i < hi; ++i) { bstart[i] = run; run += bcount[i]; }
   if (threadIdx.x == 1023) bstart[nkeys] = part[1023];
 }
 
@@ -295,29 +313,6 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   else xyzz_store<P>(bucket_acc + (size_t)g * 128, acc);
 }
 
-template <class P>
-__global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t L,
-                                               char* __restrict__ bucket_acc, const char* __restrict__ heads,
-                                               uint32_t* __restrict__ heavy) {
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nkeys) return;
-  const uint32_t s = bstart[g], e = bstart[g + 1];
-  if (e <= s) return;
-  const uint32_t tf = s / L, tl = (e - 1) / L;
-  if (tl == tf) return;
-  if (tl - tf > (uint32_t)HEAVY_SPAN) {
-    uint32_t slot = atomicAdd(&heavy[0], 1u);
-    heavy[1 + slot] = g;
-    return;
-  }
-  XYZZ<P> acc = xyzz_load<P>(bucket_acc + (size_t)g * 128);
-  for (uint32_t t = tf + 1; t <= tl; ++t) {
-    XYZZ<P> h = xyzz_load<P>(heads + (size_t)t * 128);
-    xyzz_add(acc, h);
-  }
-  xyzz_store<P>(bucket_acc + (size_t)g * 128, acc);
-}
-
 template <class P> __device__ __forceinline__ XYZZ<P> xyzz_shfl_xor(const XYZZ<P>& a, int mask) {
   XYZZ<P> r;
 #pragma unroll
@@ -328,6 +323,53 @@ template <class P> __device__ __forceinline__ XYZZ<P> xyzz_shfl_xor(const XYZZ<P
     r.zzz.v[i] = __shfl_xor(a.zzz.v[i], mask, 64);
   }
   return r;
+}
+
+// Four lanes per bucket: the heads of the slices a bucket spans are summed by its lane group
+// (strided partial sums, then a 2-step butterfly inside the group) instead of one serial chain.
+// With the fixed-base table a bucket holds ~512 entries = ~8 slices of L = 64.
+template <class P>
+__global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t L,
+                                               char* __restrict__ bucket_acc, const char* __restrict__ heads,
+                                               uint32_t* __restrict__ heavy) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t g = gid >> 2, sub = gid & 3u;
+  uint32_t tf = 0, tl = 0;
+  bool active = false;
+  if (g < nkeys) {
+    const uint32_t s = bstart[g], e = bstart[g + 1];
+    if (e > s) {
+      tf = s / L;
+      tl = (e - 1) / L;
+      if (tl > tf) {
+        if (tl - tf > (uint32_t)HEAVY_SPAN) {
+          if (sub == 0) {
+            uint32_t slot = atomicAdd(&heavy[0], 1u);
+            heavy[1 + slot] = g;
+          }
+        } else {
+          active = true;
+        }
+      }
+    }
+  }
+  if (!__any(active)) return;                         // whole wave has nothing to fix up
+  XYZZ<P> acc = xyzz_identity<P>();
+  if (active)
+    for (uint32_t t = tf + 1 + sub; t <= tl; t += 4) {
+      XYZZ<P> h = xyzz_load<P>(heads + (size_t)t * 128);
+      xyzz_add(acc, h);
+    }
+#pragma unroll 1
+  for (int m = 2; m >= 1; m >>= 1) {                  // butterfly inside the 4-lane group (all lanes take part)
+    XYZZ<P> o = xyzz_shfl_xor(acc, m);
+    xyzz_add(acc, o);
+  }
+  if (active && sub == 0) {
+    XYZZ<P> base = xyzz_load<P>(bucket_acc + (size_t)g * 128);
+    xyzz_add(base, acc);
+    xyzz_store<P>(bucket_acc + (size_t)g * 128, base);
+  }
 }
 
 // wavefront all-reduce of one XYZZ per lane (6 butterfly steps)
@@ -517,7 +559,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
+  hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
   hipLaunchKernelGGL((k_reduce1<P>), dim3(p.sets * w.red_blocks_per_set), dim3(w.red_block),
