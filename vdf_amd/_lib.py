@@ -25,6 +25,7 @@ PROTOTYPES = {
     "vdf_ctx_get_stream": (_vp, [_vp]),
     "vdf_ctx_set_async": (_i, [_vp, _i]),
     "vdf_ctx_sync": (_i, [_vp]),
+    "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),

@@ -113,7 +113,8 @@ size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF
 Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont,
                 vdf_jac* out) {
   if (!bases || !out) return Status{VDF_ERR_BAD_ARG, "null bases/out"};
-  if (bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bases belong to another context"};
+  // generators may be shared by several contexts of one device (e.g. a second stream for overlap)
+  if (bases->ctx != ctx && bases->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bases live on another device"};
   if (offset > bases->n || n > bases->n - offset) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
   if (n >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "n too large (max 2^27 - 1 points per call)"};
   Staging st(ctx);
@@ -186,6 +187,8 @@ void build_dict_consts(std::array<uint32_t, 8>& one, std::array<uint32_t, 8>& mi
 }  // namespace
 
 extern "C" {
+
+int vdf_ctx_device(vdf_ctx* ctx) { return ctx ? ctx->device : 0; }
 
 const char* vdf_version(void) { return "vdf_hip gfx950 r1 (" __DATE__ ")"; }
 

@@ -1,6 +1,7 @@
 // libvdf_nova.so: the reference crate's MinRoot + Nova proof surface (include/vdf_nova.h) on top of
 // the kernel ABI (include/vdf_hip.h).  See the header for the stage this implements.
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -145,6 +146,7 @@ struct StepRecord { Aff comm_w, comm_T; Fe r; Fe X[NUM_IO]; };
 
 struct vdf_pp {
   vdf_ctx* ctx = nullptr;
+  vdf_ctx* ctx2 = nullptr;  // second stream + MSM workspace on the same GPU: the W commitment overlaps the fold
   uint64_t t = 0;
   size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
   vdf_shape* shape = nullptr;
@@ -158,8 +160,9 @@ struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-6
   St result, input;
   uint64_t t = 0;
   std::vector<Fe> trace_xy;  // (x, y) of states 0..t: trace[0] = input, trace[t] = result
+  void* d_trace = nullptr;   // the same trace in HBM (vdf_nova_circuits_upload)
 };
-struct vdf_circuits { std::vector<Circuit> v; };
+struct vdf_circuits { std::vector<Circuit> v; vdf_ctx* ctx = nullptr; };
 
 struct vdf_proof {
   vdf_pp* pp = nullptr;
@@ -174,8 +177,13 @@ struct vdf_proof {
   void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
   void* d_trace = nullptr;
   void* d_small = nullptr;   // staging for r, u1, i0 (3 elements)
+  void* d_commw = nullptr;   // Jacobian result slot of the overlapped W commitment
   std::vector<StepRecord> steps;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // The O(1) instance fold (two 128-bit scalar multiplications on the host) of step k runs on a worker
+  // thread under the GPU work of step k+1; everything that reads comm_W / comm_E joins it first.
+  mutable std::future<void> pending;
+  void join() const { if (pending.valid()) pending.get(); }
 };
 
 namespace {
@@ -205,7 +213,7 @@ Fe challenge(const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const 
   return to_mont(r, F);
 }
 
-// Builds the COO triples of the wrapped step circuit; same layout as oracle/pasta.py step_circuit_shape
+// Builds the COO triples of the wrapped step circuit; same layout as the test oracle (step_circuit_shape)
 // (constraint order of src/nova/proof.rs:176-178, :219-227, :128-133, then the six IO-binding rows).
 struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
 void build_shape(uint64_t t, Coo m[3], size_t* num_cons, size_t* num_vars) {
@@ -244,6 +252,7 @@ int alloc_proof_buffers(vdf_proof* p) {
   for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
   HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
   HIPCALL(ctx, vdf_dev_alloc(ctx, 3 * 32, &p->d_small));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, 256, &p->d_commw));
   HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
   return VDF_OK;
 }
@@ -336,6 +345,13 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   size_t g = 1;
   while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
   pp->num_gens = g;
+  {
+    int dev = 0;
+    // the second context lives on the same device as `ctx` (one process per GPU)
+    dev = vdf_ctx_device(ctx);
+    if (vdf_ctx_create(&dev, 1, &pp->ctx2) != VDF_OK) pp->ctx2 = nullptr;
+    if (pp->ctx2) vdf_ctx_set_async(pp->ctx2, 1);
+  }
   rc = vdf_bases_generate(ctx, PRIMARY_CURVE, GENS_SEED, g, &pp->gens);
   if (rc == VDF_OK) rc = vdf_bases_precompute(ctx, pp->gens, 16, 1);
   if (rc == VDF_OK) rc = vdf_dev_alloc(ctx, pp->num_cons * 32, &pp->d_zero);
@@ -362,6 +378,7 @@ void vdf_nova_pp_free(vdf_pp* pp) {
   if (pp->d_zero) vdf_dev_free(pp->ctx, pp->d_zero);
   if (pp->shape) vdf_shape_free(pp->shape);
   if (pp->gens) vdf_bases_free(pp->gens);
+  if (pp->ctx2) vdf_ctx_destroy(pp->ctx2);
   delete pp;
 }
 int vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
@@ -401,6 +418,16 @@ int vdf_nova_eval_and_make_circuits(int mode, uint64_t t, size_t num_steps, cons
   *out = cs;
   return VDF_OK;
 }
+int vdf_nova_circuits_upload(vdf_ctx* ctx, vdf_circuits* c) {
+  if (!ctx || !c) return fail(VDF_ERR_BAD_ARG, "null argument");
+  c->ctx = ctx;
+  for (auto& k : c->v) {
+    if (k.d_trace) continue;
+    HIPCALL(ctx, vdf_dev_alloc(ctx, k.trace_xy.size() * 32, &k.d_trace));
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, k.d_trace, k.trace_xy.data(), k.trace_xy.size() * 32));
+  }
+  return VDF_OK;
+}
 size_t vdf_nova_circuits_len(const vdf_circuits* c) { return c ? c->v.size() : 0; }
 int vdf_nova_circuit_states(const vdf_circuits* c, size_t k, vdf_state* result, vdf_state* input) {
   if (!c || k >= c->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
@@ -408,7 +435,11 @@ int vdf_nova_circuit_states(const vdf_circuits* c, size_t k, vdf_state* result, 
   if (input) store_state(input, c->v[k].input);
   return VDF_OK;
 }
-void vdf_nova_circuits_free(vdf_circuits* c) { delete c; }
+void vdf_nova_circuits_free(vdf_circuits* c) {
+  if (!c) return;
+  if (c->ctx) for (auto& k : c->v) if (k.d_trace) vdf_dev_free(c->ctx, k.d_trace);
+  delete c;
+}
 
 // ---- prove_step ----------------------------------------------------------------------------------------
 int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]) {
@@ -436,27 +467,45 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   const size_t nv = pp->num_vars, nc = pp->num_cons;
   char* z2 = (char*)p->d_z2;
   // --- fresh witness: W2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i] -------------------
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_trace, c.trace_xy.data(), (pp->t + 1) * 64));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, z2, &c.result, 96));
-  HIPCALL(ctx, vdf_minroot_witness(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_trace, (const vdf_fe*)&c.input.i, pp->t,
-                                   (vdf_fe*)(z2 + 96)));
+  const void* d_trace = c.d_trace;
+  if (!d_trace) {
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_trace, c.trace_xy.data(), (pp->t + 1) * 64));
+    d_trace = p->d_trace;
+  }
   Fe X2[NUM_IO] = {c.result.x, c.result.y, c.result.i, c.input.x, c.input.y, c.input.i};
-  Fe tail[1 + NUM_IO];
-  tail[0] = one(F);
-  for (int j = 0; j < NUM_IO; ++j) tail[1 + j] = X2[j];
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, z2 + nv * 32, tail, sizeof(tail)));
+  {
+    // one small upload: z_in, [1 | X2], i0
+    Fe head[3] = {c.result.x, c.result.y, c.result.i};
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, z2, head, 96));
+    Fe tail[1 + NUM_IO];
+    tail[0] = one(F);
+    for (int j = 0; j < NUM_IO; ++j) tail[1 + j] = X2[j];
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, z2 + nv * 32, tail, sizeof(tail)));
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_small + 64, &c.input.i, 32));
+  }
+  HIPCALL(ctx, vdf_minroot_witness(ctx, PRIMARY_FIELD, (const vdf_fe*)d_trace, (const vdf_fe*)((char*)p->d_small + 64), pp->t,
+                                   (vdf_fe*)(z2 + 96)));
   HIPCALL(ctx, vdf_ctx_sync(ctx));
   const double t1 = now_ms();
-  // --- commit W2 ---------------------------------------------------------------------------------------
+  // --- commit W2: enqueued on the second stream; its result is only needed for the challenge ---------
+  vdf_ctx* cctx = pp->ctx2 ? pp->ctx2 : ctx;
   vdf_jac jw;
-  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)z2, nv, 1, &jw));
-  const Aff comm_w = jac_to_aff(jw, field_fp());
-  const double t2 = now_ms();
+  HIPCALL(cctx, vdf_msm(cctx, pp->gens, 0, (const vdf_fe*)z2, nv, 1, pp->ctx2 ? (vdf_jac*)p->d_commw : &jw));
+  auto wait_commit_w = [&](Aff* out) -> int {
+    if (pp->ctx2) {
+      HIPCALL(pp->ctx2, vdf_ctx_sync(pp->ctx2));
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, &jw, p->d_commw, sizeof(jw)));
+    }
+    *out = jac_to_aff(jw, field_fp());
+    return VDF_OK;
+  };
+  Aff comm_w;
+  double t2 = now_ms();
   StepRecord rec;
-  rec.comm_w = comm_w;
   for (int j = 0; j < NUM_IO; ++j) rec.X[j] = X2[j];
-  double t3 = t2, t4 = t2, t5 = t2, t6 = t2;
+  double t3 = t2, t4 = t2, t5 = t2, t6 = t2, wait_w = 0;
   if (first) {
+    { const double a0 = now_ms(); int rcw = wait_commit_w(&comm_w); if (rcw != VDF_OK) return rcw; wait_w = now_ms() - a0; }
     // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step
     HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_z1, p->d_z2, pp->ncols * 32));
     p->comm_W = comm_w;
@@ -470,27 +519,35 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
     // --- NIFS.prove: multiply_vec x 2, cross term, commit T, challenge, fold ------
     HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
     HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z2, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4], (vdf_fe*)p->d_abc[5]));
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
     t3 = now_ms();
     HIPCALL(ctx, vdf_cross_term(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1], (const vdf_fe*)p->d_abc[2],
                                 (const vdf_fe*)p->d_abc[3], (const vdf_fe*)p->d_abc[4], (const vdf_fe*)p->d_abc[5],
                                 (const vdf_fe*)&p->u, nc, (vdf_fe*)p->d_T));
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
     t4 = now_ms();
     vdf_jac jt;
     HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, &jt));
     const Aff comm_T = jac_to_aff(jt, field_fp());
     t5 = now_ms();
+    { int rcw = wait_commit_w(&comm_w); if (rcw != VDF_OK) return rcw; wait_w = now_ms() - t5; t5 = now_ms(); }
+    p->join();                                                   // the previous step's instance fold
     uint64_t r_raw[4];
     const Fe r = challenge(pp, p->comm_W, p->comm_E, p->u, p->X, comm_w, X2, comm_T, r_raw);
     // witness fold on the device: W <- W + r*W2, E <- E + r*T
-    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_z1, (const vdf_fe*)&r, (const vdf_fe*)p->d_z2, nv, (vdf_fe*)p->d_z1));
-    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_E, (const vdf_fe*)&r, (const vdf_fe*)p->d_T, nc, (vdf_fe*)p->d_E));
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_small, &r, 32));
+    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_z1, (const vdf_fe*)p->d_small, (const vdf_fe*)p->d_z2, nv, (vdf_fe*)p->d_z1));
+    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_E, (const vdf_fe*)p->d_small, (const vdf_fe*)p->d_T, nc, (vdf_fe*)p->d_E));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     t6 = now_ms();
-    // instance fold on the host (O(1)): commitments, u, X
-    p->comm_W = fold_commitment(p->comm_W, r_raw, comm_w);
-    p->comm_E = fold_commitment(p->comm_E, r_raw, comm_T);
+    // instance fold on the host (O(1)): commitments (deferred to a worker thread), u, X
+    {
+      const Aff cW0 = p->comm_W, cE0 = p->comm_E;
+      uint64_t rr[4] = {r_raw[0], r_raw[1], r_raw[2], r_raw[3]};
+      vdf_proof* pr = p;
+      p->pending = std::async(std::launch::async, [pr, cW0, cE0, rr, comm_w, comm_T]() {
+        pr->comm_W = fold_commitment(cW0, rr, comm_w);
+        pr->comm_E = fold_commitment(cE0, rr, comm_T);
+      });
+    }
     p->u = add(p->u, r, F);
     for (int j = 0; j < NUM_IO; ++j) p->X[j] = add(p->X[j], mul(r, X2[j], F), F);
     Fe utail[1 + NUM_IO];
@@ -500,11 +557,13 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
     rec.comm_T = comm_T;
     rec.r = r;
   }
+  rec.comm_w = comm_w;
   p->steps.push_back(rec);
   p->i += 1;
   p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
   const double t7 = now_ms();
-  p->ms[0] = t1 - t0; p->ms[1] = t2 - t1; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3; p->ms[4] = t5 - t4;
+  p->ms[0] = t1 - t0; p->ms[1] = (t2 - t1) + wait_w; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3;
+  p->ms[4] = first ? 0.0 : t5 - t4 - wait_w;
   p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
   *proof = p;
   return VDF_OK;
@@ -526,10 +585,11 @@ int vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_
 
 void vdf_nova_proof_free(vdf_proof* p) {
   if (!p) return;
+  p->join();
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
     void* bufs[] = {p->d_z1, p->d_z2, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4],
-                    p->d_abc[5], p->d_trace, p->d_small};
+                    p->d_abc[5], p->d_trace, p->d_small, p->d_commw};
     for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
   }
   delete p;
@@ -538,6 +598,7 @@ size_t vdf_nova_proof_num_steps(const vdf_proof* p) { return p ? p->i : 0; }
 
 int vdf_nova_proof_instance(const vdf_proof* p, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[6]) {
   if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+  p->join();
   if (comm_W) memcpy(comm_W, &p->comm_W, 64);
   if (comm_E) memcpy(comm_E, &p->comm_E, 64);
   if (u) memcpy(u, &p->u, 32);
@@ -570,6 +631,7 @@ int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_
   if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
   *ok = 0;
   if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+  p->join();
   vdf_ctx* ctx = pp->ctx;
   const Field& F = field(PRIMARY_FIELD);
   if (num_steps == 0 || p->steps.size() != num_steps || p->i != num_steps) return VDF_OK;   // NovaError::ProofVerifyError

@@ -19,6 +19,7 @@ for _name, _res, _args in [
     ("vdf_nova_pp_sizes", _i, [_vp] + [C.POINTER(_u64)] * 5),
     ("vdf_nova_eval_and_make_circuits", _i, [_i, _u64, _sz, C.POINTER(_State), C.POINTER(_Fe * 3), C.POINTER(_vp)]),
     ("vdf_nova_circuits_len", _sz, [_vp]),
+    ("vdf_nova_circuits_upload", _i, [_vp, _vp]),
     ("vdf_nova_circuit_states", _i, [_vp, _sz, C.POINTER(_State), C.POINTER(_State)]),
     ("vdf_nova_circuits_free", None, [_vp]),
     ("vdf_nova_prove_recursively", _i, [_vp, _vp, _u64, C.POINTER(_Fe * 3), C.POINTER(_vp)]),
@@ -80,6 +81,11 @@ class Circuits:
 
     def __len__(self) -> int:
         return nova_lib.vdf_nova_circuits_len(self.handle)
+
+    def upload(self, ctx: Context) -> None:
+        """Move the forward traces into HBM (an input of proving; outside the timed region)."""
+        _check(nova_lib.vdf_nova_circuits_upload(ctx.handle, self.handle))
+        self._ctx = ctx          # keep the context alive until the traces are freed
 
     def states(self, k: int) -> Tuple[State, State]:
         """(result, input) of circuit k: InverseMinRootCircuit.result / .input (:63-64)."""
