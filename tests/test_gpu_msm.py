@@ -225,3 +225,44 @@ def test_error_paths(ctx):
     with pytest.raises(vdf_amd.VdfError):
         ctx.axpy(7, sc, sc, sc, 4, sc)                 # unknown field
     bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_point_sum_and_sharded_ranges(ctx, cref, curve):
+    """The multi-GPU combine on one device: MSMs over generator ranges [start, start+count) (what each
+    rank owns) summed with vdf_point_sum equal the single MSM over the whole range."""
+    from vdf_amd.dist import shard_range
+    n, world = 5000, 3
+    whole = ctx.bases_generate(curve, 17, n)
+    pts = whole.download()
+    sc = rand_limbs(np.random.default_rng(4), n)
+    exp = cpu_msm(cref, curve, pts, sc)
+    partials = np.zeros((world, 12), dtype="<u8")
+    for r in range(world):
+        start, count = shard_range(n, r, world)
+        b = ctx.bases_generate(curve, 17, count, start=start)
+        assert np.array_equal(b.download(), pts[start:start + count])
+        partials[r] = ctx.msm(b, sc[start:start + count].copy())
+        b.free()
+    assert jac_to_affine(ctx.point_sum(curve, partials, world), curve) == exp
+    # identities and a single point
+    zero = np.zeros((4, 12), dtype="<u8")
+    assert jac_to_affine(ctx.point_sum(curve, zero, 4), curve) is None
+    assert jac_to_affine(ctx.point_sum(curve, partials[:1].copy(), 1), curve) == jac_to_affine(partials[0], curve)
+    whole.free()
+
+
+def test_stage_timing_api(ctx):
+    n = 1 << 14
+    bases = ctx.bases_generate(o.CURVE_PALLAS, 2, n)
+    sc = rand_limbs(np.random.default_rng(1), n)
+    ctx.set_timing(True)
+    ctx.msm_timing()
+    for _ in range(3):
+        ctx.msm(bases, sc)
+    sort_ms, acc_ms, tail_ms, total_ms, calls = ctx.msm_timing()
+    ctx.set_timing(False)
+    assert calls == 3 and acc_ms > 0 and total_ms >= acc_ms
+    assert abs(total_ms - (sort_ms + acc_ms + tail_ms)) < 0.2 * total_ms + 0.05
+    assert ctx.msm_timing()[4] == 0
+    bases.free()

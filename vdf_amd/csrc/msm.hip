@@ -232,9 +232,15 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ d
                                                   const uint32_t* __restrict__ counts,
                                                   const uint32_t* __restrict__ bstart, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t lds[];
-  const uint32_t w = blockIdx.x / K, k = blockIdx.x % K;
+  // XCD-aware block -> chunk map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an
+  // XCD, and with it an L2).  The chunks of one window write neighbouring positions of every bucket's
+  // region, so giving one XCD a run of CONSECUTIVE chunks lets its L2 merge their 4-byte scatter writes
+  // into whole lines before they leave for HBM.  Placement only affects speed, never correctness.
+  uint32_t bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t w = bid / K, k = bid % K;
   const uint32_t s = w % (uint32_t)sets, j = w / (uint32_t)sets;
-  const uint32_t* cnt = counts + (size_t)blockIdx.x * nbk;
+  const uint32_t* cnt = counts + (size_t)bid * nbk;
   const uint32_t* bs = bstart + (size_t)s * nbk;
   for (uint32_t b = threadIdx.x; b < nbk; b += blockDim.x) lds[b] = cnt[b] + bs[b];
   __syncthreads();
