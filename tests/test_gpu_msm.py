@@ -266,3 +266,34 @@ def test_stage_timing_api(ctx):
     assert abs(total_ms - (sort_ms + acc_ms + tail_ms)) < 0.2 * total_ms + 0.05
     assert ctx.msm_timing()[4] == 0
     bases.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_point_sum_exceptional_cases(ctx, curve):
+    """The quad-cooperative addition of the tail kernels on its exceptional branches: P + P (doubling),
+    P + (-P) (identity), identity operands, and points with z != 1."""
+    m = o.curve_base_modulus(curve)
+    g = o.generator(curve)
+    P1 = o.pt_mul(12345, g, m)
+    P2 = o.pt_mul(777, g, m)
+
+    def jac(pt, z=1):
+        if pt is None:
+            return [0, 0, 0]
+        x, y = pt
+        return [x * z * z % m, y * z * z * z % m, z % m]
+
+    def run(points):
+        flat = [o.to_mont(v, m) for p in points for v in p]
+        arr = limbs(flat).reshape(len(points), 12)
+        return jac_to_affine(ctx.point_sum(curve, arr, len(points)), curve)
+
+    neg = (P1[0], (-P1[1]) % m)
+    assert run([jac(P1), jac(P1)]) == o.pt_add(P1, P1, m)
+    assert run([jac(P1, 5), jac(P1, 9)]) == o.pt_add(P1, P1, m)                  # same point, different z
+    assert run([jac(P1), jac(neg)]) is None
+    assert run([jac(P1, 3), jac(neg, 11), jac(P2)]) == P2
+    assert run([jac(None), jac(P2, 7), jac(None)]) == P2
+    many = [jac(o.pt_mul(k + 1, g, m), k + 2) for k in range(40)]
+    assert run(many) == o.pt_mul(sum(range(1, 41)), g, m)
+    assert run([jac(P1)] * 33) == o.pt_mul(33 * 12345, g, m)                     # equal partials across quads

@@ -26,6 +26,7 @@
 // removes it entirely.  The table trades HBM capacity (288 GB) for the serial tail.
 #include "internal.h"
 #include "ec.cuh"
+#include "ecq.cuh"
 
 namespace vdf {
 
@@ -55,8 +56,8 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.heavy = take((nkeys + 4) * 4);
   uint32_t tps = p.nbk / RED_SEG;
   if (tps == 0) tps = 1;
-  w.red_threads_per_set = tps;
-  w.red_block = tps < 256 ? tps : 256;
+  w.red_threads_per_set = tps;                 // logical threads (quads): one per RED_SEG buckets
+  w.red_block = tps < 64 ? tps : 64;           // quads per workgroup (256 lanes)
   w.red_blocks_per_set = tps / w.red_block;
   w.partials = take((size_t)p.sets * w.red_blocks_per_set * 128);
   w.wsum = take((size_t)p.sets * 128);
@@ -319,95 +320,53 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   else xyzz_store<P>(bucket_acc + (size_t)g * 128, acc);
 }
 
-template <class P> __device__ __forceinline__ XYZZ<P> xyzz_shfl_xor(const XYZZ<P>& a, int mask) {
-  XYZZ<P> r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    r.x.v[i] = __shfl_xor(a.x.v[i], mask, 64);
-    r.y.v[i] = __shfl_xor(a.y.v[i], mask, 64);
-    r.zz.v[i] = __shfl_xor(a.zz.v[i], mask, 64);
-    r.zzz.v[i] = __shfl_xor(a.zzz.v[i], mask, 64);
-  }
-  return r;
-}
-
-// Four lanes per bucket: the heads of the slices a bucket spans are summed by its lane group
-// (strided partial sums, then a 2-step butterfly inside the group) instead of one serial chain.
-// With the fixed-base table a bucket holds ~512 entries = ~8 slices of L = 64.
+// ------------------------------------------------------------------------------------------
+// Tail of the pipeline.  Every kernel below is a short chain of dependent point additions run by few
+// waves, so they use the quad-cooperative group law of ecq.cuh: four lanes per point, four
+// multiplication stages per addition instead of fourteen serial multiplications.
+// "Logical thread" = quad = (global lane index) / 4.
+// ------------------------------------------------------------------------------------------
+// One quad per bucket: add the heads of the slices the bucket spans (table mode: ~8 per bucket).
 template <class P>
 __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t L,
                                                char* __restrict__ bucket_acc, const char* __restrict__ heads,
                                                uint32_t* __restrict__ heavy) {
-  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t g = gid >> 2, sub = gid & 3u;
-  uint32_t tf = 0, tl = 0;
-  bool active = false;
-  if (g < nkeys) {
-    const uint32_t s = bstart[g], e = bstart[g + 1];
-    if (e > s) {
-      tf = s / L;
-      tl = (e - 1) / L;
-      if (tl > tf) {
-        if (tl - tf > (uint32_t)HEAVY_SPAN) {
-          if (sub == 0) {
-            uint32_t slot = atomicAdd(&heavy[0], 1u);
-            heavy[1 + slot] = g;
-          }
-        } else {
-          active = true;
-        }
-      }
+  const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 2;
+  if (g >= nkeys) return;                                          // quad-uniform from here on
+  const uint32_t s = bstart[g], e = bstart[g + 1];
+  if (e <= s) return;
+  const uint32_t tf = s / L, tl = (e - 1) / L;
+  if (tl == tf) return;
+  if (tl - tf > (uint32_t)HEAVY_SPAN) {
+    if ((threadIdx.x & 3u) == 0) {
+      uint32_t slot = atomicAdd(&heavy[0], 1u);
+      heavy[1 + slot] = g;
     }
+    return;
   }
-  if (!__any(active)) return;                         // whole wave has nothing to fix up
-  XYZZ<P> acc = xyzz_identity<P>();
-  if (active)
-    for (uint32_t t = tf + 1 + sub; t <= tl; t += 4) {
-      XYZZ<P> h = xyzz_load<P>(heads + (size_t)t * 128);
-      xyzz_add(acc, h);
-    }
-#pragma unroll 1
-  for (int m = 2; m >= 1; m >>= 1) {                  // butterfly inside the 4-lane group (all lanes take part)
-    XYZZ<P> o = xyzz_shfl_xor(acc, m);
-    xyzz_add(acc, o);
-  }
-  if (active && sub == 0) {
-    XYZZ<P> base = xyzz_load<P>(bucket_acc + (size_t)g * 128);
-    xyzz_add(base, acc);
-    xyzz_store<P>(bucket_acc + (size_t)g * 128, base);
-  }
+  QPoint<P> acc = qpoint_load<P>(bucket_acc + (size_t)g * 128);
+  for (uint32_t t = tf + 1; t <= tl; ++t) acc = qpoint_add<P>(acc, qpoint_load<P>(heads + (size_t)t * 128));
+  qpoint_store<P>(bucket_acc + (size_t)g * 128, acc);
 }
 
-// wavefront all-reduce of one XYZZ per lane (6 butterfly steps)
-template <class P> __device__ __forceinline__ XYZZ<P> xyzz_wave_sum(XYZZ<P> v) {
-#pragma unroll 1
-  for (int m = 32; m >= 1; m >>= 1) {
-    XYZZ<P> o = xyzz_shfl_xor(v, m);
-    xyzz_add(v, o);
-  }
-  return v;
-}
-
-// One wavefront per queued heavy bucket: lanes stride over the bucket's heads, then butterfly.
+// One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a
+// 4-step butterfly of quad additions across the wavefront.
 template <class P>
 __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t L,
                                                     char* __restrict__ bucket_acc, const char* __restrict__ heads,
                                                     const uint32_t* __restrict__ heavy) {
   const uint32_t count = heavy[0];
+  const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
     const uint32_t g = heavy[1 + item];
     const uint32_t s = bstart[g], e = bstart[g + 1];
     const uint32_t tf = s / L, tl = (e - 1) / L;
-    XYZZ<P> acc = xyzz_identity<P>();
-    for (uint32_t t = tf + 1 + threadIdx.x; t <= tl; t += 64) {
-      XYZZ<P> h = xyzz_load<P>(heads + (size_t)t * 128);
-      xyzz_add(acc, h);
-    }
-    acc = xyzz_wave_sum(acc);
-    if (threadIdx.x == 0) {
-      XYZZ<P> base = xyzz_load<P>(bucket_acc + (size_t)g * 128);
-      xyzz_add(base, acc);
-      xyzz_store<P>(bucket_acc + (size_t)g * 128, base);
+    QPoint<P> acc = qpoint_identity<P>();
+    for (uint32_t t = tf + 1 + quad; t <= tl; t += 16) acc = qpoint_add<P>(acc, qpoint_load<P>(heads + (size_t)t * 128));
+    acc = qpoint_wave_sum(acc);
+    if (quad == 0) {
+      QPoint<P> base = qpoint_load<P>(bucket_acc + (size_t)g * 128);
+      qpoint_store<P>(bucket_acc + (size_t)g * 128, qpoint_add<P>(base, acc));
     }
   }
 }
@@ -420,70 +379,80 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
                                                  uint32_t threads_per_set, uint32_t blocks_per_set,
                                                  char* __restrict__ partials) {
   extern __shared__ __align__(16) char lds_raw[];
+  const uint32_t nlog = blockDim.x >> 2;                          // logical threads (quads) per block
+  const uint32_t lt = threadIdx.x >> 2;
   const uint32_t set = blockIdx.x / blocks_per_set;
   const uint32_t blk = blockIdx.x % blocks_per_set;
-  const uint32_t seg = blk * blockDim.x + threadIdx.x;          // segment index within the set
+  const uint32_t seg = blk * nlog + lt;                            // segment index within the set
   const uint32_t nseg = (nbk < (uint32_t)RED_SEG) ? nbk : (uint32_t)RED_SEG;
-  const uint32_t base = seg * nseg;                               // first bucket of the segment
-  XYZZ<P> run = xyzz_identity<P>(), tot = xyzz_identity<P>();
+  const uint32_t base = seg * nseg;                                // first bucket of the segment
+  QPoint<P> run = qpoint_identity<P>(), tot = qpoint_identity<P>();
   if (seg < threads_per_set) {
     const char* bp = bucket_acc + ((size_t)set * nbk + base) * 128;
     for (int l = (int)nseg - 1; l >= 0; --l) {
-      XYZZ<P> bkt = xyzz_load<P>(bp + (size_t)l * 128);
-      xyzz_add(run, bkt);
-      xyzz_add(tot, run);                                          // tot = sum (l+1) * B[base+l]
+      run = qpoint_add<P>(run, qpoint_load<P>(bp + (size_t)l * 128));
+      tot = qpoint_add<P>(tot, run);                               // tot = sum (l+1) * B[base+l]
     }
-    // + base * run   (double-and-add, base < 2^16)
-    if (base) {
-      XYZZ<P> m = xyzz_identity<P>();
+    if (base) {                                                    // + base * run (double-and-add, base < 2^16)
+      QPoint<P> m = qpoint_identity<P>();
       for (int bit = 31 - __builtin_clz(base); bit >= 0; --bit) {
-        m = xyzz_dbl(m);
-        if ((base >> bit) & 1u) xyzz_add(m, run);
+        m = qpoint_dbl<P>(m);
+        if ((base >> bit) & 1u) m = qpoint_add<P>(m, run);
       }
-      xyzz_add(tot, m);
+      tot = qpoint_add<P>(tot, m);
     }
   }
-  // workgroup tree reduction through LDS
-  xyzz_store<P>(lds_raw + (size_t)threadIdx.x * 128, tot);
+  // workgroup tree reduction through LDS (each lane moves its own 32-byte coordinate)
+  qpoint_store<P>(lds_raw + (size_t)lt * 128, tot);
   __syncthreads();
-  for (uint32_t stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
-    if (threadIdx.x < stride) {
-      XYZZ<P> o = xyzz_load<P>(lds_raw + (size_t)(threadIdx.x + stride) * 128);
-      xyzz_add(tot, o);
-      xyzz_store<P>(lds_raw + (size_t)threadIdx.x * 128, tot);
+  for (uint32_t stride = nlog >> 1; stride >= 1; stride >>= 1) {
+    if (lt < stride) {
+      tot = qpoint_add<P>(tot, qpoint_load<P>(lds_raw + (size_t)(lt + stride) * 128));
+      qpoint_store<P>(lds_raw + (size_t)lt * 128, tot);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) xyzz_store<P>(partials + (size_t)blockIdx.x * 128, tot);
+  if (lt == 0) qpoint_store<P>(partials + (size_t)blockIdx.x * 128, tot);
 }
 
+// one workgroup of 64 quads per set: strided partial sums, then an LDS tree
 template <class P>
-__global__ __launch_bounds__(64) void k_reduce2(const char* __restrict__ partials, uint32_t blocks_per_set,
-                                                char* __restrict__ wsum) {
+__global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partials, uint32_t blocks_per_set,
+                                                 char* __restrict__ wsum) {
+  __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t set = blockIdx.x;
-  XYZZ<P> acc = xyzz_identity<P>();
-  for (uint32_t i = threadIdx.x; i < blocks_per_set; i += 64) {
-    XYZZ<P> o = xyzz_load<P>(partials + ((size_t)set * blocks_per_set + i) * 128);
-    xyzz_add(acc, o);
+  const uint32_t lt = threadIdx.x >> 2;
+  QPoint<P> acc = qpoint_identity<P>();
+  for (uint32_t i = lt; i < blocks_per_set; i += 64)
+    acc = qpoint_add<P>(acc, qpoint_load<P>(partials + ((size_t)set * blocks_per_set + i) * 128));
+  qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+  __syncthreads();
+  for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+    if (lt < stride) {
+      acc = qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)(lt + stride) * 128));
+      qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+    }
+    __syncthreads();
   }
-  acc = xyzz_wave_sum(acc);
-  if (threadIdx.x == 0) xyzz_store<P>(wsum + (size_t)set * 128, acc);
+  if (lt == 0) qpoint_store<P>(wsum + (size_t)set * 128, acc);
 }
 
+// Horner over bucket sets (one quad), XYZZ -> Jacobian
 template <class P>
-__global__ void k_final(const char* __restrict__ wsum, int sets, int c, char* __restrict__ out_jac) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  XYZZ<P> acc = xyzz_identity<P>();
+__global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum, int sets, int c, char* __restrict__ out_jac) {
+  if (blockIdx.x != 0 || threadIdx.x >= 4) return;
+  QPoint<P> acc = qpoint_identity<P>();
   for (int s = sets - 1; s >= 0; --s) {
     if (s != sets - 1)
-      for (int k = 0; k < c; ++k) acc = xyzz_dbl(acc);
-    XYZZ<P> w = xyzz_load<P>(wsum + (size_t)s * 128);
-    xyzz_add(acc, w);
+      for (int k = 0; k < c; ++k) acc = qpoint_dbl<P>(acc);
+    acc = qpoint_add<P>(acc, qpoint_load<P>(wsum + (size_t)s * 128));
   }
-  Jac<P> j = xyzz_to_jac(acc);
-  fe_store<P>(out_jac, j.x);
-  fe_store<P>(out_jac + 32, j.y);
-  fe_store<P>(out_jac + 64, j.z);
+  const Jac<P> j = xyzz_to_jac(qpoint_gather(acc));
+  if (threadIdx.x == 0) {
+    fe_store<P>(out_jac, j.x);
+    fe_store<P>(out_jac + 32, j.y);
+    fe_store<P>(out_jac + 64, j.z);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,10 +537,10 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
-  hipLaunchKernelGGL((k_reduce1<P>), dim3(p.sets * w.red_blocks_per_set), dim3(w.red_block),
+  hipLaunchKernelGGL((k_reduce1<P>), dim3(p.sets * w.red_blocks_per_set), dim3(w.red_block * 4),
                      (size_t)w.red_block * 128, st, bucket_acc, p.nbk, w.red_threads_per_set, w.red_blocks_per_set,
                      partials);
-  hipLaunchKernelGGL((k_reduce2<P>), dim3(p.sets), dim3(64), 0, st, partials, w.red_blocks_per_set, wsum);
+  hipLaunchKernelGGL((k_reduce2<P>), dim3(p.sets), dim3(256), 0, st, partials, w.red_blocks_per_set, wsum);
   hipLaunchKernelGGL((k_final<P>), dim3(1), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
@@ -588,21 +557,21 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 
-// sum of n Jacobian points: one wavefront, lanes stride over the inputs, butterfly reduce
+// sum of n Jacobian points: one wavefront = 16 quads striding over the inputs, butterfly reduce
 template <class P>
 __global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, uint32_t n, char* __restrict__ out) {
-  XYZZ<P> acc = xyzz_identity<P>();
-  for (uint32_t i = threadIdx.x; i < n; i += 64) {
+  const uint32_t quad = threadIdx.x >> 2;
+  QPoint<P> acc = qpoint_identity<P>();
+  for (uint32_t i = quad; i < n; i += 16) {
     Jac<P> j;
     j.x = fe_load<P>(pts + (size_t)i * 96);
     j.y = fe_load<P>(pts + (size_t)i * 96 + 32);
     j.z = fe_load<P>(pts + (size_t)i * 96 + 64);
-    XYZZ<P> v = jac_to_xyzz(j);
-    xyzz_add(acc, v);
+    acc = qpoint_add<P>(acc, qpoint_scatter(jac_to_xyzz(j)));
   }
-  acc = xyzz_wave_sum(acc);
+  acc = qpoint_wave_sum(acc);
+  const Jac<P> j = xyzz_to_jac(qpoint_gather(acc));
   if (threadIdx.x == 0) {
-    Jac<P> j = xyzz_to_jac(acc);
     fe_store<P>(out, j.x);
     fe_store<P>(out + 32, j.y);
     fe_store<P>(out + 64, j.z);
