@@ -345,7 +345,12 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
     return;
   }
   QPoint<P> acc = qpoint_load<P>(bucket_acc + (size_t)g * 128);
-  for (uint32_t t = tf + 1; t <= tl; ++t) acc = qpoint_add<P>(acc, qpoint_load<P>(heads + (size_t)t * 128));
+  QPoint<P> nxt = qpoint_load<P>(heads + (size_t)(tf + 1) * 128);
+  for (uint32_t t = tf + 1; t <= tl; ++t) {
+    const QPoint<P> cur = nxt;
+    if (t < tl) nxt = qpoint_load<P>(heads + (size_t)(t + 1) * 128);   // next head in flight during the addition
+    acc = qpoint_add<P>(acc, cur);
+  }
   qpoint_store<P>(bucket_acc + (size_t)g * 128, acc);
 }
 
