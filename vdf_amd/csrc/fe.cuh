@@ -251,7 +251,6 @@ __device__ __forceinline__ void col_shift_q(uint64_t& acc, uint32_t& hi) {
   asm("v_cmp_ne_u32_e32 vcc, 0, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
       : "=&v"(nlo), "=&v"(nmid) : "v"(lo), "v"(mid), "v"(hi) : "vcc");
   acc = ((uint64_t)nmid << 32) | nlo;
-  hi = 0;
 }
 __device__ __forceinline__ void col_shift(uint64_t& acc, uint32_t& hi) {
   acc = (acc >> 32) | ((uint64_t)hi << 32);
@@ -294,49 +293,10 @@ __device__ __forceinline__ void madc_red(uint64_t& acc, uint32_t& hi, uint32_t q
 
 template <class P> __device__ __forceinline__ Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) {
   constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
-  uint32_t q[8], r[8];
-  uint64_t acc = 0;
-  uint32_t hi = 0;
   const uint32_t* A = a.v;
   const uint32_t* B = b.v;
-  // ---- low columns: products, reduction terms, q digit, shift ----
-  madc(acc, hi, A[0], B[0]);
-  q[0] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc2(acc, hi, A[0], B[1], A[1], B[0]); madc_s(acc, hi, q[0], M1);
-  q[1] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc2(acc, hi, A[0], B[2], A[1], B[1]); madc(acc, hi, A[2], B[0]); madc_s(acc, hi, q[1], M1); madc_s(acc, hi, q[0], M2);
-  q[2] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc4(acc, hi, A[0], B[3], A[1], B[2], A[2], B[1], A[3], B[0]); madc_red<3>(acc, hi, q[2], q[1], q[0], 0, M1, M2, M3, 0);
-  q[3] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc4(acc, hi, A[0], B[4], A[1], B[3], A[2], B[2], A[3], B[1]); madc(acc, hi, A[4], B[0]); madc_red<3>(acc, hi, q[3], q[2], q[1], 0, M1, M2, M3, 0);
-  q[4] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc4(acc, hi, A[0], B[5], A[1], B[4], A[2], B[3], A[3], B[2]); madc2(acc, hi, A[4], B[1], A[5], B[0]); madc_red<3>(acc, hi, q[4], q[3], q[2], 0, M1, M2, M3, 0);
-  q[5] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc4(acc, hi, A[0], B[6], A[1], B[5], A[2], B[4], A[3], B[3]); madc2(acc, hi, A[4], B[2], A[5], B[1]); madc(acc, hi, A[6], B[0]);
-  madc_red<3>(acc, hi, q[5], q[4], q[3], 0, M1, M2, M3, 0);
-  q[6] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  madc4(acc, hi, A[0], B[7], A[1], B[6], A[2], B[5], A[3], B[4]); madc4(acc, hi, A[4], B[3], A[5], B[2], A[6], B[1], A[7], B[0]);
-  madc_red<4>(acc, hi, q[6], q[5], q[4], q[0], M1, M2, M3, M7);
-  q[7] = 0u - (uint32_t)acc; col_shift_q(acc, hi);
-  // ---- high columns ----
-  madc4(acc, hi, A[1], B[7], A[2], B[6], A[3], B[5], A[4], B[4]); madc2(acc, hi, A[5], B[3], A[6], B[2]); madc(acc, hi, A[7], B[1]);
-  madc_red<4>(acc, hi, q[7], q[6], q[5], q[1], M1, M2, M3, M7);
-  r[0] = (uint32_t)acc; col_shift(acc, hi);
-  madc4(acc, hi, A[2], B[7], A[3], B[6], A[4], B[5], A[5], B[4]); madc2(acc, hi, A[6], B[3], A[7], B[2]);
-  madc_s(acc, hi, q[7], M2); madc_s(acc, hi, q[6], M3); madc_s(acc, hi, q[2], M7);
-  r[1] = (uint32_t)acc; col_shift(acc, hi);
-  madc4(acc, hi, A[3], B[7], A[4], B[6], A[5], B[5], A[6], B[4]); madc(acc, hi, A[7], B[3]);
-  madc_s(acc, hi, q[7], M3); madc_s(acc, hi, q[3], M7);
-  r[2] = (uint32_t)acc; col_shift(acc, hi);
-  madc4(acc, hi, A[4], B[7], A[5], B[6], A[6], B[5], A[7], B[4]); madc_s(acc, hi, q[4], M7);
-  r[3] = (uint32_t)acc; col_shift(acc, hi);
-  madc2(acc, hi, A[5], B[7], A[6], B[6]); madc(acc, hi, A[7], B[5]); madc_s(acc, hi, q[5], M7);
-  r[4] = (uint32_t)acc; col_shift(acc, hi);
-  madc2(acc, hi, A[6], B[7], A[7], B[6]); madc_s(acc, hi, q[6], M7);
-  r[5] = (uint32_t)acc; col_shift(acc, hi);
-  madc(acc, hi, A[7], B[7]); madc_s(acc, hi, q[7], M7);
-  r[6] = (uint32_t)acc; col_shift(acc, hi);
-  r[7] = (uint32_t)acc;
+  uint32_t r[8];
+#include "fe_mul_gfx950.inc"
   fe_cond_sub<P>(r);                      // result < 2m < 2^256: the carry word is zero
   Fe<P> o;
 #pragma unroll
