@@ -303,8 +303,72 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul_inl(const Fe<P>& a, c
   for (int i = 0; i < 8; ++i) o.v[i] = r[i];
   return o;
 }
+
+// ---- lazy domain [0, 2m + eps) for the MSM bucket loop ------------------------------------------------
+// Montgomery closure: with a, b < 2m + k*eps the unreduced product (a*b + q*m)/2^256 is below
+// 2m + (k+1)*eps, eps = m*(m/2^254 - 1) ~ 2^126, so the final conditional subtraction can be dropped as long
+// as every consumer accepts [0, 2m + small): a chain of thousands of multiplications stays below
+// 2m + 2^150 < 2^256.  Subtraction corrects a borrow with 2m instead of m (same cost), which keeps the
+// range.  Values are made canonical again (two conditional subtractions) only when a bucket is flushed.
+template <class P> __device__ __forceinline__ Fe<P> fe_mul_lazy(const Fe<P>& a, const Fe<P>& b) {
+  constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
+  const uint32_t* A = a.v;
+  const uint32_t* B = b.v;
+  uint32_t r[8];
+#include "fe_mul_gfx950.inc"
+  Fe<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = r[i];
+  return o;
+}
+
+// a - b (+ 2m on borrow) for a, b in [0, 2m + eps)
+template <class P> __device__ __forceinline__ Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r = a;
+  uint32_t mask;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+      "v_cndmask_b32_e64 %8, 0, -1, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+        "=&v"(mask)
+      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  // 2m = {2, 2*m1 (33 bits: low word + carry into limb 2), ...}: computed limb-wise at compile time
+  constexpr uint64_t D1 = 2ull * P::MOD[1], D2 = 2ull * P::MOD[2] + (D1 >> 32), D3 = 2ull * P::MOD[3] + (D2 >> 32);
+  constexpr uint32_t T0 = 2u, T1 = (uint32_t)D1, T2 = (uint32_t)D2, T3 = (uint32_t)D3, T4 = (uint32_t)(D3 >> 32), T7 = 0x80000000u;
+  const uint32_t m0 = mask & T0, m1 = mask & T1, m2 = mask & T2, m3 = mask & T3, m4 = mask & T4, m7 = mask & T7;
+  asm("v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32_e32 %4, vcc, %4, %12, vcc\n\t"
+      "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_addc_co_u32_e32 %7, vcc, %7, %13, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+      : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m7)
+      : "vcc");
+  return r;
+}
+
+// [0, 2m + eps) -> [0, m)
+template <class P> __device__ __forceinline__ Fe<P> fe_canon(Fe<P> a) {
+  fe_cond_sub<P>(a.v);
+  fe_cond_sub<P>(a.v);
+  return a;
+}
 #else
 template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
+// host pass: canonical arithmetic is a valid instance of the lazy interface
+template <class P> VDF_HD Fe<P> fe_mul_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
+template <class P> VDF_HD Fe<P> fe_canon(Fe<P> a) { return a; }
+template <class P> VDF_HD Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_sub(a, b); }
 #endif
 
 // Out-of-line multiply (by-value arguments travel in VGPRs): one copy per field per TU.

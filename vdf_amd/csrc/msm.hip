@@ -265,6 +265,41 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ d
 // ------------------------------------------------------------------------------------------
 // bucket accumulation: sequential segmented reduce over fixed-length slices of the sorted list
 // ------------------------------------------------------------------------------------------
+// Mixed addition acc += b in the lazy domain (fe.cuh): coordinates of acc in [0, 2m + eps), b canonical.
+// `have` says whether acc holds a point yet (the identity has no lazy encoding).
+template <class P>
+__device__ __forceinline__ void madd_lazy(XYZZ<P>& acc, bool& have, const Affine<P>& b) {
+  if (affine_is_identity(b)) return;
+  if (!have) { acc = xyzz_from_affine(b); have = true; return; }
+  const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
+  const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
+  const Fe<P> Pp = fe_sub_lazy(U2, acc.x);
+  const Fe<P> Rr = fe_sub_lazy(S2, acc.y);
+  // P == 0 (mod m) means P in {0, m, 2m}; m == 1 (mod 2^32), so the low limb is 0, 1 or 2: cheap filter
+  if (Pp.v[0] <= 2u && fe_is_zero(fe_canon(Pp))) {
+    if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);        // same point: double (canonical output)
+    else have = false;                                              // opposite points: identity
+    return;
+  }
+  const Fe<P> PP = fe_mul_lazy(Pp, Pp);
+  const Fe<P> PPP = fe_mul_lazy(Pp, PP);
+  const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
+  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), PPP), Qq), Qq);
+  const Fe<P> Y3 = fe_sub_lazy(fe_mul_lazy(Rr, fe_sub_lazy(Qq, X3)), fe_mul_lazy(acc.y, PPP));
+  acc.x = X3;
+  acc.y = Y3;
+  acc.zz = fe_mul_lazy(acc.zz, PP);
+  acc.zzz = fe_mul_lazy(acc.zzz, PPP);
+}
+
+template <class P>
+__device__ __forceinline__ void flush_lazy(const XYZZ<P>& acc, bool have, char* dst) {
+  XYZZ<P> o;
+  if (have) { o.x = fe_canon(acc.x); o.y = fe_canon(acc.y); o.zz = fe_canon(acc.zz); o.zzz = fe_canon(acc.zzz); }
+  else o = xyzz_identity<P>();
+  xyzz_store<P>(dst, o);
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bstart, uint32_t nkeys,
@@ -287,6 +322,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   uint32_t next = bstart[g + 1];
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
+  bool have = false;
   const uint32_t* mine = sorted + (size_t)(t >> 6) * 64u * L + (t & 63u);   // entry k of this slice: mine[k * 64]
   uint32_t e = mine[0];
   Affine<P> pt = affine_load<P>(points + (size_t)(e & ~SIGN_BIT) * 64);
@@ -296,10 +332,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
     const uint32_t en = mine[(size_t)(pn - lo) * 64u];
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
-      if (is_head) xyzz_store<P>(heads + (size_t)t * 128, acc);
-      else xyzz_store<P>(bucket_acc + (size_t)g * 128, acc);
+      flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
       is_head = false;
-      acc = xyzz_identity<P>();
+      have = false;
       ++g;
       if (bstart[g + 1] <= pos) {   // empty buckets in between: binary search
         uint32_t x = g, y = nkeys;
@@ -312,12 +347,11 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
       next = bstart[g + 1];
     }
     if (e & SIGN_BIT) pt.y = fe_neg(pt.y);
-    xyzz_madd<P, true>(acc, pt);
+    madd_lazy<P>(acc, have, pt);
     e = en;
     pt = ptn;
   }
-  if (is_head) xyzz_store<P>(heads + (size_t)t * 128, acc);
-  else xyzz_store<P>(bucket_acc + (size_t)g * 128, acc);
+  flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
 }
 
 // ------------------------------------------------------------------------------------------
