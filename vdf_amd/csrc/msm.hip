@@ -24,6 +24,7 @@
 // With a fixed-base table (vdf_bases_precompute) window w = j*sets + s reads table j
 // (2^(c*sets*j) * P_i) and feeds bucket set s, so the Horner tail is (sets-1)*c doublings; sets = 1
 // removes it entirely.  The table trades HBM capacity (288 GB) for the serial tail.
+#include <cstdlib>
 #include "internal.h"
 #include "ec.cuh"
 #include "ecq.cuh"
@@ -91,13 +92,16 @@ MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
   p.chunk = (uint32_t)chunk;
   p.K = (uint32_t)((n + chunk - 1) / chunk);
   if (p.K == 0) p.K = 1;
-  // accumulate slices: ~4 waves per SIMD worth of threads, 8 <= L <= 64, multiple of 4
+  // accumulate slices: ~4 waves per SIMD worth of threads (k_accumulate is resident at 3 per SIMD; measured on
+  // MI355X, L = 32..64 is the flat optimum at 2^18..2^20: shorter slices multiply the slice heads k_fixup must
+  // add, longer ones leave a thin last round), 32 <= L <= 64, multiple of 4.
   size_t ne = (size_t)n * p.windows;
   size_t want_threads = (size_t)num_cus * 4 * 4 * 64;
   size_t L = (ne + want_threads - 1) / want_threads;
   L = (L + 3) / 4 * 4;
-  if (L < 8) L = 8;
+  if (L < 32) L = 32;
   if (L > 64) L = 64;
+  if (const char* ov = std::getenv("VDF_MSM_L")) { long v = std::atol(ov); if (v >= 4 && v <= 4096) L = (size_t)(v + 3) / 4 * 4; }   // tuning override
   p.L = (uint32_t)L;
   p.nthreads = (uint32_t)((ne + L - 1) / L);
   if (p.nthreads == 0) p.nthreads = 1;
