@@ -87,8 +87,12 @@ struct MsmPlan {
   int sets = 0;          // bucket sets (Horner length); windows = sets * tables
   int tables = 0;
   uint32_t nbk = 0;      // buckets per set = 2^(c-1)   (digit magnitudes 1..2^(c-1))
-  uint32_t chunk = 0;    // points per sort chunk
-  uint32_t K = 0;        // chunks per window
+  // two-level counting sort: a bucket index b = (p << fb) | f; pass A partitions by p, pass B sorts by f
+  int pb = 0, fb = 0;    // partition bits / fine bits, pb + fb = c - 1
+  uint32_t bins = 0;     // sets << pb
+  uint32_t chA = 0;      // points per pass-A workgroup
+  uint32_t nblkA = 0;    // pass-A workgroups
+  uint32_t split = 0;    // pass-B workgroups per bin
   uint32_t L = 0;        // sorted entries per accumulate thread
   uint32_t nthreads = 0; // accumulate threads
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)

@@ -5,11 +5,14 @@
 // (/root/reference/src/nova/proof.rs:342-349).
 //
 // Pipeline (all on the device, one stream, no host round trip):
-//   k_digits      scalar -> signed c-bit digits (Booth-style carry), one u32 per (window, point)
-//   k_hist        per (window, point-chunk) workgroup: bucket histogram in LDS (2^(c-1) u32 counters)
-//   k_scan_chunks per bucket: exclusive scan over the chunks that feed it
-//   k_scan_keys   exclusive scan over buckets -> bucket start offsets
-//   k_scatter     per (window, chunk) workgroup: LDS offset table + ds atomics -> entries sorted by bucket
+//   Two-level counting sort of the (window, point) entries by bucket, b = (p << 8) | f:
+//   k_part_hist / k_part_scan / k_part_scatter   pass A: every workgroup turns a chunk of scalars into
+//                 signed c-bit digits (Booth-style carry) on the fly and partitions the entries by the
+//                 high bucket bits p (<= 2048 LDS counters); each (workgroup, partition) run is contiguous,
+//                 so the 8-byte records leave as whole lines instead of one 64-byte sector per 4-byte write
+//   k_fine_hist / k_fine_scan / k_scan_keys / k_fine_scatter   pass B: workgroups sort one partition
+//                 slice by the low bits f (256 LDS counters + ds atomics) inside that partition's own
+//                 region of the sorted list (L2-resident), and produce the bucket start offsets
 //   k_accumulate  every thread owns a fixed-length slice of the SORTED entry list and runs a
 //                 sequential segmented reduce over it with an XYZZ accumulator in registers
 //                 (mixed addition of gathered affine points); perfectly balanced for any scalar
@@ -36,7 +39,7 @@ static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a w
 static constexpr int RED_SEG = 2;           // buckets per thread in k_reduce1 (serial depth 2*RED_SEG)
 
 struct WsLayout {
-  size_t dig, counts, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
+  size_t countsA, pcount, pstart, recs, countsB, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
   uint32_t red_threads_per_set, red_block, red_blocks_per_set;
 };
 
@@ -47,11 +50,14 @@ static WsLayout ws_layout(const MsmPlan& p) {
   size_t off = 0;
   const size_t nkeys = (size_t)p.sets * p.nbk;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-  w.dig = take((size_t)p.windows * p.n * 4);
-  w.counts = take((size_t)p.windows * p.K * p.nbk * 4);
+  w.countsA = take((size_t)p.nblkA * p.bins * 4);
+  w.pcount = take((size_t)p.bins * 4);
+  w.pstart = take(((size_t)p.bins + 1) * 4);
+  w.recs = take((size_t)p.windows * p.n * 8);
+  w.countsB = take(nkeys * (size_t)p.split * 4);
   w.bcount = take(nkeys * 4);
   w.bstart = take((nkeys + 1) * 4);
-  w.sorted = take(((size_t)p.windows * p.n + 64 * (size_t)p.L + 64) * 4);
+  w.sorted = take(((size_t)p.windows * p.n + 64) * 4);
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
   w.heavy = take((nkeys + 4) * 4);
@@ -84,14 +90,21 @@ MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
   p.sets = sets;
   p.tables = tables;
   p.nbk = 1u << (c - 1);
-  // sort chunks: aim at ~2 workgroups per CU over all windows, 4096 <= chunk <= 65536 points
-  size_t target_blocks = (size_t)num_cus * 2;
-  size_t chunk = ((size_t)n * p.windows + target_blocks - 1) / target_blocks;
-  if (chunk < 4096) chunk = 4096;
-  if (chunk > 65536) chunk = 65536;
-  p.chunk = (uint32_t)chunk;
-  p.K = (uint32_t)((n + chunk - 1) / chunk);
-  if (p.K == 0) p.K = 1;
+  // two-level sort geometry
+  p.fb = (c - 1 < 8) ? c - 1 : 8;
+  p.pb = c - 1 - p.fb;
+  p.bins = (uint32_t)sets << p.pb;
+  size_t chA = (n + 511) / 512;                       // ~2 pass-A workgroups per CU
+  chA = (chA + 255) / 256 * 256;
+  if (chA < 256) chA = 256;
+  if (chA > 4096) chA = 4096;
+  p.chA = (uint32_t)chA;
+  p.nblkA = (uint32_t)((n + chA - 1) / chA);
+  if (p.nblkA == 0) p.nblkA = 1;
+  uint32_t split = 1024u / p.bins;                    // ~4 pass-B workgroups per CU
+  if (split < 1) split = 1;
+  if (split > 16) split = 16;
+  p.split = split;
   // accumulate slices: ~4 waves per SIMD worth of threads (k_accumulate is resident at 3 per SIMD; measured on
   // MI355X, L = 32..64 is the flat optimum at 2^18..2^20: shorter slices multiply the slice heads k_fixup must
   // add, longer ones leave a thin last round), 32 <= L <= 64, multiple of 4.
@@ -110,96 +123,102 @@ MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
 }
 
 // ------------------------------------------------------------------------------------------
-// digits
+// signed digits
 // ------------------------------------------------------------------------------------------
-template <class SP>
-__global__ __launch_bounds__(256) void k_digits(const uint32_t* __restrict__ scalars, uint32_t n, int is_mont, int c,
-                                                int windows, uint32_t* __restrict__ dig) {
-  __shared__ uint32_t limbs[9 * 256];     // SoA: limb l of thread t at [l*256 + t]; limb 8 = 0
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    Fe<SP> s = fe_load<SP>(scalars + (size_t)i * 8);
-    if (is_mont) s = fe_from_mont(s);
-#pragma unroll
-    for (int l = 0; l < 8; ++l) limbs[l * 256 + threadIdx.x] = s.v[l];
-    limbs[8 * 256 + threadIdx.x] = 0;
-  }
-  __syncthreads();
-  if (i >= n) return;
-  const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-  uint32_t carry = 0;
-  for (int w = 0; w < windows; ++w) {
+// The scalar's limbs sit in LDS (SoA, one private column per thread: no barrier needed) because the
+// windows index them dynamically.  digit(w) = signed c-bit digit of window w with the running carry.
+struct DigitIter {
+  const uint32_t* col;      // &limbs[threadIdx.x], stride 256
+  uint32_t carry;
+  __device__ __forceinline__ uint32_t next(int w, int c) {          // returns magnitude | sign<<31
     const int bit = w * c;
     const int l = bit >> 5, sh = bit & 31;
-    uint32_t lo = (l < 8) ? limbs[l * 256 + threadIdx.x] : 0u;
-    uint32_t hi = (l + 1 < 9) ? limbs[(l + 1) * 256 + threadIdx.x] : 0u;
-    uint64_t two = ((uint64_t)hi << 32) | lo;
-    uint32_t raw = ((uint32_t)(two >> sh) & mask) + carry;
-    uint32_t out;
-    if (raw > half) { out = ((1u << c) - raw) | SIGN_BIT; carry = 1; }
-    else { out = raw; carry = 0; }
-    dig[(size_t)w * n + i] = out;
+    const uint32_t lo = (l < 8) ? col[l * 256] : 0u;
+    const uint32_t hi = (l + 1 < 9) ? col[(l + 1) * 256] : 0u;
+    const uint64_t two = ((uint64_t)hi << 32) | lo;
+    const uint32_t raw = ((uint32_t)(two >> sh) & ((1u << c) - 1u)) + carry;
+    if (raw > (1u << (c - 1))) { carry = 1; return ((1u << c) - raw) | SIGN_BIT; }
+    carry = 0;
+    return raw;
   }
+};
+template <class SP>
+__device__ __forceinline__ void stage_scalar(uint32_t* limbs, const uint32_t* scalars, uint32_t i, int is_mont) {
+  Fe<SP> s = fe_load<SP>(scalars + (size_t)i * 8);
+  if (is_mont) s = fe_from_mont(s);
+#pragma unroll
+  for (int l = 0; l < 8; ++l) limbs[l * 256 + threadIdx.x] = s.v[l];
+  limbs[8 * 256 + threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// counting sort by bucket (LDS histograms)
+// pass A: partition the entries by the high bucket bits
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_hist(const uint32_t* __restrict__ dig, uint32_t n, uint32_t nbk,
-                                               uint32_t chunk, uint32_t K, uint32_t* __restrict__ counts) {
-  extern __shared__ uint32_t lds[];
-  const uint32_t w = blockIdx.x / K, k = blockIdx.x % K;
-  for (uint32_t b = threadIdx.x; b < nbk; b += blockDim.x) lds[b] = 0;
+template <class SP, bool SCATTER>
+__global__ __launch_bounds__(256) void k_part(const uint32_t* __restrict__ scalars, uint32_t n, int is_mont, int c,
+                                              int windows, int sets, int pb, int fb, uint32_t bins, uint32_t chA,
+                                              uint32_t tstride, uint32_t* __restrict__ countsA,
+                                              const uint32_t* __restrict__ pstart, uint64_t* __restrict__ recs) {
+  __shared__ uint32_t limbs[9 * 256];
+  extern __shared__ uint32_t cur[];                   // bins counters (histogram) or cursors (scatter)
+  uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
+  for (uint32_t b = threadIdx.x; b < bins; b += 256) cur[b] = SCATTER ? pstart[b] + mine[b] : 0u;
   __syncthreads();
-  const uint32_t lo = k * chunk;
-  const uint32_t hi = (lo + chunk < n) ? lo + chunk : n;
-  const uint32_t* d = dig + (size_t)w * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    uint32_t mag = d[i] & ~SIGN_BIT;
-    if (mag) atomicAdd(&lds[mag - 1], 1u);
-  }
-  __syncthreads();
-  uint32_t* out = counts + (size_t)blockIdx.x * nbk;
-  for (uint32_t b = threadIdx.x; b < nbk; b += blockDim.x) out[b] = lds[b];
-}
-
-// one thread per bucket key (set s, bucket b): exclusive scan over its feeding chunks
-// (counts[chunk][bucket]: coalesced across the threads of a wave; eight chunks are loaded before
-// their dependent stores so the loop is not one L2 round trip per chunk)
-__global__ __launch_bounds__(256) void k_scan_chunks(uint32_t* __restrict__ counts, uint32_t nbk, uint32_t K, int sets,
-                                                     int tables, uint32_t* __restrict__ bcount) {
-  const uint32_t key = blockIdx.x * 256 + threadIdx.x;
-  if (key >= (uint32_t)sets * nbk) return;
-  const uint32_t s = key / nbk, b = key % nbk;
-  uint32_t run = 0;
-  for (int j = 0; j < tables; ++j) {
-    const uint32_t w = (uint32_t)j * sets + s;
-    uint32_t* base = counts + (size_t)w * K * nbk + b;
-    uint32_t k = 0;
-    for (; k + 8 <= K; k += 8) {
-      uint32_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(k + u) * nbk];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { base[(size_t)(k + u) * nbk] = run; run += v[u]; }
-    }
-    for (; k < K; ++k) {
-      uint32_t v = base[(size_t)k * nbk];
-      base[(size_t)k * nbk] = run;
-      run += v;
+  const uint32_t lo = blockIdx.x * chA;
+  const uint32_t hi = (lo + chA < n) ? lo + chA : n;
+  const uint32_t fmask = (1u << fb) - 1u;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    stage_scalar<SP>(limbs, scalars, i, is_mont);
+    DigitIter it{limbs + threadIdx.x, 0u};
+    for (int w = 0; w < windows; ++w) {
+      const uint32_t d = it.next(w, c);
+      const uint32_t mag = d & ~SIGN_BIT;
+      if (!mag) continue;
+      const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
+      const uint32_t bin = (s << pb) | ((mag - 1) >> fb);
+      const uint32_t pos = atomicAdd(&cur[bin], 1u);
+      if (SCATTER) recs[pos] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + i) | (d & SIGN_BIT));
     }
   }
-  bcount[key] = run;
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) mine[b] = cur[b];
+  }
 }
 
-// single workgroup exclusive scan: bstart[0..nkeys], bstart[nkeys] = total entries.
-// Each thread owns a contiguous run of keys; loads are issued eight at a time so the run is a few
-// L2 round trips instead of one per key.
+// per bin: exclusive scan over the pass-A workgroups.  One 256-thread workgroup per bin scans 256 counts at
+// a time through LDS (a thread per bin walking hundreds of counts would be one L2 round trip each).
+__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ countsA, uint32_t bins, uint32_t nblk,
+                                                   uint32_t* __restrict__ pcount) {
+  __shared__ uint32_t sc[256];
+  const uint32_t b = blockIdx.x;
+  uint32_t carry = 0;
+  for (uint32_t k0 = 0; k0 < nblk; k0 += 256) {
+    const uint32_t k = k0 + threadIdx.x;
+    const uint32_t v = (k < nblk) ? countsA[(size_t)k * bins + b] : 0u;
+    sc[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+      const uint32_t t = (threadIdx.x >= d) ? sc[threadIdx.x - d] : 0u;
+      __syncthreads();
+      sc[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (k < nblk) countsA[(size_t)k * bins + b] = carry + sc[threadIdx.x] - v;
+    const uint32_t tot = sc[255];
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0) pcount[b] = carry;
+}
+
+// single workgroup exclusive scan: out[0..n], out[n] = total.  Each thread owns a contiguous run; loads are
+// issued eight at a time so the run is a few L2 round trips instead of one per element.
 __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__ bcount, uint32_t nkeys,
                                                     uint32_t* __restrict__ bstart) {
   __shared__ uint32_t part[1024];
   const uint32_t per = (nkeys + 1023) / 1024;
-  const uint32_t lo = threadIdx.x * per;
+  const uint32_t lo = threadIdx.x * per < nkeys ? threadIdx.x * per : nkeys;
   const uint32_t hi = (lo + per < nkeys) ? lo + per : nkeys;
   uint32_t sum = 0;
   uint32_t i = lo;
@@ -232,43 +251,95 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
   if (threadIdx.x == 1023) bstart[nkeys] = part[1023];
 }
 
-__global__ __launch_bounds__(1024) void k_scatter(const uint32_t* __restrict__ dig, uint32_t n, uint32_t nbk,
-                                                  uint32_t chunk, uint32_t K, int sets, uint32_t tstride, uint32_t L,
-                                                  const uint32_t* __restrict__ counts,
-                                                  const uint32_t* __restrict__ bstart, uint32_t* __restrict__ sorted) {
-  extern __shared__ uint32_t lds[];
-  // XCD-aware block -> chunk map: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an
-  // XCD, and with it an L2).  The chunks of one window write neighbouring positions of every bucket's
-  // region, so giving one XCD a run of CONSECUTIVE chunks lets its L2 merge their 4-byte scatter writes
-  // into whole lines before they leave for HBM.  Placement only affects speed, never correctness.
-  uint32_t bid = blockIdx.x;
-  if ((gridDim.x & 7u) == 0) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const uint32_t w = bid / K, k = bid % K;
-  const uint32_t s = w % (uint32_t)sets, j = w / (uint32_t)sets;
-  const uint32_t* cnt = counts + (size_t)bid * nbk;
-  const uint32_t* bs = bstart + (size_t)s * nbk;
-  for (uint32_t b = threadIdx.x; b < nbk; b += blockDim.x) lds[b] = cnt[b] + bs[b];
+// ------------------------------------------------------------------------------------------
+// pass B: sort every partition by the low bucket bits.  Workgroup (bin, sp) owns the sp-th of `split`
+// equal slices of the partition's records.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slice_of(const uint32_t* pstart, uint32_t bin, uint32_t sp, uint32_t split,
+                                         uint32_t& lo, uint32_t& hi) {
+  const uint32_t s = pstart[bin], e = pstart[bin + 1];
+  const uint64_t cnt = e - s;
+  lo = s + (uint32_t)(cnt * sp / split);
+  hi = s + (uint32_t)(cnt * (sp + 1) / split);
+}
+
+__global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
+                                                   uint32_t split, uint32_t nf, uint32_t* __restrict__ countsB) {
+  __shared__ uint32_t h[256];
+  const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
+  for (uint32_t f = threadIdx.x; f < nf; f += 256) h[f] = 0;
   __syncthreads();
-  const uint32_t lo = k * chunk;
-  const uint32_t hi = (lo + chunk < n) ? lo + chunk : n;
-  const uint32_t* d = dig + (size_t)w * n;
-  const uint32_t src_base = j * tstride;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    uint32_t v = d[i];
-    uint32_t mag = v & ~SIGN_BIT;
-    if (mag) {
-      uint32_t pos = atomicAdd(&lds[mag - 1], 1u);
-      // lane-interleaved layout: the slice of accumulate-thread t = pos / L lives at stride 64 inside
-      // its wave's 64*L block, so a wave reads entry k of all its lanes as one 256-byte line
-      const uint32_t wv = pos / (64u * L), within = pos % (64u * L);
-      sorted[(size_t)wv * 64u * L + (within % L) * 64u + within / L] = (src_base + i) | (v & SIGN_BIT);
+  uint32_t lo, hi;
+  slice_of(pstart, bin, sp, split, lo, hi);
+  uint32_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {                // eight independent loads in flight per lane
+    uint32_t f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = (uint32_t)(recs[i + u * 256] >> 32);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) atomicAdd(&h[f[u]], 1u);
+  }
+  for (; i < hi; i += 256) atomicAdd(&h[(uint32_t)(recs[i] >> 32)], 1u);
+  __syncthreads();
+  for (uint32_t f = threadIdx.x; f < nf; f += 256) countsB[(size_t)blockIdx.x * nf + f] = h[f];
+}
+
+// One workgroup per bin, one thread per fine bucket f: exclusive scan over the partition's slices, then a
+// block-wide scan over f.  A bin's buckets are contiguous inside the bin's own region, so
+// bstart[bin*nf + f] = pstart[bin] + (buckets of this bin before f): no global scan over all keys.
+__global__ __launch_bounds__(256) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
+                                                   uint32_t bins, uint32_t nf, uint32_t split,
+                                                   uint32_t* __restrict__ bstart) {
+  __shared__ uint32_t sc[256];
+  const uint32_t bin = blockIdx.x, f = threadIdx.x;
+  uint32_t run = 0;
+  for (uint32_t sp = 0; sp < split; ++sp) {
+    const size_t idx = ((size_t)bin * split + sp) * nf + f;
+    const uint32_t v = countsB[idx];
+    countsB[idx] = run;
+    run += v;
+  }
+  sc[f] = run;
+  __syncthreads();
+  for (uint32_t d = 1; d < nf; d <<= 1) {
+    const uint32_t t = (f >= d) ? sc[f - d] : 0u;
+    __syncthreads();
+    sc[f] += t;
+    __syncthreads();
+  }
+  bstart[(size_t)bin * nf + f] = pstart[bin] + sc[f] - run;
+  if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
+}
+
+__global__ __launch_bounds__(256) void k_fine_scatter(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
+                                                      uint32_t split, uint32_t nf, const uint32_t* __restrict__ countsB,
+                                                      const uint32_t* __restrict__ bstart,
+                                                      uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cur[256];
+  const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
+  for (uint32_t f = threadIdx.x; f < nf; f += 256)
+    cur[f] = bstart[(size_t)bin * nf + f] + countsB[(size_t)blockIdx.x * nf + f];
+  __syncthreads();
+  uint32_t lo, hi;
+  slice_of(pstart, bin, sp, split, lo, hi);
+  uint32_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {                // eight independent loads in flight per lane
+    uint64_t r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = recs[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t pos = atomicAdd(&cur[(uint32_t)(r[u] >> 32)], 1u);
+      sorted[pos] = (uint32_t)r[u];       // each (workgroup, bucket) run is contiguous: whole lines leave L2
     }
+  }
+  for (; i < hi; i += 256) {
+    const uint64_t r = recs[i];
+    const uint32_t pos = atomicAdd(&cur[(uint32_t)(r >> 32)], 1u);
+    sorted[pos] = (uint32_t)r;
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// bucket accumulation: sequential segmented reduce over fixed-length slices of the sorted list
-// ------------------------------------------------------------------------------------------
 // Mixed addition acc += b in the lazy domain (fe.cuh): coordinates of acc in [0, 2m + eps), b canonical.
 // `have` says whether acc holds a point yet (the identity has no lazy encoding).
 template <class P>
@@ -327,13 +398,18 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
   bool have = false;
-  const uint32_t* mine = sorted + (size_t)(t >> 6) * 64u * L + (t & 63u);   // entry k of this slice: mine[k * 64]
-  uint32_t e = mine[0];
+  // the slice [lo, lo + L) is contiguous and 16-byte aligned (L is a multiple of 4): entries arrive four at a
+  // time as one dwordx4 per lane
+  const uint4* mine4 = reinterpret_cast<const uint4*>(sorted + lo);
+  uint4 q4 = mine4[0];
+  uint32_t e = q4.x;
   Affine<P> pt = affine_load<P>(points + (size_t)(e & ~SIGN_BIT) * 64);
   for (uint32_t pos = lo; pos < hi; ++pos) {
     // prefetch the next entry's point while this one is added
-    const uint32_t pn = (pos + 1 < hi) ? pos + 1 : pos;
-    const uint32_t en = mine[(size_t)(pn - lo) * 64u];
+    const uint32_t kn = pos + 1 - lo;                       // index of the next entry inside the slice
+    if ((kn & 3u) == 0 && pos + 1 < hi) q4 = mine4[kn >> 2];
+    const uint32_t sel = (pos + 1 < hi) ? (kn & 3u) : ((pos - lo) & 3u);
+    const uint32_t en = sel == 0 ? q4.x : sel == 1 ? q4.y : sel == 2 ? q4.z : q4.w;
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
       flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
@@ -545,9 +621,11 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
                         void* d_out, hipStream_t st, hipEvent_t* ev) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
-  uint32_t* dig = reinterpret_cast<uint32_t*>(base + w.dig);
-  uint32_t* counts = reinterpret_cast<uint32_t*>(base + w.counts);
-  uint32_t* bcount = reinterpret_cast<uint32_t*>(base + w.bcount);
+  uint32_t* countsA = reinterpret_cast<uint32_t*>(base + w.countsA);
+  uint32_t* pcount = reinterpret_cast<uint32_t*>(base + w.pcount);
+  uint32_t* pstart = reinterpret_cast<uint32_t*>(base + w.pstart);
+  uint64_t* recs = reinterpret_cast<uint64_t*>(base + w.recs);
+  uint32_t* countsB = reinterpret_cast<uint32_t*>(base + w.countsB);
   uint32_t* bstart = reinterpret_cast<uint32_t*>(base + w.bstart);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + w.sorted);
   char* bucket_acc = base + w.bucket_acc;
@@ -556,23 +634,25 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   char* partials = base + w.partials;
   char* wsum = base + w.wsum;
   const uint32_t nkeys = (uint32_t)p.sets * p.nbk;
-  const size_t lds_sort = (size_t)p.nbk * 4;
+  const uint32_t nf = 1u << p.fb;
+  const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
+  const size_t lds_bins = (size_t)p.bins * 4;
 
-  if (lds_sort > 64 * 1024) {
-    VDF_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-    VDF_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-  }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   VDF_TRY_HIP(hipMemsetAsync(bucket_acc, 0, (size_t)nkeys * 128, st));
   VDF_TRY_HIP(hipMemsetAsync(heavy, 0, 4, st));
-  hipLaunchKernelGGL((k_digits<SP>), dim3((p.n + 255) / 256), dim3(256), 0, st,
-                     reinterpret_cast<const uint32_t*>(d_scalars), p.n, is_mont ? 1 : 0, p.c, p.windows, dig);
-  hipLaunchKernelGGL(k_hist, dim3(p.windows * p.K), dim3(1024), lds_sort, st, dig, p.n, p.nbk, p.chunk, p.K, counts);
-  hipLaunchKernelGGL(k_scan_chunks, dim3((nkeys + 255) / 256), dim3(256), 0, st, counts, p.nbk, p.K, p.sets, p.tables,
-                     bcount);
-  hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, bcount, nkeys, bstart);
-  hipLaunchKernelGGL(k_scatter, dim3(p.windows * p.K), dim3(1024), lds_sort, st, dig, p.n, p.nbk, p.chunk, p.K, p.sets,
-                     p.tstride, p.L, counts, bstart, sorted);
+  // pass A
+  hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, sc, p.n, is_mont ? 1 : 0, p.c, p.windows,
+                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
+  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount);
+  hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
+  hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, sc, p.n, is_mont ? 1 : 0, p.c, p.windows,
+                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
+  // pass B
+  hipLaunchKernelGGL(k_fine_hist, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB);
+  hipLaunchKernelGGL(k_fine_scan, dim3(p.bins), dim3(nf), 0, st, countsB, pstart, p.bins, nf, p.split, bstart);
+  hipLaunchKernelGGL(k_fine_scatter, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB, bstart,
+                     sorted);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
