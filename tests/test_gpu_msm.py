@@ -109,7 +109,7 @@ def test_duplicate_and_identity_bases(ctx, cref, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16, 17, 19, 20])
 def test_window_sizes(ctx, cref, curve, c):
     n = 3000
     bases = ctx.bases_generate(curve, 8, n)
@@ -125,7 +125,7 @@ def test_window_sizes(ctx, cref, curve, c):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("c,sets", [(16, 1), (16, 4), (13, 1), (8, 2), (16, 16)])
+@pytest.mark.parametrize("c,sets", [(16, 1), (16, 4), (13, 1), (8, 2), (16, 16), (17, 1), (18, 1), (19, 2), (20, 1)])
 def test_fixed_base_tables(ctx, cref, curve, c, sets):
     n = 5000
     bases = ctx.bases_generate(curve, 13, n)

@@ -1,6 +1,6 @@
 """Timing probe: MSM at 2^k with device-resident scalars (torch), plain and fixed-base-table modes."""
-import sys, time
-sys.path.insert(0, ".")
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import pasta as o
 import vdf_amd as v
@@ -49,3 +49,9 @@ for mode in modes:
     ctx.sync(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"{mode}: n=2^{lg} {ms:.3f} ms/MSM  {n / ms / 1e6:.3f} GPoints/s  HBM-alg {96 * n / ms / 1e6:.1f} GB/s")
+    ctx.set_timing(True); ctx.msm_timing()
+    for _ in range(reps): ctx.msm(bases, sc, n=n, out=out)
+    ctx.sync()
+    s_, a_, t_, tot_, calls = ctx.msm_timing()
+    ctx.set_timing(False)
+    print(f"{mode}: stages sort {s_/calls:.3f} accumulate {a_/calls:.3f} tail {t_/calls:.3f} ms")

@@ -1,6 +1,6 @@
 """prove_step timing at t = 2^k (BASELINE config 3): per-stage breakdown."""
-import sys, time
-sys.path.insert(0, ".")
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pasta as o
 import vdf_amd
 from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode

@@ -262,7 +262,7 @@ int vdf_ctx_sync(vdf_ctx* ctx) {
 
 int vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits) {
   return guarded(ctx, [&]() -> Status {
-    if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return Status{VDF_ERR_BAD_ARG, "window_bits must be 0 or 4..16"};
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 20)) return Status{VDF_ERR_BAD_ARG, "window_bits must be 0 or 4..20"};
     ctx->msm_window = window_bits;
     return Status{};
   });
@@ -318,7 +318,7 @@ int vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t star
 int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets) {
   return guarded(ctx, [&]() -> Status {
     if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
-    if (window_bits < 4 || window_bits > 16) return Status{VDF_ERR_BAD_ARG, "window_bits must be 4..16"};
+    if (window_bits < 4 || window_bits > 20) return Status{VDF_ERR_BAD_ARG, "window_bits must be 4..20"};
     const int windows = (256 + window_bits - 1) / window_bits;
     if (sets <= 0) sets = 1;
     if (sets > windows) sets = windows;

@@ -36,11 +36,12 @@ namespace vdf {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
 static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
-static constexpr int RED_SEG = 2;           // buckets per thread in k_reduce1 (serial depth 2*RED_SEG)
+static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enough to fill the chip, few enough that the
+                                             // per-quad offset multiplication (~30 point ops) stays a small share
 
 struct WsLayout {
   size_t countsA, pcount, pstart, recs, countsB, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
-  uint32_t red_threads_per_set, red_block, red_blocks_per_set;
+  uint32_t red_seg, red_threads_per_set, red_block, red_blocks_per_set;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -61,9 +62,12 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
   w.heavy = take((nkeys + 4) * 4);
-  uint32_t tps = p.nbk / RED_SEG;
-  if (tps == 0) tps = 1;
-  w.red_threads_per_set = tps;                 // logical threads (quads): one per RED_SEG buckets
+  uint32_t seg = 2;                            // buckets per quad in k_reduce1 (serial depth 2*seg), power of two
+  while (seg < 64 && nkeys / seg > RED_QUADS) seg <<= 1;
+  if (seg > p.nbk) seg = p.nbk;
+  w.red_seg = seg;
+  uint32_t tps = p.nbk / seg;
+  w.red_threads_per_set = tps;                 // logical threads (quads): one per red_seg buckets
   w.red_block = tps < 64 ? tps : 64;           // quads per workgroup (256 lanes)
   w.red_blocks_per_set = tps / w.red_block;
   w.partials = take((size_t)p.sets * w.red_blocks_per_set * 128);
@@ -90,9 +94,11 @@ MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
   p.sets = sets;
   p.tables = tables;
   p.nbk = 1u << (c - 1);
-  // two-level sort geometry
+  // two-level sort geometry: pass A splits on the high pb bucket bits (its cursors live in LDS: <= 8192 bins),
+  // pass B on the low fb (<= 10: one thread per fine bucket in k_fine_scan)
   p.fb = (c - 1 < 8) ? c - 1 : 8;
   p.pb = c - 1 - p.fb;
+  while (p.pb > 0 && ((uint32_t)sets << p.pb) > 8192u) { --p.pb; ++p.fb; }
   p.bins = (uint32_t)sets << p.pb;
   size_t chA = (n + 511) / 512;                       // ~2 pass-A workgroups per CU
   chA = (chA + 255) / 256 * 256;
@@ -143,8 +149,7 @@ struct DigitIter {
   }
 };
 template <class SP>
-__device__ __forceinline__ void stage_scalar(uint32_t* limbs, const uint32_t* scalars, uint32_t i, int is_mont) {
-  Fe<SP> s = fe_load<SP>(scalars + (size_t)i * 8);
+__device__ __forceinline__ void stage_scalar(uint32_t* limbs, Fe<SP> s, int is_mont) {
   if (is_mont) s = fe_from_mont(s);
 #pragma unroll
   for (int l = 0; l < 8; ++l) limbs[l * 256 + threadIdx.x] = s.v[l];
@@ -167,8 +172,13 @@ __global__ __launch_bounds__(256) void k_part(const uint32_t* __restrict__ scala
   const uint32_t lo = blockIdx.x * chA;
   const uint32_t hi = (lo + chA < n) ? lo + chA : n;
   const uint32_t fmask = (1u << fb) - 1u;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-    stage_scalar<SP>(limbs, scalars, i, is_mont);
+  uint32_t i = lo + threadIdx.x;
+  Fe<SP> nxt = fe_zero<SP>();
+  if (i < hi) nxt = fe_load<SP>(scalars + (size_t)i * 8);
+  for (; i < hi; i += 256) {
+    const Fe<SP> curs = nxt;
+    if (i + 256 < hi) nxt = fe_load<SP>(scalars + (size_t)(i + 256) * 8);   // next scalar in flight
+    stage_scalar<SP>(limbs, curs, is_mont);
     DigitIter it{limbs + threadIdx.x, 0u};
     for (int w = 0; w < windows; ++w) {
       const uint32_t d = it.next(w, c);
@@ -265,7 +275,7 @@ __device__ __forceinline__ void slice_of(const uint32_t* pstart, uint32_t bin, u
 
 __global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
                                                    uint32_t split, uint32_t nf, uint32_t* __restrict__ countsB) {
-  __shared__ uint32_t h[256];
+  __shared__ uint32_t h[1024];
   const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
   for (uint32_t f = threadIdx.x; f < nf; f += 256) h[f] = 0;
   __syncthreads();
@@ -287,10 +297,10 @@ __global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ 
 // One workgroup per bin, one thread per fine bucket f: exclusive scan over the partition's slices, then a
 // block-wide scan over f.  A bin's buckets are contiguous inside the bin's own region, so
 // bstart[bin*nf + f] = pstart[bin] + (buckets of this bin before f): no global scan over all keys.
-__global__ __launch_bounds__(256) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
-                                                   uint32_t bins, uint32_t nf, uint32_t split,
-                                                   uint32_t* __restrict__ bstart) {
-  __shared__ uint32_t sc[256];
+__global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
+                                                    uint32_t bins, uint32_t nf, uint32_t split,
+                                                    uint32_t* __restrict__ bstart) {
+  __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
   uint32_t run = 0;
   for (uint32_t sp = 0; sp < split; ++sp) {
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(const uint64_t* __restrict
                                                       uint32_t split, uint32_t nf, const uint32_t* __restrict__ countsB,
                                                       const uint32_t* __restrict__ bstart,
                                                       uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cur[256];
+  __shared__ uint32_t cur[1024];
   const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
   for (uint32_t f = threadIdx.x; f < nf; f += 256)
     cur[f] = bstart[(size_t)bin * nf + f] + countsB[(size_t)blockIdx.x * nf + f];
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
 // bucket reduction  sum_{b} (b+1) * B[b]  per set
 // ------------------------------------------------------------------------------------------
 template <class P>
-__global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket_acc, uint32_t nbk,
+__global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket_acc, uint32_t nbk, uint32_t nseg,
                                                  uint32_t threads_per_set, uint32_t blocks_per_set,
                                                  char* __restrict__ partials) {
   extern __shared__ __align__(16) char lds_raw[];
@@ -503,7 +513,6 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
   const uint32_t set = blockIdx.x / blocks_per_set;
   const uint32_t blk = blockIdx.x % blocks_per_set;
   const uint32_t seg = blk * nlog + lt;                            // segment index within the set
-  const uint32_t nseg = (nbk < (uint32_t)RED_SEG) ? nbk : (uint32_t)RED_SEG;
   const uint32_t base = seg * nseg;                                // first bucket of the segment
   QPoint<P> run = qpoint_identity<P>(), tot = qpoint_identity<P>();
   if (seg < threads_per_set) {
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
       run = qpoint_add<P>(run, qpoint_load<P>(bp + (size_t)l * 128));
       tot = qpoint_add<P>(tot, run);                               // tot = sum (l+1) * B[base+l]
     }
-    if (base) {                                                    // + base * run (double-and-add, base < 2^16)
+    if (base) {                                                    // + base * run (double-and-add, base < 2^19)
       QPoint<P> m = qpoint_identity<P>();
       for (int bit = 31 - __builtin_clz(base); bit >= 0; --bit) {
         m = qpoint_dbl<P>(m);
@@ -661,7 +670,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
   hipLaunchKernelGGL((k_reduce1<P>), dim3(p.sets * w.red_blocks_per_set), dim3(w.red_block * 4),
-                     (size_t)w.red_block * 128, st, bucket_acc, p.nbk, w.red_threads_per_set, w.red_blocks_per_set,
+                     (size_t)w.red_block * 128, st, bucket_acc, p.nbk, w.red_seg, w.red_threads_per_set, w.red_blocks_per_set,
                      partials);
   hipLaunchKernelGGL((k_reduce2<P>), dim3(p.sets), dim3(256), 0, st, partials, w.red_blocks_per_set, wsum);
   hipLaunchKernelGGL((k_final<P>), dim3(1), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
