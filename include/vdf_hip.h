@@ -68,6 +68,7 @@ int  vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream);
 void* vdf_ctx_get_stream(vdf_ctx* ctx);
 /* async != 0: calls whose buffers are all device-resident return after enqueueing. */
 int  vdf_ctx_set_async(vdf_ctx* ctx, int async);
+int  vdf_ctx_get_async(vdf_ctx* ctx, int* async);
 int  vdf_ctx_sync(vdf_ctx* ctx);
 int  vdf_ctx_device(vdf_ctx* ctx);                      /* the HIP device ordinal this context drives */
 const char* vdf_last_error(vdf_ctx* ctx);              /* ctx may be NULL: last create error */
@@ -144,6 +145,33 @@ int  vdf_axpy(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* r, const v
 int  vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const vdf_fe* i0, uint64_t t,
                          vdf_fe* W_segment);
 
+/* ---- fused step operations (one kernel launch each) --------------------------------------- */
+/* The three entry points below do what a sequence of the calls above does, in a single launch and with
+ * every single-field-element operand read from HOST memory and passed as a kernel argument: no staging
+ * copy, no stream synchronisation.  They exist because one NIFS fold at 2^16 iterations is ~1 ms of GPU
+ * work, so a dozen launches and half a dozen 32-byte uploads per step are a measurable share of it.
+ * Vector operands must already be in device memory (VDF_ERR_BAD_ARG otherwise); results are identical,
+ * bit for bit, to the unfused calls. */
+
+/* The whole fresh column vector z = (W, u, X) of the exposed-IO MinRoot step circuit:
+ *   z = [ z_in[0..3) | new_x, tmp1, tmp2, new_y per round (4t, as vdf_minroot_witness) | i0 | u | X[0..6) ]
+ * i.e. vdf_minroot_witness plus the seven scalar stores around it.  z has 3 + 4t + 1 + 1 + 6 elements.
+ * z_in, i0, u, X: host memory. */
+int  vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3],
+                        const vdf_fe* i0, const vdf_fe* u, const vdf_fe X[6], vdf_fe* z);
+/* vdf_spmv3(shape, z2) followed by vdf_cross_term(Az1, Bz1, Cz1, Az2, Bz2, Cz2, u1): writes Az2, Bz2, Cz2
+ * (num_cons each) and T.  u1: host memory.  (nova-snark NIFS::prove -> commit_T, K4 + K5.) */
+int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
+                         const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T);
+/* acc[i] <- acc[i] + r * add[i], i < k <= 8, n[i] elements each: k vdf_axpy calls with a common r (host
+ * memory).  The fold of a relaxed witness is k = 2 (W, E); a prover that keeps A z, B z, C z of the running
+ * instance folds them too (they are linear in z), k = 5, instead of recomputing three sparse products. */
+int  vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* const acc[], const vdf_fe* const add[],
+                   const size_t n[]);
+/* Stream order across contexts of one device: work enqueued on `ctx` after this call starts only after
+ * everything enqueued on `other` so far has finished (an event; the host does not wait). */
+int  vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other);
+
 /* ---- utilities the host layer and the tests need ---------------------------------------- */
 /* Element-wise Montgomery product / conversions, n elements (test + host plumbing). */
 int  vdf_fe_mul(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* b, size_t n, vdf_fe* out);
@@ -156,6 +184,11 @@ int  vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int it
 int  vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out);
 int  vdf_dev_free(vdf_ctx* ctx, void* p);
 int  vdf_dev_memcpy(vdf_ctx* ctx, void* dst, const void* src, size_t bytes);   /* any direction */
+/* Pinned host memory mapped into the device's address space.  Calls treat such a pointer like device memory
+ * (used in place, no staging, no implicit synchronisation): a kernel's small result -- an MSM's point -- lands
+ * in host memory by itself and is readable after vdf_ctx_sync, with no device-to-host copy. */
+int  vdf_host_alloc(vdf_ctx* ctx, size_t bytes, void** out);
+int  vdf_host_free(vdf_ctx* ctx, void* p);
 int  vdf_dev_memset(vdf_ctx* ctx, void* dst, int value, size_t bytes);
 /* Library build identification ("vdf_hip gfx950 <date>"). */
 const char* vdf_version(void);

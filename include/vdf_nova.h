@@ -89,9 +89,9 @@ int  vdf_nova_proof_instance(const vdf_proof* proof, vdf_affine* comm_W, vdf_aff
 int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, const void** d_W, const void** d_E);
 /* per-step record k: fresh commitment, cross-term commitment, challenge, public IO */
 int  vdf_nova_proof_step_record(const vdf_proof* proof, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]);
-/* wall-clock of the last prove_step by stage, milliseconds: witness, commit_W (time spent waiting for
- * it: the W commitment runs on a second stream under the fold's other work), spmv, cross_term,
- * commit_T, fold (axpy), host (transcript + instance fold), total */
+/* host wall-clock of the last prove_step, milliseconds.  A step is enqueued asynchronously, so the slots are
+ * launch times except [4]: witness launch, commit_W launch, cross-term launch, commit_T launch, wait (previous
+ * step's host instance fold, then both commitments), transcript + fold launch, bookkeeping, total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 const char* vdf_nova_last_error(void);
 

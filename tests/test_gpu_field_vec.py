@@ -166,3 +166,116 @@ def test_fold_linearity_property_full_size(ctx):
     d = np.zeros_like(a)
     ctx.axpy(o.FIELD_FQ, s1, minus_one, a, n, d)
     assert np.array_equal(d, s2)
+
+
+# ---- fused step operations: must equal the composition of the unfused references, bit for bit ----------
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view("<u8")
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("t", [1, 10, 1000, 65536])
+def test_step_z_equals_witness_plus_scalar_stores(ctx, cref, field, t):
+    L, m = cref.lib(), o.modulus(field)
+    st = mont([o.rand_fe(t + 3, 0, m), 0, 7], m)
+    so, tr = cref.fe_array(3), cref.fe_array(2 * (t + 1))
+    L.ref_minroot_eval(field, 1, cref.p(st), t, cref.p(so), cref.p(tr))
+    W = cref.fe_array(4 * t + 1)
+    L.ref_step_witness(field, cref.p(so), t, cref.p(W))
+    rng = np.random.default_rng(t)
+    z_in, u, X = rand_limbs(rng, 3), rand_limbs(rng, 1), rand_limbs(rng, 6)
+    i0 = st[2:3].copy()
+    exp = np.concatenate([z_in, W, u, X])
+    assert np.array_equal(W[-1], i0[0])
+    z = _dev(np.zeros_like(exp))
+    ctx.minroot_step_z(field, _dev(tr), t, z_in, i0, u, X, z)
+    ctx.sync()
+    assert np.array_equal(_host(z), exp)
+
+
+@pytest.mark.parametrize("t", [5, 64, 4096])
+def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
+    field, m = o.FIELD_FQ, o.Q
+    sh = o.step_circuit_shape(t, field)
+    mats = [_shape_arrays(e, m) for e in (sh.A, sh.B, sh.C)]
+    ncols, nc = sh.num_vars + 1 + sh.num_io, sh.num_cons
+    shape = ctx.shape_create(field, nc, ncols, mats)
+    rng = np.random.default_rng(t + 100)
+    z2 = rand_limbs(rng, ncols)
+    abc1 = [rand_limbs(rng, nc) for _ in range(3)]
+    u1 = rand_limbs(rng, 1)
+    abc2 = []
+    for rows, cols, vals in mats:
+        e = cref.fe_array(nc)
+        cref.lib().ref_spmv(field, cref.p(rows), cref.p(cols), cref.p(vals), len(rows), cref.p(z2), nc, cref.p(e))
+        abc2.append(e)
+    expT = cref.fe_array(nc)
+    cref.lib().ref_cross_term(field, *(cref.p(x) for x in abc1 + abc2), cref.p(u1), nc, cref.p(expT))
+    d1 = [_dev(x) for x in abc1]
+    d2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    dT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term(shape, _dev(z2), *d1, u1, *d2, dT)
+    ctx.sync()
+    for got, e in zip(d2, abc2):
+        assert np.array_equal(_host(got), e)
+    assert np.array_equal(_host(dT), expT)
+    # scalars of fused calls must be host memory; vectors device memory
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term(shape, z2, *d1, u1, *d2, dT)
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term(shape, _dev(z2), *d1, _dev(u1), *d2, dT)
+    shape.free()
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_fold_many_equals_axpy_per_vector(ctx, cref, field):
+    rng = np.random.default_rng(42)
+    sizes = [262155, 196615, 1, 0, 255, 256, 257, 70000]
+    r = rand_limbs(rng, 1)
+    acc = [rand_limbs(rng, n) for n in sizes]
+    add = [rand_limbs(rng, n) for n in sizes]
+    exp = []
+    for a, b, n in zip(acc, add, sizes):
+        e = np.zeros_like(a)
+        cref.lib().ref_axpy(field, cref.p(a), cref.p(r), cref.p(b), n, cref.p(e))
+        exp.append(e)
+    dacc = [_dev(a) if len(a) else None for a in acc]
+    dadd = [_dev(b) if len(b) else None for b in add]
+    ctx.fold_many(field, r, dacc, dadd, sizes)
+    ctx.sync()
+    for d, e, n in zip(dacc, exp, sizes):
+        if n:
+            assert np.array_equal(_host(d), e)
+    with pytest.raises(Exception):
+        ctx.fold_many(field, r, dacc * 2, dadd * 2, sizes * 2)      # more than 8 vectors
+
+
+def test_ctx_wait_orders_two_contexts(ctx):
+    """vdf_ctx_wait: work on the second context sees the results of the first without a host sync."""
+    import vdf_amd
+    n = 1 << 16
+    rng = np.random.default_rng(9)
+    a, b = rand_limbs(rng, n), rand_limbs(rng, n)
+    ctx2 = vdf_amd.Context(ctx.device)
+    was = ctx.get_async()
+    ctx.set_async(True); ctx2.set_async(True)
+    try:
+        da, db = _dev(a), _dev(b)
+        d1, d2 = _dev(np.zeros_like(a)), _dev(np.zeros_like(a))
+        ctx.fe_mul(o.FIELD_FQ, da, db, n, d1)          # d1 = a*b on ctx
+        ctx2.wait(ctx)
+        ctx2.fe_mul(o.FIELD_FQ, d1, db, n, d2)         # d2 = d1*b on ctx2, ordered after the first
+        ctx2.sync()
+        exp1, exp2 = np.zeros_like(a), np.zeros_like(a)
+        ctx.set_async(False)
+        ctx.fe_mul(o.FIELD_FQ, a, b, n, exp1)
+        ctx.fe_mul(o.FIELD_FQ, exp1, b, n, exp2)
+        assert np.array_equal(_host(d2), exp2)
+    finally:
+        ctx.set_async(was)
+        ctx2.close()

@@ -14,8 +14,16 @@ initial = State.from_ints(FIELD_FQ, o.rand_fe(1, 0, o.Q), 0, 0)
 t0 = time.time(); z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, n, initial)
 print("forward evaluation of %d x 2^%d rounds: %.2f s (host, sequential)" % (n, lg, time.time() - t0))
 circuits.upload(ctx)
+ctx.set_async(True)
 proof = None
 for k in range(n):
     t0 = time.perf_counter(); proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0); dt = time.perf_counter() - t0
     print("step %d: %.2f ms " % (k, dt * 1e3), {a: round(b, 3) for a, b in proof.last_step_ms().items()})
+ctx.sync()
+proof.free()
+proof = NovaVDFProof.prove_step(pp, None, circuits, 0, z0); ctx.sync()
+t0 = time.perf_counter()
+for k in range(1, n): proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+ctx.sync(); dt = (time.perf_counter() - t0) / (n - 1)
+print("steady state: %.3f ms/step = %.1f prove_step/s" % (dt * 1e3, 1 / dt))
 t0 = time.time(); ok = proof.verify(pp, n, z0, [initial.x, initial.y, initial.i]); print("verify", ok, "%.1f ms" % ((time.time() - t0) * 1e3))

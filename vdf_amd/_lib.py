@@ -24,7 +24,9 @@ PROTOTYPES = {
     "vdf_ctx_set_stream": (_i, [_vp, _vp]),
     "vdf_ctx_get_stream": (_vp, [_vp]),
     "vdf_ctx_set_async": (_i, [_vp, _i]),
+    "vdf_ctx_get_async": (_i, [_vp, C.POINTER(_i)]),
     "vdf_ctx_sync": (_i, [_vp]),
+    "vdf_ctx_wait": (_i, [_vp, _vp]),
     "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
@@ -48,6 +50,9 @@ PROTOTYPES = {
     "vdf_cross_term": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vdf_axpy": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "vdf_minroot_witness": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_fe_mul": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     "vdf_fe_to_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_from_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
@@ -56,6 +61,8 @@ PROTOTYPES = {
     "vdf_dev_free": (_i, [_vp, _vp]),
     "vdf_dev_memcpy": (_i, [_vp, _vp, _vp, _sz]),
     "vdf_dev_memset": (_i, [_vp, _vp, _i, _sz]),
+    "vdf_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "vdf_host_free": (_i, [_vp, _vp]),
     "vdf_version": (C.c_char_p, []),
 }
 

@@ -4,6 +4,7 @@
 #include <map>
 #include <array>
 #include <new>
+#include <utility>
 #include "internal.h"
 #include "fe.cuh"
 
@@ -15,8 +16,19 @@ thread_local std::string g_create_err;
 std::mutex g_default_mu;
 vdf_ctx* g_default_ctx = nullptr;
 
+// pinned, device-mapped host allocations handed out by vdf_host_alloc: kernels use them in place
+std::mutex g_host_mu;
+std::vector<std::pair<const char*, size_t>> g_host_allocs;
+bool ptr_is_mapped_host(const void* p) {
+  std::lock_guard<std::mutex> lock(g_host_mu);
+  for (auto& a : g_host_allocs)
+    if ((const char*)p >= a.first && (const char*)p < a.first + a.second) return true;
+  return false;
+}
+
 bool ptr_is_device(const void* p) {
   if (!p) return false;
+  if (ptr_is_mapped_host(p)) return true;
   hipPointerAttribute_t a;
   hipError_t e = hipPointerGetAttributes(&a, p);
   if (e != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -29,6 +41,7 @@ struct Staging {
   std::vector<void*> temps;
   struct Out { void* host; void* dev; size_t bytes; };
   std::vector<Out> outs;
+  Out pinned_out{nullptr, nullptr, 0};
   bool any_host = false;
   size_t small_used = 0;     // bytes taken from the context's small staging pool (calls hold ctx->mu)
   explicit Staging(vdf_ctx* c) : ctx(c) {}
@@ -60,6 +73,13 @@ struct Staging {
     if (!p) return Status{VDF_ERR_BAD_ARG, "null output pointer"};
     if (ptr_is_device(p)) { *dev = p; return Status{}; }
     any_host = true;
+    // tiny results (an MSM's point): the kernel stores into pinned, device-mapped host memory, so the call ends
+    // with one stream synchronisation and a host-side copy instead of a device-to-host transfer of its own
+    if (bytes <= vdf_ctx::PINNED_OUT_BYTES && ctx->h_out && !pinned_out.host) {
+      pinned_out = {p, ctx->h_out, bytes};
+      *dev = ctx->h_out_dev;
+      return Status{};
+    }
     void* t = nullptr;
     VDF_TRY(temp(bytes, &t));
     outs.push_back({p, t, bytes});
@@ -69,6 +89,7 @@ struct Staging {
   Status finish() {
     for (auto& o : outs) VDF_TRY_HIP(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (any_host || !ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    if (pinned_out.host) std::memcpy(pinned_out.host, pinned_out.dev, pinned_out.bytes);
     return Status{};
   }
 };
@@ -214,6 +235,15 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&c->d_out, 256);
   if (e == hipSuccess) e = hipMalloc(&c->small_pool, vdf_ctx::SMALL_POOL_BYTES);
+  if (e == hipSuccess) {
+    // optional fast path; without it small results take the ordinary staged copy
+    if (hipHostMalloc(&c->h_out, vdf_ctx::PINNED_OUT_BYTES, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&c->h_out_dev, c->h_out, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (c->h_out) (void)hipHostFree(c->h_out);
+      c->h_out = c->h_out_dev = nullptr;
+    }
+  }
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
   if (e != hipSuccess) {
@@ -234,8 +264,10 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->small_pool) (void)hipFree(ctx->small_pool);
+  if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -254,6 +286,14 @@ void* vdf_ctx_get_stream(vdf_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ct
 
 int vdf_ctx_set_async(vdf_ctx* ctx, int async) {
   return guarded(ctx, [&]() -> Status { ctx->async = async != 0; return Status{}; });
+}
+
+int vdf_ctx_get_async(vdf_ctx* ctx, int* async) {
+  return guarded(ctx, [&]() -> Status {
+    if (!async) return Status{VDF_ERR_BAD_ARG, "null output"};
+    *async = ctx->async ? 1 : 0;
+    return Status{};
+  });
 }
 
 int vdf_ctx_sync(vdf_ctx* ctx) {
@@ -541,6 +581,66 @@ int vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const v
   });
 }
 
+// ---- fused step operations ------------------------------------------------------------------------
+int vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0,
+                       const vdf_fe* u, const vdf_fe X[6], vdf_fe* z) {
+  return guarded(ctx, [&]() -> Status {
+    if (t == 0 || t >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
+    if (!z_in || !i0 || !u || !X) return Status{VDF_ERR_BAD_ARG, "null scalar operand"};
+    if (ptr_is_device(z_in) || ptr_is_device(i0) || ptr_is_device(u) || ptr_is_device(X))
+      return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    if (!ptr_is_device(trace_xy) || !ptr_is_device(z)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    VDF_TRY(vdf::vec_step_z(field, trace_xy, t, z_in, i0, u, X, z, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
+                        const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status {
+    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+    if (!u1 || ptr_is_device(u1)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    const void* vec[8] = {z2, Az1, Bz1, Cz1, Az2, Bz2, Cz2, T};
+    for (const void* v : vec)
+      if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
+                                u1, shape->num_cons, Az2, Bz2, Cz2, T, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* const acc[], const vdf_fe* const add[],
+                  const size_t n[]) {
+  return guarded(ctx, [&]() -> Status {
+    if (k < 0 || k > 8) return Status{VDF_ERR_BAD_ARG, "k must be 0..8"};
+    if (k == 0) return Status{};
+    if (!r || !acc || !add || !n) return Status{VDF_ERR_BAD_ARG, "null argument"};
+    if (ptr_is_device(r)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    void* a[8]; const void* b[8];
+    for (int i = 0; i < k; ++i) {
+      if (n[i] && (!ptr_is_device(acc[i]) || !ptr_is_device(add[i])))
+        return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+      a[i] = acc[i]; b[i] = add[i];
+    }
+    VDF_TRY(vdf::vec_fold_many(field, r, k, a, b, n, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other) {
+  if (!other || other == ctx) return ctx ? VDF_OK : VDF_ERR_BAD_ARG;
+  return guarded(ctx, [&]() -> Status {
+    if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
+    if (!ctx->wait_ev) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
+    VDF_TRY_HIP(hipEventRecord(ctx->wait_ev, other->stream));
+    VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, ctx->wait_ev, 0));
+    return Status{};
+  });
+}
+
 int vdf_fe_mul(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* b, size_t n, vdf_fe* out) {
   return guarded(ctx, [&]() -> Status {
     Staging st(ctx);
@@ -601,6 +701,41 @@ int vdf_dev_free(vdf_ctx* ctx, void* p) {
     if (!p) return Status{};
     VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     VDF_TRY_HIP(hipFree(p));
+    return Status{};
+  });
+}
+
+int vdf_host_alloc(vdf_ctx* ctx, size_t bytes, void** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    void* h = nullptr;
+    VDF_TRY_HIP(hipHostMalloc(&h, bytes ? bytes : 1, hipHostMallocMapped));
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || d != h) {      // unified addressing is what "in place" relies on
+      (void)hipGetLastError();
+      (void)hipHostFree(h);
+      return Status{VDF_ERR_DEVICE, "pinned host memory is not addressable in place by the device"};
+    }
+    std::lock_guard<std::mutex> lock(g_host_mu);
+    g_host_allocs.emplace_back((const char*)h, bytes ? bytes : 1);
+    *out = h;
+    return Status{};
+  });
+}
+
+int vdf_host_free(vdf_ctx* ctx, void* p) {
+  return guarded(ctx, [&]() -> Status {
+    if (!p) return Status{};
+    {
+      std::lock_guard<std::mutex> lock(g_host_mu);
+      bool found = false;
+      for (size_t i = 0; i < g_host_allocs.size(); ++i)
+        if (g_host_allocs[i].first == (const char*)p) { g_host_allocs.erase(g_host_allocs.begin() + i); found = true; break; }
+      if (!found) return Status{VDF_ERR_BAD_ARG, "not a vdf_host_alloc pointer"};
+    }
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    VDF_TRY_HIP(hipHostFree(p));
     return Status{};
   });
 }

@@ -77,6 +77,24 @@ Aff jac_to_aff(const vdf_jac& j, const Field& F) {
   return r;
 }
 
+// Two Jacobian points to affine with one shared field inversion (Montgomery's trick).
+void jac_to_aff2(const vdf_jac& ja, const vdf_jac& jb, const Field& F, Aff* a, Aff* b) {
+  Fe Za, Zb;
+  memcpy(Za.l, ja.z.l, 32); memcpy(Zb.l, jb.z.l, 32);
+  if (Za.is_zero() || Zb.is_zero()) { *a = jac_to_aff(ja, F); *b = jac_to_aff(jb, F); return; }
+  const Fe inv_ab = inverse(mul(Za, Zb, F), F);
+  const Fe zia = mul(inv_ab, Zb, F), zib = mul(inv_ab, Za, F);
+  auto fin = [&](const vdf_jac& j, const Fe& zi, Aff* o) {
+    Fe X, Y;
+    memcpy(X.l, j.x.l, 32); memcpy(Y.l, j.y.l, 32);
+    const Fe zi2 = sqr(zi, F);
+    o->x = mul(X, zi2, F);
+    o->y = mul(Y, mul(zi2, zi, F), F);
+  };
+  fin(ja, zia, a);
+  fin(jb, zib, b);
+}
+
 // ---- Keccak-f[1600] / SHAKE256 (FIPS 202) ---------------------------------------------------------
 static inline uint64_t rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 static void keccak_f(uint64_t s[25]) {

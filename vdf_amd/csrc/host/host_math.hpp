@@ -131,6 +131,7 @@ Pt pt_add(const Pt& a, const Pt& b, const Field& F);
 Pt pt_mul(const Pt& a, const uint64_t k[4], int bits, const Field& F);
 Aff pt_to_aff(const Pt& a, const Field& F);
 Aff jac_to_aff(const vdf_jac& j, const Field& F);
+void jac_to_aff2(const vdf_jac& ja, const vdf_jac& jb, const Field& F, Aff* a, Aff* b);
 
 // ---- SHAKE256 (FIPS 202) for the transcript -----------------------------------------------------
 struct Shake256 {

@@ -177,13 +177,14 @@ struct vdf_proof {
   void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
   void* d_trace = nullptr;
   void* d_small = nullptr;   // staging for r, u1, i0 (3 elements)
-  void* d_commw = nullptr;   // Jacobian result slot of the overlapped W commitment
+  vdf_jac* h_comm = nullptr; // pinned, device-mapped result slots: [0] = commitment of W2, [1] = commitment of T
   std::vector<StepRecord> steps;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // The O(1) instance fold (two 128-bit scalar multiplications on the host) of step k runs on a worker
-  // thread under the GPU work of step k+1; everything that reads comm_W / comm_E joins it first.
-  mutable std::future<void> pending;
-  void join() const { if (pending.valid()) pending.get(); }
+  // The O(1) instance fold of step k (two 128-bit scalar multiplications on the host) is deferred: step k+1
+  // performs it while the GPU works on its commitments; everything else that reads comm_W / comm_E joins first.
+  struct Deferred { bool valid = false; Aff cW0, cE0, cw, cT; uint64_t r[4]; };
+  mutable Deferred pending;
+  void join() const;
 };
 
 namespace {
@@ -252,7 +253,7 @@ int alloc_proof_buffers(vdf_proof* p) {
   for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
   HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
   HIPCALL(ctx, vdf_dev_alloc(ctx, 3 * 32, &p->d_small));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, 256, &p->d_commw));
+  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&p->h_comm));
   HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
   return VDF_OK;
 }
@@ -264,6 +265,14 @@ Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b) {      
 }
 
 }  // namespace
+
+void vdf_proof::join() const {
+  if (!pending.valid) return;
+  vdf_proof* self = const_cast<vdf_proof*>(this);
+  self->comm_W = fold_commitment(pending.cW0, pending.r, pending.cw);
+  self->comm_E = fold_commitment(pending.cE0, pending.r, pending.cT);
+  pending.valid = false;
+}
 
 extern "C" {
 
@@ -465,8 +474,13 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   }
   const double t0 = now_ms();
   const size_t nv = pp->num_vars, nc = pp->num_cons;
-  char* z2 = (char*)p->d_z2;
-  // --- fresh witness: W2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i] -------------------
+  // The step is enqueued asynchronously: every call below is stream-ordered, and the host waits only for the
+  // two commitments the transcript needs.  The caller's synchronisation mode is restored on the way out.
+  int was_async = 0;
+  HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
+  HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
+  struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
+  // --- fresh z2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i | 1 | X2] in one launch ------------
   const void* d_trace = c.d_trace;
   if (!d_trace) {
     HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_trace, c.trace_xy.data(), (pp->t + 1) * 64));
@@ -474,40 +488,28 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   }
   Fe X2[NUM_IO] = {c.result.x, c.result.y, c.result.i, c.input.x, c.input.y, c.input.i};
   {
-    // one small upload: z_in, [1 | X2], i0
-    Fe head[3] = {c.result.x, c.result.y, c.result.i};
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, z2, head, 96));
-    Fe tail[1 + NUM_IO];
-    tail[0] = one(F);
-    for (int j = 0; j < NUM_IO; ++j) tail[1 + j] = X2[j];
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, z2 + nv * 32, tail, sizeof(tail)));
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_small + 64, &c.input.i, 32));
+    const Fe head[3] = {c.result.x, c.result.y, c.result.i};
+    const Fe u2 = one(F);
+    HIPCALL(ctx, vdf_minroot_step_z(ctx, PRIMARY_FIELD, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)head,
+                                    (const vdf_fe*)&c.input.i, (const vdf_fe*)&u2, (const vdf_fe*)X2, (vdf_fe*)p->d_z2));
   }
-  HIPCALL(ctx, vdf_minroot_witness(ctx, PRIMARY_FIELD, (const vdf_fe*)d_trace, (const vdf_fe*)((char*)p->d_small + 64), pp->t,
-                                   (vdf_fe*)(z2 + 96)));
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
   const double t1 = now_ms();
-  // --- commit W2: enqueued on the second stream; its result is only needed for the challenge ---------
   vdf_ctx* cctx = pp->ctx2 ? pp->ctx2 : ctx;
-  vdf_jac jw;
-  HIPCALL(cctx, vdf_msm(cctx, pp->gens, 0, (const vdf_fe*)z2, nv, 1, pp->ctx2 ? (vdf_jac*)p->d_commw : &jw));
-  auto wait_commit_w = [&](Aff* out) -> int {
-    if (pp->ctx2) {
-      HIPCALL(pp->ctx2, vdf_ctx_sync(pp->ctx2));
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, &jw, p->d_commw, sizeof(jw)));
-    }
-    *out = jac_to_aff(jw, field_fp());
-    return VDF_OK;
-  };
+  vdf_jac* jw = &p->h_comm[0];
+  vdf_jac* jt = &p->h_comm[1];
   Aff comm_w;
-  double t2 = now_ms();
   StepRecord rec;
   for (int j = 0; j < NUM_IO; ++j) rec.X[j] = X2[j];
-  double t3 = t2, t4 = t2, t5 = t2, t6 = t2, wait_w = 0;
+  double t2 = t1, t3 = t1, t4 = t1, t5 = t1, t6 = t1;
   if (first) {
-    { const double a0 = now_ms(); int rcw = wait_commit_w(&comm_w); if (rcw != VDF_OK) return rcw; wait_w = now_ms() - a0; }
-    // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step
+    // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step.  A z, B z, C z of
+    // the running instance are computed here once and folded from then on (they are linear in z).
+    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_z2, nv, 1, jw));
     HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_z1, p->d_z2, pp->ncols * 32));
+    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    t2 = now_ms();
+    comm_w = jac_to_aff(*jw, field_fp());
     p->comm_W = comm_w;
     p->comm_E.x = p->comm_E.y = zero();
     p->u = one(F);
@@ -516,44 +518,43 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
     rec.r = zero();
     t6 = now_ms();
   } else {
-    // --- NIFS.prove: multiply_vec x 2, cross term, commit T, challenge, fold ------
-    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
-    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z2, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4], (vdf_fe*)p->d_abc[5]));
+    // --- NIFS.prove.  Launch order: multiply_vec(z2) + cross term (one launch, before the
+    // commitments fill the GPU), commit W2 on the second stream, commit T on the first; both results land in
+    // pinned host memory.  While the GPU works the host finishes the previous step's instance fold.
+    HIPCALL(ctx, vdf_nifs_cross_term(ctx, pp->shape, (const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1],
+                                     (const vdf_fe*)p->d_abc[2], (const vdf_fe*)&p->u, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4],
+                                     (vdf_fe*)p->d_abc[5], (vdf_fe*)p->d_T));
+    t2 = now_ms();
+    if (pp->ctx2) HIPCALL(pp->ctx2, vdf_ctx_wait(pp->ctx2, ctx));
+    HIPCALL(cctx, vdf_msm(cctx, pp->gens, 0, (const vdf_fe*)p->d_z2, nv, 1, jw));
     t3 = now_ms();
-    HIPCALL(ctx, vdf_cross_term(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1], (const vdf_fe*)p->d_abc[2],
-                                (const vdf_fe*)p->d_abc[3], (const vdf_fe*)p->d_abc[4], (const vdf_fe*)p->d_abc[5],
-                                (const vdf_fe*)&p->u, nc, (vdf_fe*)p->d_T));
+    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, jt));
     t4 = now_ms();
-    vdf_jac jt;
-    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, &jt));
-    const Aff comm_T = jac_to_aff(jt, field_fp());
-    t5 = now_ms();
-    { int rcw = wait_commit_w(&comm_w); if (rcw != VDF_OK) return rcw; wait_w = now_ms() - t5; t5 = now_ms(); }
     p->join();                                                   // the previous step's instance fold
+    if (pp->ctx2) HIPCALL(pp->ctx2, vdf_ctx_sync(pp->ctx2));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    t5 = now_ms();
+    Aff comm_T;
+    jac_to_aff2(*jw, *jt, field_fp(), &comm_w, &comm_T);         // one shared inversion
     uint64_t r_raw[4];
     const Fe r = challenge(pp, p->comm_W, p->comm_E, p->u, p->X, comm_w, X2, comm_T, r_raw);
-    // witness fold on the device: W <- W + r*W2, E <- E + r*T
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_small, &r, 32));
-    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_z1, (const vdf_fe*)p->d_small, (const vdf_fe*)p->d_z2, nv, (vdf_fe*)p->d_z1));
-    HIPCALL(ctx, vdf_axpy(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_E, (const vdf_fe*)p->d_small, (const vdf_fe*)p->d_T, nc, (vdf_fe*)p->d_E));
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
-    t6 = now_ms();
-    // instance fold on the host (O(1)): commitments (deferred to a worker thread), u, X
+    // witness fold on the device, one launch: z1 += r*z2 (W, and with it u and X), E += r*T, and the running
+    // A z, B z, C z += r * (A z2, B z2, C z2)
     {
-      const Aff cW0 = p->comm_W, cE0 = p->comm_E;
-      uint64_t rr[4] = {r_raw[0], r_raw[1], r_raw[2], r_raw[3]};
-      vdf_proof* pr = p;
-      p->pending = std::async(std::launch::async, [pr, cW0, cE0, rr, comm_w, comm_T]() {
-        pr->comm_W = fold_commitment(cW0, rr, comm_w);
-        pr->comm_E = fold_commitment(cE0, rr, comm_T);
-      });
+      vdf_fe* acc[5] = {(vdf_fe*)p->d_z1, (vdf_fe*)p->d_E, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]};
+      const vdf_fe* add[5] = {(const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_T, (const vdf_fe*)p->d_abc[3],
+                              (const vdf_fe*)p->d_abc[4], (const vdf_fe*)p->d_abc[5]};
+      const size_t len[5] = {pp->ncols, nc, nc, nc, nc};
+      HIPCALL(ctx, vdf_fold_many(ctx, PRIMARY_FIELD, (const vdf_fe*)&r, 5, acc, add, len));
     }
+    t6 = now_ms();
+    // instance fold on the host (O(1)): u and X now, the two commitments deferred (vdf_proof::join)
+    p->pending.cW0 = p->comm_W; p->pending.cE0 = p->comm_E;
+    p->pending.cw = comm_w; p->pending.cT = comm_T;
+    memcpy(p->pending.r, r_raw, 32);
+    p->pending.valid = true;
     p->u = add(p->u, r, F);
     for (int j = 0; j < NUM_IO; ++j) p->X[j] = add(p->X[j], mul(r, X2[j], F), F);
-    Fe utail[1 + NUM_IO];
-    utail[0] = p->u;
-    for (int j = 0; j < NUM_IO; ++j) utail[1 + j] = p->X[j];
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z1 + nv * 32, utail, sizeof(utail)));
     rec.comm_T = comm_T;
     rec.r = r;
   }
@@ -562,9 +563,10 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   p->i += 1;
   p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
   const double t7 = now_ms();
-  p->ms[0] = t1 - t0; p->ms[1] = (t2 - t1) + wait_w; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3;
-  p->ms[4] = first ? 0.0 : t5 - t4 - wait_w;
-  p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
+  // witness launch | cross-term launch | commit_W launch | commit_T launch | host fold of the previous step +
+  // wait for both commitments | transcript + fold launch | bookkeeping | total
+  p->ms[0] = t1 - t0; p->ms[1] = t3 - t2; p->ms[2] = t2 - t1; p->ms[3] = t4 - t3;
+  p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
   *proof = p;
   return VDF_OK;
 }
@@ -589,8 +591,9 @@ void vdf_nova_proof_free(vdf_proof* p) {
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
     void* bufs[] = {p->d_z1, p->d_z2, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4],
-                    p->d_abc[5], p->d_trace, p->d_small, p->d_commw};
+                    p->d_abc[5], p->d_trace, p->d_small};
     for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
+    if (p->h_comm) vdf_host_free(ctx, p->h_comm);
   }
   delete p;
 }
@@ -607,6 +610,7 @@ int vdf_nova_proof_instance(const vdf_proof* p, vdf_affine* comm_W, vdf_affine* 
 }
 int vdf_nova_proof_witness_ptrs(const vdf_proof* p, const void** d_W, const void** d_E) {
   if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+  HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
   if (d_W) *d_W = p->d_z1;
   if (d_E) *d_E = p->d_E;
   return VDF_OK;

@@ -21,12 +21,16 @@ struct vdf_ctx {
   void* d_out = nullptr;       // 128 B result slot
   static constexpr size_t SMALL_POOL_BYTES = 16 * 1024;
   void* small_pool = nullptr;  // staging for tiny host operands (challenge scalars, result points)
+  static constexpr size_t PINNED_OUT_BYTES = 256;
+  void* h_out = nullptr;       // pinned host memory mapped into the device: result slot kernels write directly
+  void* h_out_dev = nullptr;   // its device-side address
   int num_cus = 256;
   // stage timing (bench.py roofline leg)
   bool timing = false;
   struct TimedCall { hipEvent_t ev[4]; };
   std::vector<TimedCall> timed;      // events of calls not yet queried
   std::vector<hipEvent_t> ev_pool;   // recycled events
+  hipEvent_t wait_ev = nullptr;      // vdf_ctx_wait
 };
 
 struct vdf_bases {
@@ -117,6 +121,15 @@ Status vec_cross_term(int field, const void* az1, const void* bz1, const void* c
 Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint64_t t, void* W, hipStream_t s);
 Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const uint32_t* coef, const void* dict,
                 const void* z, size_t rows, void* out, hipStream_t s);
+// fused step kernels; vdf_fe* arguments are HOST pointers whose values travel as kernel arguments
+Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
+                  const vdf_fe X[6], void* z, hipStream_t s);
+Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
+                      const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
+                      const void* cz1, const vdf_fe* u1, size_t rows, void* az2, void* bz2, void* cz2, void* T,
+                      hipStream_t s);
+Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
+                     hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);
 Status vec_to_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t s);

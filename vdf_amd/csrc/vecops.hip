@@ -7,6 +7,7 @@
 //   k_spmv            R1CSShape::multiply_vec    Az, Bz, Cz (CSR, coefficient dictionary) (K4, a13)
 //   k_minroot_witness InverseMinRootCircuit::synthesize / inverse_round witness values
 //                     (/root/reference/src/nova/proof.rs:107-126, :162-189)          (K7, a1/a2)
+#include <cstring>
 #include "internal.h"
 #include "fe.cuh"
 
@@ -86,6 +87,99 @@ __global__ __launch_bounds__(256) void k_spmv(const uint32_t* __restrict__ rowpt
   fe_store<P>(out + r * 32, acc);
 }
 
+// ---- fused NIFS step kernels: one launch per stage of a fold, small operands by value ---------------------
+struct FeVal { uint32_t v[8]; };                      // a field element as a kernel argument
+struct StepConsts { FeVal z_in[3], i0, u, X[6]; };    // everything of a fresh z that is not a round value
+template <class P> __device__ __forceinline__ Fe<P> fe_from_val(const FeVal& a) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = a.v[i];
+  return r;
+}
+
+// z = [ z_in(3) | per round new_x, tmp1, tmp2, new_y (4t) | final_i | u | X(6) ]: the whole fresh column vector
+// of the exposed-IO step circuit; round values as in k_minroot_witness, the rest from kernel arguments.
+template <class P>
+__global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, StepConsts k, uint64_t t,
+                                                char* __restrict__ z) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > t) return;
+  if (j == t) {
+    for (int i = 0; i < 3; ++i) fe_store<P>(z + i * 32, fe_from_val<P>(k.z_in[i]));
+    char* tail = z + (3 + 4 * t) * 32;
+    fe_store<P>(tail, fe_from_val<P>(k.i0));
+    fe_store<P>(tail + 32, fe_from_val<P>(k.u));
+    for (int i = 0; i < 6; ++i) fe_store<P>(tail + 64 + i * 32, fe_from_val<P>(k.X[i]));
+    return;
+  }
+  const Fe<P> x = fe_load<P>(trace + (t - j) * 64);
+  const Fe<P> nx = fe_load<P>(trace + (t - j - 1) * 64);
+  const Fe<P> ny = fe_load<P>(trace + (t - j - 1) * 64 + 32);
+  const Fe<P> t1 = fe_sqr(x);
+  const Fe<P> t2 = fe_sqr(t1);
+  char* o = z + 96 + j * 128;
+  fe_store<P>(o, nx);
+  fe_store<P>(o + 32, t1);
+  fe_store<P>(o + 64, t2);
+  fe_store<P>(o + 96, ny);
+}
+
+struct Csr3 { const uint32_t* rowptr[3]; const uint32_t* col[3]; const uint32_t* coef[3]; };
+
+template <class P>
+__device__ __forceinline__ Fe<P> spmv_row(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
+                                          const uint32_t* __restrict__ coef, const char* __restrict__ dict,
+                                          const char* __restrict__ z, size_t r) {
+  const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
+  Fe<P> acc = fe_zero<P>();
+  for (uint32_t k = lo; k < hi; ++k) {
+    const Fe<P> v = fe_load<P>(z + (size_t)col[k] * 32);
+    const uint32_t ci = coef[k];
+    if (ci == 0) acc = fe_add(acc, v);
+    else if (ci == 1) acc = fe_sub(acc, v);
+    else acc = fe_add(acc, fe_mul(v, fe_load<P>(dict + (size_t)ci * 32)));
+  }
+  return acc;
+}
+
+// multiply_vec(z2) and the cross term in one pass over the rows:
+//   (a2, b2, c2) = (A z2, B z2, C z2)[row];  T[row] = a1*b2 + a2*b1 - u1*c2 - c1      (u2 = 1)
+template <class P>
+__global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
+                                                    const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                    const char* __restrict__ cz1, FeVal u1, size_t rows,
+                                                    char* __restrict__ az2, char* __restrict__ bz2,
+                                                    char* __restrict__ cz2, char* __restrict__ T) {
+  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+  const Fe<P> a2 = spmv_row<P>(m.rowptr[0], m.col[0], m.coef[0], dict, z2, r);
+  const Fe<P> b2 = spmv_row<P>(m.rowptr[1], m.col[1], m.coef[1], dict, z2, r);
+  const Fe<P> c2 = spmv_row<P>(m.rowptr[2], m.col[2], m.coef[2], dict, z2, r);
+  fe_store<P>(az2 + r * 32, a2);
+  fe_store<P>(bz2 + r * 32, b2);
+  fe_store<P>(cz2 + r * 32, c2);
+  Fe<P> t = fe_add(fe_mul(a1, b2), fe_mul(a2, b1));
+  t = fe_sub(t, fe_mul(fe_from_val<P>(u1), c2));
+  t = fe_sub(t, c1);
+  fe_store<P>(T + r * 32, t);
+}
+
+// acc_k <- acc_k + r * add_k for up to 8 vectors in one launch (the witness fold W, E and the running Az, Bz, Cz)
+struct FoldArgs { char* acc[8]; const char* add[8]; uint32_t blk_end[8]; uint64_t n[8]; int k; };
+template <class P>
+__global__ __launch_bounds__(256) void k_fold_many(FoldArgs a, FeVal rv) {
+  int seg = 0;
+  while (seg < a.k - 1 && blockIdx.x >= a.blk_end[seg]) ++seg;
+  const uint32_t blk0 = seg ? a.blk_end[seg - 1] : 0u;
+  const size_t i = (size_t)(blockIdx.x - blk0) * 256 + threadIdx.x;
+  if (i >= a.n[seg]) return;
+  const Fe<P> r = fe_from_val<P>(rv);
+  const Fe<P> x = fe_load<P>(a.acc[seg] + i * 32);
+  const Fe<P> y = fe_load<P>(a.add[seg] + i * 32);
+  fe_store<P>(a.acc[seg] + i * 32, fe_add(x, fe_mul(r, y)));
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void k_mul(const char* __restrict__ a, const char* __restrict__ b, size_t n,
                                              char* __restrict__ out) {
@@ -147,6 +241,49 @@ Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const ui
                 const void* z, size_t rows, void* out, hipStream_t s) {
   if (rows == 0) return Status{};
   FIELD_DISPATCH(field, k_spmv, grid_for(rows), dim3(256), 0, s, rowptr, col, coef, C(dict), C(z), rows, M(out));
+  return Status{};
+}
+
+static FeVal to_val(const vdf_fe* p) { FeVal v; std::memcpy(v.v, p, 32); return v; }
+
+Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
+                  const vdf_fe X[6], void* z, hipStream_t s) {
+  StepConsts k;
+  for (int i = 0; i < 3; ++i) k.z_in[i] = to_val(&z_in[i]);
+  k.i0 = to_val(i0);
+  k.u = to_val(u);
+  for (int i = 0; i < 6; ++i) k.X[i] = to_val(&X[i]);
+  FIELD_DISPATCH(field, k_step_z, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), k, t, M(z));
+  return Status{};
+}
+
+Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
+                      const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
+                      const void* cz1, const vdf_fe* u1, size_t rows, void* az2, void* bz2, void* cz2, void* T,
+                      hipStream_t s) {
+  if (rows == 0) return Status{};
+  Csr3 m;
+  for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
+  FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                 to_val(u1), rows, M(az2), M(bz2), M(cz2), M(T));
+  return Status{};
+}
+
+Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
+                     hipStream_t s) {
+  if (k <= 0) return Status{};
+  if (k > 8) return Status{VDF_ERR_BAD_ARG, "at most 8 vectors per fold"};
+  FoldArgs a{};
+  a.k = k;
+  uint64_t blocks = 0;
+  for (int i = 0; i < k; ++i) {
+    a.acc[i] = M(acc[i]); a.add[i] = C(add[i]); a.n[i] = n[i];
+    blocks += (n[i] + 255) / 256;
+    if (blocks >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "fold too large"};
+    a.blk_end[i] = (uint32_t)blocks;
+  }
+  if (blocks == 0) return Status{};
+  FIELD_DISPATCH(field, k_fold_many, dim3((unsigned)blocks), dim3(256), 0, s, a, to_val(r));
   return Status{};
 }
 

@@ -132,8 +132,17 @@ class Context:
     def set_async(self, flag: bool) -> None:
         self._check(lib.vdf_ctx_set_async(self.handle, int(flag)))
 
+    def get_async(self) -> bool:
+        v = C.c_int()
+        self._check(lib.vdf_ctx_get_async(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def sync(self) -> None:
         self._check(lib.vdf_ctx_sync(self.handle))
+
+    def wait(self, other: "Context") -> None:
+        """Work enqueued on this context from now on starts after everything enqueued on `other` so far."""
+        self._check(lib.vdf_ctx_wait(self.handle, other.handle))
 
     def set_msm_window(self, c: int) -> None:
         self._check(lib.vdf_ctx_set_msm_window(self.handle, c))
@@ -202,6 +211,22 @@ class Context:
 
     def minroot_witness(self, field, trace_xy, i0, t, out) -> None:
         self._check(lib.vdf_minroot_witness(self.handle, field, _ptr(trace_xy), _ptr(i0), t, _ptr(out)))
+
+    # ---- fused step operations: scalar operands are HOST arrays, vectors are device buffers ----
+    def minroot_step_z(self, field, trace_xy, t, z_in, i0, u, X, z) -> None:
+        self._check(lib.vdf_minroot_step_z(self.handle, field, _ptr(trace_xy), t, _ptr(z_in), _ptr(i0), _ptr(u), _ptr(X),
+                                           _ptr(z)))
+
+    def nifs_cross_term(self, shape: Shape, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
+        self._check(lib.vdf_nifs_cross_term(self.handle, shape.handle, _ptr(z2), _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(u1),
+                                            _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
+
+    def fold_many(self, field, r, acc, add, n) -> None:
+        k = len(acc)
+        a = (C.c_void_p * k)(*[_ptr(x) for x in acc])
+        b = (C.c_void_p * k)(*[_ptr(x) for x in add])
+        ln = (C.c_size_t * k)(*[int(x) for x in n])
+        self._check(lib.vdf_fold_many(self.handle, field, _ptr(r), k, a, b, ln))
 
     def fe_mul(self, field, a, b, n, out) -> None:
         self._check(lib.vdf_fe_mul(self.handle, field, _ptr(a), _ptr(b), n, _ptr(out)))
