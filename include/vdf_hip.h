@@ -98,6 +98,13 @@ void vdf_bases_free(vdf_bases* bases);
  * is_mont: scalars are in Montgomery form (as pasta-msm's `is_mont = true`). */
 int  vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n,
              int is_mont, vdf_jac* out);
+/* k <= 4 MSMs over the same generator table in one pipeline: out[i] = sum_j scalars[i][j] * bases[offset[i] + j],
+ * j < n[i].  The results equal k vdf_msm calls bit for bit; the batch shares every launch -- one sort, one
+ * bucket-accumulation grid balanced over all entries, one latency-bound tail -- which is what a fold needs when it
+ * commits to the fresh witness and to the cross term under the same generators (nova-snark commit_W / commit_T).
+ * `out` holds k points, host or device. */
+int  vdf_msm_batch(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const vdf_fe* const scalars[],
+                   const size_t n[], int is_mont, vdf_jac out[]);
 /* Window size override for tuning (0 = automatic). */
 int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
 /* out = sum of n Jacobian points (the combine step of a point-chunk-sharded MSM: each GPU

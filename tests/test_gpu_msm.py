@@ -297,3 +297,58 @@ def test_point_sum_exceptional_cases(ctx, curve):
     many = [jac(o.pt_mul(k + 1, g, m), k + 2) for k in range(40)]
     assert run(many) == o.pt_mul(sum(range(1, 41)), g, m)
     assert run([jac(P1)] * 33) == o.pt_mul(33 * 12345, g, m)                     # equal partials across quads
+
+
+# ---- batched MSM: k vectors over one generator table, one pipeline -----------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("mode", ["plain", "tbl16x1", "tbl13x2"])
+def test_msm_batch_equals_separate_calls(ctx, cref, curve, mode):
+    nb = 6000
+    bases = ctx.bases_generate(curve, 21, nb)
+    pts = bases.download()
+    if mode != "plain":
+        c, s = mode[3:].split("x")
+        bases.precompute(int(c), int(s))
+    rng = np.random.default_rng(77)
+    sizes = [6000, 4099, 1, 0]
+    offs = [0, 1901, 5999, 17]
+    sc = [rand_limbs(rng, n) for n in sizes]
+    sc[1][:50] = sc[1][0]                       # a heavy bucket inside one group only
+    for k in (1, 2, 3, 4):
+        got = ctx.msm_batch(bases, sc[:k], offsets=offs[:k])
+        for g in range(k):
+            exp = cpu_msm(cref, curve, pts[offs[g]:offs[g] + sizes[g]].copy(), sc[g]) if sizes[g] else None
+            a = jac_to_affine(got[g], curve)
+            assert a == exp, (mode, k, g)
+            if sizes[g]:
+                assert a == jac_to_affine(ctx.msm(bases, sc[g], offset=offs[g]), curve)
+    with pytest.raises(Exception):
+        ctx.msm_batch(bases, sc + sc[:1], offsets=offs + [0])          # more than 4 groups
+    with pytest.raises(Exception):
+        ctx.msm_batch(bases, sc[:2], offsets=[0, 5000])                # offset + n beyond the table
+    bases.free()
+
+
+def test_msm_batch_fold_shapes_dlog_identity(ctx):
+    """The two commitments of one fold at t = 2^16 (|W| = 262148, |T| = 196615) in one batch, device-resident,
+    checked with the discrete-log identity of the synthetic generators."""
+    import torch
+    curve, seed = o.CURVE_PALLAS, 0x4E6F7661
+    nb = 1 << 19
+    bases = ctx.bases_generate(curve, seed, nb)
+    bases.precompute(16, 1)
+    sizes = [262148, 196615]
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    scs = []
+    for n in sizes:
+        t = torch.randint(0, 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        t[:, 3] &= 0x3FFFFFFFFFFFFFFF
+        scs.append(t)
+    out = torch.zeros((2, 12), dtype=torch.int64, device="cuda")
+    ctx.msm_batch(bases, scs, out=out)
+    ctx.sync()
+    res = out.cpu().numpy().view("<u8")
+    for k, n in enumerate(sizes):
+        vals = ints(scs[k].cpu().numpy().view("<u8"))
+        assert jac_to_affine(res[k], curve) == o.msm_by_dlog(vals, curve, seed)
+    bases.free()

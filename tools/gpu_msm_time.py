@@ -5,9 +5,10 @@ import numpy as np, torch
 from oracle import pasta as o
 import vdf_amd as v
 
-lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+arg = sys.argv[1] if len(sys.argv) > 1 else "20"
+n = int(arg[1:]) if arg.startswith("n") else 1 << int(arg)       # "18" = 2^18 points, "n196615" = that many
+lg = n.bit_length() - 1
 modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["plain", "tbl16x1", "tbl16x4"]
-n = 1 << lg
 ctx = v.Context(0)
 curve = v.CURVE_PALLAS
 sm, bm_ = o.Q, o.P
@@ -48,7 +49,7 @@ for mode in modes:
         e1.record(st)
     ctx.sync(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{mode}: n=2^{lg} {ms:.3f} ms/MSM  {n / ms / 1e6:.3f} GPoints/s  HBM-alg {96 * n / ms / 1e6:.1f} GB/s")
+    print(f"{mode}: n={n} {ms:.3f} ms/MSM  {n / ms / 1e6:.3f} GPoints/s  HBM-alg {96 * n / ms / 1e6:.1f} GB/s")
     ctx.set_timing(True); ctx.msm_timing()
     for _ in range(reps): ctx.msm(bases, sc, n=n, out=out)
     ctx.sync()

@@ -131,36 +131,42 @@ Status ensure_ws(vdf_ctx* ctx, size_t bytes) {
 
 size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 
-Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont,
-                vdf_jac* out) {
-  if (!bases || !out) return Status{VDF_ERR_BAD_ARG, "null bases/out"};
+Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* offset, const vdf_fe* const* scalars,
+                const size_t* n, int is_mont, vdf_jac* out) {
+  if (!bases || !out || !offset || !scalars || !n) return Status{VDF_ERR_BAD_ARG, "null bases/out/arrays"};
+  if (groups < 1 || groups > vdf::MSM_MAX_GROUPS) return Status{VDF_ERR_BAD_ARG, "1..4 MSMs per batch"};
   // generators may be shared by several contexts of one device (e.g. a second stream for overlap)
   if (bases->ctx != ctx && bases->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bases live on another device"};
-  if (offset > bases->n || n > bases->n - offset) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
-  if (n >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "n too large (max 2^27 - 1 points per call)"};
+  size_t ntot = 0, nmax = 0;
+  for (int g = 0; g < groups; ++g) {
+    if (offset[g] > bases->n || n[g] > bases->n - offset[g]) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
+    ntot += n[g];
+    if (n[g] > nmax) nmax = n[g];
+  }
+  if (ntot >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "n too large (max 2^27 - 1 points per call)"};
   Staging st(ctx);
   void* d_out = nullptr;
-  VDF_TRY(st.out(out, sizeof(vdf_jac), &d_out));
-  if (n == 0) {
-    VDF_TRY_HIP(hipMemsetAsync(d_out, 0, sizeof(vdf_jac), ctx->stream));
+  VDF_TRY(st.out(out, groups * sizeof(vdf_jac), &d_out));
+  if (ntot == 0) {
+    VDF_TRY_HIP(hipMemsetAsync(d_out, 0, groups * sizeof(vdf_jac), ctx->stream));
     return st.finish();
   }
-  const void* d_scalars = nullptr;
-  VDF_TRY(st.in(scalars, n * sizeof(vdf_fe), &d_scalars));
+  const void* d_scalars[vdf::MSM_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+  for (int g = 0; g < groups; ++g) VDF_TRY(st.in(scalars[g], n[g] * sizeof(vdf_fe), &d_scalars[g]));
   vdf::MsmPlan plan;
   const char* pts;
   if (bases->d_table && (ctx->msm_window == 0 || ctx->msm_window == bases->tbl_c)) {
-    plan = vdf::msm_make_plan(n, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus);
+    plan = vdf::msm_make_plan(groups, n, offset, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus);
     plan.tstride = (uint32_t)bases->n;
-    pts = reinterpret_cast<const char*>(bases->d_table) + offset * 64;
+    pts = reinterpret_cast<const char*>(bases->d_table);
   } else {
-    int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(n);
-    plan = vdf::msm_make_plan(n, c, 0, 0, ctx->num_cus);
+    int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(nmax);
+    plan = vdf::msm_make_plan(groups, n, offset, c, 0, 0, ctx->num_cus);
     plan.tstride = 0;
-    pts = reinterpret_cast<const char*>(bases->d_pts) + offset * 64;
+    pts = reinterpret_cast<const char*>(bases->d_pts);
   }
-  if ((size_t)plan.tstride * plan.tables + n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "table index exceeds 31 bits"};
-  if ((uint64_t)n * plan.windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
+  if ((size_t)plan.tstride * plan.tables + bases->n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "table index exceeds 31 bits"};
+  if ((uint64_t)ntot * plan.windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
   VDF_TRY(ensure_ws(ctx, plan.ws_bytes));
   hipEvent_t* ev = nullptr;
   vdf_ctx::TimedCall tc;
@@ -404,7 +410,12 @@ void vdf_bases_free(vdf_bases* bases) {
 
 // ---- MSM ------------------------------------------------------------------------------------
 int vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* scalars, size_t n, int is_mont, vdf_jac* out) {
-  return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, offset, scalars, n, is_mont, out); });
+  return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, 1, &offset, &scalars, &n, is_mont, out); });
+}
+
+int vdf_msm_batch(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const vdf_fe* const scalars[],
+                  const size_t n[], int is_mont, vdf_jac out[]) {
+  return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, k, offset, scalars, n, is_mont, out); });
 }
 
 int vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_jac* out) {

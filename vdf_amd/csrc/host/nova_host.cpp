@@ -146,7 +146,6 @@ struct StepRecord { Aff comm_w, comm_T; Fe r; Fe X[NUM_IO]; };
 
 struct vdf_pp {
   vdf_ctx* ctx = nullptr;
-  vdf_ctx* ctx2 = nullptr;  // second stream + MSM workspace on the same GPU: the W commitment overlaps the fold
   uint64_t t = 0;
   size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
   vdf_shape* shape = nullptr;
@@ -354,13 +353,6 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   size_t g = 1;
   while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
   pp->num_gens = g;
-  {
-    int dev = 0;
-    // the second context lives on the same device as `ctx` (one process per GPU)
-    dev = vdf_ctx_device(ctx);
-    if (vdf_ctx_create(&dev, 1, &pp->ctx2) != VDF_OK) pp->ctx2 = nullptr;
-    if (pp->ctx2) vdf_ctx_set_async(pp->ctx2, 1);
-  }
   rc = vdf_bases_generate(ctx, PRIMARY_CURVE, GENS_SEED, g, &pp->gens);
   if (rc == VDF_OK) rc = vdf_bases_precompute(ctx, pp->gens, 16, 1);
   if (rc == VDF_OK) rc = vdf_dev_alloc(ctx, pp->num_cons * 32, &pp->d_zero);
@@ -387,7 +379,6 @@ void vdf_nova_pp_free(vdf_pp* pp) {
   if (pp->d_zero) vdf_dev_free(pp->ctx, pp->d_zero);
   if (pp->shape) vdf_shape_free(pp->shape);
   if (pp->gens) vdf_bases_free(pp->gens);
-  if (pp->ctx2) vdf_ctx_destroy(pp->ctx2);
   delete pp;
 }
 int vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
@@ -494,7 +485,6 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
                                     (const vdf_fe*)&c.input.i, (const vdf_fe*)&u2, (const vdf_fe*)X2, (vdf_fe*)p->d_z2));
   }
   const double t1 = now_ms();
-  vdf_ctx* cctx = pp->ctx2 ? pp->ctx2 : ctx;
   vdf_jac* jw = &p->h_comm[0];
   vdf_jac* jt = &p->h_comm[1];
   Aff comm_w;
@@ -518,20 +508,20 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
     rec.r = zero();
     t6 = now_ms();
   } else {
-    // --- NIFS.prove.  Launch order: multiply_vec(z2) + cross term (one launch, before the
-    // commitments fill the GPU), commit W2 on the second stream, commit T on the first; both results land in
-    // pinned host memory.  While the GPU works the host finishes the previous step's instance fold.
+    // --- NIFS.prove: multiply_vec(z2) + cross term (one launch), then the commitments to
+    // W2 and T as ONE batched MSM whose two points land in pinned host memory.  While the GPU works the host
+    // finishes the previous step's instance fold.
     HIPCALL(ctx, vdf_nifs_cross_term(ctx, pp->shape, (const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1],
                                      (const vdf_fe*)p->d_abc[2], (const vdf_fe*)&p->u, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4],
                                      (vdf_fe*)p->d_abc[5], (vdf_fe*)p->d_T));
     t2 = now_ms();
-    if (pp->ctx2) HIPCALL(pp->ctx2, vdf_ctx_wait(pp->ctx2, ctx));
-    HIPCALL(cctx, vdf_msm(cctx, pp->gens, 0, (const vdf_fe*)p->d_z2, nv, 1, jw));
-    t3 = now_ms();
-    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, jt));
-    t4 = now_ms();
+    {
+      const size_t off[2] = {0, 0}, len[2] = {nv, nc};
+      const vdf_fe* sc[2] = {(const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_T};
+      HIPCALL(ctx, vdf_msm_batch(ctx, pp->gens, 2, off, sc, len, 1, p->h_comm));   // h_comm[0] = W2, [1] = T
+    }
+    t3 = t4 = now_ms();
     p->join();                                                   // the previous step's instance fold
-    if (pp->ctx2) HIPCALL(pp->ctx2, vdf_ctx_sync(pp->ctx2));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     t5 = now_ms();
     Aff comm_T;
@@ -563,7 +553,7 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   p->i += 1;
   p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
   const double t7 = now_ms();
-  // witness launch | cross-term launch | commit_W launch | commit_T launch | host fold of the previous step +
+  // witness launch | commitments launch (batched) | cross-term launch | - | host fold of the previous step +
   // wait for both commitments | transcript + fold launch | bookkeeping | total
   p->ms[0] = t1 - t0; p->ms[1] = t3 - t2; p->ms[2] = t2 - t1; p->ms[3] = t4 - t3;
   p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;

@@ -84,16 +84,26 @@ inline Status hip_status(hipError_t e, const char* what) {
   } while (0)
 
 // ---- msm.hip --------------------------------------------------------------------------
+constexpr int MSM_MAX_GROUPS = 4;
+// A plan covers a BATCH of 1..4 independent MSMs ("groups") over the same generator table: each group has its
+// own scalar vector, length and generator offset and yields its own point.  The groups share every launch
+// (one sort, one accumulate grid balanced over all entries, one latency-bound tail); to everything after pass A
+// a group is simply `sets` more bucket sets.
 struct MsmPlan {
-  uint32_t n = 0;        // points
+  int groups = 1;
+  uint32_t gn[MSM_MAX_GROUPS] = {0, 0, 0, 0};       // points per group
+  uint32_t goff[MSM_MAX_GROUPS] = {0, 0, 0, 0};     // generator offset per group (points)
+  uint32_t gblk_end[MSM_MAX_GROUPS] = {0, 0, 0, 0}; // pass-A workgroups: group g owns [gblk_end[g-1], gblk_end[g])
+  uint32_t n = 0;        // points, all groups
   int c = 0;             // window bits
   int windows = 0;       // ceil(256 / c)
-  int sets = 0;          // bucket sets (Horner length); windows = sets * tables
+  int sets = 0;          // bucket sets per group (Horner length); windows = sets * tables
+  int gsets = 0;         // groups * sets
   int tables = 0;
   uint32_t nbk = 0;      // buckets per set = 2^(c-1)   (digit magnitudes 1..2^(c-1))
   // two-level counting sort: a bucket index b = (p << fb) | f; pass A partitions by p, pass B sorts by f
   int pb = 0, fb = 0;    // partition bits / fine bits, pb + fb = c - 1
-  uint32_t bins = 0;     // sets << pb
+  uint32_t bins = 0;     // gsets << pb
   uint32_t chA = 0;      // points per pass-A workgroup
   uint32_t nblkA = 0;    // pass-A workgroups
   uint32_t split = 0;    // pass-B workgroups per bin
@@ -102,12 +112,16 @@ struct MsmPlan {
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)
   size_t ws_bytes = 0;
 };
-MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus);
+MsmPlan msm_make_plan(int groups, const size_t* n, const size_t* offsets, int c, int sets, int tables, int num_cus);
+inline MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
+  const size_t zero = 0;
+  return msm_make_plan(1, &n, &zero, c, sets, tables, num_cus);
+}
 int msm_auto_window(size_t n);
-// d_points: table (tables*n affine) or plain bases (tables == 1).  d_scalars: n x 32 B device.
-// d_out: 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
+// d_points: table (tables*tstride affine) or plain bases (tables == 1).  d_scalars[g]: gn[g] x 32 B device.
+// d_out: groups x 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
 // ev (optional): 4 events recorded at start / before accumulate / after accumulate / end.
-Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* d_scalars, bool is_mont,
+Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont,
                void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr);
 Status bases_generate(int curve, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);

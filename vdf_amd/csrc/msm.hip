@@ -35,6 +35,13 @@
 namespace vdf {
 
 static constexpr uint32_t SIGN_BIT = 0x80000000u;
+
+// Every kernel of the pipeline except k_accumulate is short or latency-bound; k_accumulate is a long pure-ALU
+// grid that keeps every SIMD's issue port busy.  When two MSMs run on two streams (prove_step commits W and T
+// side by side) the light kernels of one would starve behind the other's accumulate waves, which the
+// oldest-first arbiter favours; a raised wave priority lets them through.
+__device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
 static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
 static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enough to fill the chip, few enough that the
                                              // per-quad offset multiplication (~30 point ops) stays a small share
@@ -49,7 +56,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static WsLayout ws_layout(const MsmPlan& p) {
   WsLayout w{};
   size_t off = 0;
-  const size_t nkeys = (size_t)p.sets * p.nbk;
+  const size_t nkeys = (size_t)p.gsets * p.nbk;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   w.countsA = take((size_t)p.nblkA * p.bins * 4);
   w.pcount = take((size_t)p.bins * 4);
@@ -70,8 +77,8 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.red_threads_per_set = tps;                 // logical threads (quads): one per red_seg buckets
   w.red_block = tps < 64 ? tps : 64;           // quads per workgroup (256 lanes)
   w.red_blocks_per_set = tps / w.red_block;
-  w.partials = take((size_t)p.sets * w.red_blocks_per_set * 128);
-  w.wsum = take((size_t)p.sets * 128);
+  w.partials = take((size_t)p.gsets * w.red_blocks_per_set * 128);
+  w.wsum = take((size_t)p.gsets * 128);
   w.total = off;
   return w;
 }
@@ -85,42 +92,54 @@ int msm_auto_window(size_t n) {
   return c;
 }
 
-MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
+MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus) {
   MsmPlan p;
+  p.groups = groups;
+  size_t n = 0, nmax = 0;
+  for (int g = 0; g < groups; ++g) {
+    p.gn[g] = (uint32_t)gn[g];
+    p.goff[g] = (uint32_t)goff[g];
+    n += gn[g];
+    if (gn[g] > nmax) nmax = gn[g];
+  }
   p.n = (uint32_t)n;
   p.c = c;
   p.windows = (256 + c - 1) / c;
   if (sets <= 0 || tables <= 0) { sets = p.windows; tables = 1; }
   p.sets = sets;
+  p.gsets = groups * sets;
   p.tables = tables;
   p.nbk = 1u << (c - 1);
   // two-level sort geometry: pass A splits on the high pb bucket bits (its cursors live in LDS: <= 8192 bins),
   // pass B on the low fb (<= 10: one thread per fine bucket in k_fine_scan)
   p.fb = (c - 1 < 8) ? c - 1 : 8;
   p.pb = c - 1 - p.fb;
-  while (p.pb > 0 && ((uint32_t)sets << p.pb) > 8192u) { --p.pb; ++p.fb; }
-  p.bins = (uint32_t)sets << p.pb;
+  while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) { --p.pb; ++p.fb; }
+  p.bins = (uint32_t)p.gsets << p.pb;
   size_t chA = (n + 511) / 512;                       // ~2 pass-A workgroups per CU
   chA = (chA + 255) / 256 * 256;
   if (chA < 256) chA = 256;
   if (chA > 4096) chA = 4096;
   p.chA = (uint32_t)chA;
-  p.nblkA = (uint32_t)((n + chA - 1) / chA);
-  if (p.nblkA == 0) p.nblkA = 1;
+  uint32_t blk = 0;
+  for (int g = 0; g < groups; ++g) {
+    blk += (uint32_t)((gn[g] + chA - 1) / chA);
+    p.gblk_end[g] = blk;
+  }
+  p.nblkA = blk ? blk : 1;
   uint32_t split = 1024u / p.bins;                    // ~4 pass-B workgroups per CU
   if (split < 1) split = 1;
   if (split > 16) split = 16;
   p.split = split;
-  // accumulate slices: ~4 waves per SIMD worth of threads (k_accumulate is resident at 3 per SIMD; measured on
-  // MI355X, L = 32..64 is the flat optimum at 2^18..2^20: shorter slices multiply the slice heads k_fixup must
-  // add, longer ones leave a thin last round), 32 <= L <= 64, multiple of 4.
+  // accumulate slices.  k_accumulate is resident at ACC_WG_PER_CU workgroups per CU (register-limited) and
+  // ALU-issue-bound: measured on MI355X, a grid that exactly fills the resident slots takes L x 14.1 us, and a
+  // single workgroup more costs a whole extra round.  So: one round, every slot used, L = ceil(entries / slots)
+  // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
-  size_t want_threads = (size_t)num_cus * 4 * 4 * 64;
-  size_t L = (ne + want_threads - 1) / want_threads;
-  L = (L + 3) / 4 * 4;
-  if (L < 32) L = 32;
-  if (L > 64) L = 64;
-  if (const char* ov = std::getenv("VDF_MSM_L")) { long v = std::atol(ov); if (v >= 4 && v <= 4096) L = (size_t)(v + 3) / 4 * 4; }   // tuning override
+  const size_t slots = (size_t)num_cus * ACC_WG_PER_CU * 256;
+  size_t L = (ne + slots - 1) / slots;
+  if (L < 8) L = 8;
+  if (const char* ov = std::getenv("VDF_MSM_L")) { long v = std::atol(ov); if (v >= 1 && v <= 65536) L = (size_t)v; }   // tuning override
   p.L = (uint32_t)L;
   p.nthreads = (uint32_t)((ne + L - 1) / L);
   if (p.nthreads == 0) p.nthreads = 1;
@@ -159,19 +178,33 @@ __device__ __forceinline__ void stage_scalar(uint32_t* limbs, Fe<SP> s, int is_m
 // ------------------------------------------------------------------------------------------
 // pass A: partition the entries by the high bucket bits
 // ------------------------------------------------------------------------------------------
+struct PartGroups {
+  const uint32_t* scalars[MSM_MAX_GROUPS];
+  uint32_t n[MSM_MAX_GROUPS], off[MSM_MAX_GROUPS], blk_end[MSM_MAX_GROUPS];
+  int groups;
+};
+
 template <class SP, bool SCATTER>
-__global__ __launch_bounds__(256) void k_part(const uint32_t* __restrict__ scalars, uint32_t n, int is_mont, int c,
-                                              int windows, int sets, int pb, int fb, uint32_t bins, uint32_t chA,
-                                              uint32_t tstride, uint32_t* __restrict__ countsA,
-                                              const uint32_t* __restrict__ pstart, uint64_t* __restrict__ recs) {
+__global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c, int windows, int sets, int pb, int fb,
+                                              uint32_t bins, uint32_t chA, uint32_t tstride,
+                                              uint32_t* __restrict__ countsA, const uint32_t* __restrict__ pstart,
+                                              uint64_t* __restrict__ recs) {
+  raise_wave_priority();
   __shared__ uint32_t limbs[9 * 256];
   extern __shared__ uint32_t cur[];                   // bins counters (histogram) or cursors (scatter)
   uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
   for (uint32_t b = threadIdx.x; b < bins; b += 256) cur[b] = SCATTER ? pstart[b] + mine[b] : 0u;
   __syncthreads();
-  const uint32_t lo = blockIdx.x * chA;
+  int g = 0;
+  while (g < pg.groups - 1 && blockIdx.x >= pg.blk_end[g]) ++g;
+  const uint32_t blk0 = g ? pg.blk_end[g - 1] : 0u;
+  const uint32_t* __restrict__ scalars = pg.scalars[g];
+  const uint32_t n = pg.n[g];
+  const uint32_t lo = (blockIdx.x - blk0) * chA;
   const uint32_t hi = (lo + chA < n) ? lo + chA : n;
   const uint32_t fmask = (1u << fb) - 1u;
+  const uint32_t set0 = (uint32_t)g * (uint32_t)sets;        // a group is `sets` bucket sets of its own
+  const uint32_t pbase = pg.off[g];
   uint32_t i = lo + threadIdx.x;
   Fe<SP> nxt = fe_zero<SP>();
   if (i < hi) nxt = fe_load<SP>(scalars + (size_t)i * 8);
@@ -185,9 +218,9 @@ __global__ __launch_bounds__(256) void k_part(const uint32_t* __restrict__ scala
       const uint32_t mag = d & ~SIGN_BIT;
       if (!mag) continue;
       const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
-      const uint32_t bin = (s << pb) | ((mag - 1) >> fb);
+      const uint32_t bin = ((set0 + s) << pb) | ((mag - 1) >> fb);
       const uint32_t pos = atomicAdd(&cur[bin], 1u);
-      if (SCATTER) recs[pos] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + i) | (d & SIGN_BIT));
+      if (SCATTER) recs[pos] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + pbase + i) | (d & SIGN_BIT));
     }
   }
   if (!SCATTER) {
@@ -200,6 +233,7 @@ __global__ __launch_bounds__(256) void k_part(const uint32_t* __restrict__ scala
 // a time through LDS (a thread per bin walking hundreds of counts would be one L2 round trip each).
 __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ countsA, uint32_t bins, uint32_t nblk,
                                                    uint32_t* __restrict__ pcount) {
+  raise_wave_priority();
   __shared__ uint32_t sc[256];
   const uint32_t b = blockIdx.x;
   uint32_t carry = 0;
@@ -226,6 +260,7 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ counts
 // issued eight at a time so the run is a few L2 round trips instead of one per element.
 __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__ bcount, uint32_t nkeys,
                                                     uint32_t* __restrict__ bstart) {
+  raise_wave_priority();
   __shared__ uint32_t part[1024];
   const uint32_t per = (nkeys + 1023) / 1024;
   const uint32_t lo = threadIdx.x * per < nkeys ? threadIdx.x * per : nkeys;
@@ -275,6 +310,7 @@ __device__ __forceinline__ void slice_of(const uint32_t* pstart, uint32_t bin, u
 
 __global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
                                                    uint32_t split, uint32_t nf, uint32_t* __restrict__ countsB) {
+  raise_wave_priority();
   __shared__ uint32_t h[1024];
   const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
   for (uint32_t f = threadIdx.x; f < nf; f += 256) h[f] = 0;
@@ -300,6 +336,7 @@ __global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ 
 __global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
                                                     uint32_t bins, uint32_t nf, uint32_t split,
                                                     uint32_t* __restrict__ bstart) {
+  raise_wave_priority();
   __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
   uint32_t run = 0;
@@ -325,6 +362,7 @@ __global__ __launch_bounds__(256) void k_fine_scatter(const uint64_t* __restrict
                                                       uint32_t split, uint32_t nf, const uint32_t* __restrict__ countsB,
                                                       const uint32_t* __restrict__ bstart,
                                                       uint32_t* __restrict__ sorted) {
+  raise_wave_priority();
   __shared__ uint32_t cur[1024];
   const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
   for (uint32_t f = threadIdx.x; f < nf; f += 256)
@@ -408,18 +446,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
   bool have = false;
-  // the slice [lo, lo + L) is contiguous and 16-byte aligned (L is a multiple of 4): entries arrive four at a
-  // time as one dwordx4 per lane
-  const uint4* mine4 = reinterpret_cast<const uint4*>(sorted + lo);
-  uint4 q4 = mine4[0];
-  uint32_t e = q4.x;
+  // software pipeline: while entry `pos` is added, the point of entry pos+1 and the index of entry pos+2 are in
+  // flight (one addition is ~10 us of ALU work per wave: ample cover for both loads)
+  uint32_t e = sorted[lo];
+  uint32_t en = (lo + 1 < hi) ? sorted[lo + 1] : e;
   Affine<P> pt = affine_load<P>(points + (size_t)(e & ~SIGN_BIT) * 64);
   for (uint32_t pos = lo; pos < hi; ++pos) {
-    // prefetch the next entry's point while this one is added
-    const uint32_t kn = pos + 1 - lo;                       // index of the next entry inside the slice
-    if ((kn & 3u) == 0 && pos + 1 < hi) q4 = mine4[kn >> 2];
-    const uint32_t sel = (pos + 1 < hi) ? (kn & 3u) : ((pos - lo) & 3u);
-    const uint32_t en = sel == 0 ? q4.x : sel == 1 ? q4.y : sel == 2 ? q4.z : q4.w;
+    const uint32_t e2 = (pos + 2 < hi) ? sorted[pos + 2] : en;
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
       flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
@@ -439,6 +472,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
     if (e & SIGN_BIT) pt.y = fe_neg(pt.y);
     madd_lazy<P>(acc, have, pt);
     e = en;
+    en = e2;
     pt = ptn;
   }
   flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
@@ -455,6 +489,7 @@ template <class P>
 __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t L,
                                                char* __restrict__ bucket_acc, const char* __restrict__ heads,
                                                uint32_t* __restrict__ heavy) {
+  raise_wave_priority();
   const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 2;
   if (g >= nkeys) return;                                          // quad-uniform from here on
   const uint32_t s = bstart[g], e = bstart[g + 1];
@@ -484,6 +519,7 @@ template <class P>
 __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t L,
                                                     char* __restrict__ bucket_acc, const char* __restrict__ heads,
                                                     const uint32_t* __restrict__ heavy) {
+  raise_wave_priority();
   const uint32_t count = heavy[0];
   const uint32_t quad = threadIdx.x >> 2;
   for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
@@ -507,6 +543,7 @@ template <class P>
 __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket_acc, uint32_t nbk, uint32_t nseg,
                                                  uint32_t threads_per_set, uint32_t blocks_per_set,
                                                  char* __restrict__ partials) {
+  raise_wave_priority();
   extern __shared__ __align__(16) char lds_raw[];
   const uint32_t nlog = blockDim.x >> 2;                          // logical threads (quads) per block
   const uint32_t lt = threadIdx.x >> 2;
@@ -547,6 +584,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
 template <class P>
 __global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partials, uint32_t blocks_per_set,
                                                  char* __restrict__ wsum) {
+  raise_wave_priority();
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t set = blockIdx.x;
   const uint32_t lt = threadIdx.x >> 2;
@@ -565,10 +603,13 @@ __global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partia
   if (lt == 0) qpoint_store<P>(wsum + (size_t)set * 128, acc);
 }
 
-// Horner over bucket sets (one quad), XYZZ -> Jacobian
+// Horner over a group's bucket sets (one quad per group, one workgroup each), XYZZ -> Jacobian
 template <class P>
-__global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum, int sets, int c, char* __restrict__ out_jac) {
-  if (blockIdx.x != 0 || threadIdx.x >= 4) return;
+__global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum_all, int sets, int c, char* __restrict__ out_all) {
+  raise_wave_priority();
+  if (threadIdx.x >= 4) return;
+  const char* wsum = wsum_all + (size_t)blockIdx.x * sets * 128;
+  char* out_jac = out_all + (size_t)blockIdx.x * 96;
   QPoint<P> acc = qpoint_identity<P>();
   for (int s = sets - 1; s >= 0; --s) {
     if (s != sets - 1)
@@ -626,7 +667,7 @@ __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts
 // host drivers
 // ------------------------------------------------------------------------------------------
 template <class P, class SP>
-static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_scalars, bool is_mont, void* ws,
+static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
                         void* d_out, hipStream_t st, hipEvent_t* ev) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
@@ -642,20 +683,25 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   uint32_t* heavy = reinterpret_cast<uint32_t*>(base + w.heavy);
   char* partials = base + w.partials;
   char* wsum = base + w.wsum;
-  const uint32_t nkeys = (uint32_t)p.sets * p.nbk;
+  const uint32_t nkeys = (uint32_t)p.gsets * p.nbk;
   const uint32_t nf = 1u << p.fb;
-  const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
+  PartGroups pg{};
+  pg.groups = p.groups;
+  for (int g = 0; g < p.groups; ++g) {
+    pg.scalars[g] = reinterpret_cast<const uint32_t*>(d_scalars[g]);
+    pg.n[g] = p.gn[g]; pg.off[g] = p.goff[g]; pg.blk_end[g] = p.gblk_end[g];
+  }
   const size_t lds_bins = (size_t)p.bins * 4;
 
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   VDF_TRY_HIP(hipMemsetAsync(bucket_acc, 0, (size_t)nkeys * 128, st));
   VDF_TRY_HIP(hipMemsetAsync(heavy, 0, 4, st));
   // pass A
-  hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, sc, p.n, is_mont ? 1 : 0, p.c, p.windows,
+  hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
-  hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, sc, p.n, is_mont ? 1 : 0, p.c, p.windows,
+  hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   // pass B
   hipLaunchKernelGGL(k_fine_hist, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB);
@@ -669,17 +715,17 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* d_sc
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
-  hipLaunchKernelGGL((k_reduce1<P>), dim3(p.sets * w.red_blocks_per_set), dim3(w.red_block * 4),
+  hipLaunchKernelGGL((k_reduce1<P>), dim3(p.gsets * w.red_blocks_per_set), dim3(w.red_block * 4),
                      (size_t)w.red_block * 128, st, bucket_acc, p.nbk, w.red_seg, w.red_threads_per_set, w.red_blocks_per_set,
                      partials);
-  hipLaunchKernelGGL((k_reduce2<P>), dim3(p.sets), dim3(256), 0, st, partials, w.red_blocks_per_set, wsum);
-  hipLaunchKernelGGL((k_final<P>), dim3(1), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
+  hipLaunchKernelGGL((k_reduce2<P>), dim3(p.gsets), dim3(256), 0, st, partials, w.red_blocks_per_set, wsum);
+  hipLaunchKernelGGL((k_final<P>), dim3(p.groups), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 
-Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* d_scalars, bool is_mont, void* ws,
+Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
                void* d_out, hipStream_t stream, hipEvent_t* ev) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
   if (curve == VDF_CURVE_PALLAS)
@@ -692,6 +738,7 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
 // sum of n Jacobian points: one wavefront = 16 quads striding over the inputs, butterfly reduce
 template <class P>
 __global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, uint32_t n, char* __restrict__ out) {
+  raise_wave_priority();
   const uint32_t quad = threadIdx.x >> 2;
   QPoint<P> acc = qpoint_identity<P>();
   for (uint32_t i = quad; i < n; i += 16) {

@@ -18,6 +18,7 @@ static inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + 255) / 256))
 template <class P>
 __global__ __launch_bounds__(256) void k_axpy(const char* __restrict__ a, const char* __restrict__ r,
                                               const char* __restrict__ b, size_t n, char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const Fe<P> rr = fe_load<P>(r);
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void k_cross_term(const char* __restrict__ az1
                                                     const char* __restrict__ cz1, const char* __restrict__ az2,
                                                     const char* __restrict__ bz2, const char* __restrict__ cz2,
                                                     const char* __restrict__ u1, size_t n, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const Fe<P> u = fe_load<P>(u1);
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256) void k_cross_term(const char* __restrict__ az1
 template <class P>
 __global__ __launch_bounds__(256) void k_minroot_witness(const char* __restrict__ trace, const char* __restrict__ i0,
                                                          uint64_t t, char* __restrict__ W) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j > t) return;
   if (j == t) {
@@ -73,6 +76,7 @@ template <class P>
 __global__ __launch_bounds__(256) void k_spmv(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
                                               const uint32_t* __restrict__ coef, const char* __restrict__ dict,
                                               const char* __restrict__ z, size_t rows, char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
@@ -102,6 +106,7 @@ template <class P> __device__ __forceinline__ Fe<P> fe_from_val(const FeVal& a) 
 template <class P>
 __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, StepConsts k, uint64_t t,
                                                 char* __restrict__ z) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j > t) return;
   if (j == t) {
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
                                                     const char* __restrict__ cz1, FeVal u1, size_t rows,
                                                     char* __restrict__ az2, char* __restrict__ bz2,
                                                     char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
 struct FoldArgs { char* acc[8]; const char* add[8]; uint32_t blk_end[8]; uint64_t n[8]; int k; };
 template <class P>
 __global__ __launch_bounds__(256) void k_fold_many(FoldArgs a, FeVal rv) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   int seg = 0;
   while (seg < a.k - 1 && blockIdx.x >= a.blk_end[seg]) ++seg;
   const uint32_t blk0 = seg ? a.blk_end[seg - 1] : 0u;

@@ -169,6 +169,18 @@ class Context:
         self._check(lib.vdf_msm(self.handle, bases.handle, offset, _ptr(scalars), n, int(is_mont), _ptr(out)))
         return out
 
+    def msm_batch(self, bases: Bases, scalars, n=None, offsets=None, is_mont: bool = False, out=None):
+        """k <= 4 MSMs over the same generators in one pipeline; returns uint64[k, 12] unless `out` is given."""
+        k = len(scalars)
+        n = [s.shape[0] for s in scalars] if n is None else list(n)
+        offsets = [0] * k if offsets is None else list(offsets)
+        if out is None:
+            out = np.zeros((k, 12), dtype="<u8")
+        sc = (C.c_void_p * k)(*[_ptr(x) for x in scalars])
+        self._check(lib.vdf_msm_batch(self.handle, bases.handle, k, (C.c_size_t * k)(*offsets), sc, (C.c_size_t * k)(*n),
+                                      int(is_mont), _ptr(out)))
+        return out
+
     def point_sum(self, curve: int, points, n: int, out=None):
         host_out = out is None
         if host_out:
