@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c,
 // per bin: exclusive scan over the pass-A workgroups.  One 256-thread workgroup per bin scans 256 counts at
 // a time through LDS (a thread per bin walking hundreds of counts would be one L2 round trip each).
 __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ countsA, uint32_t bins, uint32_t nblk,
-                                                   uint32_t* __restrict__ pcount) {
+                                                   uint32_t* __restrict__ pcount, uint32_t* __restrict__ heavy) {
   raise_wave_priority();
   __shared__ uint32_t sc[256];
   const uint32_t b = blockIdx.x;
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ counts
     carry += tot;
   }
   if (threadIdx.x == 0) pcount[b] = carry;
+  if (b == 0 && threadIdx.x == 0) heavy[0] = 0;       // the heavy-bucket queue of this run starts empty
 }
 
 // single workgroup exclusive scan: out[0..n], out[n] = total.  Each thread owns a contiguous run; loads are
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ 
 // bstart[bin*nf + f] = pstart[bin] + (buckets of this bin before f): no global scan over all keys.
 __global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
                                                     uint32_t bins, uint32_t nf, uint32_t split,
-                                                    uint32_t* __restrict__ bstart) {
+                                                    uint32_t* __restrict__ bstart, char* __restrict__ bucket_acc) {
   raise_wave_priority();
   __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
@@ -355,6 +356,12 @@ __global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ count
     __syncthreads();
   }
   bstart[(size_t)bin * nf + f] = pstart[bin] + sc[f] - run;
+  // every non-empty bucket is written exactly once by k_accumulate; an empty one must read as the identity
+  if (run == 0) {
+    uint4* z = reinterpret_cast<uint4*>(bucket_acc + ((size_t)bin * nf + f) * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
 }
 
@@ -694,18 +701,16 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   const size_t lds_bins = (size_t)p.bins * 4;
 
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
-  VDF_TRY_HIP(hipMemsetAsync(bucket_acc, 0, (size_t)nkeys * 128, st));
-  VDF_TRY_HIP(hipMemsetAsync(heavy, 0, 4, st));
   // pass A
   hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
-  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount);
+  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   // pass B
   hipLaunchKernelGGL(k_fine_hist, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB);
-  hipLaunchKernelGGL(k_fine_scan, dim3(p.bins), dim3(nf), 0, st, countsB, pstart, p.bins, nf, p.split, bstart);
+  hipLaunchKernelGGL(k_fine_scan, dim3(p.bins), dim3(nf), 0, st, countsB, pstart, p.bins, nf, p.split, bstart, bucket_acc);
   hipLaunchKernelGGL(k_fine_scatter, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB, bstart,
                      sorted);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
