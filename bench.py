@@ -190,6 +190,8 @@ def main():
         acc_avg_ms = acc_ms / max(calls, 1)
         alg_bytes = 96.0 * n
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+        windows_eff = (256 + args.window - 1) // args.window          # entries per point (zero digits are rare)
+        ctx_num_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
@@ -211,7 +213,13 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_accumulate", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": acc_avg_ms,
-                         "note": "MSM is integer-ALU-bound (SURVEY.md 7.3 H5); see DESIGN.md for the v_mad_u64_u32 issue ceiling"},
+                         # the bound that actually holds: integer VALU issue.  2,586 VALU
+                         # instructions per mixed addition (PMC SQ_INSTS_VALU), 4.1 cycles per wave-instruction per
+                         # SIMD and 2.375 GHz sustained (tools/ubench/op_rates.hip, clock_probe.hip), 4 SIMDs per CU
+                         "valu_issue_frac": (2586.0 * n * windows_eff / 64.0) /
+                                            (ctx_num_simds * acc_avg_ms * 1e-3 * 2.375e9 / 4.1),
+                         "note": "k_accumulate is integer-VALU-issue bound, neither HBM nor MFMA: frac is the contract's "
+                                 "HBM figure, valu_issue_frac the fraction of the measured issue ceiling (DESIGN.md 4.1, 4.2)"},
         }
         if world == 1 and not args.no_prove:
             ctx.set_async(False)
