@@ -106,7 +106,6 @@ struct MsmPlan {
   uint32_t bins = 0;     // gsets << pb
   uint32_t chA = 0;      // points per pass-A workgroup
   uint32_t nblkA = 0;    // pass-A workgroups
-  uint32_t split = 0;    // pass-B workgroups per bin
   uint32_t L = 0;        // sorted entries per accumulate thread
   uint32_t nthreads = 0; // accumulate threads
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)

@@ -47,7 +47,7 @@ static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enoug
                                              // per-quad offset multiplication (~30 point ops) stays a small share
 
 struct WsLayout {
-  size_t countsA, pcount, pstart, recs, countsB, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
+  size_t countsA, pcount, pstart, recs, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
   uint32_t red_seg, red_threads_per_set, red_block, red_blocks_per_set;
 };
 
@@ -62,7 +62,6 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.pcount = take((size_t)p.bins * 4);
   w.pstart = take(((size_t)p.bins + 1) * 4);
   w.recs = take((size_t)p.windows * p.n * 8);
-  w.countsB = take(nkeys * (size_t)p.split * 4);
   w.bcount = take(nkeys * 4);
   w.bstart = take((nkeys + 1) * 4);
   w.sorted = take(((size_t)p.windows * p.n + 64) * 4);
@@ -110,11 +109,16 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.gsets = groups * sets;
   p.tables = tables;
   p.nbk = 1u << (c - 1);
-  // two-level sort geometry: pass A splits on the high pb bucket bits (its cursors live in LDS: <= 8192 bins),
-  // pass B on the low fb (<= 10: one thread per fine bucket in k_fine_scan)
-  p.fb = (c - 1 < 8) ? c - 1 : 8;
-  p.pb = c - 1 - p.fb;
-  while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) { --p.pb; ++p.fb; }
+  // two-level sort geometry: pass A splits on the high pb bucket bits, pass B on the low fb.  One pass-B
+  // workgroup sorts one partition, so: about one partition per CU (measured optimum at 2^18 and 2^20; more
+  // partitions shorten pass A's contiguous runs), at most 8192 (pass A keeps a cursor per partition in LDS),
+  // fine bits <= 10 (one thread per fine bucket in k_fine)
+  p.pb = 0;
+  while (p.pb < c - 1 && ((uint32_t)p.gsets << p.pb) < (uint32_t)num_cus) ++p.pb;
+  if (const char* ov = std::getenv("VDF_MSM_PB")) { int v = std::atoi(ov); if (v >= 0 && v <= c - 1) p.pb = v; }   // tuning override
+  while (c - 1 - p.pb > 10) ++p.pb;
+  while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) --p.pb;
+  p.fb = c - 1 - p.pb;
   p.bins = (uint32_t)p.gsets << p.pb;
   size_t chA = (n + 511) / 512;                       // ~2 pass-A workgroups per CU
   chA = (chA + 255) / 256 * 256;
@@ -127,10 +131,6 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
     p.gblk_end[g] = blk;
   }
   p.nblkA = blk ? blk : 1;
-  uint32_t split = 1024u / p.bins;                    // ~4 pass-B workgroups per CU
-  if (split < 1) split = 1;
-  if (split > 16) split = 16;
-  p.split = split;
   // accumulate slices.  k_accumulate is resident at ACC_WG_PER_CU workgroups per CU (register-limited) and
   // ALU-issue-bound: measured on MI355X, a grid that exactly fills the resident slots takes L x 14.1 us, and a
   // single workgroup more costs a whole extra round.  So: one round, every slot used, L = ceil(entries / slots)
@@ -298,56 +298,35 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// pass B: sort every partition by the low bucket bits.  Workgroup (bin, sp) owns the sp-th of `split`
-// equal slices of the partition's records.
+// pass B: sort every partition by the low bucket bits.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void slice_of(const uint32_t* pstart, uint32_t bin, uint32_t sp, uint32_t split,
-                                         uint32_t& lo, uint32_t& hi) {
-  const uint32_t s = pstart[bin], e = pstart[bin + 1];
-  const uint64_t cnt = e - s;
-  lo = s + (uint32_t)(cnt * sp / split);
-  hi = s + (uint32_t)(cnt * (sp + 1) / split);
-}
-
-__global__ __launch_bounds__(256) void k_fine_hist(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
-                                                   uint32_t split, uint32_t nf, uint32_t* __restrict__ countsB) {
+// One 1024-thread workgroup per partition does all of pass B for it: histogram of the fine bucket bits in LDS,
+// exclusive scan (which yields the partition's bucket starts: a partition's buckets are contiguous inside the
+// partition's own region, so there is no scan over all keys), then the scatter with the scanned counters as
+// cursors.  The second read of the records comes from L2 / MALL.  The scan also zeroes the accumulator of every
+// empty bucket (k_accumulate writes each non-empty one exactly once), so the pipeline needs no memset.
+__global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
+                                               uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
+                                               uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc) {
   raise_wave_priority();
   __shared__ uint32_t h[1024];
-  const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
-  for (uint32_t f = threadIdx.x; f < nf; f += 256) h[f] = 0;
-  __syncthreads();
-  uint32_t lo, hi;
-  slice_of(pstart, bin, sp, split, lo, hi);
-  uint32_t i = lo + threadIdx.x;
-  for (; i + 7 * 256 < hi; i += 8 * 256) {                // eight independent loads in flight per lane
-    uint32_t f[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) f[u] = (uint32_t)(recs[i + u * 256] >> 32);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) atomicAdd(&h[f[u]], 1u);
-  }
-  for (; i < hi; i += 256) atomicAdd(&h[(uint32_t)(recs[i] >> 32)], 1u);
-  __syncthreads();
-  for (uint32_t f = threadIdx.x; f < nf; f += 256) countsB[(size_t)blockIdx.x * nf + f] = h[f];
-}
-
-// One workgroup per bin, one thread per fine bucket f: exclusive scan over the partition's slices, then a
-// block-wide scan over f.  A bin's buckets are contiguous inside the bin's own region, so
-// bstart[bin*nf + f] = pstart[bin] + (buckets of this bin before f): no global scan over all keys.
-__global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ countsB, const uint32_t* __restrict__ pstart,
-                                                    uint32_t bins, uint32_t nf, uint32_t split,
-                                                    uint32_t* __restrict__ bstart, char* __restrict__ bucket_acc) {
-  raise_wave_priority();
   __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
-  uint32_t run = 0;
-  for (uint32_t sp = 0; sp < split; ++sp) {
-    const size_t idx = ((size_t)bin * split + sp) * nf + f;
-    const uint32_t v = countsB[idx];
-    countsB[idx] = run;
-    run += v;
+  const uint32_t lo = pstart[bin], hi = pstart[bin + 1];
+  h[f] = 0;
+  __syncthreads();
+  uint32_t i = lo + f;
+  for (; i + 3 * 1024 < hi; i += 4 * 1024) {              // four independent loads in flight per lane
+    uint32_t k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[u] = (uint32_t)(recs[i + u * 1024] >> 32);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) atomicAdd(&h[k[u]], 1u);
   }
-  sc[f] = run;
+  for (; i < hi; i += 1024) atomicAdd(&h[(uint32_t)(recs[i] >> 32)], 1u);
+  __syncthreads();
+  const uint32_t cnt = (f < nf) ? h[f] : 0u;
+  sc[f] = cnt;
   __syncthreads();
   for (uint32_t d = 1; d < nf; d <<= 1) {
     const uint32_t t = (f >= d) ? sc[f - d] : 0u;
@@ -355,42 +334,32 @@ __global__ __launch_bounds__(1024) void k_fine_scan(uint32_t* __restrict__ count
     sc[f] += t;
     __syncthreads();
   }
-  bstart[(size_t)bin * nf + f] = pstart[bin] + sc[f] - run;
-  // every non-empty bucket is written exactly once by k_accumulate; an empty one must read as the identity
-  if (run == 0) {
-    uint4* z = reinterpret_cast<uint4*>(bucket_acc + ((size_t)bin * nf + f) * 128);
+  if (f < nf) {
+    const uint32_t start = lo + sc[f] - cnt;
+    bstart[(size_t)bin * nf + f] = start;
+    h[f] = start;                                          // cursor
+    if (cnt == 0) {
+      uint4* z = reinterpret_cast<uint4*>(bucket_acc + ((size_t)bin * nf + f) * 128);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int q = 0; q < 8; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
   }
-  if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
-}
-
-__global__ __launch_bounds__(256) void k_fine_scatter(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
-                                                      uint32_t split, uint32_t nf, const uint32_t* __restrict__ countsB,
-                                                      const uint32_t* __restrict__ bstart,
-                                                      uint32_t* __restrict__ sorted) {
-  raise_wave_priority();
-  __shared__ uint32_t cur[1024];
-  const uint32_t bin = blockIdx.x / split, sp = blockIdx.x % split;
-  for (uint32_t f = threadIdx.x; f < nf; f += 256)
-    cur[f] = bstart[(size_t)bin * nf + f] + countsB[(size_t)blockIdx.x * nf + f];
   __syncthreads();
-  uint32_t lo, hi;
-  slice_of(pstart, bin, sp, split, lo, hi);
-  uint32_t i = lo + threadIdx.x;
-  for (; i + 7 * 256 < hi; i += 8 * 256) {                // eight independent loads in flight per lane
-    uint64_t r[8];
+  i = lo + f;
+  for (; i + 3 * 1024 < hi; i += 4 * 1024) {
+    uint64_t r[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = recs[i + u * 256];
+    for (int u = 0; u < 4; ++u) r[u] = recs[i + u * 1024];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint32_t pos = atomicAdd(&cur[(uint32_t)(r[u] >> 32)], 1u);
-      sorted[pos] = (uint32_t)r[u];       // each (workgroup, bucket) run is contiguous: whole lines leave L2
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t pos = atomicAdd(&h[(uint32_t)(r[u] >> 32)], 1u);
+      sorted[pos] = (uint32_t)r[u];
     }
   }
-  for (; i < hi; i += 256) {
+  for (; i < hi; i += 1024) {
     const uint64_t r = recs[i];
-    const uint32_t pos = atomicAdd(&cur[(uint32_t)(r >> 32)], 1u);
+    const uint32_t pos = atomicAdd(&h[(uint32_t)(r >> 32)], 1u);
     sorted[pos] = (uint32_t)r;
   }
 }
@@ -682,7 +651,6 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   uint32_t* pcount = reinterpret_cast<uint32_t*>(base + w.pcount);
   uint32_t* pstart = reinterpret_cast<uint32_t*>(base + w.pstart);
   uint64_t* recs = reinterpret_cast<uint64_t*>(base + w.recs);
-  uint32_t* countsB = reinterpret_cast<uint32_t*>(base + w.countsB);
   uint32_t* bstart = reinterpret_cast<uint32_t*>(base + w.bstart);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + w.sorted);
   char* bucket_acc = base + w.bucket_acc;
@@ -709,10 +677,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   // pass B
-  hipLaunchKernelGGL(k_fine_hist, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB);
-  hipLaunchKernelGGL(k_fine_scan, dim3(p.bins), dim3(nf), 0, st, countsB, pstart, p.bins, nf, p.split, bstart, bucket_acc);
-  hipLaunchKernelGGL(k_fine_scatter, dim3(p.bins * p.split), dim3(256), 0, st, recs, pstart, p.split, nf, countsB, bstart,
-                     sorted);
+  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
