@@ -303,7 +303,17 @@ int vdf_ctx_get_async(vdf_ctx* ctx, int* async) {
 }
 
 int vdf_ctx_sync(vdf_ctx* ctx) {
-  return guarded(ctx, [&]() -> Status { VDF_TRY_HIP(hipStreamSynchronize(ctx->stream)); return Status{}; });
+  return guarded(ctx, [&]() -> Status {
+    // poll first: a prover waits ~1 ms for a commitment, and the interrupt-driven wake-up of a blocking
+    // synchronise costs 10-20 us of it; after a few milliseconds fall back to the blocking call
+    for (int spin = 0; spin < 4000; ++spin) {
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) return Status{};
+      if (q != hipErrorNotReady) return vdf::hip_status(q, "hipStreamQuery");
+    }
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
 }
 
 int vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits) {
