@@ -422,13 +422,21 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
   bool have = false;
-  // software pipeline: while entry `pos` is added, the point of entry pos+1 and the index of entry pos+2 are in
-  // flight (one addition is ~10 us of ALU work per wave: ample cover for both loads)
-  uint32_t e = sorted[lo];
-  uint32_t en = (lo + 1 < hi) ? sorted[lo + 1] : e;
+  // software pipeline: while entry `pos` is added, the point of entry pos+1 is in flight.  Entry indices arrive
+  // four at a time as one aligned dwordx4 (every sorted line is then fetched from HBM once; one dword per
+  // iteration re-fetched lines the L1 had already dropped: +20 % FETCH_SIZE); the chunk for positions 4k..4k+3
+  // is requested while position 4k-2 is processed.  The slice may start and end inside a chunk: the list is
+  // padded, and positions outside [lo, hi) are never used.
+  const uint4* chunks = reinterpret_cast<const uint4*>(sorted);
+  uint4 cq = chunks[lo >> 2];                                   // chunk holding `pos`
+  uint4 nq = chunks[(lo >> 2) + 1];                             // the following chunk
+  auto pick = [](const uint4& q, uint32_t k) { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; };
+  uint32_t e = pick(cq, lo & 3u);
   Affine<P> pt = affine_load<P>(points + (size_t)(e & ~SIGN_BIT) * 64);
   for (uint32_t pos = lo; pos < hi; ++pos) {
-    const uint32_t e2 = (pos + 2 < hi) ? sorted[pos + 2] : en;
+    const uint32_t pn = pos + 1;
+    if ((pn & 3u) == 0) { cq = nq; nq = chunks[(pn >> 2) + 1]; }   // crossed into the next chunk: rotate, prefetch
+    const uint32_t en = (pn < hi) ? pick(cq, pn & 3u) : e;
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
       flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
@@ -448,7 +456,6 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
     if (e & SIGN_BIT) pt.y = fe_neg(pt.y);
     madd_lazy<P>(acc, have, pt);
     e = en;
-    en = e2;
     pt = ptn;
   }
   flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
