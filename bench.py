@@ -39,10 +39,12 @@ def parse():
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU (2^k)")
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
+    ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
+                    help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the prove_step leg (BASELINE config 3)")
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
-    ap.add_argument("--prove-steps", type=int, default=6)
+    ap.add_argument("--prove-steps", type=int, default=12, help="1 base case + 1 warm-up fold + timed steady-state folds")
     return ap.parse_args()
 
 
@@ -59,6 +61,12 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     t0 = time.perf_counter()
     L.ref_msm(curve, cref.p(pts), cref.p(sc), n, 0, cores, 0, cref.p(out))
     dt = time.perf_counter() - t0
+    # one thread, on the first 2^17 points of the same inputs (SURVEY.md 8d asks for a 1-thread figure beside it)
+    n1 = min(n, 1 << 17)
+    out1 = np.zeros(12, dtype="<u8")
+    t0 = time.perf_counter()
+    L.ref_msm(curve, cref.p(pts), cref.p(sc), n1, 0, 1, 0, cref.p(out1))
+    dt1 = time.perf_counter() - t0
     aff_cpu = np.zeros(8, dtype="<u8")
     aff_gpu = np.zeros(8, dtype="<u8")
     L.ref_jac_to_affine(curve, cref.p(out), cref.p(aff_cpu))
@@ -69,6 +77,7 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
         "sample": f"the full 2^{n.bit_length() - 1}-point MSM of the timed workload (same bases and scalars), "
                   f"{dt:.2f} s wall on {cores} threads, windows spread over a pthread pool",
         "parity_bit_exact": bool(np.array_equal(aff_cpu, aff_gpu)),
+        "single_thread": {"value": n1 / dt1 / 1e9, "unit": "GPoints/s", "sample": f"first 2^{n1.bit_length() - 1} points, {dt1:.2f} s"},
     }
 
 
@@ -95,20 +104,29 @@ def prove_step_leg(ctx, log2t, nsteps):
     proof = NovaVDFProof.prove_step(pp, proof, circuits, 0, z0)
     ctx.sync()
     base_case = time.perf_counter() - a
+    # the first fold is a warm-up (it grows the MSM workspace for the two-commitment batch); the rest are timed
+    first_fold = 0.0
+    if nsteps > 2:
+        a = time.perf_counter()
+        proof = NovaVDFProof.prove_step(pp, proof, circuits, 1, z0)
+        ctx.sync()
+        first_fold = time.perf_counter() - a
+    first_timed = 2 if nsteps > 2 else 1
     a = time.perf_counter()
-    for k in range(1, nsteps):
+    for k in range(first_timed, nsteps):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
         stages.append(proof.last_step_ms())
     ctx.sync()
     steady_total = time.perf_counter() - a
     ctx.set_async(was_async)
     ok = proof.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
-    nsteady = max(nsteps - 1, 1)
+    nsteady = max(nsteps - first_timed, 1)
     avg = steady_total / nsteady if nsteps > 1 else base_case
     stage_avg = {k: sum(s[k] for s in stages) / len(stages) for k in stages[-1]} if stages else {}
     sizes = pp.sizes()
     out = {"metric": "Nova prove_step/sec (MinRoot, 2^%d iters/step)" % log2t, "value": 1.0 / avg, "unit": "prove_step/s",
-           "ms_per_step": avg * 1e3, "base_case_ms": base_case * 1e3, "steady_state_steps": nsteady if nsteps > 1 else 0,
+           "ms_per_step": avg * 1e3, "base_case_ms": base_case * 1e3, "first_fold_ms_untimed_warmup": first_fold * 1e3,
+           "steady_state_steps": nsteady if nsteps > 1 else 0,
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes,
            "forward_eval_s_per_step_host": eval_s / nsteps,
            "stage": "folding-only (step circuit + NIFS on the primary curve; no augmented circuit / secondary curve)"}
@@ -139,7 +157,9 @@ def main():
     curve = vdf_amd.CURVE_PALLAS
     n = 1 << args.log2n
     ctx = vdf_amd.Context(local_rank)
-    sh = ShardedMsm(ctx, curve, seed=7, n_total=n * world, rank=rank, world=world, table=(args.window, args.sets))
+    family = vdf_amd.GENS_TRY_AND_INCREMENT if args.bases == "tai" else vdf_amd.GENS_KNOWN_DLOG
+    sh = ShardedMsm(ctx, curve, seed=7, n_total=n * world, rank=rank, world=world, table=(args.window, args.sets),
+                    family=family)
 
     # synthetic scalars, uniform 254-bit (< q), generated on the device
     g = torch.Generator(device="cuda")
@@ -204,7 +224,8 @@ def main():
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
-            "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU, uniform 254-bit scalars resident in HBM, "
+            "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU ({'seeded try-and-increment' if args.bases == 'tai' else '[k_i]G'} "
+                                   f"generators, seed 7), uniform 254-bit scalars (torch Philox, seed 1234+rank) resident in HBM, "
                                    f"fixed-base table c={args.window} sets={args.sets}; N>1: point-chunk shards + all-gather of 96-B partials",
                        "points_per_gpu": n, "window_bits": args.window, "bucket_sets": args.sets},
             "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),

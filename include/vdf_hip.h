@@ -83,6 +83,13 @@ int  vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n
 int  vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out);
 /* Same, for the index range [start, start + n): the shard a rank owns in a multi-GPU MSM. */
 int  vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, vdf_bases** out);
+/* Generator families.  KNOWN_DLOG is the one above (it makes full-size results checkable in O(n) through
+ * sum s_i P_i = [sum s_i k_i] G).  TRY_AND_INCREMENT has no known discrete logarithms, like generators derived
+ * from a hash: per index a xoshiro256** stream seeded by splitmix64(seed, index) yields candidates
+ * x = 256 bits mod p; the first x with x^3 + 5 a square is taken, y = the even root (SURVEY.md 8d, config 2;
+ * restated in oracle/pasta.py tai_base).  Setup-time only. */
+enum { VDF_GENS_KNOWN_DLOG = 0, VDF_GENS_TRY_AND_INCREMENT = 1 };
+int  vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed, size_t start, size_t n, vdf_bases** out);
 /* Build the fixed-base table  2^(window_bits*sets*j) * P_i, j = 0..tables-1, so that an MSM
  * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table). */
 int  vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets);

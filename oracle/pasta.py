@@ -195,6 +195,66 @@ def synthetic_bases(curve: int, seed: int, n: int, start: int = 0) -> List[Point
     return [pt_mul(base_dlog(seed, start + i), g, m) for i in range(n)]
 
 
+def sqrt_mod(a: int, m: int) -> Optional[int]:
+    """A square root of a mod the prime m (Tonelli-Shanks), or None for a non-residue."""
+    a %= m
+    if a == 0:
+        return 0
+    if pow(a, (m - 1) // 2, m) != 1:
+        return None
+    s, t = 0, m - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (m - 1) // 2, m) != m - 1:
+        z += 1
+    c, x, b = pow(z, t, m), pow(a, (t + 1) // 2, m), pow(a, t, m)
+    while b != 1:
+        k, tt = 0, b
+        while tt != 1:
+            tt, k = tt * tt % m, k + 1
+        g = pow(c, 1 << (s - k - 1), m)
+        x, c = x * g % m, g * g % m
+        b, s = b * c % m, k
+    return x
+
+
+def tai_base(curve: int, seed: int, i: int) -> Point:
+    """Generator family 1 (include/vdf_hip.h VDF_GENS_TRY_AND_INCREMENT): xoshiro256**
+    seeded by four splitmix64 words of (seed, index); candidates x = 256 stream bits mod m until x^3 + 5 is a
+    square; y = the even root."""
+    m = curve_base_modulus(curve)
+    sm = (seed * 0xD1342543DE82EF95 + i * 0x9E3779B97F4A7C15) & MASK64
+    st = []
+    for _ in range(4):
+        st.append(splitmix64(sm))
+        sm = (sm + 0x9E3779B97F4A7C15) & MASK64
+
+    def rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & MASK64
+
+    def nxt():
+        r = (rotl(st[1] * 5 & MASK64, 7) * 9) & MASK64
+        t = (st[1] << 17) & MASK64
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]
+        st[2] ^= t
+        st[3] = rotl(st[3], 45)
+        return r
+
+    while True:
+        x = sum(nxt() << (64 * k) for k in range(4)) % m
+        y = sqrt_mod(x * x * x + 5, m)
+        if y is None:
+            continue
+        if y & 1:
+            y = m - y
+        return (x, y)
+
+
+def tai_bases(curve: int, seed: int, n: int, start: int = 0) -> List[Point]:
+    return [tai_base(curve, seed, start + i) for i in range(n)]
+
+
 def msm_by_dlog(scalars: Iterable[int], curve: int, seed: int, start: int = 0) -> Point:
     """Expected MSM over synthetic_bases in O(n) field work: [sum s_i k_i mod r] G."""
     r = curve_scalar_modulus(curve)

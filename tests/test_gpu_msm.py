@@ -352,3 +352,26 @@ def test_msm_batch_fold_shapes_dlog_identity(ctx):
         vals = ints(scs[k].cpu().numpy().view("<u8"))
         assert jac_to_affine(res[k], curve) == o.msm_by_dlog(vals, curve, seed)
     bases.free()
+
+
+# ---- generator family 1: try-and-increment (no known discrete logs) --------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+def test_try_and_increment_bases_match_oracle(ctx, cref, curve):
+    import vdf_amd
+    n, start, seed = 300, 12345, 99
+    bases = ctx.bases_generate(curve, seed, n, start=start, family=vdf_amd.GENS_TRY_AND_INCREMENT)
+    got = bases.download()
+    exp = affine_array(o.tai_bases(curve, seed, n, start), curve)
+    assert np.array_equal(got, exp)
+    m = o.curve_base_modulus(curve)
+    for x, y in (tuple(unmont(got[i].reshape(2, 4), m)) for i in range(0, n, 37)):
+        assert (y * y - x * x * x - 5) % m == 0 and y % 2 == 0
+    # an MSM over them against the C restatement (plain and table paths)
+    sc = rand_limbs(np.random.default_rng(3), n)
+    want = cpu_msm(cref, curve, got, sc)
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == want
+    bases.precompute(16, 1)
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == want
+    with pytest.raises(Exception):
+        ctx.bases_generate(curve, seed, 4, family=7)
+    bases.free()

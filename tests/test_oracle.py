@@ -245,3 +245,18 @@ def test_c_msm_golden_and_dlog(cref, golden, curve):
         sc_arr = limbs(sc)
         L.ref_msm(curve, cref.p(pts), cref.p(sc_arr), n, 0, 4, c_bits, cref.p(out))
         assert jac_to_affine(out, curve) == exp
+
+
+def test_try_and_increment_generators_are_curve_points_with_even_y():
+    """Generator family 1: on the curve, even y, deterministic per (seed, index)."""
+    for curve in (o.CURVE_PALLAS, o.CURVE_VESTA):
+        m = o.curve_base_modulus(curve)
+        pts = o.tai_bases(curve, 7, 40, start=1000)
+        assert len(set(pts)) == 40
+        for x, y in pts:
+            assert (y * y - x * x * x - 5) % m == 0 and y % 2 == 0 and 0 <= x < m
+        assert o.tai_base(curve, 7, 1003) == pts[3]
+        assert o.tai_base(curve, 8, 1003) != pts[3]
+    for a in (0, 1, 4, 5, 12345678901234567890):
+        r = o.sqrt_mod(a * a, o.P)
+        assert r in (a % o.P, (-a) % o.P)

@@ -6,4 +6,4 @@ library and fails loudly if it has not been built: there is no CPU fallback.
 """
 from . import _lib  # noqa: F401  (raises ImportError when libvdf_hip.so is missing)
 from .hip import Context, Bases, Shape, VdfError, ints_to_limbs, limbs_to_ints  # noqa: F401
-from ._lib import CURVE_PALLAS, CURVE_VESTA, FIELD_FP, FIELD_FQ  # noqa: F401
+from ._lib import CURVE_PALLAS, CURVE_VESTA, FIELD_FP, FIELD_FQ, GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT  # noqa: F401

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvdf_hip.so")
 VDF_OK, VDF_ERR_BAD_ARG, VDF_ERR_BAD_LENGTH, VDF_ERR_NONCANONICAL, VDF_ERR_DEVICE, VDF_ERR_OOM, VDF_ERR_NO_DEVICE = range(7)
 CURVE_PALLAS, CURVE_VESTA = 0, 1
 FIELD_FP, FIELD_FQ = 0, 1
+GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT = 0, 1
 
 # every symbol include/vdf_hip.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
@@ -32,6 +33,7 @@ PROTOTYPES = {
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate_range": (_i, [_vp, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
+    "vdf_bases_generate_family": (_i, [_vp, _i, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
     "vdf_bases_precompute": (_i, [_vp, _vp, _i, _i]),
     "vdf_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "vdf_bases_len": (_sz, [_vp]),

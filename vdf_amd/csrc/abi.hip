@@ -352,6 +352,10 @@ int vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bas
 }
 
 int vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t start, size_t n, vdf_bases** out) {
+  return vdf_bases_generate_family(ctx, curve, VDF_GENS_KNOWN_DLOG, seed, start, n, out);
+}
+
+int vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed, size_t start, size_t n, vdf_bases** out) {
   return guarded(ctx, [&]() -> Status {
     if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
     *out = nullptr;
@@ -362,7 +366,7 @@ int vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t star
     if (n) {
       hipError_t e = hipMalloc(&b->d_pts, n * sizeof(vdf_affine));
       if (e != hipSuccess) { delete b; return vdf::hip_status(e, "hipMalloc(bases)"); }
-      Status s = vdf::bases_generate(curve, seed, start, n, b->d_pts, ctx->stream);
+      Status s = vdf::bases_generate(curve, family, seed, start, n, b->d_pts, ctx->stream);
       if (s.ok()) s = vdf::hip_status(hipStreamSynchronize(ctx->stream), "bases_generate");
       if (!s.ok()) { (void)hipFree(b->d_pts); delete b; return s; }
     }

@@ -122,7 +122,7 @@ int msm_auto_window(size_t n);
 // ev (optional): 4 events recorded at start / before accumulate / after accumulate / end.
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont,
                void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr);
-Status bases_generate(int curve, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
+Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,
                         hipStream_t stream);

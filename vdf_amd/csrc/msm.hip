@@ -629,6 +629,77 @@ __global__ __launch_bounds__(256) void k_bases_generate(uint64_t seed, uint64_t 
   affine_store<P>(pts + (size_t)i * 64, xyzz_to_affine(r));
 }
 
+// Square root in a Pasta field (2-adicity 32) by Tonelli-Shanks; ok = false when a is a non-residue.
+template <class P>
+__device__ bool fe_sqrt(const Fe<P>& a, Fe<P>& root) {
+  if (fe_is_zero(a)) { root = a; return true; }
+  uint32_t e[8];
+  Fe<P> z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = P::TS_EXP[i]; z.v[i] = P::TS_Z[i]; }
+  const Fe<P> w = fe_pow(a, e);                 // a^((T-1)/2)
+  Fe<P> x = fe_mul(a, w);                       // a^((T+1)/2)
+  Fe<P> b = fe_mul(x, w);                       // a^T: order divides 2^32
+  const Fe<P> one = fe_one<P>();
+  int v = 32;
+  while (!fe_eq(b, one)) {
+    int k = 0;
+    Fe<P> t = b;
+    while (!fe_eq(t, one)) { t = fe_sqr(t); ++k; if (k == v) return false; }   // order 2^v: non-residue
+    Fe<P> zz = z;
+    for (int i = 0; i < v - k - 1; ++i) zz = fe_sqr(zz);
+    x = fe_mul(x, zz);
+    z = fe_sqr(zz);
+    b = fe_mul(b, z);
+    v = k;
+  }
+  root = x;
+  return true;
+}
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+// Generator family 1, "try and increment" (SURVEY.md 8d, config 2): per index a xoshiro256** stream seeded with
+// four splitmix64 words of (seed, index); a candidate x is 256 stream bits reduced mod m; it is accepted when
+// x^3 + 5 is a square, and y is the root whose canonical value is even.  Discrete logarithms are unknown, as for
+// generators derived from a hash.
+template <class P>
+__global__ __launch_bounds__(256) void k_bases_generate_tai(uint64_t seed, uint64_t start, uint32_t n, char* __restrict__ pts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t st[4];
+  uint64_t sm = seed * 0xD1342543DE82EF95ull + (start + i) * 0x9E3779B97F4A7C15ull;
+  for (int k = 0; k < 4; ++k) { st[k] = splitmix64(sm); sm += 0x9E3779B97F4A7C15ull; }
+  Fe<P> five;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) five.v[l] = P::FIVE[l];
+  for (;;) {
+    Fe<P> x;
+    for (int k = 0; k < 4; ++k) {                                  // xoshiro256** (Blackman, Vigna; public domain)
+      const uint64_t r = rotl64(st[1] * 5, 7) * 9, t = st[1] << 17;
+      st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3]; st[2] ^= t; st[3] = rotl64(st[3], 45);
+      x.v[2 * k] = (uint32_t)r; x.v[2 * k + 1] = (uint32_t)(r >> 32);
+    }
+    for (int k = 0; k < 3; ++k) {                                  // 2^256 < 4m: at most three subtractions of m
+      if (fe_is_canonical(x)) break;
+      uint32_t borrow = 0;
+      for (int l = 0; l < 8; ++l) {
+        const uint64_t d = (uint64_t)x.v[l] - P::MOD[l] - borrow;
+        x.v[l] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+      }
+    }
+    const Fe<P> xm = fe_to_mont(x);
+    const Fe<P> rhs = fe_add(fe_mul(fe_sqr(xm), xm), five);
+    Fe<P> y;
+    if (!fe_sqrt(rhs, y)) continue;
+    if (fe_from_mont(y).v[0] & 1u) y = fe_neg(y);
+    Affine<P> a; a.x = xm; a.y = y;
+    affine_store<P>(pts + (size_t)i * 64, a);
+    return;
+  }
+}
+
 // table[j][i] = 2^(shift*j) * P_i
 template <class P>
 __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts, uint32_t n, int shift, int tables,
@@ -747,9 +818,22 @@ Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_
   return Status{};
 }
 
-Status bases_generate(int curve, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream) {
+Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream) {
   if (n == 0) return Status{};
   dim3 grid((unsigned)((n + 255) / 256));
+  if (family == VDF_GENS_TRY_AND_INCREMENT) {
+    if (curve == VDF_CURVE_PALLAS)
+      hipLaunchKernelGGL((k_bases_generate_tai<FpParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
+                         reinterpret_cast<char*>(d_pts));
+    else if (curve == VDF_CURVE_VESTA)
+      hipLaunchKernelGGL((k_bases_generate_tai<FqParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
+                         reinterpret_cast<char*>(d_pts));
+    else
+      return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+    VDF_TRY_HIP(hipGetLastError());
+    return Status{};
+  }
+  if (family != VDF_GENS_KNOWN_DLOG) return Status{VDF_ERR_BAD_ARG, "unknown generator family"};
   if (curve == VDF_CURVE_PALLAS)
     hipLaunchKernelGGL((k_bases_generate<FpParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
                        reinterpret_cast<char*>(d_pts));

@@ -26,11 +26,16 @@ class ShardedMsm:
     bases_generate / msm / point_sum surface can be injected by a test."""
 
     def __init__(self, backend, curve: int, seed: int, n_total: int, rank: int, world: int,
-                 table: Tuple[int, int] | None = (16, 1)):
+                 table: Tuple[int, int] | None = (16, 1), family: int = 0):
         self.backend, self.curve, self.rank, self.world = backend, curve, rank, world
         self.n_total = n_total
         self.start, self.count = shard_range(n_total, rank, world)
-        self.bases = backend.bases_generate(curve, seed, self.count, start=self.start)
+        # family 0: [k_i]G (known discrete logs), 1: try-and-increment; both are index-addressed, so a rank
+        # generates exactly its own range
+        if family:
+            self.bases = backend.bases_generate(curve, seed, self.count, start=self.start, family=family)
+        else:
+            self.bases = backend.bases_generate(curve, seed, self.count, start=self.start)
         if table is not None and self.count:
             self.bases.precompute(*table)
 

@@ -154,9 +154,10 @@ class Context:
         self._check(lib.vdf_bases_upload(self.handle, curve, _ptr(pts), n, C.byref(h)))
         return Bases(self, h.value, curve)
 
-    def bases_generate(self, curve: int, seed: int, n: int, start: int = 0) -> Bases:
+    def bases_generate(self, curve: int, seed: int, n: int, start: int = 0, family: int = 0) -> Bases:
+        """family 0: P_i = [k_i]G (known discrete logs); 1: try-and-increment (unknown discrete logs)."""
         h = C.c_void_p()
-        self._check(lib.vdf_bases_generate_range(self.handle, curve, seed, start, n, C.byref(h)))
+        self._check(lib.vdf_bases_generate_family(self.handle, curve, family, seed, start, n, C.byref(h)))
         return Bases(self, h.value, curve)
 
     # ---- msm ---------------------------------------------------------------------------
