@@ -141,6 +141,15 @@ template <class P> __device__ __forceinline__ QPoint<P> qpoint_load(const char* 
   r.inf = quad_bcast_flag<2>(z);                                  // zz == 0
   return r;
 }
+// the same for a point k_accumulate flushed in its lazy domain (coordinates in [0, 2m + eps), identity all-zero):
+// every lane brings its own coordinate to canonical form, one fe_canon per lane instead of four per flush
+template <class P> __device__ __forceinline__ QPoint<P> qpoint_load_lazy(const char* p) {
+  QPoint<P> r;
+  r.c = fe_canon(fe_load<P>(p + 32 * quad_pos()));
+  const bool z = fe_is_zero(r.c);
+  r.inf = quad_bcast_flag<2>(z);                                  // zz == 0
+  return r;
+}
 template <class P> __device__ __forceinline__ void qpoint_store(char* p, const QPoint<P>& a) {
   fe_store<P>(p + 32 * quad_pos(), a.inf ? fe_zero<P>() : a.c);
 }

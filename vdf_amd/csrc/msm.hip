@@ -47,7 +47,7 @@ static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enoug
                                              // per-quad offset multiplication (~30 point ops) stays a small share
 
 struct WsLayout {
-  size_t countsA, pcount, pstart, recs, bcount, bstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
+  size_t countsA, pcount, pstart, recs, bcount, bstart, tstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
   uint32_t red_seg, red_threads_per_set, red_block, red_blocks_per_set;
 };
 
@@ -64,6 +64,7 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.recs = take((size_t)p.windows * p.n * 8);
   w.bcount = take(nkeys * 4);
   w.bstart = take((nkeys + 1) * 4);
+  w.tstart = take(((size_t)p.nthreads + 1) * 4);
   w.sorted = take(((size_t)p.windows * p.n + 64) * 4);
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
 // empty bucket (k_accumulate writes each non-empty one exactly once), so the pipeline needs no memset.
 __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
                                                uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
-                                               uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc) {
+                                               uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc,
+                                               uint32_t L, uint32_t* __restrict__ tstart) {
   raise_wave_priority();
   __shared__ uint32_t h[1024];
   __shared__ uint32_t sc[1024];
@@ -344,6 +346,9 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
       for (int q = 0; q < 8; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
+    // k_accumulate thread t starts at sorted position t * L: tell it which bucket that is (replaces a 16-step
+    // binary search over bstart, a chain of dependent loads at the start of every thread)
+    for (uint32_t t = (start + L - 1) / L; (uint64_t)t * L < (uint64_t)start + cnt; ++t) tstart[t] = bin * nf + f;
   }
   __syncthreads();
   i = lo + f;
@@ -393,15 +398,15 @@ __device__ __forceinline__ void madd_lazy(XYZZ<P>& acc, bool& have, const Affine
 
 template <class P>
 __device__ __forceinline__ void flush_lazy(const XYZZ<P>& acc, bool have, char* dst) {
-  XYZZ<P> o;
-  if (have) { o.x = fe_canon(acc.x); o.y = fe_canon(acc.y); o.zz = fe_canon(acc.zz); o.zzz = fe_canon(acc.zzz); }
-  else o = xyzz_identity<P>();
-  xyzz_store<P>(dst, o);
+  // stored as is, in the lazy domain: the tail kernels canonicalise on load (qpoint_load_lazy), each lane its
+  // own coordinate, which takes ~140 instructions out of a path most iterations execute for a few lanes
+  xyzz_store<P>(dst, have ? acc : xyzz_identity<P>());
 }
 
 template <class P>
 __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bstart, uint32_t nkeys,
+                                                    const uint32_t* __restrict__ tstart,
                                                     const char* __restrict__ points, char* __restrict__ bucket_acc,
                                                     char* __restrict__ heads, uint32_t L, uint32_t nthreads) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -411,13 +416,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   if (lo64 >= ne) return;
   const uint32_t lo = (uint32_t)lo64;
   const uint32_t hi = (lo64 + L < ne) ? lo + L : ne;
-  // bucket containing position lo: bstart[g] <= lo < bstart[g+1]
-  uint32_t a = 0, b = nkeys;
-  while (b - a > 1) {
-    uint32_t mid = (a + b) >> 1;
-    if (bstart[mid] <= lo) a = mid; else b = mid;
-  }
-  uint32_t g = a;
+  uint32_t g = tstart[t];                    // bucket containing position lo (written by k_fine)
   uint32_t next = bstart[g + 1];
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
@@ -486,11 +485,11 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
     }
     return;
   }
-  QPoint<P> acc = qpoint_load<P>(bucket_acc + (size_t)g * 128);
-  QPoint<P> nxt = qpoint_load<P>(heads + (size_t)(tf + 1) * 128);
+  QPoint<P> acc = qpoint_load_lazy<P>(bucket_acc + (size_t)g * 128);
+  QPoint<P> nxt = qpoint_load_lazy<P>(heads + (size_t)(tf + 1) * 128);
   for (uint32_t t = tf + 1; t <= tl; ++t) {
     const QPoint<P> cur = nxt;
-    if (t < tl) nxt = qpoint_load<P>(heads + (size_t)(t + 1) * 128);   // next head in flight during the addition
+    if (t < tl) nxt = qpoint_load_lazy<P>(heads + (size_t)(t + 1) * 128);   // next head in flight during the addition
     acc = qpoint_add<P>(acc, cur);
   }
   qpoint_store<P>(bucket_acc + (size_t)g * 128, acc);
@@ -510,10 +509,10 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
     const uint32_t s = bstart[g], e = bstart[g + 1];
     const uint32_t tf = s / L, tl = (e - 1) / L;
     QPoint<P> acc = qpoint_identity<P>();
-    for (uint32_t t = tf + 1 + quad; t <= tl; t += 16) acc = qpoint_add<P>(acc, qpoint_load<P>(heads + (size_t)t * 128));
+    for (uint32_t t = tf + 1 + quad; t <= tl; t += 16) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(heads + (size_t)t * 128));
     acc = qpoint_wave_sum(acc);
     if (quad == 0) {
-      QPoint<P> base = qpoint_load<P>(bucket_acc + (size_t)g * 128);
+      QPoint<P> base = qpoint_load_lazy<P>(bucket_acc + (size_t)g * 128);
       qpoint_store<P>(bucket_acc + (size_t)g * 128, qpoint_add<P>(base, acc));
     }
   }
@@ -538,7 +537,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
   if (seg < threads_per_set) {
     const char* bp = bucket_acc + ((size_t)set * nbk + base) * 128;
     for (int l = (int)nseg - 1; l >= 0; --l) {
-      run = qpoint_add<P>(run, qpoint_load<P>(bp + (size_t)l * 128));
+      run = qpoint_add<P>(run, qpoint_load_lazy<P>(bp + (size_t)l * 128));
       tot = qpoint_add<P>(tot, run);                               // tot = sum (l+1) * B[base+l]
     }
     if (base) {                                                    // + base * run (double-and-add, base < 2^19)
@@ -755,10 +754,11 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   // pass B
-  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc);
+  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.L,
+                     reinterpret_cast<uint32_t*>(base + w.tstart));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
-                     reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
+                     reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
