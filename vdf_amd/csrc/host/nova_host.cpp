@@ -175,7 +175,6 @@ struct vdf_proof {
   void* d_T = nullptr;
   void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
   void* d_trace = nullptr;
-  void* d_small = nullptr;   // staging for r, u1, i0 (3 elements)
   vdf_jac* h_comm = nullptr; // pinned, device-mapped result slots: [0] = commitment of W2, [1] = commitment of T
   std::vector<StepRecord> steps;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,7 +250,6 @@ int alloc_proof_buffers(vdf_proof* p) {
   HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
   for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
   HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, 3 * 32, &p->d_small));
   HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&p->h_comm));
   HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
   return VDF_OK;
@@ -442,7 +440,18 @@ void vdf_nova_circuits_free(vdf_circuits* c) {
 }
 
 // ---- prove_step ----------------------------------------------------------------------------------------
+static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3],
+                           vdf_proof** fresh);
+
 int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]) {
+  vdf_proof* fresh = nullptr;                     // a proof object this call created (the `None` case)
+  const int rc = prove_step_impl(pp, proof, circuits, k, z0, &fresh);
+  if (rc != VDF_OK && fresh) vdf_nova_proof_free(fresh);      // never leak a half-built proof
+  return rc;
+}
+
+static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3],
+                           vdf_proof** fresh) {
   if (!pp || !proof || !circuits || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
   if (k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
   const Circuit& c = circuits->v[k];
@@ -453,16 +462,15 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   const bool first = (p == nullptr);
   if (first) {
     p = new vdf_proof();
+    *fresh = p;
     p->pp = pp;
     memcpy(p->zi, z0, 96);
     int rc = alloc_proof_buffers(p);
-    if (rc != VDF_OK) { vdf_nova_proof_free(p); return rc; }
+    if (rc != VDF_OK) return rc;
   }
   // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
-  if (memcmp(p->zi, &c.result, 96) != 0) {
-    if (first) vdf_nova_proof_free(p);
+  if (memcmp(p->zi, &c.result, 96) != 0)
     return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
-  }
   const double t0 = now_ms();
   const size_t nv = pp->num_vars, nc = pp->num_cons;
   // The step is enqueued asynchronously: every call below is stream-ordered, and the host waits only for the
@@ -558,6 +566,7 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   p->ms[0] = t1 - t0; p->ms[1] = t3 - t2; p->ms[2] = t2 - t1; p->ms[3] = t4 - t3;
   p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
   *proof = p;
+  *fresh = nullptr;                               // handed over to the caller
   return VDF_OK;
 }
 
@@ -581,7 +590,7 @@ void vdf_nova_proof_free(vdf_proof* p) {
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
     void* bufs[] = {p->d_z1, p->d_z2, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4],
-                    p->d_abc[5], p->d_trace, p->d_small};
+                    p->d_abc[5], p->d_trace};
     for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
     if (p->h_comm) vdf_host_free(ctx, p->h_comm);
   }
