@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
     ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
                     help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
+    ap.add_argument("--depth", type=int, default=2, help="independent MSM steps in flight (contexts / streams)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the prove_step leg (BASELINE config 3)")
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
@@ -156,30 +157,43 @@ def main():
 
     curve = vdf_amd.CURVE_PALLAS
     n = 1 << args.log2n
-    ctx = vdf_amd.Context(local_rank)
+    # `depth` contexts (stream + MSM workspace each) share one generator table; step i runs on context i % depth.
+    # Steps are independent MSMs, so two in flight let one pipeline's sort and latency-bound tail run under the
+    # other's ALU-bound bucket accumulation (light kernels carry a raised wave priority for exactly this).
+    depth = max(1, args.depth)
+    ctxs = [vdf_amd.Context(local_rank) for _ in range(depth)]
+    ctx = ctxs[0]
     family = vdf_amd.GENS_TRY_AND_INCREMENT if args.bases == "tai" else vdf_amd.GENS_KNOWN_DLOG
-    sh = ShardedMsm(ctx, curve, seed=7, n_total=n * world, rank=rank, world=world, table=(args.window, args.sets),
-                    family=family)
+    shs = [ShardedMsm(ctx, curve, seed=7, n_total=n * world, rank=rank, world=world, table=(args.window, args.sets),
+                      family=family)]
+    for k in range(1, depth):
+        shs.append(ShardedMsm(ctxs[k], curve, seed=7, n_total=n * world, rank=rank, world=world, bases=shs[0].bases))
+    sh = shs[0]
 
     # synthetic scalars, uniform 254-bit (< q), generated on the device
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
     sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
     sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
-    partial = torch.zeros(12, dtype=torch.int64, device="cuda")
-    gathered = torch.zeros(world * 12, dtype=torch.int64, device="cuda")
-    result = torch.zeros(12, dtype=torch.int64, device="cuda")
+    partial = [torch.zeros(12, dtype=torch.int64, device="cuda") for _ in range(depth)]
+    gathered = [torch.zeros(world * 12, dtype=torch.int64, device="cuda") for _ in range(depth)]
+    results = [torch.zeros(12, dtype=torch.int64, device="cuda") for _ in range(depth)]
+    result = results[0]
     torch.cuda.synchronize()
 
-    # run the library on torch's current stream so the collective and the kernels are ordered
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_async(True)
+    # each context runs on a torch stream of its own, so the collective of a step is ordered with its kernels
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    for c, s_ in zip(ctxs, streams):
+        c.set_stream(s_.cuda_stream)
+        c.set_async(True)
 
     def all_gather(dst, src):
         dist.all_gather_into_tensor(dst, src)
 
-    def step():
-        sh.run(sc, partial, gathered, all_gather, out=result)
+    def step(i):
+        k = i % depth
+        with torch.cuda.stream(streams[k]):
+            shs[k].run(sc, partial[k], gathered[k], all_gather, out=results[k])
 
     def fence():
         torch.cuda.synchronize()
@@ -187,18 +201,36 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, depth)):
+        step(i)
     fence()
-    ctx.set_timing(True)
-    ctx.msm_timing()                      # clear
+    for c in ctxs:
+        c.set_timing(True)
+        c.msm_timing()                    # clear
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    sort_ms, acc_ms, tail_ms, total_ms, calls = ctx.msm_timing()
-    ctx.set_timing(False)
+    sort_ms = acc_ms = tail_ms = total_ms = 0.0
+    calls = 0
+    for c in ctxs:
+        a_, b_, c_, d_, n_ = c.msm_timing()
+        sort_ms += a_; acc_ms += b_; tail_ms += c_; total_ms += d_; calls += n_
+        c.set_timing(False)
+    # One more short pass, one step at a time on context 0 (not part of `value`): with steps in flight a kernel's
+    # HIP-event (and rocprof) duration includes the time its workgroups queue behind the other stream's, so the
+    # isolated duration of the dominant kernel is measured separately for the issue-rate figure.
+    iso = None
+    if depth > 1:
+        ctx.set_timing(True)
+        ctx.msm_timing()
+        for _ in range(5):
+            step(0)
+            ctx.sync()
+        a_, b_, c_, d_, n_ = ctx.msm_timing()
+        ctx.set_timing(False)
+        iso = {"sort": a_ / n_, "accumulate": b_ / n_, "tail": c_ / n_, "pipeline": d_ / n_}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -208,6 +240,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = (n * world) / (elapsed / args.steps) / 1e9
         acc_avg_ms = acc_ms / max(calls, 1)
+        acc_iso_ms = iso["accumulate"] if iso else acc_avg_ms
         alg_bytes = 96.0 * n
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
         windows_eff = (256 + args.window - 1) // args.window          # entries per point (zero digits are rare)
@@ -226,10 +259,12 @@ def main():
             "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU ({'seeded try-and-increment' if args.bases == 'tai' else '[k_i]G'} "
                                    f"generators, seed 7), uniform 254-bit scalars (torch Philox, seed 1234+rank) resident in HBM, "
-                                   f"fixed-base table c={args.window} sets={args.sets}; N>1: point-chunk shards + all-gather of 96-B partials",
-                       "points_per_gpu": n, "window_bits": args.window, "bucket_sets": args.sets},
+                                   f"fixed-base table c={args.window} sets={args.sets}; {depth} independent steps in flight on {depth} streams; "
+                                   f"N>1: point-chunk shards + all-gather of 96-B partials",
+                       "points_per_gpu": n, "window_bits": args.window, "bucket_sets": args.sets, "steps_in_flight": depth},
             "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),
                          "pipeline": total_ms / max(calls, 1)},
+            "stage_ms_one_step_at_a_time": iso,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_accumulate", "algorithmic_bytes_per_launch": alg_bytes,
@@ -238,9 +273,15 @@ def main():
                          # instructions per mixed addition (PMC SQ_INSTS_VALU), 4.1 cycles per wave-instruction per
                          # SIMD and 2.375 GHz sustained (tools/ubench/op_rates.hip, clock_probe.hip), 4 SIMDs per CU
                          "valu_issue_frac": (2586.0 * n * windows_eff / 64.0) /
-                                            (ctx_num_simds * acc_avg_ms * 1e-3 * 2.375e9 / 4.1),
-                         "note": "k_accumulate is integer-VALU-issue bound, neither HBM nor MFMA: frac is the contract's "
-                                 "HBM figure, valu_issue_frac the fraction of the measured issue ceiling (DESIGN.md 4.1, 4.2)"},
+                                            (ctx_num_simds * acc_iso_ms * 1e-3 * 2.375e9 / 4.1),
+                         "isolated_launch_ms": acc_iso_ms,
+                         # the same instructions over the whole timed region (all kernels of all steps in flight)
+                         "valu_issue_frac_of_timed_region_accumulate_only": (2586.0 * n * windows_eff / 64.0) /
+                                            (ctx_num_simds * (elapsed / args.steps) * 2.375e9 / 4.1),
+                         "note": "k_accumulate is integer-VALU-issue bound, neither HBM nor MFMA: frac is the contract's HBM "
+                                 "figure.  avg_launch_ms is the HIP-event duration in the timed region, where a launch also "
+                                 "waits for the other in-flight step's workgroups to retire; isolated_launch_ms (one step at "
+                                 "a time) is the kernel itself and valu_issue_frac is computed from it (DESIGN.md 4.1, 4.2)"},
         }
         if world == 1 and not args.no_prove:
             ctx.set_async(False)

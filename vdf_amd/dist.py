@@ -26,12 +26,16 @@ class ShardedMsm:
     bases_generate / msm / point_sum surface can be injected by a test."""
 
     def __init__(self, backend, curve: int, seed: int, n_total: int, rank: int, world: int,
-                 table: Tuple[int, int] | None = (16, 1), family: int = 0):
+                 table: Tuple[int, int] | None = (16, 1), family: int = 0, bases=None):
         self.backend, self.curve, self.rank, self.world = backend, curve, rank, world
         self.n_total = n_total
         self.start, self.count = shard_range(n_total, rank, world)
         # family 0: [k_i]G (known discrete logs), 1: try-and-increment; both are index-addressed, so a rank
-        # generates exactly its own range
+        # generates exactly its own range.  `bases`: reuse another instance's generators (and table) -- several
+        # contexts of one device can run MSMs over the same table concurrently.
+        if bases is not None:
+            self.bases = bases
+            return
         if family:
             self.bases = backend.bases_generate(curve, seed, self.count, start=self.start, family=family)
         else:
