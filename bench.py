@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
                     help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
     ap.add_argument("--depth", type=int, default=2, help="independent MSM steps in flight (contexts / streams)")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="take the N > 1 code path (process group, all-gather on the step's stream) with a world of one")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the prove_step leg (BASELINE config 3)")
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
@@ -148,8 +150,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.rehearse_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import vdf_amd
@@ -193,11 +196,11 @@ def main():
     def step(i):
         k = i % depth
         with torch.cuda.stream(streams[k]):
-            shs[k].run(sc, partial[k], gathered[k], all_gather, out=results[k])
+            shs[k].run(sc, partial[k], gathered[k], all_gather, out=results[k], always_gather=args.rehearse_collective)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.rehearse_collective:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -290,7 +293,7 @@ def main():
             ctx.set_async(False)
             line["cpu_baseline"] = cpu_baseline_leg(ctx, sh.bases, sc, n, curve, result.cpu().numpy().view("<u8"))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.rehearse_collective:
         dist.barrier()
         dist.destroy_process_group()
 

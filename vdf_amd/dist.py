@@ -51,10 +51,12 @@ class ShardedMsm:
         """Sum of the world partials (gathered: world x 12 words, rank-major)."""
         return self.backend.point_sum(self.curve, gathered, self.world, out=out)
 
-    def run(self, scalars_local, partial_buf, gathered_buf, all_gather: Callable, out=None, is_mont: bool = False):
-        """One sharded MSM.  all_gather(dst, src) fills dst (world x 12) from every rank's src (12)."""
+    def run(self, scalars_local, partial_buf, gathered_buf, all_gather: Callable, out=None, is_mont: bool = False,
+            always_gather: bool = False):
+        """One sharded MSM.  all_gather(dst, src) fills dst (world x 12) from every rank's src (12).
+        always_gather: take the collective path even for world == 1 (rehearsal of the N > 1 code on one GPU)."""
         self.local_partial(scalars_local, partial_buf, is_mont=is_mont)
-        if self.world == 1:
+        if self.world == 1 and not always_gather:
             return self.combine(partial_buf, out=out)
         all_gather(gathered_buf, partial_buf)
         return self.combine(gathered_buf, out=out)
