@@ -112,6 +112,19 @@ int  vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* 
  * `out` holds k points, host or device. */
 int  vdf_msm_batch(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const vdf_fe* const scalars[],
                    const size_t n[], int is_mont, vdf_jac out[]);
+/* The same batch with the vectors arriving one at a time -- an MSM *job*.  vdf_msm_job_push(g) starts the sort and
+ * bucket accumulation of vector g on a stream of its own, ordered after the work already enqueued on the context
+ * (the kernel that produces the vector) and leaving the context's stream free: a fold pushes the fresh witness,
+ * enqueues the cross-term kernel, pushes T -- and T's production and sort run under the witness's ALU-bound
+ * accumulation.  vdf_msm_job_finish waits for all vectors, runs the one shared bucket reduction and delivers the k
+ * points (host, pinned or device memory) like vdf_msm_batch; it ends the job in every case.  Needs a fixed-base
+ * table with one bucket set; scalars in device memory; one job per context at a time, and no other MSM on the
+ * context while it is open.  Results equal vdf_msm / vdf_msm_batch bit for bit (as affine points). */
+typedef struct vdf_msm_job vdf_msm_job;
+int  vdf_msm_job_begin(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const size_t n[], int is_mont,
+                       vdf_msm_job** out);
+int  vdf_msm_job_push(vdf_msm_job* job, int g, const vdf_fe* scalars);
+int  vdf_msm_job_finish(vdf_msm_job* job, vdf_jac out[]);
 /* Window size override for tuning (0 = automatic). */
 int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
 /* out = sum of n Jacobian points (the combine step of a point-chunk-sharded MSM: each GPU

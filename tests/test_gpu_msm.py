@@ -375,3 +375,56 @@ def test_try_and_increment_bases_match_oracle(ctx, cref, curve):
     with pytest.raises(Exception):
         ctx.bases_generate(curve, seed, 4, family=7)
     bases.free()
+
+
+# ---- MSM jobs: vectors pushed one at a time, one shared bucket reduction ------------------------------------
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_job_equals_separate_calls(ctx, cref, curve):
+    import torch
+    nb = 9000
+    bases = ctx.bases_generate(curve, 31, nb)
+    pts = bases.download()
+    rng = np.random.default_rng(5)
+    sizes, offs = [9000, 5003, 1, 777], [0, 1234, 8999, 100]
+    sc = [rand_limbs(rng, n) for n in sizes]
+    dev = [torch.from_numpy(x.view(np.int64)).cuda() for x in sc]
+    with pytest.raises(Exception):
+        ctx.msm_job(bases, sizes[:2], offs[:2])                 # no fixed-base table yet
+    bases.precompute(16, 1)
+    was = ctx.get_async()
+    ctx.set_async(True)
+    try:
+        for k in (1, 2, 4):
+            job = ctx.msm_job(bases, sizes[:k], offs[:k])
+            with pytest.raises(Exception):
+                ctx.msm_job(bases, sizes[:1], offs[:1])         # one job per context at a time
+            for g in reversed(range(k)):                        # any push order
+                job.push(g, dev[g])
+            got = job.finish()
+            for g in range(k):
+                assert jac_to_affine(got[g], curve) == cpu_msm(cref, curve, pts[offs[g]:offs[g] + sizes[g]].copy(), sc[g]), (k, g)
+        # a vector written by a kernel enqueued just before the push (stream order, no host sync)
+        a, b = rand_limbs(rng, sizes[1]), rand_limbs(rng, sizes[1])
+        prod = np.zeros_like(a)
+        da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+        dprod = torch.zeros_like(da)
+        field = o.FIELD_FQ if curve == o.CURVE_PALLAS else o.FIELD_FP
+        job = ctx.msm_job(bases, [sizes[0], sizes[1]], [0, 0], is_mont=True)
+        job.push(0, dev[0])
+        ctx.fe_mul(field, da, db, sizes[1], dprod)               # producer of vector 1, on the context's stream
+        job.push(1, dprod)
+        got = job.finish()
+        cref.lib().ref_fe_mul(field, cref.p(a), cref.p(b), sizes[1], cref.p(prod))
+        assert jac_to_affine(got[0], curve) == cpu_msm(cref, curve, pts[:sizes[0]].copy(), sc[0], is_mont=1)
+        assert jac_to_affine(got[1], curve) == cpu_msm(cref, curve, pts[:sizes[1]].copy(), prod, is_mont=1)
+        # unfinished pushes are an error, and the job still ends
+        job = ctx.msm_job(bases, sizes[:2], offs[:2])
+        job.push(0, dev[0])
+        with pytest.raises(Exception):
+            job.finish()
+        job = ctx.msm_job(bases, sizes[:1], offs[:1])
+        job.push(0, dev[0])
+        job.finish()
+    finally:
+        ctx.set_async(was)
+    bases.free()

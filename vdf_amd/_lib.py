@@ -41,6 +41,9 @@ PROTOTYPES = {
     "vdf_bases_free": (None, [_vp]),
     "vdf_msm": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _vp]),
     "vdf_msm_batch": (_i, [_vp, _vp, _i, C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _i, _vp]),
+    "vdf_msm_job_begin": (_i, [_vp, _vp, _i, C.POINTER(_sz), C.POINTER(_sz), _i, C.POINTER(_vp)]),
+    "vdf_msm_job_push": (_i, [_vp, _i, _vp]),
+    "vdf_msm_job_finish": (_i, [_vp, _vp]),
     "vdf_ctx_set_msm_window": (_i, [_vp, _i]),
     "vdf_point_sum": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_ctx_set_timing": (_i, [_vp, _i]),

@@ -4,6 +4,7 @@
 #include <map>
 #include <array>
 #include <new>
+#include <memory>
 #include <utility>
 #include "internal.h"
 #include "fe.cuh"
@@ -123,6 +124,7 @@ int guarded(vdf_ctx* ctx, F&& body) {
 
 Status ensure_ws(vdf_ctx* ctx, size_t bytes) {
   if (ctx->ws_bytes >= bytes) return Status{};
+  if (ctx->job_open) return Status{VDF_ERR_BAD_ARG, "the MSM workspace cannot grow while a job is open on this context"};
   if (ctx->ws) { VDF_TRY_HIP(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
   VDF_TRY_HIP(hipMalloc(&ctx->ws, bytes));
   ctx->ws_bytes = bytes;
@@ -274,6 +276,11 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
+  for (int g = 0; g < 4; ++g) {
+    if (ctx->side_go[g]) (void)hipEventDestroy(ctx->side_go[g]);
+    if (ctx->side_done[g]) (void)hipEventDestroy(ctx->side_done[g]);
+    if (ctx->side[g]) { (void)hipStreamSynchronize(ctx->side[g]); (void)hipStreamDestroy(ctx->side[g]); }
+  }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -430,6 +437,103 @@ int vdf_msm(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, const vdf_fe* s
 int vdf_msm_batch(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const vdf_fe* const scalars[],
                   const size_t n[], int is_mont, vdf_jac out[]) {
   return guarded(ctx, [&]() -> Status { return msm_core(ctx, bases, k, offset, scalars, n, is_mont, out); });
+}
+
+// ---- MSM jobs: vectors pushed one at a time, one shared tail ------------------------------------------------
+struct vdf_msm_job {
+  vdf_ctx* ctx = nullptr;
+  const vdf_bases* bases = nullptr;
+  int k = 0, is_mont = 0;
+  vdf::MsmPlan plan[vdf::MSM_MAX_GROUPS];
+  size_t ws_off[vdf::MSM_MAX_GROUPS] = {0, 0, 0, 0};
+  size_t tail_off = 0;
+  bool pushed[vdf::MSM_MAX_GROUPS] = {false, false, false, false};
+  const char* pts = nullptr;
+};
+
+int vdf_msm_job_begin(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t offset[], const size_t n[], int is_mont,
+                      vdf_msm_job** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    if (!bases || !offset || !n) return Status{VDF_ERR_BAD_ARG, "null argument"};
+    if (k < 1 || k > vdf::MSM_MAX_GROUPS) return Status{VDF_ERR_BAD_ARG, "1..4 vectors per job"};
+    if (bases->ctx != ctx && bases->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bases live on another device"};
+    if (ctx->job_open) return Status{VDF_ERR_BAD_ARG, "another MSM job is open on this context"};
+    if (!bases->d_table || bases->tbl_sets != 1)
+      return Status{VDF_ERR_BAD_ARG, "MSM jobs need a fixed-base table with one bucket set (vdf_bases_precompute(c, 1))"};
+    std::unique_ptr<vdf_msm_job> job(new vdf_msm_job());
+    job->ctx = ctx; job->bases = bases; job->k = k; job->is_mont = is_mont;
+    job->pts = reinterpret_cast<const char*>(bases->d_table);
+    size_t off = 0;
+    for (int g = 0; g < k; ++g) {
+      if (offset[g] > bases->n || n[g] > bases->n - offset[g]) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
+      if (n[g] == 0 || n[g] >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "every vector of a job needs 1 .. 2^27 - 1 elements"};
+      job->plan[g] = vdf::msm_make_plan(1, &n[g], &offset[g], bases->tbl_c, 1, bases->tbl_tables, ctx->num_cus);
+      job->plan[g].tstride = (uint32_t)bases->n;
+      if ((uint64_t)n[g] * job->plan[g].windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
+      job->ws_off[g] = off;
+      off += (job->plan[g].ws_bytes + 255) / 256 * 256;
+    }
+    if ((size_t)bases->n * (bases->tbl_tables + 1) >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "table index exceeds 31 bits"};
+    job->tail_off = off;
+    off += vdf::msm_tail_ws_bytes(k, 1, job->plan[0].nbk);
+    VDF_TRY(ensure_ws(ctx, off));
+    for (int g = 0; g < k; ++g) {
+      if (!ctx->side[g]) VDF_TRY_HIP(hipStreamCreateWithFlags(&ctx->side[g], hipStreamNonBlocking));
+      if (!ctx->side_go[g]) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->side_go[g], hipEventDisableTiming));
+      if (!ctx->side_done[g]) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->side_done[g], hipEventDisableTiming));
+    }
+    ctx->job_open = true;
+    *out = job.release();
+    return Status{};
+  });
+}
+
+int vdf_msm_job_push(vdf_msm_job* job, int g, const vdf_fe* scalars) {
+  if (!job) return VDF_ERR_BAD_ARG;
+  vdf_ctx* ctx = job->ctx;
+  return guarded(ctx, [&]() -> Status {
+    if (g < 0 || g >= job->k) return Status{VDF_ERR_BAD_ARG, "vector index out of range"};
+    if (job->pushed[g]) return Status{VDF_ERR_BAD_ARG, "vector already pushed"};
+    if (!ptr_is_device(scalars)) return Status{VDF_ERR_BAD_ARG, "job vectors live in device memory"};
+    // the vector's pipeline starts after everything enqueued on the context so far (its producer), on a stream of
+    // its own: the context's stream stays free for the caller's next kernels
+    VDF_TRY_HIP(hipEventRecord(ctx->side_go[g], ctx->stream));
+    VDF_TRY_HIP(hipStreamWaitEvent(ctx->side[g], ctx->side_go[g], 0));
+    const void* sc[vdf::MSM_MAX_GROUPS] = {scalars, nullptr, nullptr, nullptr};
+    char* ws = reinterpret_cast<char*>(ctx->ws);
+    char* buckets = ws + job->tail_off + (size_t)g * job->plan[g].nbk * 128;
+    VDF_TRY(vdf::msm_run(job->bases->curve, job->plan[g], job->pts, sc, job->is_mont != 0, ws + job->ws_off[g], nullptr,
+                         ctx->side[g], nullptr, buckets));
+    VDF_TRY_HIP(hipEventRecord(ctx->side_done[g], ctx->side[g]));
+    job->pushed[g] = true;
+    return Status{};
+  });
+}
+
+int vdf_msm_job_finish(vdf_msm_job* job, vdf_jac out[]) {
+  if (!job) return VDF_ERR_BAD_ARG;
+  vdf_ctx* ctx = job->ctx;
+  const int rc = guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    for (int g = 0; g < job->k; ++g) if (!job->pushed[g]) return Status{VDF_ERR_BAD_ARG, "not every vector was pushed"};
+    Staging st(ctx);
+    void* d_out = nullptr;
+    VDF_TRY(st.out(out, job->k * sizeof(vdf_jac), &d_out));
+    for (int g = 0; g < job->k; ++g) VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_done[g], 0));
+    VDF_TRY(vdf::msm_tail(job->bases->curve, job->plan[0].c, 1, job->k, job->plan[0].nbk,
+                          reinterpret_cast<char*>(ctx->ws) + job->tail_off, d_out, ctx->stream));
+    return st.finish();
+  });
+  // the job ends here whatever happened; an abandoned pipeline must not outlive the workspace it writes
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (rc != VDF_OK) for (int g = 0; g < job->k; ++g) if (ctx->side[g]) (void)hipStreamSynchronize(ctx->side[g]);
+    ctx->job_open = false;
+  }
+  delete job;
+  return rc;
 }
 
 int vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_jac* out) {

@@ -31,6 +31,10 @@ struct vdf_ctx {
   std::vector<TimedCall> timed;      // events of calls not yet queried
   std::vector<hipEvent_t> ev_pool;   // recycled events
   hipEvent_t wait_ev = nullptr;      // vdf_ctx_wait
+  // MSM jobs (vdf_msm_job_*): one side stream and two events per vector, created on first use
+  hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool job_open = false;
 };
 
 struct vdf_bases {
@@ -120,8 +124,12 @@ int msm_auto_window(size_t n);
 // d_points: table (tables*tstride affine) or plain bases (tables == 1).  d_scalars[g]: gn[g] x 32 B device.
 // d_out: groups x 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
 // ev (optional): 4 events recorded at start / before accumulate / after accumulate / end.
+// ext_bucket_acc (optional): the bucket accumulators of this plan's key range inside a job's shared array; the
+// run then stops after the fix-up and msm_tail reduces all groups of the job at once.
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont,
-               void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr);
+               void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr, void* ext_bucket_acc = nullptr);
+size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
+Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,

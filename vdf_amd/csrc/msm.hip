@@ -53,6 +53,19 @@ struct WsLayout {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+struct RedGeom { uint32_t seg, threads_per_set, block, blocks_per_set; };
+static RedGeom red_geom(size_t nkeys, uint32_t nbk) {
+  RedGeom r;
+  uint32_t seg = 2;                            // buckets per quad in k_reduce1 (serial depth 2*seg), power of two
+  while (seg < 64 && nkeys / seg > RED_QUADS) seg <<= 1;
+  if (seg > nbk) seg = nbk;
+  r.seg = seg;
+  r.threads_per_set = nbk / seg;               // logical threads (quads): one per seg buckets
+  r.block = r.threads_per_set < 64 ? r.threads_per_set : 64;   // quads per workgroup (256 lanes)
+  r.blocks_per_set = r.threads_per_set / r.block;
+  return r;
+}
+
 static WsLayout ws_layout(const MsmPlan& p) {
   WsLayout w{};
   size_t off = 0;
@@ -69,14 +82,9 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
   w.heavy = take((nkeys + 4) * 4);
-  uint32_t seg = 2;                            // buckets per quad in k_reduce1 (serial depth 2*seg), power of two
-  while (seg < 64 && nkeys / seg > RED_QUADS) seg <<= 1;
-  if (seg > p.nbk) seg = p.nbk;
-  w.red_seg = seg;
-  uint32_t tps = p.nbk / seg;
-  w.red_threads_per_set = tps;                 // logical threads (quads): one per red_seg buckets
-  w.red_block = tps < 64 ? tps : 64;           // quads per workgroup (256 lanes)
-  w.red_blocks_per_set = tps / w.red_block;
+  const RedGeom rg = red_geom(nkeys, p.nbk);
+  w.red_seg = rg.seg; w.red_threads_per_set = rg.threads_per_set; w.red_block = rg.block;
+  w.red_blocks_per_set = rg.blocks_per_set;
   w.partials = take((size_t)p.gsets * w.red_blocks_per_set * 128);
   w.wsum = take((size_t)p.gsets * 128);
   w.total = off;
@@ -719,9 +727,24 @@ __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts
 // ------------------------------------------------------------------------------------------
 // host drivers
 // ------------------------------------------------------------------------------------------
+template <class P>
+static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* bucket_acc, char* partials, char* wsum,
+                         void* d_out, hipStream_t st) {
+  const uint32_t gsets = (uint32_t)(groups * sets);
+  const RedGeom rg = red_geom((size_t)gsets * nbk, nbk);
+  hipLaunchKernelGGL((k_reduce1<P>), dim3(gsets * rg.blocks_per_set), dim3(rg.block * 4), (size_t)rg.block * 128, st,
+                     bucket_acc, nbk, rg.seg, rg.threads_per_set, rg.blocks_per_set, partials);
+  hipLaunchKernelGGL((k_reduce2<P>), dim3(gsets), dim3(256), 0, st, partials, rg.blocks_per_set, wsum);
+  hipLaunchKernelGGL((k_final<P>), dim3(groups), dim3(64), 0, st, wsum, sets, c, reinterpret_cast<char*>(d_out));
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
+// ext_bucket_acc != nullptr: bucket accumulators live there (a job's shared array) and the run stops after the
+// fix-up; the reduction of all groups follows in msm_tail.
 template <class P, class SP>
 static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-                        void* d_out, hipStream_t st, hipEvent_t* ev) {
+                        void* d_out, hipStream_t st, hipEvent_t* ev, char* ext_bucket_acc) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* countsA = reinterpret_cast<uint32_t*>(base + w.countsA);
@@ -730,7 +753,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   uint64_t* recs = reinterpret_cast<uint64_t*>(base + w.recs);
   uint32_t* bstart = reinterpret_cast<uint32_t*>(base + w.bstart);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + w.sorted);
-  char* bucket_acc = base + w.bucket_acc;
+  char* bucket_acc = ext_bucket_acc ? ext_bucket_acc : base + w.bucket_acc;
   char* heads = base + w.heads;
   uint32_t* heavy = reinterpret_cast<uint32_t*>(base + w.heavy);
   char* partials = base + w.partials;
@@ -763,23 +786,38 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
                      heavy);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
-  hipLaunchKernelGGL((k_reduce1<P>), dim3(p.gsets * w.red_blocks_per_set), dim3(w.red_block * 4),
-                     (size_t)w.red_block * 128, st, bucket_acc, p.nbk, w.red_seg, w.red_threads_per_set, w.red_blocks_per_set,
-                     partials);
-  hipLaunchKernelGGL((k_reduce2<P>), dim3(p.gsets), dim3(256), 0, st, partials, w.red_blocks_per_set, wsum);
-  hipLaunchKernelGGL((k_final<P>), dim3(p.groups), dim3(64), 0, st, wsum, p.sets, p.c, reinterpret_cast<char*>(d_out));
+  if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-               void* d_out, hipStream_t stream, hipEvent_t* ev) {
+               void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
+  char* ext = reinterpret_cast<char*>(ext_bucket_acc);
   if (curve == VDF_CURVE_PALLAS)
-    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev);
+    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext);
   if (curve == VDF_CURVE_VESTA)
-    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev);
+    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext);
+  return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+}
+
+// Stand-alone bucket reduction over `groups` x `sets` bucket sets laid out back to back (a job's shared array).
+// tail_ws: msm_tail_ws_bytes() bytes = the bucket array followed by the reduction scratch.
+size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk) {
+  const size_t gsets = (size_t)groups * sets;
+  const RedGeom rg = red_geom(gsets * nbk, nbk);
+  return align_up(gsets * nbk * 128, 256) + align_up(gsets * rg.blocks_per_set * 128, 256) + align_up(gsets * 128, 256);
+}
+Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream) {
+  const size_t gsets = (size_t)groups * sets;
+  const RedGeom rg = red_geom(gsets * nbk, nbk);
+  char* bucket_acc = reinterpret_cast<char*>(tail_ws);
+  char* partials = bucket_acc + align_up(gsets * nbk * 128, 256);
+  char* wsum = partials + align_up(gsets * rg.blocks_per_set * 128, 256);
+  if (curve == VDF_CURVE_PALLAS) return msm_tail_t<FpParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
+  if (curve == VDF_CURVE_VESTA) return msm_tail_t<FqParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 

@@ -98,6 +98,23 @@ class Shape:
             pass
 
 
+class MsmJob:
+    """Handle of an open MSM job; finish() ends it in every case."""
+
+    def __init__(self, ctx: "Context", handle: int, k: int):
+        self.ctx, self.handle, self.k = ctx, handle, k
+
+    def push(self, g: int, scalars) -> None:
+        self.ctx._check(lib.vdf_msm_job_push(self.handle, g, _ptr(scalars)))
+
+    def finish(self, out=None):
+        if out is None:
+            out = np.zeros((self.k, 12), dtype="<u8")
+        h, self.handle = self.handle, None
+        self.ctx._check(lib.vdf_msm_job_finish(h, _ptr(out)))
+        return out
+
+
 class Context:
     """One context per GPU (one process per GPU)."""
 
@@ -181,6 +198,15 @@ class Context:
         self._check(lib.vdf_msm_batch(self.handle, bases.handle, k, (C.c_size_t * k)(*offsets), sc, (C.c_size_t * k)(*n),
                                       int(is_mont), _ptr(out)))
         return out
+
+    def msm_job(self, bases: Bases, n, offsets=None, is_mont: bool = False) -> "MsmJob":
+        """Start an MSM job over k = len(n) vectors (see include/vdf_hip.h): push them one at a time, then finish."""
+        k = len(n)
+        offsets = [0] * k if offsets is None else list(offsets)
+        h = C.c_void_p()
+        self._check(lib.vdf_msm_job_begin(self.handle, bases.handle, k, (C.c_size_t * k)(*offsets), (C.c_size_t * k)(*n),
+                                          int(is_mont), C.byref(h)))
+        return MsmJob(self, h.value, k)
 
     def point_sum(self, curve: int, points, n: int, out=None):
         host_out = out is None
