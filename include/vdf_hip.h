@@ -9,8 +9,8 @@
  * Conventions
  *   - All integers little-endian.  A field element is 4 x u64 limbs of x*2^256 mod m
  *     (Montgomery form), the in-memory form of pasta_curves with `repr-c`
- *     (Cargo.toml:17).  Inputs must be canonical (< m); VDF_ERR_NONCANONICAL otherwise
- *     where the entry point says it checks.
+ *     (Cargo.toml:17).  Inputs must be canonical (< m); the hot path does not check
+ *     (like pasta-msm); vdf_bases_validate checks a generator table once (VDF_ERR_NONCANONICAL).
  *   - affine = {x, y}, identity = (0, 0).  jac = {x, y, z} Jacobian, identity z = 0.
  *     Jacobian outputs are not unique; parity is defined on the affine normalisation.
  *   - Every data pointer may be a HOST pointer or a DEVICE (hipMalloc / torch) pointer;
@@ -77,6 +77,10 @@ const char* vdf_last_error(vdf_ctx* ctx);              /* ctx may be NULL: last 
 /* Replaces nova-snark's CommitGens (built in PublicParams::setup, src/nova/proof.rs:236):
  * the generator table lives in HBM for the life of the public parameters. */
 int  vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n, vdf_bases** out);
+/* Setup-time check of a generator table (upload itself does not look at the points, like pasta-msm): every
+ * coordinate a canonical residue (else VDF_ERR_NONCANONICAL) and every point the identity (0, 0) or on
+ * y^2 = x^3 + 5 (else VDF_ERR_BAD_ARG); *first_bad (optional) = smallest offending index. */
+int  vdf_bases_validate(vdf_ctx* ctx, const vdf_bases* bases, size_t* first_bad);
 /* Synthetic generators P_i = [k_i]G, G = (-1, 2), k_i = splitmix64-derived 64-bit (see
  * oracle/pasta.py base_dlog); stands in for nova-snark's label -> hash-to-curve derivation,
  * which is implementation-defined and unpinned. */

@@ -428,3 +428,32 @@ def test_msm_job_equals_separate_calls(ctx, cref, curve):
     finally:
         ctx.set_async(was)
     bases.free()
+
+
+def test_bases_validate(ctx):
+    """Setup-time check of an uploaded generator table: canonical coordinates, curve membership, identity allowed."""
+    import vdf_amd
+    from vdf_amd.hip import VdfError
+    curve, m = o.CURVE_PALLAS, o.P
+    good = affine_array(o.synthetic_bases(curve, 3, 50) + [None], curve)           # 50 points + the identity
+    b = ctx.bases_upload(curve, good)
+    b.validate()
+    b.free()
+    bad = good.copy()
+    bad[17, 4:8] = limbs([o.to_mont(5, m)])[0]                                      # y replaced: off the curve
+    b = ctx.bases_upload(curve, bad)
+    with pytest.raises(VdfError) as e:
+        b.validate()
+    assert e.value.code == vdf_amd._lib.VDF_ERR_BAD_ARG and "index 17" in str(e.value)
+    b.free()
+    bad = good.copy()
+    bad[9, 0:4] = limbs([m])[0]                                                     # x = m: not canonical
+    bad[30, 4:8] = limbs([o.to_mont(5, m)])[0]
+    b = ctx.bases_upload(curve, bad)
+    with pytest.raises(VdfError) as e:
+        b.validate()
+    assert e.value.code == vdf_amd._lib.VDF_ERR_NONCANONICAL and "index 9" in str(e.value)
+    b.free()
+    g = ctx.bases_generate(curve, 3, 1000, family=vdf_amd.GENS_TRY_AND_INCREMENT)
+    g.validate()
+    g.free()

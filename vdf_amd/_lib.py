@@ -31,6 +31,7 @@ PROTOTYPES = {
     "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
+    "vdf_bases_validate": (_i, [_vp, _vp, C.POINTER(_sz)]),
     "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate_range": (_i, [_vp, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate_family": (_i, [_vp, _i, _i, _u64, _sz, _sz, C.POINTER(_vp)]),

@@ -354,6 +354,25 @@ int vdf_bases_upload(vdf_ctx* ctx, int curve, const vdf_affine* bases, size_t n,
   });
 }
 
+int vdf_bases_validate(vdf_ctx* ctx, const vdf_bases* bases, size_t* first_bad) {
+  return guarded(ctx, [&]() -> Status {
+    if (!bases || (bases->ctx != ctx && bases->ctx->device != ctx->device)) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
+    if (first_bad) *first_bad = 0;
+    if (bases->n == 0) return Status{};
+    uint32_t* d_flags = reinterpret_cast<uint32_t*>(ctx->small_pool);
+    const uint32_t init[2] = {0u, 0xFFFFFFFFu};
+    VDF_TRY_HIP(hipMemcpyAsync(d_flags, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    VDF_TRY(vdf::bases_validate(bases->curve, bases->d_pts, bases->n, d_flags, ctx->stream));
+    uint32_t res[2];
+    VDF_TRY_HIP(hipMemcpyAsync(res, d_flags, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    if (res[0] == 0) return Status{};
+    if (first_bad) *first_bad = res[1];
+    if (res[0] & 1u) return Status{VDF_ERR_NONCANONICAL, "a generator coordinate is not a canonical field element"};
+    return Status{VDF_ERR_BAD_ARG, "a generator is neither the identity nor a point of the curve"};
+  });
+}
+
 int vdf_bases_generate(vdf_ctx* ctx, int curve, uint64_t seed, size_t n, vdf_bases** out) {
   return vdf_bases_generate_range(ctx, curve, seed, 0, n, out);
 }

@@ -132,6 +132,7 @@ size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
+Status bases_validate(int curve, const void* d_pts, size_t n, uint32_t* d_flags, hipStream_t stream);   // d_flags: 2 words
 Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,
                         hipStream_t stream);
 

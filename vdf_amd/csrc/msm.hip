@@ -707,6 +707,24 @@ __global__ __launch_bounds__(256) void k_bases_generate_tai(uint64_t seed, uint6
   }
 }
 
+// flags[0] |= 1: a coordinate is not a canonical residue; |= 2: a canonical point that is neither the identity
+// (0, 0) nor on y^2 = x^3 + 5.  flags[1] = smallest offending index.
+template <class P>
+__global__ __launch_bounds__(256) void k_validate_points(const char* __restrict__ pts, uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Affine<P> a = affine_load<P>(pts + (size_t)i * 64);
+  uint32_t bad = 0;
+  if (!fe_is_canonical(a.x) || !fe_is_canonical(a.y)) bad = 1;
+  else if (!affine_is_identity(a)) {
+    Fe<P> five;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) five.v[l] = P::FIVE[l];
+    if (!fe_eq(fe_sqr(a.y), fe_add(fe_mul(fe_sqr(a.x), a.x), five))) bad = 2;
+  }
+  if (bad) { atomicOr(&flags[0], bad); atomicMin(&flags[1], i); }
+}
+
 // table[j][i] = 2^(shift*j) * P_i
 template <class P>
 __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts, uint32_t n, int shift, int tables,
@@ -878,6 +896,19 @@ Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t
   else if (curve == VDF_CURVE_VESTA)
     hipLaunchKernelGGL((k_bases_generate<FqParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
                        reinterpret_cast<char*>(d_pts));
+  else
+    return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
+Status bases_validate(int curve, const void* d_pts, size_t n, uint32_t* d_flags, hipStream_t stream) {
+  if (n == 0) return Status{};
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (curve == VDF_CURVE_PALLAS)
+    hipLaunchKernelGGL((k_validate_points<FpParams>), grid, dim3(256), 0, stream, reinterpret_cast<const char*>(d_pts), (uint32_t)n, d_flags);
+  else if (curve == VDF_CURVE_VESTA)
+    hipLaunchKernelGGL((k_validate_points<FqParams>), grid, dim3(256), 0, stream, reinterpret_cast<const char*>(d_pts), (uint32_t)n, d_flags);
   else
     return Status{VDF_ERR_BAD_ARG, "unknown curve"};
   VDF_TRY_HIP(hipGetLastError());

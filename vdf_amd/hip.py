@@ -56,6 +56,13 @@ class Bases:
     def __len__(self) -> int:
         return lib.vdf_bases_len(self.handle)
 
+    def validate(self) -> None:
+        """Raises VdfError (NONCANONICAL / BAD_ARG, with the first offending index) unless every point is valid."""
+        bad = C.c_size_t()
+        rc = lib.vdf_bases_validate(self.ctx.handle, self.handle, C.byref(bad))
+        if rc != 0:
+            raise VdfError(rc, (lib.vdf_last_error(self.ctx.handle) or b"").decode() + f" (index {bad.value})")
+
     @property
     def device_ptr(self) -> int:
         return lib.vdf_bases_device_ptr(self.handle)
