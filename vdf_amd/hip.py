@@ -77,9 +77,11 @@ class Bases:
         return out
 
     def free(self) -> None:
-        if self.handle:
+        # if the context is already gone (finalisers run in no particular order at interpreter shutdown) the
+        # device memory went with it: calling into the library with a dead context would be a use after free
+        if self.handle and self.ctx.handle:
             lib.vdf_bases_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -94,9 +96,9 @@ class Shape:
         ctx._children.add(self)
 
     def free(self) -> None:
-        if self.handle:
+        if self.handle and self.ctx.handle:      # see Bases.free
             lib.vdf_shape_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

@@ -5,6 +5,7 @@ the C ABI of libvdf_hip.so; see include/vdf_nova.h for the stage implemented (fo
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -48,6 +49,7 @@ def _z(vals: Sequence[bytes]):
 class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
     def __init__(self, ctx: Context, handle: int, t: int):
         self.ctx, self.handle, self.num_iters_per_step = ctx, handle, t
+        self._proofs = weakref.WeakSet()         # proofs made under these parameters: freed before them
         ctx._children.add(self)
 
     def sizes(self) -> dict:
@@ -56,9 +58,11 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         return dict(zip(("num_cons", "num_vars", "num_io", "nnz", "num_gens"), [x.value for x in v]))
 
     def free(self) -> None:
-        if self.handle:
+        if self.handle and self.ctx.handle:      # a dead context took the device memory with it (see hip.Bases.free)
+            for proof in list(self._proofs):     # a proof holds device buffers of this context and points at pp
+                proof.free()
             nova_lib.vdf_nova_pp_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
@@ -85,7 +89,8 @@ class Circuits:
     def upload(self, ctx: Context) -> None:
         """Move the forward traces into HBM (an input of proving; outside the timed region)."""
         _check(nova_lib.vdf_nova_circuits_upload(ctx.handle, self.handle))
-        self._ctx = ctx          # keep the context alive until the traces are freed
+        self._ctx = ctx          # keep the context alive until the traces are freed ...
+        ctx._children.add(self)  # ... and let it free them first if it is closed earlier
 
     def states(self, k: int) -> Tuple[State, State]:
         """(result, input) of circuit k: InverseMinRootCircuit.result / .input (:63-64)."""
@@ -93,11 +98,15 @@ class Circuits:
         _check(nova_lib.vdf_nova_circuit_states(self.handle, k, C.byref(r), C.byref(i)))
         return State._from_c(r), State._from_c(i)
 
+    def free(self) -> None:
+        ctx = getattr(self, "_ctx", None)
+        if self.handle and (ctx is None or ctx.handle):      # uploaded traces need a live context to be released
+            nova_lib.vdf_nova_circuits_free(self.handle)
+        self.handle = None
+
     def __del__(self):
         try:
-            if self.handle:
-                nova_lib.vdf_nova_circuits_free(self.handle)
-                self.handle = None
+            self.free()
         except Exception:
             pass
 
@@ -121,6 +130,7 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
     def __init__(self, handle: int, pp: NovaVDFPublicParams):
         self.handle, self.pp = handle, pp
         pp.ctx._children.add(self)
+        pp._proofs.add(self)
 
     @staticmethod
     def prove_recursively(pp: NovaVDFPublicParams, circuits: Circuits, num_iters_per_step: int,
@@ -180,9 +190,9 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
         return dict(zip(("witness_launch", "commit_launch", "cross_term_launch", "unused", "wait", "fold", "host", "total"), list(ms)))
 
     def free(self) -> None:
-        if self.handle:
+        if self.handle and self.pp.handle and self.pp.ctx.handle:      # needs live parameters and a live context
             nova_lib.vdf_nova_proof_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
