@@ -4,25 +4,30 @@
 // every Pedersen commitment of `RecursiveSNARK::prove_step`
 // (/root/reference/src/nova/proof.rs:342-349).
 //
-// Pipeline (all on the device, one stream, no host round trip):
-//   Two-level counting sort of the (window, point) entries by bucket, b = (p << 8) | f:
-//   k_part_hist / k_part_scan / k_part_scatter   pass A: every workgroup turns a chunk of scalars into
-//                 signed c-bit digits (Booth-style carry) on the fly and partitions the entries by the
-//                 high bucket bits p (<= 2048 LDS counters); each (workgroup, partition) run is contiguous,
-//                 so the 8-byte records leave as whole lines instead of one 64-byte sector per 4-byte write
-//   k_fine_hist / k_fine_scan / k_scan_keys / k_fine_scatter   pass B: workgroups sort one partition
-//                 slice by the low bits f (256 LDS counters + ds atomics) inside that partition's own
-//                 region of the sorted list (L2-resident), and produce the bucket start offsets
+// A call handles a batch of 1..4 MSMs ("groups") over one generator table; to everything after pass A a group is
+// just more bucket sets.  Pipeline (all on the device, one stream, no host round trip, 10 launches):
+//   Two-level counting sort of the (window, point) entries by bucket, b = (p << fb) | f:
+//   k_part<hist> / k_part_scan / k_scan_keys / k_part<scatter>   pass A: every workgroup turns a chunk of one
+//                 group's scalars into signed c-bit digits (Booth-style carry) on the fly and partitions the
+//                 entries by group, bucket set and the high bucket bits p (about one partition per CU, cursors
+//                 in LDS); each (workgroup, partition) run is contiguous, so the 8-byte records leave as whole
+//                 lines instead of one 64-byte sector per 4-byte write
+//   k_fine        pass B: one 1024-thread workgroup per partition: histogram of the low bits f in LDS, scan
+//                 (= the partition's bucket starts), scatter into the sorted list; it also zeroes the
+//                 accumulator of every empty bucket (no memset) and tells each k_accumulate thread its first bucket
 //   k_accumulate  every thread owns a fixed-length slice of the SORTED entry list and runs a
 //                 sequential segmented reduce over it with an XYZZ accumulator in registers
-//                 (mixed addition of gathered affine points); perfectly balanced for any scalar
+//                 (mixed addition of gathered affine points, lazy domain); perfectly balanced for any scalar
 //                 distribution.  Runs that start in the slice go to the bucket array; a run that
-//                 continues from the previous slice goes to a per-thread "head" slot.
-//   k_fixup       per bucket: add the heads of the slices it spans; buckets spanning many slices are
+//                 continues from the previous slice goes to a per-thread "head" slot.  The grid exactly fills
+//                 the resident workgroup slots in one round (msm_make_plan).
+//   k_fixup       per bucket (one quad): add the heads of the slices it spans; buckets spanning many slices are
 //                 queued and reduced by a whole wavefront (k_fixup_heavy: strided partial sums, then
-//                 a 6-step wavefront butterfly of XYZZ additions).
-//   k_reduce1/2   sum_b b*B_b per bucket set (running sums per segment + scalar offset, LDS tree)
-//   k_final       Horner over bucket sets, XYZZ -> Jacobian
+//                 a butterfly of quad additions).
+//   k_reduce1/2   sum_b (b+1)*B_b per bucket set (running sums per segment + scalar offset, LDS tree)
+//   k_final       per group: Horner over its bucket sets, XYZZ -> Jacobian
+// The tail kernels use the quad-cooperative group law of ecq.cuh.  msm_run with an external bucket array stops
+// after the fix-up; msm_tail then reduces the groups of an MSM job (vdf_msm_job_*) together.
 //
 // With a fixed-base table (vdf_bases_precompute) window w = j*sets + s reads table j
 // (2^(c*sets*j) * P_i) and feeds bucket set s, so the Horner tail is (sets-1)*c doublings; sets = 1
