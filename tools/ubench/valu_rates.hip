@@ -2,6 +2,9 @@
 // integer / f64 VALU ops a 255-bit Montgomery multiply can be built from, on gfx950.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rates.hip -o tools/ubench/valu_rates
 // Prints wave-cycles per instruction for one wave per SIMD and for 4 waves per SIMD.
+// SUPERSEDED by op_rates.hip: the per-wave cycle counters used here under-count at several waves per SIMD (the
+// arbiter favours the oldest wave, so the waves of a SIMD finish at staggered times); op_rates.hip measures from
+// kernel wall time.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
