@@ -1,0 +1,296 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the compression SNARK of the folding proof: a Spartan-style argument
+for relaxed R1CS with inner-product-argument openings, the shape of nova-snark 0.8.0's `CompressedSNARK`
+(`RelaxedR1CSSNARK` over `spartan_with_ipa_pc`) that /root/reference/src/nova/proof.rs:360-368 (`compress`) and
+:383 (verification of the compressed proof) reach.  PARITY UNPINNED: nova-snark is a third-party crate absent from
+/root/reference (Cargo.toml:15), the reference's only test of this path asserts `is_ok()` (src/nova/proof.rs:446-450),
+and every constant below (transcript, challenge width, padding) is this build's own.  What pins it is mathematics:
+completeness and soundness checks in tests/, and bit-exact agreement between this restatement and the product.
+
+Protocol "vdf-spartan-v1" for an instance (comm_W, comm_E, u, X) of shape (A, B, C) with witness (W, E),
+(A z) o (B z) = u (C z) + E,  z = (W, u, X):
+
+  transcript   hash chain over SHAKE256: state' = H(state | label | ':' | data); a challenge is the first 16 bytes
+               (little-endian, 128 bits) of H(state | label | '?'), the next 32 bytes become the state.
+  tables       multilinear in MSB-first order: index i = sum x_j 2^(k-j); round j of a sum-check binds x_j,
+               i.e. folds the upper half of every table onto the lower half.
+  outer        tau in F^s (s = log2 of the padded constraint count);  0 = sum_x eq(tau,x) (Az(x) Bz(x) - u Cz(x) - E(x)),
+               cubic rounds sent as g(0), g(2), g(3); ends with claims a, b, c, e at r_x.
+  inner        rho;  a + rho b + rho^2 c = sum_y M(y) z(y),  M(y) = sum_x eq(r_x,x) (A + rho B + rho^2 C)[x,y], over the
+               padded layout  y < 2^l : W (l = log2 of the padded variable count),  y = 2^l : u,  y = 2^l + 1 + i : X_i;
+               quadratic rounds sent as g(0), g(2); ends with the claim w = W~(r_y[1:]).
+  openings     two inner-product arguments under the Pedersen generators: <W, eq(r_y[1:])> = w against comm_W and
+               <E, eq(r_x)> = e against comm_E.  L = <a_lo, G_hi> + <a_lo, b_hi> Q,  R = <a_hi, G_lo> + <a_hi, b_lo> Q,
+               Q = x0 U;  a' = a_lo x + a_hi x^-1,  b' = b_lo x^-1 + b_hi x,  G' = G_lo x^-1 + G_hi x.
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from . import pasta as o
+
+Point = Optional[Tuple[int, int]]
+
+
+# ---- transcript -----------------------------------------------------------------------------------------
+def _h(data: bytes, n: int) -> bytes:
+    return hashlib.shake_256(data).digest(n)
+
+
+class Transcript:
+    def __init__(self, label: bytes):
+        self.state = _h(b"vdf-spartan-v1|" + label, 32)
+
+    def absorb(self, label: bytes, data: bytes) -> None:
+        self.state = _h(self.state + label + b":" + data, 32)
+
+    def absorb_fe(self, label: bytes, vals: Sequence[int]) -> None:
+        self.absorb(label, b"".join(int(v).to_bytes(32, "little") for v in vals))
+
+    def absorb_pt(self, label: bytes, pts: Sequence[Point]) -> None:
+        self.absorb(label, b"".join(b"\0" * 64 if p is None else p[0].to_bytes(32, "little") + p[1].to_bytes(32, "little")
+                                    for p in pts))
+
+    def challenge(self, label: bytes) -> int:
+        out = _h(self.state + label + b"?", 48)
+        self.state = out[16:48]
+        return int.from_bytes(out[:16], "little")
+
+
+# ---- multilinear helpers --------------------------------------------------------------------------------
+def eq_table(r: Sequence[int], m: int) -> List[int]:
+    """eq(r, x) for all x in {0,1}^k, x_1 the most significant bit of the index."""
+    t = [1]
+    for rj in r:
+        t = [v for e in t for v in (e * (1 - rj) % m, e * rj % m)]
+    return t
+
+
+def bind(table: Sequence[int], r: int, m: int) -> List[int]:
+    h = len(table) // 2
+    return [(table[i] + r * (table[h + i] - table[i])) % m for i in range(h)]
+
+
+def mle_eval(table: Sequence[int], r: Sequence[int], m: int) -> int:
+    t = list(table)
+    for rj in r:
+        t = bind(t, rj, m)
+    return t[0]
+
+
+def interpolate(evals_at: Sequence[Tuple[int, int]], r: int, m: int) -> int:
+    """Lagrange interpolation of the points (x_i, y_i) at r."""
+    acc = 0
+    for i, (xi, yi) in enumerate(evals_at):
+        num, den = 1, 1
+        for j, (xj, _) in enumerate(evals_at):
+            if i != j:
+                num = num * (r - xj) % m
+                den = den * (xi - xj) % m
+        acc = (acc + yi * num * pow(den, -1, m)) % m
+    return acc
+
+
+def sumcheck_prove(tr: Transcript, label: bytes, tables: List[List[int]], comb: Callable[..., int], degree: int, m: int):
+    """Returns (round messages [g(0), g(2), .., g(degree)], challenges, bound values of the tables)."""
+    msgs, rs = [], []
+    pts = [0] + list(range(2, degree + 1))
+    while len(tables[0]) > 1:
+        h = len(tables[0]) // 2
+        ev = []
+        for t in pts:
+            s = 0
+            for i in range(h):
+                s += comb(*[(tb[i] + t * (tb[h + i] - tb[i])) % m for tb in tables])
+            ev.append(s % m)
+        tr.absorb_fe(label, ev)
+        r = tr.challenge(label)
+        tables = [bind(tb, r, m) for tb in tables]
+        msgs.append(ev)
+        rs.append(r)
+    return msgs, rs, [tb[0] for tb in tables]
+
+
+def sumcheck_verify(tr: Transcript, label: bytes, claim: int, msgs: Sequence[Sequence[int]], degree: int, m: int):
+    """Returns (final claim, challenges); the caller checks the final claim against the bound polynomial."""
+    rs = []
+    for ev in msgs:
+        if len(ev) != degree:
+            raise ValueError("malformed sum-check message")
+        g1 = (claim - ev[0]) % m
+        pts = [(0, ev[0]), (1, g1)] + [(t, ev[k + 1]) for k, t in enumerate(range(2, degree + 1))]
+        tr.absorb_fe(label, ev)
+        r = tr.challenge(label)
+        claim = interpolate(pts, r, m)
+        rs.append(r)
+    return claim, rs
+
+
+# ---- inner-product argument -----------------------------------------------------------------------------
+@dataclass
+class IpaProof:
+    L: List[Point] = field(default_factory=list)
+    R: List[Point] = field(default_factory=list)
+    a: int = 0
+
+
+def _msm(s: Sequence[int], G: Sequence[Point], curve: int) -> Point:
+    return o.msm_naive(list(s), list(G), curve)
+
+
+def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Sequence[int], b: Sequence[int], v: int,
+              P: Point, curve: int) -> IpaProof:
+    q, pm = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve)
+    tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
+    Q = o.pt_mul(tr.challenge(label), U, pm)
+    a, b, G = list(a), list(b), list(G)
+    proof = IpaProof()
+    while len(a) > 1:
+        h = len(a) // 2
+        cL = sum(x * y for x, y in zip(a[:h], b[h:])) % q
+        cR = sum(x * y for x, y in zip(a[h:], b[:h])) % q
+        L = o.pt_add(_msm(a[:h], G[h:], curve), o.pt_mul(cL, Q, pm), pm)
+        R = o.pt_add(_msm(a[h:], G[:h], curve), o.pt_mul(cR, Q, pm), pm)
+        tr.absorb_pt(label, [L, R])
+        x = tr.challenge(label)
+        xi = pow(x, -1, q)
+        a = [(a[i] * x + a[h + i] * xi) % q for i in range(h)]
+        b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
+        G = [o.pt_add(o.pt_mul(xi, G[i], pm), o.pt_mul(x, G[h + i], pm), pm) for i in range(h)]
+        proof.L.append(L); proof.R.append(R)
+    proof.a = a[0]
+    return proof
+
+
+def ipa_verify(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, b: Sequence[int], v: int, P: Point,
+               proof: IpaProof, curve: int) -> bool:
+    q, pm = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve)
+    n = len(G)
+    if 1 << len(proof.L) != n or len(proof.L) != len(proof.R):
+        return False
+    tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
+    Q = o.pt_mul(tr.challenge(label), U, pm)
+    acc = o.pt_add(P, o.pt_mul(v, Q, pm), pm)
+    s = [1] * n                       # G_final = sum s_t G_t
+    b = list(b)
+    size = n
+    for L, R in zip(proof.L, proof.R):
+        tr.absorb_pt(label, [L, R])
+        x = tr.challenge(label)
+        if x == 0:
+            return False
+        xi = pow(x, -1, q)
+        acc = o.pt_add(acc, o.pt_add(o.pt_mul(x * x % q, L, pm), o.pt_mul(xi * xi % q, R, pm), pm), pm)
+        h = size // 2
+        for t in range(n):
+            s[t] = s[t] * (x if (t % size) >= h else xi) % q
+        b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
+        size = h
+    rhs = o.pt_add(o.pt_mul(proof.a, _msm(s, G, curve), pm), o.pt_mul(proof.a * b[0] % q, Q, pm), pm)
+    return acc == rhs
+
+
+# ---- the SNARK ---------------------------------------------------------------------------------------------
+def _pow2_at_least(n: int) -> int:
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
+@dataclass
+class SpartanProof:
+    outer: List[List[int]]
+    claims: Tuple[int, int, int, int]        # Az, Bz, Cz, E at r_x
+    inner: List[List[int]]
+    w_eval: int
+    ipa_W: IpaProof
+    ipa_E: IpaProof
+
+
+def _layout(shape: o.R1CSShape):
+    M = _pow2_at_least(shape.num_cons)
+    NW = _pow2_at_least(shape.num_vars)
+    return M, NW, 2 * NW
+
+
+def _col(shape: o.R1CSShape, NW: int, c: int) -> int:
+    return c if c < shape.num_vars else NW + (c - shape.num_vars)
+
+
+def _instance_bytes(tr: Transcript, digest: bytes, comm_W: Point, comm_E: Point, u: int, X: Sequence[int]) -> None:
+    tr.absorb(b"shape", digest)
+    tr.absorb_pt(b"inst", [comm_W, comm_E])
+    tr.absorb_fe(b"inst", [u] + list(X))
+
+
+def m_vector(shape: o.R1CSShape, eq_rx: Sequence[int], rho: int, NW: int, q: int) -> List[int]:
+    out = [0] * (2 * NW)
+    for coef, mat in ((1, shape.A), (rho, shape.B), (rho * rho % q, shape.C)):
+        for r, c, v in mat:
+            out[_col(shape, NW, c)] = (out[_col(shape, NW, c)] + coef * v % q * eq_rx[r]) % q
+    return out
+
+
+def prove(shape: o.R1CSShape, digest: bytes, G: Sequence[Point], U: Point, comm_W: Point, comm_E: Point, u: int,
+          X: Sequence[int], W: Sequence[int], E: Sequence[int], curve: int = o.CURVE_PALLAS) -> SpartanProof:
+    q = o.curve_scalar_modulus(curve)
+    M, NW, Z = _layout(shape)
+    s, l1 = M.bit_length() - 1, Z.bit_length() - 1
+    tr = Transcript(b"compress")
+    _instance_bytes(tr, digest, comm_W, comm_E, u, X)
+    z = list(W) + [u] + list(X)
+    az, bz, cz = o.multiply_vec(shape, z, q)
+    pad = lambda v, n: list(v) + [0] * (n - len(v))
+    tau = [tr.challenge(b"tau") for _ in range(s)]
+    tables = [eq_table(tau, q), pad(az, M), pad(bz, M), pad(cz, M), pad(E, M)]
+    outer, rx, fin = sumcheck_prove(tr, b"outer", tables, lambda e, a, b, c, d: e * ((a * b - u * c - d) % q), 3, q)
+    claims = (fin[1], fin[2], fin[3], fin[4])
+    tr.absorb_fe(b"claims", claims)
+    rho = tr.challenge(b"rho")
+    eq_rx = eq_table(rx, q)
+    zpad = pad(W, NW) + pad([u] + list(X), NW)
+    inner, ry, _ = sumcheck_prove(tr, b"inner", [m_vector(shape, eq_rx, rho, NW, q), zpad], lambda a, b: a * b, 2, q)
+    eq_ry = eq_table(ry[1:], q)
+    w_eval = sum(x * y for x, y in zip(pad(W, NW), eq_ry)) % q
+    tr.absorb_fe(b"weval", [w_eval])
+    ipa_W = ipa_prove(tr, b"ipaW", G[:NW], U, pad(W, NW), eq_ry, w_eval, comm_W, curve)
+    ipa_E = ipa_prove(tr, b"ipaE", G[:M], U, pad(E, M), eq_rx, claims[3], comm_E, curve)
+    return SpartanProof(outer, claims, inner, w_eval, ipa_W, ipa_E)
+
+
+def verify(shape: o.R1CSShape, digest: bytes, G: Sequence[Point], U: Point, comm_W: Point, comm_E: Point, u: int,
+           X: Sequence[int], proof: SpartanProof, curve: int = o.CURVE_PALLAS) -> bool:
+    q = o.curve_scalar_modulus(curve)
+    M, NW, Z = _layout(shape)
+    s, l1 = M.bit_length() - 1, Z.bit_length() - 1
+    if len(proof.outer) != s or len(proof.inner) != l1:
+        return False
+    tr = Transcript(b"compress")
+    _instance_bytes(tr, digest, comm_W, comm_E, u, X)
+    tau = [tr.challenge(b"tau") for _ in range(s)]
+    try:
+        claim, rx = sumcheck_verify(tr, b"outer", 0, proof.outer, 3, q)
+    except ValueError:
+        return False
+    a, b, c, e = proof.claims
+    if claim != mle_eval(eq_table(tau, q), rx, q) * ((a * b - u * c - e) % q) % q:
+        return False
+    tr.absorb_fe(b"claims", proof.claims)
+    rho = tr.challenge(b"rho")
+    try:
+        claim, ry = sumcheck_verify(tr, b"inner", (a + rho * b + rho * rho % q * c) % q, proof.inner, 2, q)
+    except ValueError:
+        return False
+    eq_rx = eq_table(rx, q)
+    m_ry = mle_eval(m_vector(shape, eq_rx, rho, NW, q), ry, q)
+    eq_rest = eq_table(ry[1:], q)
+    pub = sum(v * eq_rest[i] for i, v in enumerate([u] + list(X))) % q
+    z_ry = ((1 - ry[0]) * proof.w_eval + ry[0] * pub) % q
+    if claim != m_ry * z_ry % q:
+        return False
+    tr.absorb_fe(b"weval", [proof.w_eval])
+    if not ipa_verify(tr, b"ipaW", G[:NW], U, eq_rest, proof.w_eval, comm_W, proof.ipa_W, curve):
+        return False
+    return ipa_verify(tr, b"ipaE", G[:M], U, eq_rx, e, comm_E, proof.ipa_E, curve)
