@@ -203,6 +203,37 @@ int  vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* cons
  * everything enqueued on `other` so far has finished (an event; the host does not wait). */
 int  vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other);
 
+/* ---- compression SNARK building blocks ------------------------------------------------------ */
+/* The passes behind `NovaVDFProof::compress` and the verification of a compressed proof
+ * (/root/reference/src/nova/proof.rs:360-368, :383 -> nova-snark 0.8.0 CompressedSNARK: sum-checks over the relaxed
+ * R1CS and inner-product-argument openings).  Protocol and padding are restated in
+ * oracle/spartan.py.  Vectors live in device memory, single field elements in host memory (passed as kernel
+ * arguments); multilinear tables are MSB-first: index i = sum x_j 2^(k-j), binding a variable folds the upper half
+ * of a table onto the lower half. */
+/* out[i] = prod_j (bit_j(i) ? hi[j] : lo[j]), i < 2^k, k <= 24: eq(r, .) with lo = 1 - r, hi = r; the inner-product
+ * argument's generator coefficients with lo = x^-1, hi = x. */
+int  vdf_pair_table(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, int k, vdf_fe* out);
+/* v[t][i] <- c_lo[t] * v[t][i] + c_hi[t] * v[t][i + n/2], i < n/2, for t < k <= 8 vectors of length n (power of two)
+ * in one launch: a sum-check binding (1 - r, r); the argument's folds (x, x^-1) / (x^-1, x). */
+int  vdf_fold_halves(vdf_ctx* ctx, int field, int k, vdf_fe* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n);
+/* Sums over a vector pair / the five tables of the R1CS sum-check; `out` host, pinned or device:
+ *   kind 0  out[0] = sum_i a[i] b[i], i < n                                    tables = {a, b}
+ *   kind 1  g(0), g(2) of g(t) = sum_{i < n/2} p_t[i] q_t[i]                    tables = {p, q}
+ *   kind 2  g(0), g(2), g(3) of g(t) = sum eq_t (a_t b_t - u c_t - e_t)        tables = {eq, a, b, c, e}, u: host
+ *   kind 3  sum a[i] b[n/2 + i],  sum a[n/2 + i] b[i]                          tables = {a, b}
+ * with f_t[i] = f[i] + t (f[n/2 + i] - f[i]). */
+enum { VDF_REDUCE_DOT = 0, VDF_REDUCE_QUADRATIC_ROUND = 1, VDF_REDUCE_R1CS_ROUND = 2, VDF_REDUCE_IPA_CROSS = 3 };
+int  vdf_reduce(vdf_ctx* ctx, int field, int kind, const vdf_fe* const tables[], const vdf_fe* u, size_t n, vdf_fe* out);
+/* out[y] = sum_x eq[x] (A + rho B + rho^2 C)[x, y] for the num_cols columns of the shape (eq: num_cons elements). */
+int  vdf_spmv3_t(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* eq, const vdf_fe* rho, vdf_fe* out);
+/* One round of the inner-product argument without materialising folded generators: with n_j the current length of
+ * a, s[t] the coefficient of original generator t in its folded generator, h = n_j / 2 and r = t mod n_j,
+ *   sL[t] = r >= h ? s[t] a[r - h] : 0,   sR[t] = r < h ? s[t] a[r + h] : 0,   t < n,
+ * so that L = MSM(sL) and R = MSM(sR) over the original generators. */
+int  vdf_ipa_scalars(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* s, size_t n, size_t nj, vdf_fe* sL, vdf_fe* sR);
+/* s[t] *= (t mod n_j) >= n_j / 2 ? x_hi : x_lo, t < n. */
+int  vdf_scale_pattern(vdf_ctx* ctx, int field, vdf_fe* s, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi);
+
 /* ---- utilities the host layer and the tests need ---------------------------------------- */
 /* Element-wise Montgomery product / conversions, n elements (test + host plumbing). */
 int  vdf_fe_mul(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* b, size_t n, vdf_fe* out);

@@ -60,6 +60,12 @@ PROTOTYPES = {
     "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
+    "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "vdf_fold_halves": (_i, [_vp, _i, _i, C.POINTER(_vp), _vp, _vp, _sz]),
+    "vdf_reduce": (_i, [_vp, _i, _i, C.POINTER(_vp), _vp, _sz, _vp]),
+    "vdf_spmv3_t": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "vdf_ipa_scalars": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _vp]),
+    "vdf_scale_pattern": (_i, [_vp, _i, _vp, _sz, _sz, _vp, _vp]),
     "vdf_fe_mul": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     "vdf_fe_to_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_from_mont": (_i, [_vp, _i, _vp, _sz, _vp]),

@@ -5,6 +5,7 @@
 #include <array>
 #include <new>
 #include <memory>
+#include <initializer_list>
 #include <utility>
 #include "internal.h"
 #include "fe.cuh"
@@ -273,6 +274,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->d_out) (void)hipFree(ctx->d_out);
   if (ctx->small_pool) (void)hipFree(ctx->small_pool);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+  if (ctx->reduce_scratch) (void)hipFree(ctx->reduce_scratch);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
@@ -641,6 +643,7 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
     auto cleanup = [&]() {
       for (int k = 0; k < 3; ++k) { (void)hipFree(s->d_rowptr[k]); (void)hipFree(s->d_col[k]); (void)hipFree(s->d_coef[k]); }
       (void)hipFree(s->d_dict);
+      (void)hipFree(s->d_t_colptr); (void)hipFree(s->d_t_row); (void)hipFree(s->d_t_cm); (void)hipFree(s->d_t_heavy);
       delete s;
     };
     hipError_t e = hipMalloc(&s->d_dict, dict.size() * 32);
@@ -653,6 +656,34 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
       if (e == hipSuccess && nnz[k]) e = hipMemcpy(s->d_col[k], col[k].data(), nnz[k] * 4, hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_coef[k]), (nnz[k] + 1) * 4);
       if (e == hipSuccess && nnz[k]) e = hipMemcpy(s->d_coef[k], coef[k].data(), nnz[k] * 4, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+      // merged column-major form for vdf_spmv3_t
+      std::vector<uint32_t> tcol(num_cols + 1, 0);
+      for (int k = 0; k < 3; ++k) for (size_t i = 0; i < nnz[k]; ++i) tcol[cols[k][i] + 1]++;
+      for (size_t c = 0; c < num_cols; ++c) tcol[c + 1] += tcol[c];
+      const size_t nnz3 = tcol[num_cols];
+      std::vector<uint32_t> trow(nnz3 + 1), tcm(nnz3 + 1), fill(tcol.begin(), tcol.end() - 1), heavy;
+      for (int k = 0; k < 3; ++k)
+        for (size_t i = 0; i < nnz[k]; ++i) {
+          std::array<uint32_t, 8> v;
+          std::memcpy(v.data(), &vals[k][i], 32);
+          const uint32_t ci = dict_idx[v];
+          if (ci >= (1u << 30)) { e = hipErrorInvalidValue; break; }
+          const uint32_t p = fill[cols[k][i]]++;
+          trow[p] = rows[k][i];
+          tcm[p] = ci | ((uint32_t)k << 30);
+        }
+      for (size_t c = 0; c < num_cols; ++c) if (tcol[c + 1] - tcol[c] > 64) heavy.push_back((uint32_t)c);
+      s->t_nheavy = heavy.size();
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_colptr), (num_cols + 1) * 4);
+      if (e == hipSuccess) e = hipMemcpy(s->d_t_colptr, tcol.data(), (num_cols + 1) * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_row), (nnz3 + 1) * 4);
+      if (e == hipSuccess) e = hipMemcpy(s->d_t_row, trow.data(), (nnz3 + 1) * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_cm), (nnz3 + 1) * 4);
+      if (e == hipSuccess) e = hipMemcpy(s->d_t_cm, tcm.data(), (nnz3 + 1) * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_heavy), (heavy.size() + 1) * 4);
+      if (e == hipSuccess && !heavy.empty()) e = hipMemcpy(s->d_t_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { cleanup(); return vdf::hip_status(e, "vdf_shape_create upload"); }
     *out = s;
@@ -668,6 +699,7 @@ void vdf_shape_free(vdf_shape* shape) {
     (void)hipStreamSynchronize(shape->ctx->stream);
     for (int k = 0; k < 3; ++k) { (void)hipFree(shape->d_rowptr[k]); (void)hipFree(shape->d_col[k]); (void)hipFree(shape->d_coef[k]); }
     (void)hipFree(shape->d_dict);
+    (void)hipFree(shape->d_t_colptr); (void)hipFree(shape->d_t_row); (void)hipFree(shape->d_t_cm); (void)hipFree(shape->d_t_heavy);
   }
   delete shape;
 }
@@ -785,6 +817,87 @@ int vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other) {
     if (!ctx->wait_ev) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
     VDF_TRY_HIP(hipEventRecord(ctx->wait_ev, other->stream));
     VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, ctx->wait_ev, 0));
+    return Status{};
+  });
+}
+
+// ---- compression SNARK building blocks ---------------------------------------------------------------------
+namespace {
+bool all_device(std::initializer_list<const void*> ps) {
+  for (const void* p : ps) if (!ptr_is_device(p)) return false;
+  return true;
+}
+const char* kDevVec = "vector operands of the SNARK building blocks live in device memory";
+const char* kHostScalar = "scalar operands of the SNARK building blocks live in host memory";
+}  // namespace
+
+int vdf_pair_table(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, int k, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (k < 0 || k > 24) return Status{VDF_ERR_BAD_LENGTH, "0..24 variables"};
+    if (k && (!lo || !hi || ptr_is_device(lo) || ptr_is_device(hi))) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    if (!ptr_is_device(out)) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    VDF_TRY(vdf::snark_pair_table(field, lo, hi, k, out, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_fold_halves(vdf_ctx* ctx, int field, int k, vdf_fe* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n) {
+  return guarded(ctx, [&]() -> Status {
+    if (k < 0 || k > 8) return Status{VDF_ERR_BAD_ARG, "k must be 0..8"};
+    if (k == 0) return Status{};
+    if (!v || !c_lo || !c_hi || ptr_is_device(c_lo) || ptr_is_device(c_hi)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    void* dv[8];
+    for (int i = 0; i < k; ++i) { if (!ptr_is_device(v[i])) return Status{VDF_ERR_BAD_ARG, kDevVec}; dv[i] = v[i]; }
+    VDF_TRY(vdf::snark_fold_halves(field, k, dv, c_lo, c_hi, n, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_reduce(vdf_ctx* ctx, int field, int kind, const vdf_fe* const tables[], const vdf_fe* u, size_t n, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (kind < 0 || kind > 3 || !tables || !out) return Status{VDF_ERR_BAD_ARG, "bad argument"};
+    if (kind == 2 && (!u || ptr_is_device(u))) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    const int ntab = kind == 2 ? 5 : 2, nout = kind == 0 ? 1 : kind == 2 ? 3 : 2;
+    const void* t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < ntab; ++i) { if (n && !ptr_is_device(tables[i])) return Status{VDF_ERR_BAD_ARG, kDevVec}; t[i] = tables[i]; }
+    if (!ctx->reduce_scratch) VDF_TRY_HIP(hipMalloc(&ctx->reduce_scratch, vdf::snark_reduce_scratch_bytes()));
+    Staging st(ctx);
+    void* d_out = nullptr;
+    VDF_TRY(st.out(out, (size_t)nout * sizeof(vdf_fe), &d_out));
+    VDF_TRY(vdf::snark_reduce(field, kind, t, u, n, ctx->reduce_scratch, d_out, ctx->stream));
+    return st.finish();
+  });
+}
+
+int vdf_spmv3_t(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* eq, const vdf_fe* rho, vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+    if (!rho || ptr_is_device(rho)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    if (!all_device({eq, out})) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    VDF_TRY(vdf::snark_spmvt(shape->field, shape->d_t_colptr, shape->d_t_row, shape->d_t_cm, shape->d_t_heavy, shape->t_nheavy,
+                             shape->d_dict, eq, rho, shape->num_cols, out, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_ipa_scalars(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* s, size_t n, size_t nj, vdf_fe* sL, vdf_fe* sR) {
+  return guarded(ctx, [&]() -> Status {
+    if (!all_device({a, s, sL, sR})) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    VDF_TRY(vdf::snark_ipa_scalars(field, a, s, n, nj, sL, sR, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_scale_pattern(vdf_ctx* ctx, int field, vdf_fe* s, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi) {
+  return guarded(ctx, [&]() -> Status {
+    if (!x_lo || !x_hi || ptr_is_device(x_lo) || ptr_is_device(x_hi)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    if (!ptr_is_device(s)) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    VDF_TRY(vdf::snark_scale_pattern(field, s, n, nj, x_lo, x_hi, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });
 }

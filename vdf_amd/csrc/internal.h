@@ -35,6 +35,7 @@ struct vdf_ctx {
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool job_open = false;
+  void* reduce_scratch = nullptr;    // per-workgroup partial sums of vdf_reduce
 };
 
 struct vdf_bases {
@@ -57,6 +58,12 @@ struct vdf_shape {
   uint32_t* d_coef[3] = {nullptr, nullptr, nullptr};     // nnz, index into dictionary
   void* d_dict = nullptr;                                 // dictionary of field elements
   size_t dict_len = 0;
+  // the three matrices merged in column-major order (vdf_spmv3_t): entry = (row, coefficient index | matrix << 30)
+  uint32_t* d_t_colptr = nullptr;                         // num_cols + 1
+  uint32_t* d_t_row = nullptr;                            // nnz[0] + nnz[1] + nnz[2]
+  uint32_t* d_t_cm = nullptr;
+  uint32_t* d_t_heavy = nullptr;                          // columns with more than 64 entries
+  size_t t_nheavy = 0;
 };
 
 namespace vdf {
@@ -156,5 +163,17 @@ Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hip
 Status vec_to_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, hipStream_t s);
+
+// ---- snark.hip -------------------------------------------------------------------------
+// vdf_fe* arguments are HOST pointers whose values travel as kernel arguments; void* are device vectors
+Status snark_pair_table(int field, const vdf_fe* lo, const vdf_fe* hi, int k, void* out, hipStream_t s);
+Status snark_fold_halves(int field, int k, void* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n, hipStream_t s);
+size_t snark_reduce_scratch_bytes();
+Status snark_reduce(int field, int kind, const void* const tables[], const vdf_fe* u, size_t n, void* scratch, void* out,
+                    hipStream_t s);
+Status snark_spmvt(int field, const uint32_t* colptr, const uint32_t* rows, const uint32_t* cm, const uint32_t* heavy,
+                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, hipStream_t s);
+Status snark_ipa_scalars(int field, const void* a, const void* sv, size_t n, size_t nj, void* sL, void* sR, hipStream_t s);
+Status snark_scale_pattern(int field, void* sv, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi, hipStream_t s);
 
 }  // namespace vdf

@@ -276,6 +276,31 @@ class Context:
         ln = (C.c_size_t * k)(*[int(x) for x in n])
         self._check(lib.vdf_fold_many(self.handle, field, _ptr(r), k, a, b, ln))
 
+    # ---- compression SNARK building blocks: vectors on the device, scalars as host arrays ----
+    def pair_table(self, field, lo, hi, k, out) -> None:
+        self._check(lib.vdf_pair_table(self.handle, field, _ptr(lo), _ptr(hi), k, _ptr(out)))
+
+    def fold_halves(self, field, vectors, c_lo, c_hi, n) -> None:
+        k = len(vectors)
+        v = (C.c_void_p * k)(*[_ptr(x) for x in vectors])
+        self._check(lib.vdf_fold_halves(self.handle, field, k, v, _ptr(c_lo), _ptr(c_hi), n))
+
+    def reduce(self, field, kind, tables, n, u=None):
+        nout = 1 if kind == 0 else 3 if kind == 2 else 2
+        out = np.zeros((nout, 4), dtype="<u8")
+        t = (C.c_void_p * len(tables))(*[_ptr(x) for x in tables])
+        self._check(lib.vdf_reduce(self.handle, field, kind, t, _ptr(u), n, _ptr(out)))
+        return out
+
+    def spmv3_t(self, shape: Shape, eq, rho, out) -> None:
+        self._check(lib.vdf_spmv3_t(self.handle, shape.handle, _ptr(eq), _ptr(rho), _ptr(out)))
+
+    def ipa_scalars(self, field, a, s, n, nj, sL, sR) -> None:
+        self._check(lib.vdf_ipa_scalars(self.handle, field, _ptr(a), _ptr(s), n, nj, _ptr(sL), _ptr(sR)))
+
+    def scale_pattern(self, field, s, n, nj, x_lo, x_hi) -> None:
+        self._check(lib.vdf_scale_pattern(self.handle, field, _ptr(s), n, nj, _ptr(x_lo), _ptr(x_hi)))
+
     def fe_mul(self, field, a, b, n, out) -> None:
         self._check(lib.vdf_fe_mul(self.handle, field, _ptr(a), _ptr(b), n, _ptr(out)))
 
