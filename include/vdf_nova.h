@@ -8,7 +8,7 @@
  * reference also keeps sequential or O(1): the forward MinRoot evaluation (src/minroot.rs:329-359,
  * the "delay" itself), transcript hashing, and the two scalar multiplications of an instance fold.
  *
- * STAGE: folding-only.  A step is the reference's step circuit
+ * STAGE: folding-only, plus the compression SNARK over the folded instance.  A step is the reference's step circuit
  * (InverseMinRootCircuit::synthesize, src/nova/proof.rs:87-140) wrapped so that z_in / z_out are
  * public (the "exposed-IO wrapper", oracle/pasta.py step_circuit_shape) and folded with NIFS
  * (SURVEY.md Appendix C).  The in-circuit verifier (augmented circuit), the secondary curve and
@@ -49,6 +49,7 @@ int vdf_minroot_element(int field, uint64_t n, vdf_fe* out);                    
 typedef struct vdf_pp vdf_pp;             /* NovaVDFPublicParams, :38-43 */
 typedef struct vdf_circuits vdf_circuits; /* Vec<InverseMinRootCircuit<G1>>, :57-66 (reversed, :294) */
 typedef struct vdf_proof vdf_proof;       /* NovaVDFProof::Recursive, :51-55 */
+typedef struct vdf_snark vdf_snark;       /* NovaVDFProof::Compressed, :54 */
 
 /* public_params(num_iters_per_step), :232-237: R1CS shape of the wrapped step circuit, Pedersen
  * generators (synthetic, next_pow2(max(vars, cons)) of them, seeded) with their fixed-base table,
@@ -94,6 +95,27 @@ int  vdf_nova_proof_step_record(const vdf_proof* proof, size_t k, vdf_affine* co
  * unused, wait (previous step's host instance fold, then both commitments), transcript + fold launch,
  * bookkeeping, total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
+
+/* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
+ * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS
+ * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v1" (oracle/spartan.py): a
+ * Spartan-style sum-check argument with inner-product-argument openings under the same Pedersen generators; the
+ * extra generator of the openings is synthetic generator number num_gens.  Like the rest of this layer it is
+ * self-consistent, not interchangeable with nova-snark (whose constants are unpinned); in the
+ * folding-only stage the compressed proof still carries the per-step records the verifier replays.  Every pass
+ * over a vector runs on the GPU through include/vdf_hip.h. */
+int  vdf_nova_compress(const vdf_proof* proof, vdf_pp* pp, vdf_snark** out);
+/* NovaVDFProof::verify for the Compressed variant: *ok = 1 iff the step records chain from z0 to zi over num_steps
+ * steps, fold to the stated instance, and the argument for that instance verifies. */
+int  vdf_nova_verify_compressed(const vdf_snark* snark, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3],
+                                int* ok);
+void vdf_nova_snark_free(vdf_snark* snark);
+/* Flat canonical encoding of the argument (little-endian, non-Montgomery; layout in the implementation and in
+ * tests/test_gpu_compress.py): size, export, and import -- which replaces the argument of `snark` and returns
+ * VDF_ERR_NONCANONICAL for out-of-range field elements. */
+size_t vdf_nova_snark_size(const vdf_snark* snark);
+int  vdf_nova_snark_bytes(const vdf_snark* snark, uint8_t* out, size_t cap);
+int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
 const char* vdf_nova_last_error(void);
 
 #ifdef __cplusplus

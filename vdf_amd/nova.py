@@ -32,6 +32,12 @@ for _name, _res, _args in [
     ("vdf_nova_proof_witness_ptrs", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     ("vdf_nova_proof_step_record", _i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     ("vdf_nova_last_step_ms", _i, [_vp, C.POINTER(C.c_double * 8)]),
+    ("vdf_nova_compress", _i, [_vp, _vp, C.POINTER(_vp)]),
+    ("vdf_nova_verify_compressed", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
+    ("vdf_nova_snark_free", None, [_vp]),
+    ("vdf_nova_snark_size", _sz, [_vp]),
+    ("vdf_nova_snark_bytes", _i, [_vp, _vp, _sz]),
+    ("vdf_nova_snark_set_bytes", _i, [_vp, _vp, _sz]),
 ]:
     getattr(nova_lib, _name).argtypes = _args
     getattr(nova_lib, _name).restype = _res
@@ -153,8 +159,10 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
         _check(nova_lib.vdf_nova_verify(self.handle, pp.handle, num_steps, C.byref(_z(z0)), C.byref(_z(zi)), C.byref(ok)))
         return bool(ok.value)
 
-    def compress(self, pp: NovaVDFPublicParams):                                        # :360-368
-        raise NotImplementedError("CompressedSNARK (Spartan + IPA) is the next row of SURVEY.md 8f; not built in this round")
+    def compress(self, pp: NovaVDFPublicParams) -> "CompressedNovaVDFProof":            # :360-368
+        h = C.c_void_p()
+        _check(nova_lib.vdf_nova_compress(self.handle, pp.handle, C.byref(h)))
+        return CompressedNovaVDFProof(h.value, pp)
 
     # ---- introspection used by the parity tests and the bench ----
     def num_steps(self) -> int:
@@ -192,6 +200,40 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
     def free(self) -> None:
         if self.handle and self.pp.handle and self.pp.ctx.handle:      # needs live parameters and a live context
             nova_lib.vdf_nova_proof_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CompressedNovaVDFProof:     # NovaVDFProof::Compressed, src/nova/proof.rs:54
+    def __init__(self, handle: int, pp: NovaVDFPublicParams):
+        self.handle, self.pp = handle, pp
+        pp.ctx._children.add(self)
+        pp._proofs.add(self)
+
+    def verify(self, pp: NovaVDFPublicParams, num_steps: int, z0: Sequence[bytes], zi: Sequence[bytes]) -> bool:   # :370-387
+        ok = C.c_int(0)
+        _check(nova_lib.vdf_nova_verify_compressed(self.handle, pp.handle, num_steps, C.byref(_z(z0)), C.byref(_z(zi)), C.byref(ok)))
+        return bool(ok.value)
+
+    def to_bytes(self) -> bytes:
+        """The argument in its flat canonical encoding (include/vdf_nova.h)."""
+        n = nova_lib.vdf_nova_snark_size(self.handle)
+        buf = (C.c_uint8 * n)()
+        _check(nova_lib.vdf_nova_snark_bytes(self.handle, buf, n))
+        return bytes(buf)
+
+    def set_bytes(self, data: bytes) -> None:
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        _check(nova_lib.vdf_nova_snark_set_bytes(self.handle, buf, len(data)))
+
+    def free(self) -> None:
+        if self.handle and self.pp.handle and self.pp.ctx.handle:
+            nova_lib.vdf_nova_snark_free(self.handle)
         self.handle = None
 
     def __del__(self):
