@@ -702,7 +702,7 @@ int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_
 
 // =============================================================================================================
 // Compression SNARK: NovaVDFProof::compress / verification of the compressed proof (src/nova/proof.rs:360-368, :383).
-// Protocol "vdf-spartan-v1", restated line by line in oracle/spartan.py (prove / verify); every pass over a vector is
+// Protocol "vdf-spartan-v1", restated line by line by the test oracle (spartan.py: prove / verify); every pass over a vector is
 // a call through include/vdf_hip.h, the host keeps the transcript, O(log n) field work and O(log n) point work.
 // =============================================================================================================
 namespace {
