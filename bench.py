@@ -135,6 +135,17 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2):
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes,
            "forward_eval_s_per_step_host": eval_s / nsteps,
            "stage": "folding-only (step circuit + NIFS on the primary curve; no augmented circuit / secondary curve)"}
+    # compress (src/nova/proof.rs:360-368) and verification of the compressed proof, once, outside `value`
+    a = time.perf_counter()
+    snark = proof.compress(pp)
+    compress_ms = (time.perf_counter() - a) * 1e3
+    a = time.perf_counter()
+    ok_c = snark.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
+    verify_c_ms = (time.perf_counter() - a) * 1e3
+    out["compress"] = {"compress_ms": compress_ms, "verify_compressed_ms": verify_c_ms, "verified": bool(ok_c),
+                       "argument_bytes": len(snark.to_bytes()),
+                       "what": "Spartan-style argument with inner-product-argument openings for the folded instance (vdf_nova.h)"}
+    snark.free()
     proof.free()
     # Aggregate rate of TWO independent chains proven concurrently on this GPU (two host threads, two contexts):
     # one chain's bucket reduction and host transcript run under the other's accumulation.  The headline `value`

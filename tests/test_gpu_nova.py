@@ -60,7 +60,7 @@ def make(ctx, t, n, seed=42, i0=1):
 
 
 def test_nova_proof(ctx):
-    """test_nova_proof_aux(5, 3), src/nova/proof.rs:403-451 (without the compress leg)."""
+    """test_nova_proof_aux(5, 3), src/nova/proof.rs:403-451, including its compress leg (:446-450)."""
     t, n = 5, 3
     pp, z0, circuits, initial, init_ints = make(ctx, t, n)
     zi = [initial.x, initial.y, initial.i]
@@ -71,8 +71,9 @@ def test_nova_proof(ctx):
     assert proof.verify(pp, n, z0, wrong) is False
     assert proof.verify(pp, n + 1, z0, zi) is False
     assert proof.verify(pp, n, zi, zi) is False
-    with pytest.raises(NotImplementedError):
-        proof.compress(pp)
+    compressed = proof.compress(pp)                              # :446-448
+    assert compressed.verify(pp, n, z0, zi) is True              # :449-450
+    assert compressed.verify(pp, n, z0, wrong) is False
 
 
 def test_eval_and_make_circuits_order(ctx):
