@@ -4,6 +4,9 @@
 namespace vdfhost {
 
 static Field make_field(const uint32_t mod[8], const uint32_t one_[8], const uint32_t r2_[8]) {
+  static_assert(FpParams::MOD[4] == 0 && FpParams::MOD[5] == 0 && FpParams::MOD[6] == 0 && FpParams::MOD[7] == 0x40000000u &&
+                FqParams::MOD[4] == 0 && FqParams::MOD[5] == 0 && FqParams::MOD[6] == 0 && FqParams::MOD[7] == 0x40000000u,
+                "mont_reduce hard-codes m[2] = 0, m[3] = 2^62");
   Field F;
   for (int i = 0; i < 4; ++i) {
     F.m[i] = ((uint64_t)mod[2 * i + 1] << 32) | mod[2 * i];

@@ -70,25 +70,41 @@ inline Fe neg(const Fe& a, const Field& F) {
   Fe z = {{0, 0, 0, 0}};
   return a.is_zero() ? a : sub(z, a, F);
 }
-// coarsely integrated operand scanning Montgomery product
+// Montgomery product for the two Pasta moduli, m = 2^254 + c with c < 2^126: in 64-bit limbs m[2] = 0 and
+// m[3] = 2^62 (checked in host_math.cpp), so a reduction step is two multiplications and a shift instead of four.
+// Inline on purpose: the forward MinRoot evaluation -- the delay itself, ~285 of these per iteration, strictly
+// sequential (src/minroot.rs:329-359) -- is the end-to-end wall-clock floor of a prover, and its entry points are
+// compiled twice (baseline x86-64 and a BMI2/ADX clone picked at load time) with everything inlined into them.
 inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
-  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i) {
+  uint64_t t[8];
+  {
     u128 c = 0;
-    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-    c += t[4];
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[0]; t[j] = (uint64_t)c; c >>= 64; }
     t[4] = (uint64_t)c;
-    t[5] = (uint64_t)(c >> 64);
-    const uint64_t q = t[0] * F.inv;
-    c = ((u128)q * F.m[0] + t[0]) >> 64;
-    for (int j = 1; j < 4; ++j) { c += (u128)q * F.m[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-    c += t[4];
-    t[3] = (uint64_t)c;
-    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  for (int i = 1; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    t[i + 4] = (uint64_t)c;
+  }
+  uint64_t top = 0;                                   // carry out of limb 7
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t q = t[i] * F.inv;
+    // t += q * (m0 + m1 * 2^64 + 2^254) * 2^(64 i)
+    u128 c = (u128)q * F.m[0] + t[i];
+    c = (c >> 64) + (u128)q * F.m[1] + t[i + 1];
+    t[i + 1] = (uint64_t)c;
+    c = (c >> 64) + t[i + 2];
+    t[i + 2] = (uint64_t)c;
+    c = (c >> 64) + t[i + 3] + (q << 62);
+    t[i + 3] = (uint64_t)c;
+    c = (c >> 64) + (q >> 2);
+    for (int j = i + 4; j < 8; ++j) { c += t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    top += (uint64_t)c;
   }
   Fe r;
-  memcpy(r.l, t, 32);
-  if (t[4] || geq(r.l, F.m)) sub4(r.l, F.m);
+  memcpy(r.l, t + 4, 32);
+  if (top || geq(r.l, F.m)) sub4(r.l, F.m);
   return r;
 }
 inline Fe sqr(const Fe& a, const Field& F) { return mul(a, a, F); }
