@@ -846,6 +846,31 @@ Pt pt_mul_fe(const Pt& p, const Fe& k_mont, const Field& Fscalar) {       // k i
   return pt_mul(p, k.l, 255, field_fp());
 }
 
+// Fixed-base multiples of one point (the Q of an inner-product argument is multiplied by two fresh scalars per
+// round): 4-bit windows, d * 16^w * Q for d = 1..15, so a product is 64 additions and no doubling.
+struct FixedBase {
+  std::vector<Pt> tab;            // [w * 15 + (d - 1)]
+  explicit FixedBase(const Pt& q) : tab(64 * 15) {
+    const Field& Fb = field_fp();
+    Pt base = q;
+    for (int w = 0; w < 64; ++w) {
+      Pt acc = base;
+      for (int d = 1; d <= 15; ++d) { tab[w * 15 + d - 1] = acc; acc = pt_add(acc, base, Fb); }
+      base = acc;                  // 16 * base
+    }
+  }
+  Pt mul(const Fe& k_mont, const Field& Fscalar) const {
+    const Field& Fb = field_fp();
+    const Fe k = from_mont(k_mont, Fscalar);
+    Pt r = pt_identity();
+    for (int w = 0; w < 64; ++w) {
+      const unsigned d = (unsigned)(k.l[w / 16] >> (4 * (w % 16))) & 15u;
+      if (d) r = pt_add(r, tab[w * 15 + d - 1], Fb);
+    }
+    return r;
+  }
+};
+
 // <a, b> = v under P = <a, G[0..n)>; a, b, s: device vectors of length n that this function consumes (s = all ones)
 int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a, void* d_b, void* d_s, void* d_sL, void* d_sR,
               const Fe& v, const Aff& P, vdf_jac* h_lr, Ipa* out) {
@@ -857,6 +882,7 @@ int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a
   uint64_t raw[4];
   tr.challenge(label, F, raw);
   const Pt Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
+  const FixedBase Qtab(Qp);
   out->L.clear(); out->R.clear();
   for (size_t nj = n; nj > 1; nj >>= 1) {
     Fe cross[2];
@@ -869,8 +895,8 @@ int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     Aff l0, r0;
     jac_to_aff2(h_lr[0], h_lr[1], Fb, &l0, &r0);
-    const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), pt_mul_fe(Qp, cross[0], F), Fb), Fb);
-    const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), pt_mul_fe(Qp, cross[1], F), Fb), Fb);
+    const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), Qtab.mul(cross[0], F), Fb), Fb);
+    const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), Qtab.mul(cross[1], F), Fb), Fb);
     const Aff lr[2] = {Lp, Rp};
     tr.absorb_pt(label, lr, 2);
     const Fe x = tr.challenge(label, F, raw);
