@@ -52,7 +52,8 @@ typedef struct vdf_proof vdf_proof;       /* NovaVDFProof::Recursive, :51-55 */
 typedef struct vdf_snark vdf_snark;       /* NovaVDFProof::Compressed, :54 */
 
 /* public_params(num_iters_per_step), :232-237: R1CS shape of the wrapped step circuit, Pedersen
- * generators (synthetic, next_pow2(max(vars, cons)) of them, seeded) with their fixed-base table,
+ * generators (next_pow2(max(vars, cons)) of them by seeded try-and-increment -- unknown discrete logarithms,
+ * VDF_GENS_TRY_AND_INCREMENT; nova-snark's own label -> hash derivation is unpinned) with their fixed-base table,
  * shape digest.  One-time; outside every timed region (benches/nova.rs:51-58). */
 int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** out);
 void vdf_nova_pp_free(vdf_pp* pp);
@@ -100,7 +101,7 @@ int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
  * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS
  * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v1" (oracle/spartan.py): a
  * Spartan-style sum-check argument with inner-product-argument openings under the same Pedersen generators; the
- * extra generator of the openings is synthetic generator number num_gens.  Like the rest of this layer it is
+ * extra generator of the openings is generator number num_gens of the same family.  Like the rest of this layer it is
  * self-consistent, not interchangeable with nova-snark (whose constants are unpinned); in the
  * folding-only stage the compressed proof still carries the per-step records the verifier replays.  Every pass
  * over a vector runs on the GPU through include/vdf_hip.h. */

@@ -8,7 +8,7 @@ import pytest
 from oracle import pasta as o
 from oracle import spartan as sp
 from util import unmont
-from test_gpu_nova import make, shape_digest, aff_ints, GENS_SEED
+from test_gpu_nova import make, shape_digest, aff_ints, gens
 from vdf_amd.minroot import State, FIELD_FQ
 from vdf_amd.nova import NovaVDFProof
 
@@ -49,8 +49,8 @@ def test_compressed_argument_equals_the_oracles(ctx, t, n):
     cW, cE = _pt(aff_ints(inst["comm_W"])), _pt(aff_ints(inst["comm_E"]))
     assert o.is_sat_relaxed(sh, W, E, u, X, Q)
     N = pp.sizes()["num_gens"]
-    G = o.synthetic_bases(o.CURVE_PALLAS, GENS_SEED, N)
-    U = o.synthetic_bases(o.CURVE_PALLAS, GENS_SEED, 1, start=N)[0]
+    G = gens(N)
+    U = gens(1, start=N)[0]
     digest = shape_digest(sh, t)
     want = sp.prove(sh, digest, G, U, cW, cE, u, X, W, E)
     assert sp.verify(sh, digest, G, U, cW, cE, u, X, want)

@@ -139,7 +139,10 @@ bool valid_mode(int m) { return m >= 0 && m <= 3; }
 // Nova (folding-only stage)
 // ---------------------------------------------------------------------------------------------
 constexpr int NUM_IO = 6;                  // X = [z_in(3), z_out(3)]
-constexpr uint64_t GENS_SEED = 0x4e6f7661; // "Nova": label of the synthetic generator family
+constexpr uint64_t GENS_SEED = 0x4e6f7661; // "Nova": label of the generator family
+// Generators by seeded try-and-increment (include/vdf_hip.h): nobody knows their discrete logarithms, which is what
+// makes the Pedersen commitments binding -- the [k_i]G family of the kernel tests would not do for a proof system.
+constexpr int GENS_FAMILY = VDF_GENS_TRY_AND_INCREMENT;
 constexpr int PRIMARY_FIELD = VDF_FIELD_FQ;   // S1 = pallas::Scalar, src/nova/proof.rs:29
 constexpr int PRIMARY_CURVE = VDF_CURVE_PALLAS;   // G1, src/nova/proof.rs:26
 
@@ -361,11 +364,11 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   size_t g = 1;
   while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
   pp->num_gens = g;
-  rc = vdf_bases_generate(ctx, PRIMARY_CURVE, GENS_SEED, g, &pp->gens);
+  rc = vdf_bases_generate_family(ctx, PRIMARY_CURVE, GENS_FAMILY, GENS_SEED, 0, g, &pp->gens);
   if (rc == VDF_OK) rc = vdf_bases_precompute(ctx, pp->gens, 16, 1);
   if (rc == VDF_OK) {
     vdf_bases* ub = nullptr;
-    rc = vdf_bases_generate_range(ctx, PRIMARY_CURVE, GENS_SEED, g, 1, &ub);
+    rc = vdf_bases_generate_family(ctx, PRIMARY_CURVE, GENS_FAMILY, GENS_SEED, g, 1, &ub);
     if (rc == VDF_OK) rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&pp->gen_u);
     if (ub) vdf_bases_free(ub);
   }
@@ -375,7 +378,7 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   // shape digest: sizes, every COO triple in canonical form, generator family
   Shake256 h;
   h.absorb("vdf-nova-shape-v1", 17);
-  uint64_t hdr[5] = {t, (uint64_t)pp->num_cons, (uint64_t)pp->num_vars, (uint64_t)NUM_IO, GENS_SEED};
+  uint64_t hdr[6] = {t, (uint64_t)pp->num_cons, (uint64_t)pp->num_vars, (uint64_t)NUM_IO, GENS_SEED, (uint64_t)GENS_FAMILY};
   h.absorb(hdr, sizeof(hdr));
   const Field& F = field(PRIMARY_FIELD);
   for (int k = 0; k < 3; ++k)
