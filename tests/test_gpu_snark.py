@@ -108,6 +108,24 @@ def test_ipa_round_helpers(ctx):
     assert unmont(_host(ds), Q) == [s[t] * (x if (t % nj) >= h else xi) % Q for t in range(n)]
 
 
+def test_building_blocks_in_the_other_field(ctx):
+    """The same kernels instantiated for Fp (a Vesta-side argument would use them)."""
+    Fp, P = o.FIELD_FP, o.P
+    r = [o.rand_fe(7, i, P) for i in range(6)]
+    out = _dev(np.zeros((64, 4), dtype="<u8"))
+    ctx.pair_table(Fp, mont([(1 - x) % P for x in r], P), mont(r, P), 6, out)
+    ctx.sync()
+    assert unmont(_host(out), P) == sp.eq_table(r, P)
+    a, b = [o.rand_fe(8, i, P) for i in range(64)], [o.rand_fe(9, i, P) for i in range(64)]
+    da, db = _dev(mont(a, P)), _dev(mont(b, P))
+    assert unmont(ctx.reduce(Fp, 0, [da, db], 64), P) == [sum(x * y for x, y in zip(a, b)) % P]
+    assert unmont(ctx.reduce(Fp, 3, [da, db], 64), P) == [sum(a[i] * b[32 + i] for i in range(32)) % P,
+                                                           sum(a[32 + i] * b[i] for i in range(32)) % P]
+    ctx.fold_halves(Fp, [da], mont([(1 - r[0]) % P], P), mont([r[0]], P), 64)
+    ctx.sync()
+    assert unmont(_host(da)[:32], P) == sp.bind(a, r[0], P)
+
+
 def test_scalar_and_vector_placement_is_checked(ctx):
     v = _dev(np.zeros((8, 4), dtype="<u8"))
     one = mont([1], Q)
