@@ -86,6 +86,38 @@ out["fold_t5"] = {
     "z1": [H(v) for v in z1], "az1": [H(v) for v in az1], "bz1": [H(v) for v in bz1], "cz1": [H(v) for v in cz1],
     "T": [H(v) for v in T], "r": H(r), "W_fold": [H(v) for v in o.axpy(z1[:sh.num_vars], r, W, o.Q)],
 }
+# --- generator family 1 (seeded try-and-increment), first points on both curves -------------------------------
+out["tai_bases_seed7"] = {str(c): [[H(p[0]), H(p[1])] for p in o.tai_bases(c, 7, 4)] for c in (o.CURVE_PALLAS, o.CURVE_VESTA)}
+
+# --- compression SNARK on a folded t = 3 instance (oracle/spartan.py); same construction as tests/test_oracle_spartan.py --
+from oracle import spartan as sp  # noqa: E402
+t3 = 3
+sh3 = o.step_circuit_shape(t3, o.FIELD_FQ)
+def fresh(x0, i0):
+    st = o.State(x0 % o.Q, 0, i0)
+    rs = o.minroot_eval(st, t3, o.FIELD_FQ)
+    return [rs.x, rs.y, rs.i] + o.step_witness_segment(rs, t3, o.FIELD_FQ), [rs.x, rs.y, rs.i, st.x, st.y, st.i]
+W1, X1 = fresh(123456789, 5)
+W2, X2 = fresh(987654321, 9)
+abc1, abc2 = o.multiply_vec(sh3, W1 + [1] + X1, o.Q), o.multiply_vec(sh3, W2 + [1] + X2, o.Q)
+T3 = o.cross_term(*abc1, *abc2, 1, o.Q)
+r3 = 0x1234567890ABCDEF1234567890ABCDEF
+Wf, Ef, uf, Xf = o.axpy(W1, r3, W2, o.Q), [r3 * v % o.Q for v in T3], (1 + r3) % o.Q, o.axpy(X1, r3, X2, o.Q)
+N3 = 32
+G3 = o.tai_bases(o.CURVE_PALLAS, 0x4E6F7661, N3)
+U3 = o.tai_base(o.CURVE_PALLAS, 0x4E6F7661, N3)
+cW3, cE3 = o.msm_naive(Wf, G3[:len(Wf)], o.CURVE_PALLAS), o.msm_naive(Ef, G3[:len(Ef)], o.CURVE_PALLAS)
+pf = sp.prove(sh3, b"\x07" * 32, G3, U3, cW3, cE3, uf, Xf, Wf, Ef)
+assert sp.verify(sh3, b"\x07" * 32, G3, U3, cW3, cE3, uf, Xf, pf)
+fe = lambda v: int(v).to_bytes(32, "little")
+pt = lambda q: b"\0" * 64 if q is None else fe(q[0]) + fe(q[1])
+enc = b"".join(fe(v) for ev in pf.outer for v in ev) + b"".join(fe(v) for v in pf.claims)
+enc += b"".join(fe(v) for ev in pf.inner for v in ev) + fe(pf.w_eval)
+for ipa in (pf.ipa_W, pf.ipa_E):
+    enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
+out["spartan_t3"] = {"comm_W": [H(cW3[0]), H(cW3[1])], "comm_E": [H(cE3[0]), H(cE3[1])], "u": H(uf), "X": [H(v) for v in Xf],
+                     "argument_hex": enc.hex()}
+
 path = os.path.join(os.path.dirname(__file__), "vectors.json")
 json.dump(out, open(path, "w"), indent=0)
 print("wrote", path, os.path.getsize(path), "bytes")

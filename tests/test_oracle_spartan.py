@@ -101,3 +101,32 @@ def test_unsatisfied_witness_cannot_be_proved(relaxed):
     r["comm_W"] = o.msm_naive(r["W"], r["G"][:len(r["W"])], o.CURVE_PALLAS)
     assert not o.is_sat_relaxed(r["shape"], r["W"], r["E"], r["u"], r["X"], Q)
     assert not _verify(r, _prove(r))
+
+
+def test_against_the_committed_golden_argument():
+    """tests/golden/vectors.json pins the restatement (generator family, transcript, encoding) against regressions."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
+    for c in (o.CURVE_PALLAS, o.CURVE_VESTA):
+        assert [[("%064x" % p[0]), ("%064x" % p[1])] for p in o.tai_bases(c, 7, 4)] == g["tai_bases_seed7"][str(c)]
+    t = 3
+    shape = o.step_circuit_shape(t, o.FIELD_FQ)
+    W1, X1 = _fresh(shape, t, 123456789, 5)
+    W2, X2 = _fresh(shape, t, 987654321, 9)
+    abc1, abc2 = o.multiply_vec(shape, W1 + [1] + X1, Q), o.multiply_vec(shape, W2 + [1] + X2, Q)
+    T = o.cross_term(*abc1, *abc2, 1, Q)
+    r = 0x1234567890ABCDEF1234567890ABCDEF
+    W, E, u, X = o.axpy(W1, r, W2, Q), [r * v % Q for v in T], (1 + r) % Q, o.axpy(X1, r, X2, Q)
+    G = o.tai_bases(o.CURVE_PALLAS, 0x4E6F7661, 32)
+    U = o.tai_base(o.CURVE_PALLAS, 0x4E6F7661, 32)
+    cW, cE = o.msm_naive(W, G[:len(W)], o.CURVE_PALLAS), o.msm_naive(E, G[:len(E)], o.CURVE_PALLAS)
+    gs = g["spartan_t3"]
+    assert ["%064x" % cW[0], "%064x" % cW[1]] == gs["comm_W"] and "%064x" % u == gs["u"]
+    pf = sp.prove(shape, b"\x07" * 32, G, U, cW, cE, u, X, W, E)
+    fe = lambda v: int(v).to_bytes(32, "little")
+    pt = lambda q: b"\0" * 64 if q is None else fe(q[0]) + fe(q[1])
+    enc = b"".join(fe(v) for ev in pf.outer for v in ev) + b"".join(fe(v) for v in pf.claims)
+    enc += b"".join(fe(v) for ev in pf.inner for v in ev) + fe(pf.w_eval)
+    for ipa in (pf.ipa_W, pf.ipa_E):
+        enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
+    assert enc.hex() == gs["argument_hex"]
