@@ -131,24 +131,19 @@ __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, 
 
 struct Csr3 { const uint32_t* rowptr[3]; const uint32_t* col[3]; const uint32_t* coef[3]; };
 
+// One term of a sparse row: +-z[col] or coefficient * z[col] (dictionary index 0 = +1, 1 = -1).
 template <class P>
-__device__ __forceinline__ Fe<P> spmv_row(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col,
-                                          const uint32_t* __restrict__ coef, const char* __restrict__ dict,
-                                          const char* __restrict__ z, size_t r) {
-  const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
-  Fe<P> acc = fe_zero<P>();
-  for (uint32_t k = lo; k < hi; ++k) {
-    const Fe<P> v = fe_load<P>(z + (size_t)col[k] * 32);
-    const uint32_t ci = coef[k];
-    if (ci == 0) acc = fe_add(acc, v);
-    else if (ci == 1) acc = fe_sub(acc, v);
-    else acc = fe_add(acc, fe_mul(v, fe_load<P>(dict + (size_t)ci * 32)));
-  }
-  return acc;
+__device__ __forceinline__ Fe<P> spmv_term(const Fe<P>& v, uint32_t ci, const char* __restrict__ dict) {
+  if (ci == 0) return v;
+  if (ci == 1) return fe_neg(v);
+  return fe_mul(v, fe_load<P>(dict + (size_t)ci * 32));
 }
 
 // multiply_vec(z2) and the cross term in one pass over the rows:
 //   (a2, b2, c2) = (A z2, B z2, C z2)[row];  T[row] = a1*b2 + a2*b1 - u1*c2 - c1      (u2 = 1)
+// The loads are issued in three waves instead of nine dependent steps: all six row pointers, then the first column /
+// coefficient of each matrix, then the three z values (R1CS rows are short: the first entry is usually the only one);
+// the remaining entries of a row follow in a plain loop.
 template <class P>
 __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
                                                     const char* __restrict__ az1, const char* __restrict__ bz1,
@@ -158,15 +153,29 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
   __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
+  uint32_t lo[3], hi[3], c0[3], k0[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
   const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
-  const Fe<P> a2 = spmv_row<P>(m.rowptr[0], m.col[0], m.coef[0], dict, z2, r);
-  const Fe<P> b2 = spmv_row<P>(m.rowptr[1], m.col[1], m.coef[1], dict, z2, r);
-  const Fe<P> c2 = spmv_row<P>(m.rowptr[2], m.col[2], m.coef[2], dict, z2, r);
-  fe_store<P>(az2 + r * 32, a2);
-  fe_store<P>(bz2 + r * 32, b2);
-  fe_store<P>(cz2 + r * 32, c2);
-  Fe<P> t = fe_add(fe_mul(a1, b2), fe_mul(a2, b1));
-  t = fe_sub(t, fe_mul(fe_from_val<P>(u1), c2));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {      // hi > lo is the common case; an empty row reads a padding slot (arrays are nnz + 1 long)
+    c0[k] = m.col[k][lo[k]];
+    k0[k] = m.coef[k][lo[k]];
+  }
+  Fe<P> v[3], acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = fe_load<P>(z2 + (size_t)(hi[k] > lo[k] ? c0[k] : 0u) * 32);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    acc[k] = hi[k] > lo[k] ? spmv_term<P>(v[k], k0[k], dict) : fe_zero<P>();
+    for (uint32_t e = lo[k] + 1; e < hi[k]; ++e)
+      acc[k] = fe_add(acc[k], spmv_term<P>(fe_load<P>(z2 + (size_t)m.col[k][e] * 32), m.coef[k][e], dict));
+  }
+  fe_store<P>(az2 + r * 32, acc[0]);
+  fe_store<P>(bz2 + r * 32, acc[1]);
+  fe_store<P>(cz2 + r * 32, acc[2]);
+  Fe<P> t = fe_add(fe_mul(a1, acc[1]), fe_mul(acc[0], b1));
+  t = fe_sub(t, fe_mul(fe_from_val<P>(u1), acc[2]));
   t = fe_sub(t, c1);
   fe_store<P>(T + r * 32, t);
 }
