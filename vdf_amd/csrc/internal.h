@@ -117,7 +117,9 @@ struct MsmPlan {
   uint32_t bins = 0;     // gsets << pb
   uint32_t chA = 0;      // points per pass-A workgroup
   uint32_t nblkA = 0;    // pass-A workgroups
-  uint32_t L = 0;        // sorted entries per accumulate thread
+  uint32_t L = 0;        // sorted entries per accumulate thread: upper bound (the kernels use the actual entry count)
+  uint32_t Lfixed = 0;   // tuning override: a fixed slice length (0 = computed on the device)
+  uint32_t slots = 0;    // resident k_accumulate thread slots (workgroups per CU x 256 x CUs)
   uint32_t nthreads = 0; // accumulate threads
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)
   size_t ws_bytes = 0;

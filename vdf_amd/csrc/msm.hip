@@ -48,11 +48,23 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
 static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
+static constexpr uint32_t GIANT_SPAN = 1024; // ... and above which GIANT_PARTS wavefronts share the bucket
+static constexpr uint32_t GIANT_PARTS = 256;
+static constexpr uint32_t MAX_GIANTS = 192;  // more giant buckets than this cannot exist (slots / GIANT_SPAN)
+
+// Slice length of k_accumulate, computed on the device from the ACTUAL entry count (zero digits are skipped, so
+// scalars with few non-zero windows produce far fewer entries than n * windows): one round over `slots` threads,
+// at least 8 entries per slice.  `fixed` != 0 (tuning override) wins.
+__device__ __forceinline__ uint32_t slice_len(uint32_t ne, uint32_t slots, uint32_t fixed) {
+  if (fixed) return fixed;
+  const uint32_t L = (ne + slots - 1) / slots;
+  return L < 8u ? 8u : L;
+}
 static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enough to fill the chip, few enough that the
                                              // per-quad offset multiplication (~30 point ops) stays a small share
 
 struct WsLayout {
-  size_t countsA, pcount, pstart, recs, bcount, bstart, tstart, sorted, bucket_acc, heads, heavy, partials, wsum, total;
+  size_t countsA, pcount, pstart, recs, bcount, bstart, tstart, sorted, bucket_acc, heads, heavy, giant, partials, wsum, total;
   uint32_t red_seg, red_threads_per_set, red_block, red_blocks_per_set;
 };
 
@@ -86,7 +98,8 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.sorted = take(((size_t)p.windows * p.n + 64) * 4);
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
-  w.heavy = take((nkeys + 4) * 4);
+  w.heavy = take((nkeys + 4 + MAX_GIANTS) * 4);            // count, queued buckets, giant arrival counters
+  w.giant = take((size_t)MAX_GIANTS * GIANT_PARTS * 128);     // partial sums of giant buckets
   const RedGeom rg = red_geom(nkeys, p.nbk);
   w.red_seg = rg.seg; w.red_threads_per_set = rg.threads_per_set; w.red_block = rg.block;
   w.red_blocks_per_set = rg.blocks_per_set;
@@ -151,12 +164,16 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
   const size_t slots = (size_t)num_cus * ACC_WG_PER_CU * 256;
-  size_t L = (ne + slots - 1) / slots;
+  size_t L = (ne + slots - 1) / slots;           // upper bound: the kernels shorten it to the actual entry count
   if (L < 8) L = 8;
-  if (const char* ov = std::getenv("VDF_MSM_L")) { long v = std::atol(ov); if (v >= 1 && v <= 65536) L = (size_t)v; }   // tuning override
   p.L = (uint32_t)L;
-  p.nthreads = (uint32_t)((ne + L - 1) / L);
-  if (p.nthreads == 0) p.nthreads = 1;
+  p.Lfixed = 0;
+  p.slots = (uint32_t)slots;
+  p.nthreads = (uint32_t)slots;
+  if (const char* ov = std::getenv("VDF_MSM_L")) {                      // tuning override: a fixed slice length
+    long v = std::atol(ov);
+    if (v >= 1 && v <= 65536) { p.L = p.Lfixed = (uint32_t)v; p.nthreads = (uint32_t)((ne + v - 1) / v); if (p.nthreads < 1) p.nthreads = 1; }
+  }
   p.ws_bytes = ws_layout(p).total;
   return p;
 }
@@ -246,7 +263,8 @@ __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c,
 // per bin: exclusive scan over the pass-A workgroups.  One 256-thread workgroup per bin scans 256 counts at
 // a time through LDS (a thread per bin walking hundreds of counts would be one L2 round trip each).
 __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ countsA, uint32_t bins, uint32_t nblk,
-                                                   uint32_t* __restrict__ pcount, uint32_t* __restrict__ heavy) {
+                                                   uint32_t* __restrict__ pcount, uint32_t* __restrict__ heavy,
+                                                   uint32_t* __restrict__ giant_done) {
   raise_wave_priority();
   __shared__ uint32_t sc[256];
   const uint32_t b = blockIdx.x;
@@ -269,6 +287,7 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ counts
   }
   if (threadIdx.x == 0) pcount[b] = carry;
   if (b == 0 && threadIdx.x == 0) heavy[0] = 0;       // the heavy-bucket queue of this run starts empty
+  if (b == 0 && threadIdx.x < MAX_GIANTS) giant_done[threadIdx.x] = 0;
 }
 
 // single workgroup exclusive scan: out[0..n], out[n] = total.  Each thread owns a contiguous run; loads are
@@ -319,15 +338,30 @@ __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__
 // partition's own region, so there is no scan over all keys), then the scatter with the scanned counters as
 // cursors.  The second read of the records comes from L2 / MALL.  The scan also zeroes the accumulator of every
 // empty bucket (k_accumulate writes each non-empty one exactly once), so the pipeline needs no memset.
+// atomicAdd(&h[key], 1) for every active lane; when the whole wavefront holds ONE key (a hot bucket: scalars with a
+// repeated digit, 0/1 witnesses) one lane adds the lane count instead of 64 serialised atomics on one address
+__device__ __forceinline__ uint32_t lds_take_slot(uint32_t* h, uint32_t key) {
+  const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+  const uint64_t act = __ballot(1);
+  if (__ballot(key == first) == act) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(&h[first], (uint32_t)__popcll(act));
+    return (uint32_t)__builtin_amdgcn_readfirstlane(base) + rank;
+  }
+  return atomicAdd(&h[key], 1u);
+}
+
 __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
                                                uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
                                                uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc,
-                                               uint32_t L, uint32_t* __restrict__ tstart) {
+                                               uint32_t slots, uint32_t Lfixed, uint32_t* __restrict__ tstart) {
   raise_wave_priority();
   __shared__ uint32_t h[1024];
   __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
   const uint32_t lo = pstart[bin], hi = pstart[bin + 1];
+  const uint32_t L = slice_len(pstart[bins], slots, Lfixed);
   h[f] = 0;
   __syncthreads();
   uint32_t i = lo + f;
@@ -336,9 +370,9 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
 #pragma unroll
     for (int u = 0; u < 4; ++u) k[u] = (uint32_t)(recs[i + u * 1024] >> 32);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) atomicAdd(&h[k[u]], 1u);
+    for (int u = 0; u < 4; ++u) lds_take_slot(h, k[u]);
   }
-  for (; i < hi; i += 1024) atomicAdd(&h[(uint32_t)(recs[i] >> 32)], 1u);
+  for (; i < hi; i += 1024) lds_take_slot(h, (uint32_t)(recs[i] >> 32));
   __syncthreads();
   const uint32_t cnt = (f < nf) ? h[f] : 0u;
   sc[f] = cnt;
@@ -360,8 +394,17 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
     }
     if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
     // k_accumulate thread t starts at sorted position t * L: tell it which bucket that is (replaces a 16-step
-    // binary search over bstart, a chain of dependent loads at the start of every thread)
-    for (uint32_t t = (start + L - 1) / L; (uint64_t)t * L < (uint64_t)start + cnt; ++t) tstart[t] = bin * nf + f;
+    // binary search over bstart, a chain of dependent loads at the start of every thread).  Buckets of up to 32
+    // slices are written by their own thread; hot buckets (thousands of slices) by the whole workgroup below.
+    if ((uint64_t)cnt <= 32ull * L)
+      for (uint32_t t = (start + L - 1) / L; (uint64_t)t * L < (uint64_t)start + cnt; ++t) tstart[t] = bin * nf + f;
+  }
+  __syncthreads();
+  for (uint32_t ff = 0; ff < nf; ++ff) {
+    const uint32_t c = sc[ff] - (ff ? sc[ff - 1] : 0u);
+    if ((uint64_t)c <= 32ull * L) continue;
+    const uint32_t st = h[ff];                              // cursors still hold the bucket starts here
+    for (uint32_t t = (st + L - 1) / L + f; (uint64_t)t * L < (uint64_t)st + c; t += 1024) tstart[t] = bin * nf + ff;
   }
   __syncthreads();
   i = lo + f;
@@ -371,13 +414,13 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
     for (int u = 0; u < 4; ++u) r[u] = recs[i + u * 1024];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t pos = atomicAdd(&h[(uint32_t)(r[u] >> 32)], 1u);
+      const uint32_t pos = lds_take_slot(h, (uint32_t)(r[u] >> 32));
       sorted[pos] = (uint32_t)r[u];
     }
   }
   for (; i < hi; i += 1024) {
     const uint64_t r = recs[i];
-    const uint32_t pos = atomicAdd(&h[(uint32_t)(r >> 32)], 1u);
+    const uint32_t pos = lds_take_slot(h, (uint32_t)(r >> 32));
     sorted[pos] = (uint32_t)r;
   }
 }
@@ -421,10 +464,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ bstart, uint32_t nkeys,
                                                     const uint32_t* __restrict__ tstart,
                                                     const char* __restrict__ points, char* __restrict__ bucket_acc,
-                                                    char* __restrict__ heads, uint32_t L, uint32_t nthreads) {
+                                                    char* __restrict__ heads, uint32_t slots, uint32_t Lfixed,
+                                                    uint32_t nthreads) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nthreads) return;
   const uint32_t ne = bstart[nkeys];
+  const uint32_t L = slice_len(ne, slots, Lfixed);
   const uint64_t lo64 = (uint64_t)t * L;
   if (lo64 >= ne) return;
   const uint32_t lo = (uint32_t)lo64;
@@ -481,12 +526,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // One quad per bucket: add the heads of the slices the bucket spans (table mode: ~8 per bucket).
 template <class P>
-__global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t L,
-                                               char* __restrict__ bucket_acc, const char* __restrict__ heads,
-                                               uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
+                                               uint32_t Lfixed, char* __restrict__ bucket_acc,
+                                               const char* __restrict__ heads, uint32_t* __restrict__ heavy) {
   raise_wave_priority();
   const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 2;
   if (g >= nkeys) return;                                          // quad-uniform from here on
+  const uint32_t L = slice_len(bstart[nkeys], slots, Lfixed);
   const uint32_t s = bstart[g], e = bstart[g + 1];
   if (e <= s) return;
   const uint32_t tf = s / L, tl = (e - 1) / L;
@@ -508,19 +554,54 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
   qpoint_store<P>(bucket_acc + (size_t)g * 128, acc);
 }
 
-// One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a
-// 4-step butterfly of quad additions across the wavefront.
+// One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a 4-step butterfly of
+// quad additions across the wavefront.  A GIANT bucket (more than GIANT_SPAN heads: a hot digit shared by most
+// scalars) is shared by the first GIANT_PARTS wavefronts of the grid: each sums a contiguous chunk of the heads into
+// a scratch slot, and the last one to arrive (a counter per giant bucket) adds the slots to the bucket.  Every
+// wavefront walks the same queue in the same order, so the index of a giant bucket needs no communication.
 template <class P>
-__global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t L,
-                                                    char* __restrict__ bucket_acc, const char* __restrict__ heads,
-                                                    const uint32_t* __restrict__ heavy) {
+__global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
+                                                    uint32_t Lfixed, char* __restrict__ bucket_acc,
+                                                    const char* __restrict__ heads, uint32_t* __restrict__ heavy,
+                                                    char* __restrict__ giant) {
   raise_wave_priority();
   const uint32_t count = heavy[0];
+  if (count == 0) return;
+  const uint32_t L = slice_len(bstart[nkeys], slots, Lfixed);
   const uint32_t quad = threadIdx.x >> 2;
-  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+  uint32_t* done = heavy + 1 + nkeys + 2;                          // MAX_GIANTS arrival counters, zeroed by k_part_scan
+  uint32_t gi = 0;                                                 // giant buckets seen so far
+  for (uint32_t item = 0; item < count; ++item) {
     const uint32_t g = heavy[1 + item];
     const uint32_t s = bstart[g], e = bstart[g + 1];
-    const uint32_t tf = s / L, tl = (e - 1) / L;
+    const uint32_t tf = s / L, tl = (e - 1) / L, span = tl - tf;  // heads tf+1 .. tl
+    if (span > GIANT_SPAN && gi < MAX_GIANTS) {
+      const uint32_t my = gi++;
+      if (blockIdx.x >= GIANT_PARTS) continue;
+      const uint32_t chunk = (span + GIANT_PARTS - 1) / GIANT_PARTS;
+      const uint32_t t0 = tf + 1 + blockIdx.x * chunk;
+      const uint32_t t1 = (t0 + chunk - 1 < tl) ? t0 + chunk - 1 : tl;
+      QPoint<P> acc = qpoint_identity<P>();
+      for (uint32_t t = t0 + quad; t <= t1; t += 16) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(heads + (size_t)t * 128));
+      acc = qpoint_wave_sum(acc);
+      char* slot = giant + ((size_t)my * GIANT_PARTS + blockIdx.x) * 128;
+      if (quad == 0) qpoint_store<P>(slot, acc);
+      __threadfence();
+      uint32_t arrived = 0;
+      if (threadIdx.x == 0) arrived = atomicAdd(&done[my], 1u);
+      arrived = (uint32_t)__builtin_amdgcn_readfirstlane(arrived);
+      if (arrived != GIANT_PARTS - 1) continue;
+      __threadfence();
+      QPoint<P> tot = qpoint_identity<P>();
+      for (uint32_t p = quad; p < GIANT_PARTS; p += 16) tot = qpoint_add<P>(tot, qpoint_load<P>(giant + ((size_t)my * GIANT_PARTS + p) * 128));
+      tot = qpoint_wave_sum(tot);
+      if (quad == 0) {
+        QPoint<P> base = qpoint_load_lazy<P>(bucket_acc + (size_t)g * 128);
+        qpoint_store<P>(bucket_acc + (size_t)g * 128, qpoint_add<P>(base, tot));
+      }
+      continue;
+    }
+    if (item % gridDim.x != blockIdx.x) continue;
     QPoint<P> acc = qpoint_identity<P>();
     for (uint32_t t = tf + 1 + quad; t <= tl; t += 16) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(heads + (size_t)t * 128));
     acc = qpoint_wave_sum(acc);
@@ -795,20 +876,21 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   // pass A
   hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
-  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy);
+  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy, heavy + 1 + nkeys + 2);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   // pass B
-  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.L,
+  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
                      reinterpret_cast<uint32_t*>(base + w.tstart));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
-                     reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.L, p.nthreads);
+                     reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.slots, p.Lfixed, p.nthreads);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
-  hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.L, bucket_acc, heads,
+  hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
                      heavy);
-  hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, p.L, bucket_acc, heads, heavy);
+  hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
+                     base + w.giant);
   if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
