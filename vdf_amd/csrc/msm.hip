@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
 
 // One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a 4-step butterfly of
 // quad additions across the wavefront.  A GIANT bucket (more than GIANT_SPAN heads: a hot digit shared by most
-// scalars) is shared by the first GIANT_PARTS wavefronts of the grid: each sums a contiguous chunk of the heads into
+// scalars) is shared by GIANT_PARTS wavefronts (the grid holds 16 such groups, so 16 giant buckets proceed side by side): each sums a contiguous chunk of the heads into
 // a scratch slot, and the last one to arrive (a counter per giant bucket) adds the slots to the bucket.  Every
 // wavefront walks the same queue in the same order, so the index of a giant bucket needs no communication.
 template <class P>
@@ -577,14 +577,15 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
     const uint32_t tf = s / L, tl = (e - 1) / L, span = tl - tf;  // heads tf+1 .. tl
     if (span > GIANT_SPAN && gi < MAX_GIANTS) {
       const uint32_t my = gi++;
-      if (blockIdx.x >= GIANT_PARTS) continue;
+      const uint32_t part = blockIdx.x % GIANT_PARTS, ngroups = gridDim.x / GIANT_PARTS;
+      if (blockIdx.x >= ngroups * GIANT_PARTS || my % ngroups != blockIdx.x / GIANT_PARTS) continue;   // giants run side by side
       const uint32_t chunk = (span + GIANT_PARTS - 1) / GIANT_PARTS;
-      const uint32_t t0 = tf + 1 + blockIdx.x * chunk;
+      const uint32_t t0 = tf + 1 + part * chunk;
       const uint32_t t1 = (t0 + chunk - 1 < tl) ? t0 + chunk - 1 : tl;
       QPoint<P> acc = qpoint_identity<P>();
       for (uint32_t t = t0 + quad; t <= t1; t += 16) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(heads + (size_t)t * 128));
       acc = qpoint_wave_sum(acc);
-      char* slot = giant + ((size_t)my * GIANT_PARTS + blockIdx.x) * 128;
+      char* slot = giant + ((size_t)my * GIANT_PARTS + part) * 128;
       if (quad == 0) qpoint_store<P>(slot, acc);
       __threadfence();
       uint32_t arrived = 0;
@@ -889,7 +890,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
                      heavy);
-  hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(1024), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
+  hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(16 * GIANT_PARTS), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
                      base + w.giant);
   if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
