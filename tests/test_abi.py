@@ -70,3 +70,9 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
                 assert "pasta_ref" not in src and "oracle/" not in src.replace("oracle/pasta.py base_dlog", ""), fn
+
+
+def test_c_example_builds_against_the_headers():
+    """The plain-C client links against the two libraries (no GPU needed to build it)."""
+    exe = os.path.join(ROOT, "examples", "prove_chain")
+    assert os.path.exists(exe), "make -C vdf_amd/csrc"

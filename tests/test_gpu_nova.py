@@ -203,3 +203,13 @@ def test_config1_t1024_three_steps(ctx):
         assert proof.verify(pp, n, z0, [initial.x, initial.y, initial.i])
         ms = proof.last_step_ms()
         assert ms["total"] > 0
+
+
+def test_plain_c_client_of_both_abis():
+    """examples/prove_chain.c: eval -> prove -> verify -> compress -> verify, from C, in a process of its own."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "prove_chain")
+    assert os.path.exists(exe), "build it with `make -C vdf_amd/csrc` (part of __graft_entry__.build())"
+    r = subprocess.run([exe, "8", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify: true" in r.stdout and "verify (compressed): true" in r.stdout
