@@ -457,3 +457,39 @@ def test_bases_validate(ctx):
     g = ctx.bases_generate(curve, 3, 1000, family=vdf_amd.GENS_TRY_AND_INCREMENT)
     g.validate()
     g.free()
+
+
+def test_one_context_from_several_threads(ctx, cref):
+    """Calls are re-entrant across threads on one context (per-context mutex; include/vdf_hip.h): four threads issue
+    host-buffer MSMs of different sizes concurrently and every result is the right one."""
+    import threading
+    curve = o.CURVE_PALLAS
+    nb = 6000
+    bases = ctx.bases_generate(curve, 17, nb)
+    pts = bases.download()
+    bases.precompute(16, 1)
+    rng = np.random.default_rng(123)
+    jobs = []
+    for k in range(4):
+        n = [6000, 4000, 1234, 77][k]
+        sc = rand_limbs(rng, n)
+        jobs.append((n, sc, cpu_msm(cref, curve, pts[:n].copy(), sc)))
+    errors = []
+
+    def worker(k):
+        n, sc, want = jobs[k]
+        try:
+            for _ in range(8):
+                got = jac_to_affine(ctx.msm(bases, sc, n=n), curve)
+                if got != want:
+                    errors.append((k, "mismatch"))
+        except Exception as e:          # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    bases.free()
