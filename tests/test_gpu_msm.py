@@ -398,6 +398,8 @@ def test_msm_job_equals_separate_calls(ctx, cref, curve):
             job = ctx.msm_job(bases, sizes[:k], offs[:k])
             with pytest.raises(Exception):
                 ctx.msm_job(bases, sizes[:1], offs[:1])         # one job per context at a time
+            with pytest.raises(Exception):
+                ctx.msm(bases, dev[0], n=sizes[0])              # nor any other MSM: the job owns the workspace
             for g in reversed(range(k)):                        # any push order
                 job.push(g, dev[g])
             got = job.finish()

@@ -138,6 +138,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
                 const size_t* n, int is_mont, vdf_jac* out) {
   if (!bases || !out || !offset || !scalars || !n) return Status{VDF_ERR_BAD_ARG, "null bases/out/arrays"};
   if (groups < 1 || groups > vdf::MSM_MAX_GROUPS) return Status{VDF_ERR_BAD_ARG, "1..4 MSMs per batch"};
+  if (ctx->job_open) return Status{VDF_ERR_BAD_ARG, "an MSM job is open on this context: its workspace is in use"};
   // generators may be shared by several contexts of one device (e.g. a second stream for overlap)
   if (bases->ctx != ctx && bases->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bases live on another device"};
   size_t ntot = 0, nmax = 0;
