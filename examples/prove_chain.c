@@ -4,6 +4,7 @@
  *   Nova proof, one prove_step per 2^k iterations (GPU)                  vdf_nova_prove_recursively
  *   verification of the recursive proof                                  vdf_nova_verify
  *   compression and verification of the compressed proof (GPU)           vdf_nova_compress / vdf_nova_verify_compressed
+ *   the compressed proof as bytes, decoded again as a verifier would     vdf_nova_snark_serialize / _deserialize
  *
  * The flow of the reference's own test (/root/reference/src/nova/proof.rs:403-451).
  * Build:  cc -O2 examples/prove_chain.c -Iinclude -Lvdf_amd -lvdf_nova -lvdf_hip -Wl,-rpath,'$ORIGIN/../vdf_amd' -o examples/prove_chain
@@ -75,6 +76,18 @@ int main(int argc, char** argv) {
   CHECK(vdf_nova_verify_compressed(snark, pp, steps, z0, zi, &ok), "verify_compressed");
   printf("verify (compressed): %s (%.1f ms)\n", ok ? "true" : "FALSE", now_ms() - a);
   all_ok = all_ok && ok;
+
+  /* what travels to a verifier: bytes; what it does with them: decode under its own parameters, verify */
+  const size_t wire_len = vdf_nova_snark_serialized_size(snark);
+  uint8_t* wire = (uint8_t*)malloc(wire_len);
+  vdf_snark* received = NULL;
+  CHECK(vdf_nova_snark_serialize(snark, wire, wire_len), "serialize");
+  CHECK(vdf_nova_snark_deserialize(pp, wire, wire_len, &received), "deserialize");
+  CHECK(vdf_nova_verify_compressed(received, pp, steps, z0, zi, &ok), "verify_compressed (decoded)");
+  printf("compressed proof on the wire: %zu bytes; decoded and verified: %s\n", wire_len, ok ? "true" : "FALSE");
+  all_ok = all_ok && ok;
+  free(wire);
+  vdf_nova_snark_free(received);
 
   vdf_nova_snark_free(snark);
   vdf_nova_proof_free(proof);

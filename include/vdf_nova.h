@@ -117,6 +117,37 @@ void vdf_nova_snark_free(vdf_snark* snark);
 size_t vdf_nova_snark_size(const vdf_snark* snark);
 int  vdf_nova_snark_bytes(const vdf_snark* snark, uint8_t* out, size_t cap);
 int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
+
+/* ---- wire formats ---------------------------------------------------------------------
+ * The reference keeps its proofs in memory only (src/nova/proof.rs:52-55 derives no serialisation); these encodings
+ * are this library's own, versioned by their magic.  Field elements: 32 bytes, canonical, little-endian.  Points:
+ * 32 bytes, canonical little-endian x with the parity of y in bit 255, the identity as 32 zero bytes.
+ *
+ *   chain  = magic[8] | t u64 | num_steps u64 | digest of the public parameters [32] | z_0 [96]
+ *            | per step k: z_{k+1} [96], commitment of the fresh witness [32], (k >= 1) cross-term commitment [32]
+ *   "VDFSNK01" compressed proof = chain | the argument of vdf_nova_snark_bytes with 32-byte points
+ *   "VDFRSK01" running proof    = chain | W [num_vars x 32] | E [num_cons x 32]
+ *
+ * Challenges and the folded instance are not stored: deserialisation replays the folds (as verification does), so a
+ * decoded proof states nothing the reader did not derive.  Deserialisation fails with VDF_ERR_BAD_ARG for a foreign
+ * magic or other public parameters, VDF_ERR_BAD_LENGTH for a length that does not fit the shape, and
+ * VDF_ERR_NONCANONICAL for an out-of-range field element or bytes that decode to no curve point.
+ *
+ * The compressed proof is what a prover ships to a verifier in another process: 56 + 96 + 160 n - 32 bytes of chain
+ * plus 5.5 KB of argument at t = 2^16.  The running proof is a checkpoint: vdf_nova_proof_deserialize rebuilds the
+ * device-resident state (including A z, B z, C z of the running instance), refuses a witness that does not open the
+ * commitments its records fold to, and vdf_nova_prove_step continues from it. */
+/* The 32-byte point encoding by itself (host arithmetic only, no device): commitments are points of Pallas, in
+ * Montgomery coordinates like everywhere in this ABI.  decompress: VDF_ERR_NONCANONICAL unless the bytes are exactly
+ * what compress writes for some point. */
+int  vdf_nova_point_compress(const vdf_affine* p, uint8_t out[32]);
+int  vdf_nova_point_decompress(const uint8_t in[32], vdf_affine* out);
+size_t vdf_nova_snark_serialized_size(const vdf_snark* snark);
+int  vdf_nova_snark_serialize(const vdf_snark* snark, uint8_t* out, size_t cap);
+int  vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out);
+size_t vdf_nova_proof_serialized_size(const vdf_proof* proof);
+int  vdf_nova_proof_serialize(const vdf_proof* proof, uint8_t* out, size_t cap);
+int  vdf_nova_proof_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_proof** out);
 const char* vdf_nova_last_error(void);
 
 #ifdef __cplusplus

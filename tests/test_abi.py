@@ -31,11 +31,25 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.PROTOTYPES, f"vdf_amd/_lib.py has no prototype for {name}"
 
 
+def test_nova_library_exports_every_declared_symbol():
+    """include/vdf_nova.h against libvdf_nova.so, and against the ctypes tables of the two Python mirrors."""
+    txt = open(os.path.join(ROOT, "include", "vdf_nova.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vdf_(?:nova|minroot)_\w+)\s*\(", txt)))
+    assert len(names) > 30
+    from vdf_amd.minroot import nova_lib
+    import vdf_amd.nova                                       # noqa: F401  (sets its prototypes on import)
+    for name in names:
+        assert hasattr(nova_lib, name), f"libvdf_nova.so does not export {name}"
+        assert getattr(nova_lib, name).argtypes is not None, f"no ctypes prototype for {name}"
+
+
 def test_no_torch_types_in_the_boundary():
-    txt = open(os.path.join(ROOT, "include", "vdf_hip.h")).read()
-    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # comments may mention torch; signatures may not
-    assert "torch" not in code.lower() and "at::" not in code and "std::" not in code
-    assert "#include <torch" not in txt and "ATen" not in txt
+    for header in ("vdf_hip.h", "vdf_nova.h"):
+        txt = open(os.path.join(ROOT, "include", header)).read()
+        code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # comments may mention torch; signatures may not
+        assert "torch" not in code.lower() and "at::" not in code and "std::" not in code
+        assert "#include <torch" not in txt and "ATen" not in txt
 
 
 def test_no_gpu_means_loud_failure():

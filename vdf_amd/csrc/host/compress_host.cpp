@@ -419,6 +419,8 @@ struct vdf_snark {          // NovaVDFProof::Compressed, src/nova/proof.rs:54
   Aff comm_W, comm_E;       // the folded instance the argument is about
   Fe u, X[NUM_IO];
   Spartan sp;
+  uint64_t t = 0;           // the public parameters it was made under (wire header)
+  uint8_t digest[32];
 };
 
 extern "C" {
@@ -437,6 +439,8 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
   struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
   std::unique_ptr<vdf_snark> s(new vdf_snark());
   s->steps = p->steps;
+  s->t = pp->t;
+  memcpy(s->digest, pp->digest, 32);
   s->comm_W = p->comm_W; s->comm_E = p->comm_E; s->u = p->u;
   for (int j = 0; j < NUM_IO; ++j) s->X[j] = p->X[j];
   int rc = spartan_prove(pp, s->comm_W, s->comm_E, s->u, s->X, p->d_z1, p->d_E, &s->sp);
@@ -496,6 +500,73 @@ int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
   return VDF_OK;
 }
 
+// ---- the whole compressed proof as one byte string: chain (wire_host.cpp) | argument with 32-byte points --------
+static size_t argument_wire_size(const Layout& L) {
+  return 32 * (3 * (size_t)L.s + 4 + 2 * (size_t)L.l1 + 1 + 2) + 64 * ((size_t)(L.l1 - 1) + (size_t)L.s);
+}
+
+size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
+  if (!s) return 0;
+  const Spartan& p = s->sp;
+  return wire_chain_size(s->steps.size()) + 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + 2) +
+         64 * (p.ipaW.L.size() + p.ipaE.L.size());
+}
+
+int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
+  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (cap < vdf_nova_snark_serialized_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
+  const Field& F = field(PRIMARY_FIELD);
+  const Field& Fb = field_fp();
+  uint8_t* o = wire_put_chain(out, WIRE_MAGIC_SNARK, s->t, s->digest, s->steps);
+  for (const auto& ev : s->sp.outer) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+  for (const Fe& v : s->sp.claims) o = wire_put_fe(o, v, F);
+  for (const auto& ev : s->sp.inner) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+  o = wire_put_fe(o, s->sp.w_eval, F);
+  for (const Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
+    for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
+    o = wire_put_fe(o, ip->a, F);
+  }
+  return VDF_OK;
+}
+
+// A verifier that never saw the prover's objects: bytes -> vdf_snark.  The folded instance is recomputed from the
+// chain (a verifier replays the folds anyway), so a decoded proof states nothing it does not derive.
+int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out) {
+  if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  const Field& F = field(PRIMARY_FIELD);
+  const Field& Fb = field_fp();
+  std::unique_ptr<vdf_snark> s(new vdf_snark());
+  int rc = wire_get_chain(&in, &len, WIRE_MAGIC_SNARK, pp, &s->steps, &s->comm_W, &s->comm_E, &s->u, s->X);
+  if (rc != VDF_OK) return rc;
+  s->t = pp->t;
+  memcpy(s->digest, pp->digest, 32);
+  const Layout L = layout_of(pp);
+  if (len != argument_wire_size(L)) return fail(VDF_ERR_BAD_LENGTH, "argument section has the wrong length for this shape");
+  Spartan& p = s->sp;
+  p.outer.resize(L.s); p.inner.resize(L.l1);
+  p.ipaW.L.resize(L.l1 - 1); p.ipaW.R.resize(L.l1 - 1);
+  p.ipaE.L.resize(L.s); p.ipaE.R.resize(L.s);
+  bool canonical = true, on_curve = true;
+  auto get = [&](Fe& v) { canonical &= wire_get_fe(in, F, &v); in += 32; };
+  for (auto& ev : p.outer) for (Fe& v : ev) get(v);
+  for (Fe& v : p.claims) get(v);
+  for (auto& ev : p.inner) for (Fe& v : ev) get(v);
+  get(p.w_eval);
+  for (Ipa* ip : {&p.ipaW, &p.ipaE}) {
+    for (size_t j = 0; j < ip->L.size(); ++j) {
+      on_curve &= pt_decompress(in, Fb, &ip->L[j]);
+      on_curve &= pt_decompress(in + 32, Fb, &ip->R[j]);
+      in += 64;
+    }
+    get(ip->a);
+  }
+  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the argument is not canonical");
+  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the argument does not decode to a curve point");
+  *out = s.release();
+  return VDF_OK;
+}
+
 // verification of the compressed proof (src/nova/proof.rs:383): the fold replay of vdf_nova_verify without the
 // witness, then the argument that the folded instance is satisfiable
 int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
@@ -509,20 +580,9 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
   const Fe tfe = from_u64(pp->t, F);
   for (size_t k = 0; k < num_steps; ++k)
     if (sub(s->steps[k].X[2], s->steps[k].X[5], F) != tfe) return VDF_OK;
-  Aff cW = s->steps[0].comm_w, cE;
-  cE.x = cE.y = zero();
-  Fe u = one(F), X[NUM_IO];
-  for (int j = 0; j < NUM_IO; ++j) X[j] = s->steps[0].X[j];
-  for (size_t k = 1; k < num_steps; ++k) {
-    const StepRecord& st = s->steps[k];
-    uint64_t r_raw[4];
-    const Fe r = challenge(pp, cW, cE, u, X, st.comm_w, st.X, st.comm_T, r_raw);
-    if (r != st.r) return VDF_OK;
-    cW = fold_commitment(cW, r_raw, st.comm_w);
-    cE = fold_commitment(cE, r_raw, st.comm_T);
-    u = add(u, r, F);
-    for (int j = 0; j < NUM_IO; ++j) X[j] = add(X[j], mul(r, st.X[j], F), F);
-  }
+  Aff cW, cE;
+  Fe u, X[NUM_IO];
+  if (!fold_replay(pp, s->steps, nullptr, &cW, &cE, &u, X)) return VDF_OK;
   if (memcmp(&cW, &s->comm_W, 64) || memcmp(&cE, &s->comm_E, 64) || u != s->u || memcmp(X, s->X, sizeof(X))) return VDF_OK;
   vdf_ctx* ctx = pp->ctx;
   int was_async = 0;

@@ -98,6 +98,56 @@ void jac_to_aff2(const vdf_jac& ja, const vdf_jac& jb, const Field& F, Aff* a, A
   fin(jb, zib, b);
 }
 
+// ---- square roots and the 32-byte point encoding --------------------------------------------------
+// m - 1 = 2^32 * T with T odd.  5 generates the multiplicative group of both fields, so z = 5^T has order 2^32.
+bool fe_sqrt(const Fe& a, const Field& F, Fe* out) {
+  if (a.is_zero()) { *out = a; return true; }
+  uint64_t T[4] = {(F.m[0] >> 32) | (F.m[1] << 32), (F.m[1] >> 32) | (F.m[2] << 32), (F.m[2] >> 32) | (F.m[3] << 32), F.m[3] >> 32};
+  uint64_t Th[4] = {(T[0] >> 1) | (T[1] << 63), (T[1] >> 1) | (T[2] << 63), (T[2] >> 1) | (T[3] << 63), T[3] >> 1};   // (T - 1) / 2
+  Fe z = pow_vartime(from_u64(5, F), T, F);
+  const Fe w = pow_vartime(a, Th, F);
+  Fe x = mul(a, w, F);            // a^((T+1)/2)
+  Fe b = mul(x, w, F);            // a^T
+  const Fe o = one(F);
+  int v = 32;
+  while (b != o) {
+    int k = 0;
+    for (Fe t = b; t != o; t = sqr(t, F)) if (++k == v) return false;     // order 2^v: not a square
+    for (int j = 0; j < v - k - 1; ++j) z = sqr(z, F);
+    x = mul(x, z, F);
+    z = sqr(z, F);
+    b = mul(b, z, F);
+    v = k;
+  }
+  *out = x;
+  return true;
+}
+
+void pt_compress(const Aff& a, const Field& F, uint8_t out[32]) {
+  if (a.is_id()) { memset(out, 0, 32); return; }
+  const Fe x = from_mont(a.x, F), y = from_mont(a.y, F);
+  memcpy(out, x.l, 32);
+  out[31] |= (uint8_t)((y.l[0] & 1) << 7);
+}
+
+bool pt_decompress(const uint8_t in[32], const Field& F, Aff* out) {
+  Fe x;
+  memcpy(x.l, in, 32);
+  const uint64_t odd = x.l[3] >> 63;
+  x.l[3] &= ~(1ull << 63);
+  if (geq(x.l, F.m)) return false;
+  if (x.is_zero()) {
+    out->x = out->y = zero();
+    return !odd;                  // the identity has one encoding
+  }
+  const Fe xm = to_mont(x, F);
+  Fe y;
+  if (!fe_sqrt(add(mul(sqr(xm, F), xm, F), from_u64(5, F), F), F, &y)) return false;
+  if ((from_mont(y, F).l[0] & 1) != odd) y = neg(y, F);
+  out->x = xm; out->y = y;
+  return true;
+}
+
 // ---- Keccak-f[1600] / SHAKE256 (FIPS 202) ---------------------------------------------------------
 static inline uint64_t rotl(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 static void keccak_f(uint64_t s[25]) {

@@ -149,6 +149,14 @@ Aff pt_to_aff(const Pt& a, const Field& F);
 Aff jac_to_aff(const vdf_jac& j, const Field& F);
 void jac_to_aff2(const vdf_jac& ja, const vdf_jac& jb, const Field& F, Aff* a, Aff* b);
 
+// Square root (Tonelli-Shanks; both Pasta moduli are 1 mod 2^32): false when `a` is not a square.
+bool fe_sqrt(const Fe& a, const Field& F, Fe* out);
+// 32-byte point encoding of the wire formats: canonical little-endian x with the parity of y in bit 255; the
+// identity is 32 zero bytes (x = 0 is on neither curve: 5 is not a square).  decompress: false unless the bytes
+// are exactly what compress would write for some point.
+void pt_compress(const Aff& a, const Field& F, uint8_t out[32]);
+bool pt_decompress(const uint8_t in[32], const Field& F, Aff* out);
+
 // ---- SHAKE256 (FIPS 202) for the transcript -----------------------------------------------------
 struct Shake256 {
   uint64_t st[25];

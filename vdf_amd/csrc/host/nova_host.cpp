@@ -49,19 +49,6 @@ void build_shape(uint64_t t, Coo m[3], size_t* num_cons, size_t* num_vars) {
   *num_vars = nv;
 }
 
-int alloc_proof_buffers(vdf_proof* p) {
-  vdf_pp* pp = p->pp;
-  vdf_ctx* ctx = pp->ctx;
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z1));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_E));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
-  for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
-  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&p->h_comm));
-  HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
-  return VDF_OK;
-}
 
 
 }  // namespace
@@ -90,6 +77,41 @@ Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b) {      
   const Field& F = field_fp();
   Pt rb = pt_mul(pt_from_aff(b, F), r_raw, 128, F);
   return pt_to_aff(pt_add(pt_from_aff(a, F), rb, F), F);
+}
+
+bool fold_replay(const vdf_pp* pp, const std::vector<StepRecord>& steps, Fe* r_out, Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]) {
+  const Field& F = field(PRIMARY_FIELD);
+  *cW = steps[0].comm_w;
+  cE->x = cE->y = zero();
+  *u = one(F);
+  for (int j = 0; j < NUM_IO; ++j) X[j] = steps[0].X[j];
+  if (r_out) r_out[0] = zero();
+  for (size_t k = 1; k < steps.size(); ++k) {
+    const StepRecord& s = steps[k];
+    uint64_t r_raw[4];
+    const Fe r = challenge(pp, *cW, *cE, *u, X, s.comm_w, s.X, s.comm_T, r_raw);
+    if (r_out) r_out[k] = r;
+    else if (r != s.r) return false;
+    *cW = fold_commitment(*cW, r_raw, s.comm_w);
+    *cE = fold_commitment(*cE, r_raw, s.comm_T);
+    *u = add(*u, r, F);
+    for (int j = 0; j < NUM_IO; ++j) X[j] = add(X[j], mul(r, s.X[j], F), F);
+  }
+  return true;
+}
+
+int alloc_proof_buffers(vdf_proof* p) {
+  vdf_pp* pp = p->pp;
+  vdf_ctx* ctx = pp->ctx;
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z1));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_E));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
+  for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
+  HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
+  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&p->h_comm));
+  HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
+  return VDF_OK;
 }
 }  // namespace vdfnova
 
@@ -428,20 +450,9 @@ int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_
   for (size_t k = 0; k < num_steps; ++k)
     if (sub(p->steps[k].X[2], p->steps[k].X[5], F) != tfe) return VDF_OK;
   // (2) replay the folds of the instances
-  Aff cW = p->steps[0].comm_w, cE;
-  cE.x = cE.y = zero();
-  Fe u = one(F), X[NUM_IO];
-  for (int j = 0; j < NUM_IO; ++j) X[j] = p->steps[0].X[j];
-  for (size_t k = 1; k < num_steps; ++k) {
-    const StepRecord& s = p->steps[k];
-    uint64_t r_raw[4];
-    const Fe r = challenge(pp, cW, cE, u, X, s.comm_w, s.X, s.comm_T, r_raw);
-    if (r != s.r) return VDF_OK;
-    cW = fold_commitment(cW, r_raw, s.comm_w);
-    cE = fold_commitment(cE, r_raw, s.comm_T);
-    u = add(u, r, F);
-    for (int j = 0; j < NUM_IO; ++j) X[j] = add(X[j], mul(r, s.X[j], F), F);
-  }
+  Aff cW, cE;
+  Fe u, X[NUM_IO];
+  if (!fold_replay(pp, p->steps, nullptr, &cW, &cE, &u, X)) return VDF_OK;
   if (memcmp(&cW, &p->comm_W, 64) || memcmp(&cE, &p->comm_E, 64) || u != p->u || memcmp(X, p->X, sizeof(X))) return VDF_OK;
   // (3) the running witness opens the folded instance: commitments and relaxed satisfiability
   const size_t nv = pp->num_vars, nc = pp->num_cons;

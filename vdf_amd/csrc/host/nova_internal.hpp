@@ -98,4 +98,25 @@ namespace vdfnova {
 Fe challenge(const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Aff& cw2, const Fe* X2,
              const Aff& cT, uint64_t r_raw[4]);
 Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b);      // a + r*b on Pallas
+// The verifier's replay of the instance folds over the step records (steps must not be empty).  r_out == nullptr:
+// every record's challenge must be the transcript's (false otherwise); else the challenges are written to r_out.
+bool fold_replay(const vdf_pp* pp, const std::vector<StepRecord>& steps, Fe* r_out, Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]);
+int alloc_proof_buffers(vdf_proof* p);
+
+// ---- wire formats (wire_host.cpp; layout in include/vdf_nova.h) --------------------------------------------
+constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK01";      // compressed proof
+constexpr char WIRE_MAGIC_PROOF[9] = "VDFRSK01";      // running proof (checkpoint)
+size_t wire_chain_size(size_t num_steps);
+uint8_t* wire_put_chain(uint8_t* o, const char magic[8], uint64_t t, const uint8_t digest[32], const std::vector<StepRecord>& steps);
+// parses the chain, replays the folds (filling every record's challenge and the folded instance), advances *in
+int wire_get_chain(const uint8_t** in, size_t* len, const char magic[8], const vdf_pp* pp, std::vector<StepRecord>* steps,
+                   Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]);
+inline uint8_t* wire_put_fe(uint8_t* o, const Fe& v, const Field& F) { const Fe c = from_mont(v, F); memcpy(o, c.l, 32); return o + 32; }
+inline bool wire_get_fe(const uint8_t* i, const Field& F, Fe* v) {
+  Fe c;
+  memcpy(c.l, i, 32);
+  if (geq(c.l, F.m)) return false;
+  *v = to_mont(c, F);
+  return true;
+}
 }  // namespace vdfnova

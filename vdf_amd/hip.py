@@ -141,6 +141,12 @@ class Context:
         if rc != _lib.VDF_OK:
             raise VdfError(rc, (lib.vdf_last_error(self.handle) or b"").decode())
 
+    def __enter__(self) -> "Context":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     def close(self) -> None:
         if self.handle:
             for child in list(self._children):   # bases / shapes must go before their context

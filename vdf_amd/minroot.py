@@ -52,6 +52,7 @@ for _name, _args in {
     getattr(nova_lib, _name).argtypes = _args
     getattr(nova_lib, _name).restype = _i
 nova_lib.vdf_nova_last_error.restype = C.c_char_p
+nova_lib.vdf_nova_last_error.argtypes = []
 
 
 def _modulus(field: int) -> int:

@@ -38,6 +38,14 @@ for _name, _res, _args in [
     ("vdf_nova_snark_size", _sz, [_vp]),
     ("vdf_nova_snark_bytes", _i, [_vp, _vp, _sz]),
     ("vdf_nova_snark_set_bytes", _i, [_vp, _vp, _sz]),
+    ("vdf_nova_point_compress", _i, [_vp, _vp]),
+    ("vdf_nova_point_decompress", _i, [_vp, _vp]),
+    ("vdf_nova_snark_serialized_size", _sz, [_vp]),
+    ("vdf_nova_snark_serialize", _i, [_vp, _vp, _sz]),
+    ("vdf_nova_snark_deserialize", _i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    ("vdf_nova_proof_serialized_size", _sz, [_vp]),
+    ("vdf_nova_proof_serialize", _i, [_vp, _vp, _sz]),
+    ("vdf_nova_proof_deserialize", _i, [_vp, _vp, _sz, C.POINTER(_vp)]),
 ]:
     getattr(nova_lib, _name).argtypes = _args
     getattr(nova_lib, _name).restype = _res
@@ -46,6 +54,22 @@ for _name, _res, _args in [
 def _check(rc: int) -> None:
     if rc != 0:
         raise VdfError(rc, (nova_lib.vdf_nova_last_error() or b"").decode())
+
+
+def point_compress(aff: np.ndarray) -> bytes:
+    """32-byte encoding of a Pallas point given as 8 Montgomery words (x, y); host arithmetic only."""
+    a = np.ascontiguousarray(aff, dtype="<u8").reshape(8)
+    out = (C.c_uint8 * 32)()
+    _check(nova_lib.vdf_nova_point_compress(a.ctypes.data, out))
+    return bytes(out)
+
+
+def point_decompress(data: bytes) -> np.ndarray:
+    if len(data) != 32:
+        raise ValueError("32 bytes")
+    out = np.zeros(8, dtype="<u8")
+    _check(nova_lib.vdf_nova_point_decompress((C.c_uint8 * 32).from_buffer_copy(data), out.ctypes.data))
+    return out
 
 
 def _z(vals: Sequence[bytes]):
@@ -164,6 +188,21 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
         _check(nova_lib.vdf_nova_compress(self.handle, pp.handle, C.byref(h)))
         return CompressedNovaVDFProof(h.value, pp)
 
+    # ---- checkpoint: the running proof as bytes ("VDFRSK01", include/vdf_nova.h) ----
+    def serialize(self) -> bytes:
+        n = nova_lib.vdf_nova_proof_serialized_size(self.handle)
+        buf = (C.c_uint8 * n)()
+        _check(nova_lib.vdf_nova_proof_serialize(self.handle, buf, n))
+        return bytes(buf)
+
+    @staticmethod
+    def deserialize(pp: NovaVDFPublicParams, data: bytes) -> "NovaVDFProof":
+        """Rebuilds the device-resident running proof; prove_step continues from it."""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        h = C.c_void_p()
+        _check(nova_lib.vdf_nova_proof_deserialize(pp.handle, buf, len(data), C.byref(h)))
+        return NovaVDFProof(h.value, pp)
+
     # ---- introspection used by the parity tests and the bench ----
     def num_steps(self) -> int:
         return nova_lib.vdf_nova_proof_num_steps(self.handle)
@@ -230,6 +269,20 @@ class CompressedNovaVDFProof:     # NovaVDFProof::Compressed, src/nova/proof.rs:
     def set_bytes(self, data: bytes) -> None:
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
         _check(nova_lib.vdf_nova_snark_set_bytes(self.handle, buf, len(data)))
+
+    def serialize(self) -> bytes:
+        """The whole compressed proof (step chain + argument, 32-byte points): "VDFSNK01", include/vdf_nova.h."""
+        n = nova_lib.vdf_nova_snark_serialized_size(self.handle)
+        buf = (C.c_uint8 * n)()
+        _check(nova_lib.vdf_nova_snark_serialize(self.handle, buf, n))
+        return bytes(buf)
+
+    @staticmethod
+    def deserialize(pp: NovaVDFPublicParams, data: bytes) -> "CompressedNovaVDFProof":
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        h = C.c_void_p()
+        _check(nova_lib.vdf_nova_snark_deserialize(pp.handle, buf, len(data), C.byref(h)))
+        return CompressedNovaVDFProof(h.value, pp)
 
     def free(self) -> None:
         if self.handle and self.pp.handle and self.pp.ctx.handle:
