@@ -190,6 +190,14 @@ int  vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const 
  * z_in, i0, u, X: host memory. */
 int  vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3],
                         const vdf_fe* i0, const vdf_fe* u, const vdf_fe X[6], vdf_fe* z);
+/* The same, and also the witness without its new_x values:
+ *   w_packed = [ z_in[0..3) | tmp1, tmp2, new_y per round (3t) | i0 ],  3t + 4 elements.
+ * new_x of round j equals y_j - (i_j - 1), where y_j is z_in[1] (j = 0) or the previous round's new_y and i_j = z_in[2] - j
+ * (src/nova/proof.rs:162-173): an affine image of another witness value.  A Pedersen commitment to W therefore needs
+ * no term for it -- sum_j new_x_j G_j folds into the generators of the y_j and a point that depends on z_in[2] only --
+ * and is an MSM over 3t + 4 instead of 4t + 4 points, with the same value (libvdf_nova.so uses this). */
+int  vdf_minroot_step_z_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3],
+                               const vdf_fe* i0, const vdf_fe* u, const vdf_fe X[6], vdf_fe* z, vdf_fe* w_packed);
 /* vdf_spmv3(shape, z2) followed by vdf_cross_term(Az1, Bz1, Cz1, Az2, Bz2, Cz2, u1): writes Az2, Bz2, Cz2
  * (num_cons each) and T.  u1: host memory.  (nova-snark NIFS::prove -> commit_T, K4 + K5.) */
 int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
@@ -202,6 +210,11 @@ int  vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* cons
 /* Stream order across contexts of one device: work enqueued on `ctx` after this call starts only after
  * everything enqueued on `other` so far has finished (an event; the host does not wait). */
 int  vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other);
+/* Marks: vdf_ctx_mark remembers the current end of the context's queue under `slot` (0..3); vdf_ctx_sync_mark
+ * blocks the host until everything enqueued before that mark has finished, while later work keeps running.  A
+ * prover that looks one step ahead waits for this step's commitment without waiting for the next step's. */
+int  vdf_ctx_mark(vdf_ctx* ctx, int slot);
+int  vdf_ctx_sync_mark(vdf_ctx* ctx, int slot);
 
 /* ---- compression SNARK building blocks ------------------------------------------------------ */
 /* The passes behind `NovaVDFProof::compress` and the verification of a compressed proof

@@ -92,8 +92,9 @@ int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, const void** d_W, const
 /* per-step record k: fresh commitment, cross-term commitment, challenge, public IO */
 int  vdf_nova_proof_step_record(const vdf_proof* proof, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]);
 /* host wall-clock of the last prove_step, milliseconds.  A step is enqueued asynchronously, so the slots are
- * launch times except [4]: witness launch, commitments launch (one batched MSM for W2 and T), cross-term launch,
- * unused, wait (previous step's host instance fold, then both commitments), transcript + fold launch,
+ * launch times except [3] and [4]: fresh witness + its commitment (zero when the previous step looked ahead),
+ * launch of the commitment of T, cross-term launch, wait for the fresh commitment + launch of the next step's
+ * lookahead, wait (previous step's host instance fold, then the commitment of T), transcript + fold launch,
  * bookkeeping, total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 

@@ -198,6 +198,36 @@ def test_step_z_equals_witness_plus_scalar_stores(ctx, cref, field, t):
     assert np.array_equal(_host(z), exp)
 
 
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("t", [1, 7, 1000])
+def test_step_z_packed_is_the_witness_without_new_x(ctx, cref, field, t):
+    """w_packed = [z_in | tmp1, tmp2, new_y per round | i0]; and the relation that makes new_x redundant in a commitment
+    (src/nova/proof.rs:162-173): new_x_j = y_j - (i_j - 1), y_0 = z_in.y, y_j = new_y_{j-1}, i_j = z_in.i - j."""
+    L, m = cref.lib(), o.modulus(field)
+    st = mont([o.rand_fe(t + 5, 0, m), 0, 11], m)
+    so, tr = cref.fe_array(3), cref.fe_array(2 * (t + 1))
+    L.ref_minroot_eval(field, 1, cref.p(st), t, cref.p(so), cref.p(tr))
+    rng = np.random.default_rng(t)
+    u, X = rand_limbs(rng, 1), rand_limbs(rng, 6)
+    z_in, i0 = so.copy(), st[2:3].copy()                 # the step starts from the evaluation's result
+    z = _dev(np.zeros((4 * t + 11, 4), dtype="<u8"))
+    wp = _dev(np.zeros((3 * t + 4, 4), dtype="<u8"))
+    ctx.minroot_step_z_packed(field, _dev(tr), t, z_in, i0, u, X, z, wp)
+    ctx.sync()
+    zz, ww = _host(z), _host(wp)
+    rounds = zz[3:3 + 4 * t].reshape(t, 4, 4)
+    exp = np.concatenate([zz[:3], rounds[:, 1:, :].reshape(3 * t, 4), zz[3 + 4 * t:4 + 4 * t]])
+    assert np.array_equal(ww, exp)
+    W = unmont(zz[:4 * t + 4], m)
+    y, i = W[1], W[2]
+    for j in range(t):
+        new_x, new_y = W[3 + 4 * j], W[6 + 4 * j]
+        assert new_x == (y - (i - j - 1)) % m
+        y = new_y
+    with pytest.raises(Exception):
+        ctx.minroot_step_z_packed(field, _dev(tr), t, z_in, i0, u, X, z, np.zeros((3 * t + 4, 4), dtype="<u8"))   # host buffer
+
+
 @pytest.mark.parametrize("t", [5, 64, 4096])
 def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
     field, m = o.FIELD_FQ, o.Q

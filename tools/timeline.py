@@ -1,10 +1,12 @@
-"""Print the kernel timeline of the last complete prove_step from a rocprofv3 rocpd database."""
+"""Print a kernel timeline from a rocprofv3 rocpd database: the span between two occurrences of an anchor kernel
+(default: the two k_nifs_cross before the last three, i.e. one steady-state prove_step with its overlaps)."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-anchor = sys.argv[2] if len(sys.argv) > 2 else "k_step_z"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "k_nifs_cross"
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows = list(db.execute("select name,start,end,stream_id from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if anchor in r[0]]
-i0, i1 = idx[-2], idx[-1]
+i0, i1 = idx[-back], idx[-back + 1]
 t0 = rows[i0][1]
 for r in rows[i0:i1 + 1]:
     nm = r[0].split('(')[0].replace('void vdf::', '').replace('vdf::', '')

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "vdf_ctx_get_async": (_i, [_vp, C.POINTER(_i)]),
     "vdf_ctx_sync": (_i, [_vp]),
     "vdf_ctx_wait": (_i, [_vp, _vp]),
+    "vdf_ctx_mark": (_i, [_vp, _i]),
+    "vdf_ctx_sync_mark": (_i, [_vp, _i]),
     "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),
@@ -58,6 +60,7 @@ PROTOTYPES = {
     "vdf_axpy": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "vdf_minroot_witness": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
     "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_minroot_step_z_packed": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),

@@ -279,6 +279,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
+  for (hipEvent_t& m : ctx->marks) if (m) (void)hipEventDestroy(m);
   for (int g = 0; g < 4; ++g) {
     if (ctx->side_go[g]) (void)hipEventDestroy(ctx->side_go[g]);
     if (ctx->side_done[g]) (void)hipEventDestroy(ctx->side_done[g]);
@@ -763,18 +764,30 @@ int vdf_minroot_witness(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, const v
 }
 
 // ---- fused step operations ------------------------------------------------------------------------
-int vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0,
-                       const vdf_fe* u, const vdf_fe X[6], vdf_fe* z) {
+static int step_z_impl(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0,
+                       const vdf_fe* u, const vdf_fe X[6], vdf_fe* z, vdf_fe* packed) {
   return guarded(ctx, [&]() -> Status {
     if (t == 0 || t >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
     if (!z_in || !i0 || !u || !X) return Status{VDF_ERR_BAD_ARG, "null scalar operand"};
     if (ptr_is_device(z_in) || ptr_is_device(i0) || ptr_is_device(u) || ptr_is_device(X))
       return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
-    if (!ptr_is_device(trace_xy) || !ptr_is_device(z)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
-    VDF_TRY(vdf::vec_step_z(field, trace_xy, t, z_in, i0, u, X, z, ctx->stream));
+    if (!ptr_is_device(trace_xy) || !ptr_is_device(z) || (packed && !ptr_is_device(packed)))
+      return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    VDF_TRY(vdf::vec_step_z(field, trace_xy, t, z_in, i0, u, X, z, packed, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });
+}
+
+int vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0,
+                       const vdf_fe* u, const vdf_fe X[6], vdf_fe* z) {
+  return step_z_impl(ctx, field, trace_xy, t, z_in, i0, u, X, z, nullptr);
+}
+
+int vdf_minroot_step_z_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3],
+                              const vdf_fe* i0, const vdf_fe* u, const vdf_fe X[6], vdf_fe* z, vdf_fe* w_packed) {
+  if (!w_packed) return ctx ? (ctx->err = "null w_packed", VDF_ERR_BAD_ARG) : VDF_ERR_BAD_ARG;
+  return step_z_impl(ctx, field, trace_xy, t, z_in, i0, u, X, z, w_packed);
 }
 
 int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
@@ -818,6 +831,29 @@ int vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other) {
     if (!ctx->wait_ev) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
     VDF_TRY_HIP(hipEventRecord(ctx->wait_ev, other->stream));
     VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, ctx->wait_ev, 0));
+    return Status{};
+  });
+}
+
+int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
+  return guarded(ctx, [&]() -> Status {
+    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (!ctx->marks[slot]) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->marks[slot], hipEventDisableTiming));
+    VDF_TRY_HIP(hipEventRecord(ctx->marks[slot], ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_ctx_sync_mark(vdf_ctx* ctx, int slot) {
+  return guarded(ctx, [&]() -> Status {
+    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (!ctx->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
+    for (int spin = 0; spin < 4000; ++spin) {                    // poll first, as vdf_ctx_sync does
+      hipError_t q = hipEventQuery(ctx->marks[slot]);
+      if (q == hipSuccess) return Status{};
+      if (q != hipErrorNotReady) return vdf::hip_status(q, "hipEventQuery");
+    }
+    VDF_TRY_HIP(hipEventSynchronize(ctx->marks[slot]));
     return Status{};
   });
 }

@@ -51,6 +51,76 @@ void build_shape(uint64_t t, Coo m[3], size_t* num_cons, size_t* num_vars) {
 
 
 
+
+// a[i] + b[i] for affine points with one shared inversion (Montgomery's trick); identities and equal abscissae take
+// the general formulas
+void batch_add_affine(const std::vector<Aff>& a, const std::vector<Aff>& b, std::vector<Aff>* out) {
+  const Field& F = field_fp();
+  const size_t n = a.size();
+  out->resize(n);
+  std::vector<Fe> d(n), pre(n);
+  std::vector<char> special(n, 0);
+  Fe run = one(F);
+  for (size_t i = 0; i < n; ++i) {
+    d[i] = sub(b[i].x, a[i].x, F);
+    if (a[i].is_id() || b[i].is_id() || d[i].is_zero()) { special[i] = 1; d[i] = one(F); }
+    pre[i] = run;
+    run = mul(run, d[i], F);
+  }
+  Fe inv = inverse(run, F);
+  for (size_t i = n; i-- > 0;) {
+    const Fe di = mul(inv, pre[i], F);           // 1 / d[i]
+    inv = mul(inv, d[i], F);
+    if (special[i]) { (*out)[i] = pt_to_aff(pt_add(pt_from_aff(a[i], F), pt_from_aff(b[i], F), F), F); continue; }
+    const Fe lam = mul(sub(b[i].y, a[i].y, F), di, F);
+    const Fe x3 = sub(sub(sqr(lam, F), a[i].x, F), b[i].x, F);
+    (*out)[i].x = x3;
+    (*out)[i].y = sub(mul(lam, sub(a[i].x, x3, F), F), a[i].y, F);
+  }
+}
+
+// generators of the packed witness [z_in(3) | tmp1, tmp2, new_y per round | final_i] and the two fixed points of the
+// correction (nova_internal.hpp)
+int setup_packed_generators(vdf_pp* pp) {
+  vdf_ctx* ctx = pp->ctx;
+  const size_t t = pp->t, nv = pp->num_vars;
+  std::vector<Aff> G(nv);
+  HIPCALL(ctx, vdf_bases_download(ctx, pp->gens, 0, nv, (vdf_affine*)G.data()));
+  pp->num_w = 3 * t + 4;
+  std::vector<Aff> Gw(pp->num_w), a, b, sum, Gx(t);
+  for (size_t j = 0; j < t; ++j) Gx[j] = G[3 + 4 * j];
+  a.push_back(G[1]); b.push_back(G[3]);                                     // y_0 = z_in.y carries round 0's new_x
+  for (size_t j = 0; j + 1 < t; ++j) { a.push_back(G[6 + 4 * j]); b.push_back(G[3 + 4 * (j + 1)]); }
+  batch_add_affine(a, b, &sum);
+  Gw[0] = G[0]; Gw[1] = sum[0]; Gw[2] = G[2];
+  for (size_t j = 0; j < t; ++j) {
+    Gw[3 + 3 * j] = G[4 + 4 * j];
+    Gw[4 + 3 * j] = G[5 + 4 * j];
+    Gw[5 + 3 * j] = (j + 1 < t) ? sum[1 + j] : G[6 + 4 * j];
+  }
+  Gw[3 + 3 * t] = G[3 + 4 * t];
+  HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)Gw.data(), pp->num_w, &pp->gens_w));
+  HIPCALL(ctx, vdf_bases_precompute(ctx, pp->gens_w, 16, 1));
+  // S0 = sum_j G_{3+4j}, S1 = sum_j j G_{3+4j}: two MSMs with small scalars
+  vdf_bases* bx = nullptr;
+  HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)Gx.data(), t, &bx));
+  std::vector<Fe> ones(t), idx(t);
+  for (size_t j = 0; j < t; ++j) { ones[j] = Fe{{1, 0, 0, 0}}; idx[j] = Fe{{(uint64_t)j, 0, 0, 0}}; }
+  vdf_jac j0, j1;
+  int rc = vdf_msm(ctx, bx, 0, (const vdf_fe*)ones.data(), t, 0, &j0);
+  if (rc == VDF_OK) rc = vdf_msm(ctx, bx, 0, (const vdf_fe*)idx.data(), t, 0, &j1);
+  if (rc == VDF_OK) rc = vdf_ctx_sync(ctx);
+  const std::string err = rc == VDF_OK ? "" : vdf_last_error(ctx);
+  vdf_bases_free(bx);
+  if (rc != VDF_OK) return fail(rc, "packed generators: " + err);
+  const Field& Fb = field_fp();
+  pp->S0 = jac_to_aff(j0, Fb);
+  pp->S1 = jac_to_aff(j1, Fb);
+  const uint64_t tk[4] = {t, 0, 0, 0};
+  pp->tS0 = pt_to_aff(pt_mul(pt_from_aff(pp->S0, Fb), tk, 64, Fb), Fb);
+  return VDF_OK;
+}
+
 }  // namespace
 
 namespace vdfnova {
@@ -104,12 +174,20 @@ int alloc_proof_buffers(vdf_proof* p) {
   vdf_pp* pp = p->pp;
   vdf_ctx* ctx = pp->ctx;
   HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z1));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2));
+  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2s[k]));
+  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_w * 32, &p->d_wps[k]));
+  p->slot = 0;
+  p->d_z2 = p->d_z2s[0];
+  for (int k = 0; k < vdf_proof::DEPTH; ++k) {
+    const int dev = vdf_ctx_device(ctx);
+    if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
+      return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
+    HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
+  }
   HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_E));
   HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
   for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &p->d_trace));
-  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&p->h_comm));
+  HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 1) * sizeof(vdf_jac), (void**)&p->h_comm));
   HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
   return VDF_OK;
 }
@@ -156,6 +234,7 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
     if (rc == VDF_OK) rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&pp->gen_u);
     if (ub) vdf_bases_free(ub);
   }
+  if (rc == VDF_OK) rc = setup_packed_generators(pp);
   if (rc == VDF_OK) rc = vdf_dev_alloc(ctx, pp->num_cons * 32, &pp->d_zero);
   if (rc == VDF_OK) rc = vdf_dev_memset(ctx, pp->d_zero, 0, pp->num_cons * 32);
   if (rc != VDF_OK) { std::string e = vdf_last_error(ctx); vdf_nova_pp_free(pp); return fail(rc, "generator setup: " + e); }
@@ -180,6 +259,7 @@ void vdf_nova_pp_free(vdf_pp* pp) {
   if (pp->d_zero) vdf_dev_free(pp->ctx, pp->d_zero);
   if (pp->shape) vdf_shape_free(pp->shape);
   if (pp->gens) vdf_bases_free(pp->gens);
+  if (pp->gens_w) vdf_bases_free(pp->gens_w);
   delete pp;
 }
 int vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
@@ -275,68 +355,148 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   if (memcmp(p->zi, &c.result, 96) != 0)
     return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
   const double t0 = now_ms();
-  const size_t nv = pp->num_vars, nc = pp->num_cons;
+  const size_t nc = pp->num_cons;
   // The step is enqueued asynchronously: every call below is stream-ordered, and the host waits only for the
   // two commitments the transcript needs.  The caller's synchronisation mode is restored on the way out.
   int was_async = 0;
   HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
-  // --- fresh z2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i | 1 | X2] in one launch ------------
-  const void* d_trace = c.d_trace;
-  if (!d_trace) {
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_trace, c.trace_xy.data(), (pp->t + 1) * 64));
-    d_trace = p->d_trace;
-  }
+  // --- fresh z2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i | 1 | X2] in one launch, and its
+  // commitment: both depend on the trace only.  Steady state: an earlier step already enqueued them on a lookahead
+  // context; otherwise they are enqueued here, the same way.
+  constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
   Fe X2[NUM_IO] = {c.result.x, c.result.y, c.result.i, c.input.x, c.input.y, c.input.i};
-  {
-    const Fe head[3] = {c.result.x, c.result.y, c.result.i};
+  enum { MARK_Z = 0, MARK_W = 1 };                // marks on a lookahead context: z2 written / its commitment landed
+  bool touched[D] = {};                           // lookahead contexts that were given work by this call
+  // enqueues z2 of step j into ring slot s on that step's lookahead context, makes the first context wait for z2
+  // (not for the commitment: vdf_ctx_wait covers what is enqueued so far), then the commitment
+  auto enqueue_fresh = [&](size_t j, int s, bool cold) -> int {
+    const Circuit& cc = circuits->v[j];
+    vdf_ctx* q = p->ctx2[j % D];
+    if (cold) HIPCALL(q, vdf_ctx_wait(q, ctx));   // outside the steady state the ring slot may still be read by a fold
+    const void* d_trace = cc.d_trace;
+    if (!d_trace) {                               // trace not resident: staged through the proof's own buffer
+      void*& stage = p->d_traces[j % D];
+      if (!stage) HIPCALL(ctx, vdf_dev_alloc(ctx, (pp->t + 1) * 64, &stage));
+      HIPCALL(q, vdf_dev_memcpy(q, stage, cc.trace_xy.data(), (pp->t + 1) * 64));
+      d_trace = stage;
+    }
+    const Fe Xf[NUM_IO] = {cc.result.x, cc.result.y, cc.result.i, cc.input.x, cc.input.y, cc.input.i};
     const Fe u2 = one(F);
-    HIPCALL(ctx, vdf_minroot_step_z(ctx, PRIMARY_FIELD, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)head,
-                                    (const vdf_fe*)&c.input.i, (const vdf_fe*)&u2, (const vdf_fe*)X2, (vdf_fe*)p->d_z2));
+    HIPCALL(q, vdf_minroot_step_z_packed(q, PRIMARY_FIELD, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)Xf,
+                                         (const vdf_fe*)&cc.input.i, (const vdf_fe*)&u2, (const vdf_fe*)Xf, (vdf_fe*)p->d_z2s[s],
+                                         (vdf_fe*)p->d_wps[s]));
+    HIPCALL(q, vdf_ctx_mark(q, MARK_Z));
+    HIPCALL(ctx, vdf_ctx_wait(ctx, q));
+    // the commitment over the packed witness and the merged generators: 3t + 4 terms instead of 4t + 4
+    HIPCALL(q, vdf_msm(q, pp->gens_w, 0, (const vdf_fe*)p->d_wps[s], pp->num_w, 1, &p->h_comm[s]));
+    HIPCALL(q, vdf_ctx_mark(q, MARK_W));
+    touched[j % D] = true;
+    vdf_proof::Ahead a;
+    a.result = cc.result; a.input = cc.input; a.slot = s;
+    p->ahead.push_back(a);
+    return VDF_OK;
+  };
+  const bool hit = !p->ahead.empty() && p->ahead_circuits == circuits && p->ahead_k == k &&
+                   memcmp(&p->ahead[0].result, &c.result, sizeof(St)) == 0 && memcmp(&p->ahead[0].input, &c.input, sizeof(St)) == 0;
+  if (!hit) {
+    if (!p->ahead.empty()) for (vdf_ctx* q : p->ctx2) HIPCALL(q, vdf_ctx_sync(q));       // lookaheads nobody came for
+    p->ahead.clear();
+    p->ahead_circuits = circuits;
+    p->ahead_k = k;
+    int rc = enqueue_fresh(k, first ? 0 : (p->slot + 1) % R, !first);
+    if (rc != VDF_OK) return rc;
   }
+  const int slot = p->ahead[0].slot;
+  vdf_ctx* cq = p->ctx2[k % D];
+  p->slot = slot;
+  p->d_z2 = p->d_z2s[slot];
   const double t1 = now_ms();
-  vdf_jac* jw = &p->h_comm[0];
-  vdf_jac* jt = &p->h_comm[1];
+  vdf_jac* jw = &p->h_comm[slot];
+  vdf_jac* jt = &p->h_comm[R];
   Aff comm_w;
   StepRecord rec;
   for (int j = 0; j < NUM_IO; ++j) rec.X[j] = X2[j];
   double t2 = t1, t3 = t1, t4 = t1, t5 = t1, t6 = t1;
+  // keeps the fresh work of the next D steps enqueued (called once this step's commitment has landed: its
+  // context is free again)
+  auto look_ahead = [&]() -> int {
+    p->ahead.erase(p->ahead.begin());
+    p->ahead_k = k + 1;
+    while (p->ahead.size() < (size_t)D) {
+      const size_t j = p->ahead_k + p->ahead.size();
+      if (j >= circuits->v.size() || circuits->v[j].t != pp->t) break;
+      const int last = p->ahead.empty() ? slot : p->ahead.back().slot;
+      int rc = enqueue_fresh(j, (last + 1) % R, !hit);
+      if (rc != VDF_OK) return rc;
+    }
+    return VDF_OK;
+  };
+  // commitment of the fresh witness = (MSM over the packed witness) - ((i_0 - 1) S0 - S1), i_0 = the step's counter
+  auto fresh_commitment = [&](const vdf_jac& j) -> Aff {
+    const Field& Fb = field_fp();
+    if (p->c_valid && sub(p->c_i0, from_u64(pp->t, F), F) == c.result.i) {
+      Aff m = pp->tS0;
+      m.y = neg(m.y, Fb);
+      p->c_pt = pt_add(p->c_pt, pt_from_aff(m, Fb), Fb);                     // consecutive steps: C -= t S0
+    } else {
+      const Fe k = from_mont(sub(c.result.i, one(F), F), F);
+      Aff s1 = pp->S1;
+      s1.y = neg(s1.y, Fb);
+      p->c_pt = pt_add(pt_mul(pt_from_aff(pp->S0, Fb), k.l, 255, Fb), pt_from_aff(s1, Fb), Fb);
+    }
+    p->c_i0 = c.result.i;
+    p->c_valid = true;
+    Fe X, Y, Z;
+    memcpy(X.l, j.x.l, 32); memcpy(Y.l, j.y.l, 32); memcpy(Z.l, j.z.l, 32);
+    Pt w;
+    w.x = X; w.y = Y; w.zz = sqr(Z, Fb); w.zzz = mul(w.zz, Z, Fb);
+    Pt cneg = p->c_pt;
+    cneg.y = neg(cneg.y, Fb);
+    return pt_to_aff(pt_add(w, cneg, Fb), Fb);
+  };
   if (first) {
     // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step.  A z, B z, C z of
     // the running instance are computed here once and folded from then on (they are linear in z).
-    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_z2, nv, 1, jw));
     HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_z1, p->d_z2, pp->ncols * 32));
     HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
+    HIPCALL(cq, vdf_ctx_sync(cq));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     t2 = now_ms();
-    comm_w = jac_to_aff(*jw, field_fp());
+    comm_w = fresh_commitment(*jw);
     p->comm_W = comm_w;
     p->comm_E.x = p->comm_E.y = zero();
     p->u = one(F);
     for (int j = 0; j < NUM_IO; ++j) p->X[j] = X2[j];
     rec.comm_T.x = rec.comm_T.y = zero();
     rec.r = zero();
+    int rc = look_ahead();
+    if (rc != VDF_OK) return rc;
     t6 = now_ms();
   } else {
-    // --- NIFS.prove: multiply_vec(z2) + cross term (one launch), then the commitments to
-    // W2 and T as ONE batched MSM whose two points land in pinned host memory.  While the GPU works the host
+    // --- NIFS.prove, the critical path of the chain: multiply_vec(z2) + cross term (one
+    // launch), the commitment to T into pinned host memory, the challenge, the fold.  While the GPU works the host
     // finishes the previous step's instance fold.
     HIPCALL(ctx, vdf_nifs_cross_term(ctx, pp->shape, (const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1],
                                      (const vdf_fe*)p->d_abc[2], (const vdf_fe*)&p->u, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4],
                                      (vdf_fe*)p->d_abc[5], (vdf_fe*)p->d_T));
     t2 = now_ms();
+    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, jt));
+    t3 = now_ms();
+    // this step's fresh commitment has been in flight since an earlier step; once it has landed its context is
+    // free for a later step's
+    HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
     {
-      const size_t off[2] = {0, 0}, len[2] = {nv, nc};
-      const vdf_fe* sc[2] = {(const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_T};
-      HIPCALL(ctx, vdf_msm_batch(ctx, pp->gens, 2, off, sc, len, 1, p->h_comm));   // h_comm[0] = W2, [1] = T
+      int rc = look_ahead();
+      if (rc != VDF_OK) return rc;
     }
-    t3 = t4 = now_ms();
+    t4 = now_ms();
+    comm_w = fresh_commitment(*jw);                              // host point work while the GPU commits to T
     p->join();                                                   // the previous step's instance fold
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     t5 = now_ms();
-    Aff comm_T;
-    jac_to_aff2(*jw, *jt, field_fp(), &comm_w, &comm_T);         // one shared inversion
+    const Aff comm_T = jac_to_aff(*jt, field_fp());
     uint64_t r_raw[4];
     const Fe r = challenge(pp, p->comm_W, p->comm_E, p->u, p->X, comm_w, X2, comm_T, r_raw);
     // witness fold on the device, one launch: z1 += r*z2 (W, and with it u and X), E += r*T, and the running
@@ -359,13 +519,16 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     rec.comm_T = comm_T;
     rec.r = r;
   }
+  // nothing in flight reads the circuits' memory once this call returns (a lookahead's z2 is long written)
+  for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   rec.comm_w = comm_w;
   p->steps.push_back(rec);
   p->i += 1;
   p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
   const double t7 = now_ms();
-  // witness launch | commitments launch (batched) | cross-term launch | - | host fold of the previous step +
-  // wait for both commitments | transcript + fold launch | bookkeeping | total
+  // fresh witness (only without lookahead) | commitment-of-T launch | cross-term launch | wait for the fresh
+  // commitment + lookahead launch | host fold of the previous step + wait for T | transcript + fold launch |
+  // bookkeeping | total
   p->ms[0] = t1 - t0; p->ms[1] = t3 - t2; p->ms[2] = t2 - t1; p->ms[3] = t4 - t3;
   p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
   *proof = p;
@@ -392,9 +555,14 @@ void vdf_nova_proof_free(vdf_proof* p) {
   p->join();
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
-    void* bufs[] = {p->d_z1, p->d_z2, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4],
-                    p->d_abc[5], p->d_trace};
+    for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_sync(q);                   // lookaheads may still be in flight
+    vdf_ctx_sync(ctx);
+    void* bufs[] = {p->d_z1, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4], p->d_abc[5]};
     for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
+    for (void* b : p->d_z2s) if (b) vdf_dev_free(ctx, b);
+    for (void* b : p->d_wps) if (b) vdf_dev_free(ctx, b);
+    for (void* b : p->d_traces) if (b) vdf_dev_free(ctx, b);
+    for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_destroy(q);
     if (p->h_comm) vdf_host_free(ctx, p->h_comm);
   }
   delete p;

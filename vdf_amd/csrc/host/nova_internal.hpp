@@ -58,6 +58,12 @@ struct vdf_pp {
   vdf_shape* shape = nullptr;
   vdf_bases* gens = nullptr;
   uint8_t digest[32];
+  // Commitment to a fresh witness over 3t + 4 instead of 4t + 4 generators (vdf_minroot_step_z_packed): new_x of round
+  // j is y_j - (i_0 - 1 - j), so its generator G_{3+4j} is merged into the generator of y_j, and what remains,
+  // sum_j (i_0 - 1 - j) G_{3+4j} = (i_0 - 1) S0 - S1, depends on the step's counter i_0 only.
+  vdf_bases* gens_w = nullptr;
+  size_t num_w = 0;
+  Aff S0, S1, tS0;          // S0 = sum_j G_{3+4j}, S1 = sum_j j G_{3+4j}, tS0 = t * S0
   Aff gen_u;                // the extra generator U of the inner-product arguments: synthetic generator number num_gens
   void* d_zero = nullptr;   // num_cons zero elements (satisfiability residual)
 };
@@ -78,12 +84,31 @@ struct vdf_proof {
   Aff comm_W, comm_E;        // running relaxed instance
   Fe u, X[NUM_IO];
   void* d_z1 = nullptr;      // [W | u | X] of the running instance (W aliases the front)
-  void* d_z2 = nullptr;      // [W | 1 | X] of the fresh instance
+  void* d_z2 = nullptr;      // [W | 1 | X] of the fresh instance: the ring slot of the current step
+  // Lookahead.  The fresh witness of a later step and its commitment depend on the trace only, not on the fold
+  // chain, so they are computed on further contexts of the same device while the critical path of the chain (cross
+  // term -> commitment of T -> challenge -> fold) runs on the first: step j's fresh work goes to context j mod DEPTH,
+  // enqueued DEPTH steps early.  DEPTH + 2 ring slots: the slot step j is written to was last read by step
+  // j - DEPTH - 2, whose fold is known complete (the host has synchronised the first context since).
+  static constexpr int DEPTH = 1, RING = DEPTH + 2;
+  vdf_ctx* ctx2[DEPTH] = {};
+  void* d_z2s[RING] = {};
+  void* d_wps[RING] = {};       // the same slots' packed witnesses (3t + 4 values, what the commitment is taken over)
+  // correction point of the packed commitment for the counter c_i0: (c_i0 - 1) S0 - S1; consecutive steps differ by t S0
+  bool c_valid = false;
+  Fe c_i0;
+  vdfhost::Pt c_pt;
+  void* d_traces[DEPTH] = {};   // staging for traces that are not device-resident, one per lookahead context
+  int slot = 0;
+  // steps [ahead_k, ahead_end) of `ahead_circuits` are in flight or landed; entry j lives in slot ahead_slot0 + (j - ahead_k)
+  struct Ahead { vdfnova::St result, input; int slot; };
+  const vdf_circuits* ahead_circuits = nullptr;
+  size_t ahead_k = 0;
+  std::vector<Ahead> ahead;     // ahead[i] describes step ahead_k + i
   void* d_E = nullptr;       // running error vector
   void* d_T = nullptr;
   void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
-  void* d_trace = nullptr;
-  vdf_jac* h_comm = nullptr; // pinned, device-mapped result slots: [0] = commitment of W2, [1] = commitment of T
+  vdf_jac* h_comm = nullptr; // pinned, device-mapped result slots: [0..RING) = commitment of W2 per ring slot, [RING] = of T
   std::vector<vdfnova::StepRecord> steps;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // The O(1) instance fold of step k (two 128-bit scalar multiplications on the host) is deferred: step k+1

@@ -31,6 +31,7 @@ struct vdf_ctx {
   std::vector<TimedCall> timed;      // events of calls not yet queried
   std::vector<hipEvent_t> ev_pool;   // recycled events
   hipEvent_t wait_ev = nullptr;      // vdf_ctx_wait
+  hipEvent_t marks[4] = {nullptr, nullptr, nullptr, nullptr};   // vdf_ctx_mark
   // MSM jobs (vdf_msm_job_*): one side stream and two events per vector, created on first use
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -154,7 +155,7 @@ Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const ui
                 const void* z, size_t rows, void* out, hipStream_t s);
 // fused step kernels; vdf_fe* arguments are HOST pointers whose values travel as kernel arguments
 Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
-                  const vdf_fe X[6], void* z, hipStream_t s);
+                  const vdf_fe X[6], void* z, void* packed, hipStream_t s);
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
                       const void* cz1, const vdf_fe* u1, size_t rows, void* az2, void* bz2, void* cz2, void* T,

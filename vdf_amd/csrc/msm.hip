@@ -47,6 +47,8 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 // oldest-first arbiter favours; a raised wave priority lets them through.
 __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
+static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many: two waves per SIMD already issue at ~99 % of three,
+                                            // and a third fewer slices means a third fewer slice heads for k_fixup to add
 static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
 static constexpr uint32_t GIANT_SPAN = 1024; // ... and above which GIANT_PARTS wavefronts share the bucket
 static constexpr uint32_t GIANT_PARTS = 256;
@@ -60,7 +62,7 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t ne, uint32_t slots, uint3
   const uint32_t L = (ne + slots - 1) / slots;
   return L < 8u ? 8u : L;
 }
-static constexpr uint32_t RED_QUADS = 16384; // k_reduce1 quads aimed for: enough to fill the chip, few enough that the
+static constexpr uint32_t RED_QUADS = 8192;  // k_reduce1 quads aimed for: enough to fill the chip, few enough that the
                                              // per-quad offset multiplication (~30 point ops) stays a small share
 
 struct WsLayout {
@@ -74,7 +76,12 @@ struct RedGeom { uint32_t seg, threads_per_set, block, blocks_per_set; };
 static RedGeom red_geom(size_t nkeys, uint32_t nbk) {
   RedGeom r;
   uint32_t seg = 2;                            // buckets per quad in k_reduce1 (serial depth 2*seg), power of two
-  while (seg < 64 && nkeys / seg > RED_QUADS) seg <<= 1;
+  uint32_t quads = RED_QUADS;
+  if (const char* ov = std::getenv("VDF_MSM_RED_QUADS")) {              // tuning override
+    const long v = std::atol(ov);
+    if (v >= 64 && v <= 65536) quads = (uint32_t)v;
+  }
+  while (seg < 64 && nkeys / seg > quads) seg <<= 1;
   if (seg > nbk) seg = nbk;
   r.seg = seg;
   r.threads_per_set = nbk / seg;               // logical threads (quads): one per seg buckets
@@ -163,7 +170,12 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // single workgroup more costs a whole extra round.  So: one round, every slot used, L = ceil(entries / slots)
   // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
-  const size_t slots = (size_t)num_cus * ACC_WG_PER_CU * 256;
+  int acc_wg = ACC_WG_FILL;
+  if (const char* ov = std::getenv("VDF_MSM_ACC_WG")) {                 // tuning override: resident workgroups per CU to fill
+    const long v = std::atol(ov);
+    if (v >= 1 && v <= ACC_WG_PER_CU) acc_wg = (int)v;
+  }
+  const size_t slots = (size_t)num_cus * acc_wg * 256;
   size_t L = (ne + slots - 1) / slots;           // upper bound: the kernels shorten it to the actual entry count
   if (L < 8) L = 8;
   p.L = (uint32_t)L;

@@ -103,9 +103,12 @@ template <class P> __device__ __forceinline__ Fe<P> fe_from_val(const FeVal& a) 
 
 // z = [ z_in(3) | per round new_x, tmp1, tmp2, new_y (4t) | final_i | u | X(6) ]: the whole fresh column vector
 // of the exposed-IO step circuit; round values as in k_minroot_witness, the rest from kernel arguments.
+// `packed` (optional): the same witness without the new_x values, [ z_in(3) | per round tmp1, tmp2, new_y (3t) |
+// final_i ] -- new_x of a round is an affine image of another witness value, so a commitment needs no term for it
+// (vdf_minroot_step_z_packed).
 template <class P>
 __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, StepConsts k, uint64_t t,
-                                                char* __restrict__ z) {
+                                                char* __restrict__ z, char* __restrict__ packed) {
   __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j > t) return;
@@ -115,6 +118,10 @@ __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, 
     fe_store<P>(tail, fe_from_val<P>(k.i0));
     fe_store<P>(tail + 32, fe_from_val<P>(k.u));
     for (int i = 0; i < 6; ++i) fe_store<P>(tail + 64 + i * 32, fe_from_val<P>(k.X[i]));
+    if (packed) {
+      for (int i = 0; i < 3; ++i) fe_store<P>(packed + i * 32, fe_from_val<P>(k.z_in[i]));
+      fe_store<P>(packed + (3 + 3 * t) * 32, fe_from_val<P>(k.i0));
+    }
     return;
   }
   const Fe<P> x = fe_load<P>(trace + (t - j) * 64);
@@ -127,6 +134,12 @@ __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, 
   fe_store<P>(o + 32, t1);
   fe_store<P>(o + 64, t2);
   fe_store<P>(o + 96, ny);
+  if (packed) {
+    char* q = packed + 96 + j * 96;
+    fe_store<P>(q, t1);
+    fe_store<P>(q + 32, t2);
+    fe_store<P>(q + 64, ny);
+  }
 }
 
 struct Csr3 { const uint32_t* rowptr[3]; const uint32_t* col[3]; const uint32_t* coef[3]; };
@@ -263,13 +276,13 @@ Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const ui
 static FeVal to_val(const vdf_fe* p) { FeVal v; std::memcpy(v.v, p, 32); return v; }
 
 Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
-                  const vdf_fe X[6], void* z, hipStream_t s) {
+                  const vdf_fe X[6], void* z, void* packed, hipStream_t s) {
   StepConsts k;
   for (int i = 0; i < 3; ++i) k.z_in[i] = to_val(&z_in[i]);
   k.i0 = to_val(i0);
   k.u = to_val(u);
   for (int i = 0; i < 6; ++i) k.X[i] = to_val(&X[i]);
-  FIELD_DISPATCH(field, k_step_z, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), k, t, M(z));
+  FIELD_DISPATCH(field, k_step_z, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), k, t, M(z), M(packed));
   return Status{};
 }
 

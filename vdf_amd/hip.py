@@ -176,6 +176,14 @@ class Context:
         """Work enqueued on this context from now on starts after everything enqueued on `other` so far."""
         self._check(lib.vdf_ctx_wait(self.handle, other.handle))
 
+    def mark(self, slot: int = 0) -> None:
+        """Remembers the current end of this context's queue under `slot` (0..3)."""
+        self._check(lib.vdf_ctx_mark(self.handle, slot))
+
+    def sync_mark(self, slot: int = 0) -> None:
+        """Waits for everything enqueued before mark `slot`; later work keeps running."""
+        self._check(lib.vdf_ctx_sync_mark(self.handle, slot))
+
     def set_msm_window(self, c: int) -> None:
         self._check(lib.vdf_ctx_set_msm_window(self.handle, c))
 
@@ -270,6 +278,10 @@ class Context:
     def minroot_step_z(self, field, trace_xy, t, z_in, i0, u, X, z) -> None:
         self._check(lib.vdf_minroot_step_z(self.handle, field, _ptr(trace_xy), t, _ptr(z_in), _ptr(i0), _ptr(u), _ptr(X),
                                            _ptr(z)))
+
+    def minroot_step_z_packed(self, field, trace_xy, t, z_in, i0, u, X, z, w_packed) -> None:
+        self._check(lib.vdf_minroot_step_z_packed(self.handle, field, _ptr(trace_xy), t, _ptr(z_in), _ptr(i0), _ptr(u),
+                                                  _ptr(X), _ptr(z), _ptr(w_packed)))
 
     def nifs_cross_term(self, shape: Shape, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
         self._check(lib.vdf_nifs_cross_term(self.handle, shape.handle, _ptr(z2), _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(u1),

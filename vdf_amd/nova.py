@@ -234,7 +234,7 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
     def last_step_ms(self) -> dict:
         ms = (C.c_double * 8)()
         _check(nova_lib.vdf_nova_last_step_ms(self.handle, C.byref(ms)))
-        return dict(zip(("witness_launch", "commit_launch", "cross_term_launch", "unused", "wait", "fold", "host", "total"), list(ms)))
+        return dict(zip(("witness_launch", "commit_launch", "cross_term_launch", "lookahead", "wait", "fold", "host", "total"), list(ms)))
 
     def free(self) -> None:
         if self.handle and self.pp.handle and self.pp.ctx.handle:      # needs live parameters and a live context
