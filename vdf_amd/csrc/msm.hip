@@ -105,7 +105,7 @@ static WsLayout ws_layout(const MsmPlan& p) {
   w.sorted = take(((size_t)p.windows * p.n + 64) * 4);
   w.bucket_acc = take(nkeys * 128);
   w.heads = take((size_t)p.nthreads * 128);
-  w.heavy = take((nkeys + 4 + MAX_GIANTS) * 4);            // count, queued buckets, giant arrival counters
+  w.heavy = take((nkeys + 4 + 2 * MAX_GIANTS) * 4);        // count, queued buckets, giant count, giant arrival counters, giant queue
   w.giant = take((size_t)MAX_GIANTS * GIANT_PARTS * 128);     // partial sums of giant buckets
   const RedGeom rg = red_geom(nkeys, p.nbk);
   w.red_seg = rg.seg; w.red_threads_per_set = rg.threads_per_set; w.red_block = rg.block;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ counts
     carry += tot;
   }
   if (threadIdx.x == 0) pcount[b] = carry;
-  if (b == 0 && threadIdx.x == 0) heavy[0] = 0;       // the heavy-bucket queue of this run starts empty
+  if (b == 0 && threadIdx.x == 0) { heavy[0] = 0; giant_done[-1] = 0; }   // both queues of this run start empty (heavy_layout)
   if (b == 0 && threadIdx.x < MAX_GIANTS) giant_done[threadIdx.x] = 0;
 }
 
@@ -536,6 +536,18 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
 // multiplication stages per addition instead of fourteen serial multiplications.
 // "Logical thread" = quad = (global lane index) / 4.
 // ------------------------------------------------------------------------------------------
+// The queues k_fixup fills for k_fixup_heavy, in one allocation of nkeys + 4 + 2 * MAX_GIANTS words.
+struct HeavyLayout { uint32_t* count; uint32_t* items; uint32_t* giant_count; uint32_t* done; uint32_t* giants; };
+__host__ __device__ __forceinline__ HeavyLayout heavy_layout(uint32_t* heavy, uint32_t nkeys) {
+  HeavyLayout q;
+  q.count = heavy;                         // plain heavy buckets queued
+  q.items = heavy + 1;                     // ... and which (at most nkeys)
+  q.giant_count = heavy + 1 + nkeys + 1;   // giant buckets seen (may exceed MAX_GIANTS: the surplus is queued as plain)
+  q.done = heavy + 1 + nkeys + 2;          // arrival counter per giant
+  q.giants = q.done + MAX_GIANTS;          // the giants, numbered by their position
+  return q;
+}
+
 // One quad per bucket: add the heads of the slices the bucket spans (table mode: ~8 per bucket).
 template <class P>
 __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
@@ -551,8 +563,13 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
   if (tl == tf) return;
   if (tl - tf > (uint32_t)HEAVY_SPAN) {
     if ((threadIdx.x & 3u) == 0) {
-      uint32_t slot = atomicAdd(&heavy[0], 1u);
-      heavy[1 + slot] = g;
+      const HeavyLayout q = heavy_layout(heavy, nkeys);
+      bool queued = false;
+      if (tl - tf > GIANT_SPAN) {                                  // its own queue: the position is the giant's number
+        const uint32_t idx = atomicAdd(q.giant_count, 1u);
+        if (idx < MAX_GIANTS) { q.giants[idx] = g; queued = true; }
+      }
+      if (!queued) q.items[atomicAdd(q.count, 1u)] = g;
     }
     return;
   }
@@ -569,28 +586,29 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
 // One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a 4-step butterfly of
 // quad additions across the wavefront.  A GIANT bucket (more than GIANT_SPAN heads: a hot digit shared by most
 // scalars) is shared by GIANT_PARTS wavefronts (the grid holds 16 such groups, so 16 giant buckets proceed side by side): each sums a contiguous chunk of the heads into
-// a scratch slot, and the last one to arrive (a counter per giant bucket) adds the slots to the bucket.  Every
-// wavefront walks the same queue in the same order, so the index of a giant bucket needs no communication.
+// a scratch slot, and the last one to arrive (a counter per giant bucket) adds the slots to the bucket.  k_fixup
+// queues giants apart, so a giant's number is its position there and no wavefront walks a queue: with few buckets
+// and many points every bucket is heavy, and a walk would be thousands of dependent loads.
 template <class P>
 __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
                                                     uint32_t Lfixed, char* __restrict__ bucket_acc,
                                                     const char* __restrict__ heads, uint32_t* __restrict__ heavy,
                                                     char* __restrict__ giant) {
   raise_wave_priority();
-  const uint32_t count = heavy[0];
-  if (count == 0) return;
+  const HeavyLayout q = heavy_layout(heavy, nkeys);
+  const uint32_t count = *q.count;
+  uint32_t ngiant = *q.giant_count;
+  if (ngiant > MAX_GIANTS) ngiant = MAX_GIANTS;
+  if (count == 0 && ngiant == 0) return;
   const uint32_t L = slice_len(bstart[nkeys], slots, Lfixed);
   const uint32_t quad = threadIdx.x >> 2;
-  uint32_t* done = heavy + 1 + nkeys + 2;                          // MAX_GIANTS arrival counters, zeroed by k_part_scan
-  uint32_t gi = 0;                                                 // giant buckets seen so far
-  for (uint32_t item = 0; item < count; ++item) {
-    const uint32_t g = heavy[1 + item];
-    const uint32_t s = bstart[g], e = bstart[g + 1];
-    const uint32_t tf = s / L, tl = (e - 1) / L, span = tl - tf;  // heads tf+1 .. tl
-    if (span > GIANT_SPAN && gi < MAX_GIANTS) {
-      const uint32_t my = gi++;
-      const uint32_t part = blockIdx.x % GIANT_PARTS, ngroups = gridDim.x / GIANT_PARTS;
-      if (blockIdx.x >= ngroups * GIANT_PARTS || my % ngroups != blockIdx.x / GIANT_PARTS) continue;   // giants run side by side
+  // giants: GIANT_PARTS wavefronts each, several giants side by side
+  const uint32_t part = blockIdx.x % GIANT_PARTS, ngroups = gridDim.x / GIANT_PARTS;
+  if (blockIdx.x < ngroups * GIANT_PARTS)
+    for (uint32_t my = blockIdx.x / GIANT_PARTS; my < ngiant; my += ngroups) {
+      const uint32_t g = q.giants[my];
+      const uint32_t s = bstart[g], e = bstart[g + 1];
+      const uint32_t tf = s / L, tl = (e - 1) / L, span = tl - tf;  // heads tf+1 .. tl
       const uint32_t chunk = (span + GIANT_PARTS - 1) / GIANT_PARTS;
       const uint32_t t0 = tf + 1 + part * chunk;
       const uint32_t t1 = (t0 + chunk - 1 < tl) ? t0 + chunk - 1 : tl;
@@ -601,7 +619,7 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
       if (quad == 0) qpoint_store<P>(slot, acc);
       __threadfence();
       uint32_t arrived = 0;
-      if (threadIdx.x == 0) arrived = atomicAdd(&done[my], 1u);
+      if (threadIdx.x == 0) arrived = atomicAdd(&q.done[my], 1u);
       arrived = (uint32_t)__builtin_amdgcn_readfirstlane(arrived);
       if (arrived != GIANT_PARTS - 1) continue;
       __threadfence();
@@ -612,9 +630,12 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
         QPoint<P> base = qpoint_load_lazy<P>(bucket_acc + (size_t)g * 128);
         qpoint_store<P>(bucket_acc + (size_t)g * 128, qpoint_add<P>(base, tot));
       }
-      continue;
     }
-    if (item % gridDim.x != blockIdx.x) continue;
+  // plain heavy buckets: one wavefront each
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    const uint32_t g = q.items[item];
+    const uint32_t s = bstart[g], e = bstart[g + 1];
+    const uint32_t tf = s / L, tl = (e - 1) / L;
     QPoint<P> acc = qpoint_identity<P>();
     for (uint32_t t = tf + 1 + quad; t <= tl; t += 16) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(heads + (size_t)t * 128));
     acc = qpoint_wave_sum(acc);
