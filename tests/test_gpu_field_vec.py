@@ -309,3 +309,32 @@ def test_ctx_wait_orders_two_contexts(ctx):
     finally:
         ctx.set_async(was)
         ctx2.close()
+
+
+def test_ctx_marks(ctx):
+    """vdf_ctx_mark / vdf_ctx_sync_mark: the host waits for what was enqueued before the mark, no more."""
+    n = 1 << 16
+    rng = np.random.default_rng(10)
+    a, b = rand_limbs(rng, n), rand_limbs(rng, n)
+    was = ctx.get_async()
+    ctx.set_async(True)
+    try:
+        with pytest.raises(Exception):
+            ctx.sync_mark(3)                          # never set
+        for bad in (-1, 4):
+            with pytest.raises(Exception):
+                ctx.mark(bad)
+        da, db = _dev(a), _dev(b)
+        d1, d2 = _dev(np.zeros_like(a)), _dev(np.zeros_like(a))
+        ctx.fe_mul(o.FIELD_FQ, da, db, n, d1)
+        ctx.mark(2)
+        ctx.fe_mul_chain(o.FIELD_FQ, da, n, 2000, d2) # long-running work behind the mark
+        ctx.sync_mark(2)
+        exp1 = np.zeros_like(a)
+        got1 = _host(d1).copy()                       # complete although the chain may still run
+        ctx.sync()
+        ctx.set_async(False)
+        ctx.fe_mul(o.FIELD_FQ, a, b, n, exp1)
+        assert np.array_equal(got1, exp1)
+    finally:
+        ctx.set_async(was)

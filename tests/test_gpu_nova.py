@@ -182,6 +182,64 @@ def test_tampered_witness_is_rejected(ctx):
     assert proof.verify(pp, n, z0, zi) is True
 
 
+def _same_proof(a, b, n):
+    ia, ib = a.instance(), b.instance()
+    assert all(np.array_equal(ia[k], ib[k]) for k in ia)
+    for k in range(n):
+        ra, rb = a.step_record(k), b.step_record(k)
+        assert all(np.array_equal(ra[f], rb[f]) for f in ra)
+    (wa, ea), (wb, eb) = a.witness(), b.witness()
+    assert np.array_equal(wa, wb) and np.array_equal(ea, eb)
+
+
+def test_lookahead_is_invisible(ctx):
+    """prove_step enqueues the next step's fresh witness and commitment ahead of time (include/vdf_nova.h).  Whatever
+    the caller does next -- the expected step, the same step from another circuits object, a refused call in between,
+    a second proof interleaved -- the proofs are the ones a step-at-a-time prover makes."""
+    t, n = 32, 5
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
+    zi = [initial.x, initial.y, initial.i]
+    ref = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert ref.verify(pp, n, z0, zi)
+    # (a) the same states from a second circuits object: every lookahead is for the wrong object and is dropped
+    _, twin = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    p = None
+    for k in range(n):
+        p = NovaVDFProof.prove_step(pp, p, circuits if k % 2 == 0 else twin, k, z0)
+    _same_proof(ref, p, n)
+    assert p.verify(pp, n, z0, zi)
+    # (b) a refused call (wrong step) between two good ones leaves the proof and its lookahead intact
+    q = None
+    for k in range(n):
+        q = NovaVDFProof.prove_step(pp, q, circuits, k, z0)
+        if k == 1:
+            with pytest.raises(Exception):
+                NovaVDFProof.prove_step(pp, q, circuits, 4, z0)
+            with pytest.raises(Exception):
+                NovaVDFProof.prove_step(pp, q, circuits, n, z0)
+    _same_proof(ref, q, n)
+    # (c) two proofs advanced in turns over the same circuits
+    a = b = None
+    for k in range(n):
+        a = NovaVDFProof.prove_step(pp, a, circuits, k, z0)
+        b = NovaVDFProof.prove_step(pp, b, circuits, k, z0)
+    _same_proof(ref, a, n)
+    _same_proof(ref, b, n)
+    # (d) circuits whose traces were never uploaded (staged per step) and uploaded ones give the same proof
+    twin.upload(ctx)
+    u = NovaVDFProof.prove_recursively(pp, twin, t, z0)
+    _same_proof(ref, u, n)
+    # (e) freeing the circuits right after the last call is safe: nothing in flight reads them
+    _, gone = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    gone.upload(ctx)
+    g = None
+    for k in range(3):
+        g = NovaVDFProof.prove_step(pp, g, gone, k, z0)
+    gone.free()
+    g.free()
+    assert ref.compress(pp).verify(pp, n, z0, zi)
+
+
 def test_mismatched_z0_is_an_error(ctx):
     import vdf_amd
     t, n = 4, 2
