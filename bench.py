@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
     ap.add_argument("--prove-chains", type=int, default=2,
                     help="also report the aggregate rate of this many independent chains proven concurrently (1 = skip)")
-    ap.add_argument("--prove-steps", type=int, default=12, help="1 base case + 1 warm-up fold + timed steady-state folds")
+    ap.add_argument("--prove-steps", type=int, default=26, help="1 base case + 1 warm-up fold + timed steady-state folds")
     return ap.parse_args()
 
 
@@ -100,7 +100,8 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2):
         PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, nsteps, initial)
     eval_s = time.perf_counter() - t0
     circuits.upload(ctx)                     # the forward trace is an input: resident in HBM before timing starts
-    # Steps are enqueued asynchronously (a step waits only for its two commitments), so the steady state is timed
+    # Steps are enqueued asynchronously (a step waits only for its two commitments, and the next step's fresh
+    # commitment is already in flight on a second context), so the steady state is timed
     # as one region closed by a stream synchronisation, not as a sum of per-call times.
     was_async = ctx.get_async()
     ctx.set_async(True)
@@ -109,7 +110,7 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2):
     proof = NovaVDFProof.prove_step(pp, proof, circuits, 0, z0)
     ctx.sync()
     base_case = time.perf_counter() - a
-    # the first fold is a warm-up (it grows the MSM workspace for the two-commitment batch); the rest are timed
+    # the first fold is a warm-up (it grows the MSM workspaces and fills the lookahead); the rest are timed
     first_fold = 0.0
     if nsteps > 2:
         a = time.perf_counter()

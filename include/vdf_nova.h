@@ -78,7 +78,13 @@ void vdf_nova_circuits_free(vdf_circuits* c);
  * per circuit.  Returns VDF_ERR_* (the reference asserts success, :353). */
 int  vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_t num_iters_per_step,
                                 const vdf_fe z0[3], vdf_proof** out);
-/* One RecursiveSNARK::prove_step (:342-349): *proof == NULL starts a new proof (the `None` case). */
+/* One RecursiveSNARK::prove_step (:342-349): *proof == NULL starts a new proof (the `None` case).
+ * What a step computes that does not depend on the chain -- the fresh witness of circuit k and its commitment -- is
+ * enqueued one call early, for circuit k + 1 of the same `circuits`, on a second context the proof owns; a call for any
+ * other step simply finds no such work waiting and does it then.  The results are those of a prover without lookahead,
+ * and no call returns while anything in flight still reads the circuits' memory (they may be freed right after).
+ * The fresh commitment is an MSM over 3t + 4 merged generators (vdf_minroot_step_z_packed, include/vdf_hip.h): the
+ * same point as the commitment to all 4t + 4 witness values. */
 int  vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]);
 /* NovaVDFProof::verify(pp, num_steps, z0, zi), :370-387: *ok = 1 iff the proof is valid for
  * num_steps steps from z0 AND the verified zi_primary equals zi (the Ok(bool) of :386). */
