@@ -75,18 +75,11 @@ inline Fe neg(const Fe& a, const Field& F) {
 // Inline on purpose: the forward MinRoot evaluation -- the delay itself, ~285 of these per iteration, strictly
 // sequential (src/minroot.rs:329-359) -- is the end-to-end wall-clock floor of a prover, and its entry points are
 // compiled twice (baseline x86-64 and a BMI2/ADX clone picked at load time) with everything inlined into them.
-inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
-  uint64_t t[8];
-  {
-    u128 c = 0;
-    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[0]; t[j] = (uint64_t)c; c >>= 64; }
-    t[4] = (uint64_t)c;
-  }
-  for (int i = 1; i < 4; ++i) {
-    u128 c = 0;
-    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
-    t[i + 4] = (uint64_t)c;
-  }
+// LAZY: operands and result in [0, 2m) instead of [0, m): with R = 2^256 and m < 2^254 (1 + 2^-128), a, b < 2m give
+// (a b + q m) / R < (4 m^2 + R m) / R < 2m, and a b + q m < 2^512 -- so a chain of multiplications needs neither the
+// comparison nor the subtraction (a ~20 % mispredicted branch per operation) until its end (canon).
+template <bool LAZY = false>
+inline Fe mont_reduce(uint64_t t[8], const Field& F) {
   uint64_t top = 0;                                   // carry out of limb 7
   for (int i = 0; i < 4; ++i) {
     const uint64_t q = t[i] * F.inv;
@@ -104,10 +97,63 @@ inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
   }
   Fe r;
   memcpy(r.l, t + 4, 32);
-  if (top || geq(r.l, F.m)) sub4(r.l, F.m);
+  if (!LAZY && (top || geq(r.l, F.m))) sub4(r.l, F.m);
   return r;
 }
-inline Fe sqr(const Fe& a, const Field& F) { return mul(a, a, F); }
+inline Fe canon(Fe r, const Field& F) {               // [0, 2m) -> [0, m)
+  if (geq(r.l, F.m)) sub4(r.l, F.m);
+  return r;
+}
+template <bool LAZY = false>
+inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
+  uint64_t t[8];
+  {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[0]; t[j] = (uint64_t)c; c >>= 64; }
+    t[4] = (uint64_t)c;
+  }
+  for (int i = 1; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    t[i + 4] = (uint64_t)c;
+  }
+  return mont_reduce<LAZY>(t, F);
+}
+// Dedicated squaring: the six cross products once, doubled, plus the four squares -- 10 multiplications instead of
+// 16.  (On the GPU the same trick does not pay, DESIGN.md 4.2: there a carry costs what a multiplication does.)
+template <bool LAZY = false>
+inline Fe sqr(const Fe& a, const Field& F) {
+  uint64_t t[8];
+  u128 c = (u128)a.l[0] * a.l[1];
+  t[1] = (uint64_t)c;
+  c = (c >> 64) + (u128)a.l[0] * a.l[2];
+  t[2] = (uint64_t)c;
+  c = (c >> 64) + (u128)a.l[0] * a.l[3];
+  t[3] = (uint64_t)c;
+  t[4] = (uint64_t)(c >> 64);
+  c = (u128)a.l[1] * a.l[2] + t[3];
+  t[3] = (uint64_t)c;
+  c = (c >> 64) + (u128)a.l[1] * a.l[3] + t[4];
+  t[4] = (uint64_t)c;
+  t[5] = (uint64_t)(c >> 64);
+  c = (u128)a.l[2] * a.l[3] + t[5];
+  t[5] = (uint64_t)c;
+  t[6] = (uint64_t)(c >> 64);
+  t[7] = t[6] >> 63;
+  for (int i = 6; i > 1; --i) t[i] = (t[i] << 1) | (t[i - 1] >> 63);
+  t[1] <<= 1;
+  c = (u128)a.l[0] * a.l[0];
+  t[0] = (uint64_t)c;
+  c = (c >> 64) + t[1];
+  t[1] = (uint64_t)c;
+  for (int i = 1; i < 4; ++i) {
+    c = (c >> 64) + (u128)a.l[i] * a.l[i] + t[2 * i];
+    t[2 * i] = (uint64_t)c;
+    c = (c >> 64) + t[2 * i + 1];
+    t[2 * i + 1] = (uint64_t)c;
+  }
+  return mont_reduce<LAZY>(t, F);
+}
 inline Fe one(const Field& F) { Fe r; memcpy(r.l, F.one, 32); return r; }
 inline Fe zero() { Fe r = {{0, 0, 0, 0}}; return r; }
 inline Fe to_mont(const Fe& a, const Field& F) { Fe r2; memcpy(r2.l, F.r2, 32); return mul(a, r2, F); }

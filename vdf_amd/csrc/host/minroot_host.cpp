@@ -14,18 +14,22 @@ const uint64_t FP_RESCUE_INVALPHA[4] = {0xe0f0f3f0cccccccdull, 0x4e9ee0c9a10a60e
 const uint64_t FQ_RESCUE_INVALPHA[4] = {0xd69f2280cccccccdull, 0x4e9ee0c9a143ba4aull, 0x3333333333333333ull,
                                         0x3333333333333333ull};   // src/minroot.rs:280-285
 
+// The chains run in the lazy domain [0, 2m) and canonicalise once, at the end (host_math.hpp).
+inline Fe lmul(const Fe& a, const Fe& b, const Field& F) { return mul<true>(a, b, F); }
+inline Fe lsqr(const Fe& a, const Field& F) { return sqr<true>(a, F); }
+
 struct Chain {   // the closures of src/minroot.rs:89-92 / :224-227
   const Field& F;
-  Fe sq(Fe x, int n) const { for (int i = 0; i < n; ++i) x = sqr(x, F); return x; }
-  Fe sqr_mul(const Fe& x, int n, const Fe& y) const { return mul(y, sq(x, n), F); }
+  Fe sq(Fe x, int n) const { for (int i = 0; i < n; ++i) x = lsqr(x, F); return x; }
+  Fe sqr_mul(const Fe& x, int n, const Fe& y) const { return lmul(y, sq(x, n), F); }
 };
 
 // PallasVDF::forward_step_ltr_addition_chain, src/minroot.rs:88-127
 Fe fwd_ltr_addchain_fq(const Fe& x) {
   const Field& F = field_fq();
   Chain c{F};
-  Fe q1 = x, q10 = c.sq(q1, 1), q11 = mul(q10, q1, F), q101 = mul(q10, q11, F), q110 = c.sq(q11, 1);
-  Fe q111 = mul(q110, q1, F), q1001 = mul(q111, q10, F), q1111 = mul(q1001, q110, F);
+  Fe q1 = x, q10 = c.sq(q1, 1), q11 = lmul(q10, q1, F), q101 = lmul(q10, q11, F), q110 = c.sq(q11, 1);
+  Fe q111 = lmul(q110, q1, F), q1001 = lmul(q111, q10, F), q1111 = lmul(q1001, q110, F);
   Fe qr2 = c.sqr_mul(q110, 3, q11), qr4 = c.sqr_mul(qr2, 8, qr2), qr8 = c.sqr_mul(qr4, 16, qr4);
   Fe qr16 = c.sqr_mul(qr8, 32, qr8), qr32 = c.sqr_mul(qr16, 64, qr16);
   Fe v = c.sqr_mul(qr32, 5, q1001);
@@ -33,17 +37,17 @@ Fe fwd_ltr_addchain_fq(const Fe& x) {
       {7, &q101}, {7, &q111}, {4, &q111}, {5, &q1001}, {5, &q101}, {3, &q11}, {4, &q101}, {3, &q101}, {6, &q1111},
       {4, &q1001}, {6, &q101}, {37, &qr8}, {2, &q1}};
   for (auto& s : steps) v = c.sqr_mul(v, s.n, *s.y);
-  return v;
+  return canon(v, F);
 }
 // PallasVDF::forward_step_rtl_sequential, src/minroot.rs:130-151
 Fe fwd_rtl_fq(const Fe& x) {
   const Field& F = field_fq();
   Fe acc = one(F), s = x;
   for (int count = 0; count < 254; ++count) {
-    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = mul(acc, s, F);
-    s = sqr(s, F);
+    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = lmul(acc, s, F);
+    s = lsqr(s, F);
   }
-  return acc;
+  return canon(acc, F);
 }
 // PallasVDF::forward_step_sequential_rtl_addition_chain, src/minroot.rs:154-196
 Fe fwd_rtl_addchain_fq(const Fe& x) {
@@ -51,24 +55,24 @@ Fe fwd_rtl_addchain_fq(const Fe& x) {
   Fe acc = one(F), s = x, last = x;
   for (int count = 0; count < 128; ++count) {
     last = s;
-    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = mul(acc, s, F);
-    s = sqr(s, F);
+    if ((FQ_RESCUE_INVALPHA[count / 64] >> (count % 64)) & 1) acc = lmul(acc, s, F);
+    s = lsqr(s, F);
   }
   Fe sa = last;
-  sa = mul(sa, sqr(sa, F), F);                                   // :179
-  sa = mul(sa, sqr(sqr(sqr(sqr(sa, F), F), F), F), F);           // :180
+  sa = lmul(sa, lsqr(sa, F), F);                                   // :179
+  sa = lmul(sa, lsqr(lsqr(lsqr(lsqr(sa, F), F), F), F), F);           // :180
   for (int count = 1; count <= 122; ++count) {                   // :182-195
-    sa = sqr(sa, F);
-    if (count % 8 == 1) acc = mul(acc, sa, F);
+    sa = lsqr(sa, F);
+    if (count % 8 == 1) acc = lmul(acc, sa, F);
   }
-  return acc;
+  return canon(acc, F);
 }
 // VestaVDF::forward_step, src/minroot.rs:223-261
 Fe fwd_addchain_fp(const Fe& x) {
   const Field& F = field_fp();
   Chain c{F};
-  Fe p1 = x, p10 = c.sq(p1, 1), p11 = mul(p10, p1, F), p101 = mul(p10, p11, F), p110 = c.sq(p11, 1);
-  Fe p111 = mul(p110, p1, F), p1001 = mul(p111, p10, F), p1111 = mul(p1001, p110, F);
+  Fe p1 = x, p10 = c.sq(p1, 1), p11 = lmul(p10, p1, F), p101 = lmul(p10, p11, F), p110 = c.sq(p11, 1);
+  Fe p111 = lmul(p110, p1, F), p1001 = lmul(p111, p10, F), p1111 = lmul(p1001, p110, F);
   Fe pr2 = c.sqr_mul(p110, 3, p11), pr4 = c.sqr_mul(pr2, 8, pr2), pr8 = c.sqr_mul(pr4, 16, pr4);
   Fe pr16 = c.sqr_mul(pr8, 32, pr8), pr32 = c.sqr_mul(pr16, 64, pr16);
   Fe v = c.sqr_mul(pr32, 5, p1001);
@@ -76,7 +80,7 @@ Fe fwd_addchain_fp(const Fe& x) {
       {5, &p1}, {7, &p101}, {4, &p11}, {8, &p111}, {4, &p1}, {4, &p111}, {9, &p1111}, {8, &p1111}, {6, &p1111},
       {2, &p11}, {34, &pr8}, {2, &p1}};
   for (auto& s : steps) v = c.sqr_mul(v, s.n, *s.y);
-  return v;
+  return canon(v, F);
 }
 
 // dispatch of src/minroot.rs:77-84; VestaVDF ignores the mode (:203-205)
