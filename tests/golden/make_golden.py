@@ -118,6 +118,25 @@ for ipa in (pf.ipa_W, pf.ipa_E):
 out["spartan_t3"] = {"comm_W": [H(cW3[0]), H(cW3[1])], "comm_E": [H(cE3[0]), H(cE3[1])], "u": H(uf), "X": [H(v) for v in Xf],
                      "argument_hex": enc.hex()}
 
+# --- a whole proof on the wire: folding chain (oracle/nifs.py) + argument (oracle/spartan.py) + encoding (oracle/wire.py) --
+import hashlib  # noqa: E402
+from oracle import nifs, wire  # noqa: E402
+wt, wn = 3, 2
+winit = o.State(o.rand_fe(31, 0, o.Q), 0, 1)
+wproof, wsh, wdig = nifs.prove_chain(winit, wt, wn)
+wN = 1
+while wN < max(wsh.num_vars, wsh.num_cons):
+    wN <<= 1
+warg = sp.prove(wsh, wdig, nifs.gens(wN), nifs.gens(1, start=wN)[0], nifs._pt(wproof.comm_W), nifs._pt(wproof.comm_E),
+                wproof.u, wproof.X, wproof.W, wproof.E)
+wz = [wproof.steps[0].X[:3]] + [s.X[3:] for s in wproof.steps]
+wcw = [nifs._pt(s.comm_w) for s in wproof.steps]
+wcT = [nifs._pt(s.comm_T) for s in wproof.steps]
+wire_snark = wire.encode_compressed_proof(wt, wdig, wz, wcw, wcT, warg)
+wire_running = wire.encode_running_proof(wt, wdig, wz, wcw, wcT, wproof.W, wproof.E)
+out["wire_t3"] = {"t": wt, "steps": wn, "seed": 31, "i0": 1, "digest": wdig.hex(), "compressed_proof_hex": wire_snark.hex(),
+                  "running_proof_sha256": hashlib.sha256(wire_running).hexdigest(), "running_proof_len": len(wire_running)}
+
 path = os.path.join(os.path.dirname(__file__), "vectors.json")
 json.dump(out, open(path, "w"), indent=0)
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -2,68 +2,24 @@
 the reference's test_nova_proof (src/nova/proof.rs:403-451) at its own size, BASELINE config 1
 (t = 1024, 3 steps), and a full replay of the folds by the oracle (witness, error vector,
 instance, commitments through the discrete-log identity, SHAKE256 transcript)."""
-import hashlib
-
 import numpy as np
 import pytest
 
 from oracle import pasta as o
+from oracle import nifs
 from util import ints, unmont
 from vdf_amd.minroot import PallasVDF, State, FIELD_FQ
 from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
 
 pytestmark = pytest.mark.gpu
-GENS_SEED = 0x4E6F7661
-GENS_FAMILY = 1                     # VDF_GENS_TRY_AND_INCREMENT: the family public_params derives its generators from
-_GENS = {}
-
-
-def gens(n, start=0):
-    """The first n generators of public_params (oracle restatement), cached across tests."""
-    for i in range(start, start + n):
-        if i not in _GENS:
-            _GENS[i] = o.tai_base(o.CURVE_PALLAS, GENS_SEED, i)
-    return [_GENS[i] for i in range(start, start + n)]
-
-
-def commit(v):
-    """Pedersen commitment of the oracle: sum v_i G_i, (0, 0) for the identity."""
-    return o.msm_naive(list(v), gens(len(v)), o.CURVE_PALLAS) or (0, 0)
-
-
-def le32(v):
-    return int(v).to_bytes(32, "little")
+# the oracle side of the proof layer lives in oracle/nifs.py; these names are what the other GPU tests import
+GENS_SEED, GENS_FAMILY = nifs.GENS_SEED, nifs.GENS_FAMILY
+gens, commit, le32, shape_digest, challenge = nifs.gens, nifs.commit, nifs.le32, nifs.shape_digest, nifs.challenge
 
 
 def aff_ints(arr):
     x, y = unmont(np.asarray(arr).reshape(2, 4), o.P)
     return (x, y)
-
-
-def shape_digest(sh, t):
-    h = hashlib.shake_256()
-    h.update(b"vdf-nova-shape-v1")
-    for v in (t, sh.num_cons, sh.num_vars, sh.num_io, GENS_SEED, GENS_FAMILY):
-        h.update(int(v).to_bytes(8, "little"))
-    for mat in (sh.A, sh.B, sh.C):
-        for r, c, v in mat:
-            h.update(int(r).to_bytes(4, "little") + int(c).to_bytes(4, "little") + le32(v))
-    return h.digest(32)
-
-
-def challenge(digest, cW, cE, u, X, cw2, X2, cT):
-    h = hashlib.shake_256()
-    h.update(b"vdf-nova-fold-v1" + digest)
-    for p in (cW, cE):
-        h.update(le32(p[0]) + le32(p[1]))
-    h.update(le32(u))
-    for v in X:
-        h.update(le32(v))
-    h.update(le32(cw2[0]) + le32(cw2[1]))
-    for v in X2:
-        h.update(le32(v))
-    h.update(le32(cT[0]) + le32(cT[1]))
-    return int.from_bytes(h.digest(16), "little")
 
 
 def make(ctx, t, n, seed=42, i0=1):
@@ -120,43 +76,25 @@ def test_prove_steps_replayed_by_the_oracle(ctx, t, n):
     assert (sizes["num_cons"], sizes["num_vars"], sizes["num_io"]) == (sh.num_cons, sh.num_vars, 6)
     assert sizes["nnz"] == len(sh.A) + len(sh.B) + len(sh.C)
     digest = shape_digest(sh, t)
-    # forward states by the oracle
-    states = [o.State(*init_ints)]
-    for _ in range(n):
-        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    # the whole chain by the oracle, then the product step by step against its prefixes
+    states = nifs.forward_states(o.State(*init_ints), t, n)
     proof = None
-    W = E = u = X = cW = cE = None
     for k in range(n):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
-        res, inp = states[n - k], states[n - k - 1]
-        W2 = [res.x, res.y, res.i] + o.step_witness_segment(res, t, o.FIELD_FQ)
-        X2 = [res.x, res.y, res.i, inp.x, inp.y, inp.i]
-        cw2 = commit(W2)
-        rec = proof.step_record(k)
-        assert aff_ints(rec["comm_w"]) == cw2
-        assert unmont(rec["X"], m) == X2
-        if k == 0:
-            W, E, u, X, cW, cE = W2, [0] * sh.num_cons, 1, X2, cw2, (0, 0)
-        else:
-            a1, b1, c1 = o.multiply_vec(sh, W + [u] + X, m)
-            a2, b2, c2 = o.multiply_vec(sh, W2 + [1] + X2, m)
-            T = o.cross_term(a1, b1, c1, a2, b2, c2, u, m)
-            cT = commit(T)
-            assert aff_ints(rec["comm_T"]) == cT
-            r = challenge(digest, cW, cE, u, X, cw2, X2, cT)
-            assert unmont(rec["r"].reshape(1, 4), m) == [r]
-            W, E = o.axpy(W, r, W2, m), o.axpy(E, r, T, m)
-            u, X = (u + r) % m, o.axpy(X, r, X2, m)
-            cW = o.pt_add(None if cW == (0, 0) else cW, o.pt_mul(r, None if cw2 == (0, 0) else cw2, o.P), o.P) or (0, 0)
-            cE = o.pt_add(None if cE == (0, 0) else cE, o.pt_mul(r, None if cT == (0, 0) else cT, o.P), o.P) or (0, 0)
+        want, sh2, dg = nifs.prove_chain(states[n - k - 1], t, k + 1)      # the first k + 1 steps end at states[n-k-1]
+        assert dg == digest
+        for j in range(k + 1):
+            rec, ws = proof.step_record(j), want.steps[j]
+            assert aff_ints(rec["comm_w"]) == ws.comm_w and aff_ints(rec["comm_T"]) == ws.comm_T
+            assert unmont(rec["r"].reshape(1, 4), m) == [ws.r] and unmont(rec["X"], m) == ws.X
         inst = proof.instance()
         gW, gE = proof.witness()
-        assert unmont(gW, m) == W
-        assert unmont(gE, m) == E
-        assert unmont(inst["u"].reshape(1, 4), m) == [u]
-        assert unmont(inst["X"], m) == X
-        assert aff_ints(inst["comm_W"]) == cW and aff_ints(inst["comm_E"]) == cE
-        assert o.is_sat_relaxed(sh, W, E, u, X, m)
+        assert unmont(gW, m) == want.W
+        assert unmont(gE, m) == want.E
+        assert unmont(inst["u"].reshape(1, 4), m) == [want.u]
+        assert unmont(inst["X"], m) == want.X
+        assert aff_ints(inst["comm_W"]) == want.comm_W and aff_ints(inst["comm_E"]) == want.comm_E
+        assert o.is_sat_relaxed(sh, want.W, want.E, want.u, want.X, m)
     zi = [State.from_ints(FIELD_FQ, *init_ints).x, State.from_ints(FIELD_FQ, *init_ints).y, State.from_ints(FIELD_FQ, *init_ints).i]
     assert proof.verify(pp, n, z0, zi)
 

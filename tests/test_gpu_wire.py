@@ -54,6 +54,19 @@ def test_compressed_proof_bytes_equal_the_oracles(ctx, t, n):
     assert again.verify(pp, n, z0, _zi(init_ints))
 
 
+def test_product_bytes_equal_the_committed_vector(ctx, golden):
+    """tests/golden/vectors.json "wire_t3" (made on the CPU by the oracle alone): the product's bytes for the same chain."""
+    import hashlib
+    g = golden["wire_t3"]
+    t, n = g["t"], g["steps"]
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=g["seed"], i0=g["i0"])
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.compress(pp).serialize().hex() == g["compressed_proof_hex"]
+    running = proof.serialize()
+    assert len(running) == g["running_proof_len"] and hashlib.sha256(running).hexdigest() == g["running_proof_sha256"]
+    assert CompressedNovaVDFProof.deserialize(pp, bytes.fromhex(g["compressed_proof_hex"])).verify(pp, n, z0, _zi(init_ints))
+
+
 def test_a_verifier_in_its_own_context_accepts_the_bytes_and_nothing_else(ctx):
     """The prover's objects never reach the verifier: fresh context, public parameters derived again, bytes only."""
     t, n = 64, 3
