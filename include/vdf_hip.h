@@ -21,7 +21,8 @@
  *   - Calls are blocking unless the context is in async mode AND every buffer of the call
  *     is device-resident; then work is enqueued on the context's HIP stream.
  *   - Re-entrant across threads on one context (per-context mutex); no global mutable state
- *     except the lazily created default context of the two `mult_pippenger_*` shims.
+ *     except the lazily created default context of the two `mult_pippenger_*` shims and, when switched on,
+ *     their generator cache (vdf_shim_set_cache).
  *   - No C++ exception or abort crosses this boundary: int status + vdf_last_error().
  *   - There is NO CPU back-end: vdf_ctx_create fails with VDF_ERR_NO_DEVICE without a GPU.
  */
@@ -147,6 +148,14 @@ int  vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls);
  * readable through vdf_last_error(NULL)). */
 void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
 void mult_pippenger_vesta(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
+/* Generator cache of the shims: keep up to `entries` (0..64; 0 = off, the default; the environment variable
+ * VDF_SHIM_CACHE sets the initial value) generator arrays resident, recognised by (curve, address, length) and a
+ * fingerprint of 64 sampled points; from the second call on a set also gets its fixed-base table.  For callers whose
+ * generators are immutable once made -- nova-snark's CommitGens -- the unmodified pasta-msm call then costs a scalar
+ * upload and a table MSM instead of a 64-byte-per-point upload and a table-less one.  A caller that rewrites a
+ * generator array in place between calls must leave the cache off (a change outside the sampled points would go
+ * unnoticed).  The address is used as a key only and never dereferenced outside the call that passes it. */
+int  vdf_shim_set_cache(int entries);
 
 /* ---- R1CS shape + sparse mat-vec ------------------------------------------------------- */
 /* Replaces nova-snark R1CSShape{A,B,C} (COO triples over z = (W, u, X)) and

@@ -213,6 +213,53 @@ def test_pippenger_shims(cref):
         assert jac_to_affine(out, curve) == o.msm_by_dlog(sc, curve, 2)
 
 
+def test_pippenger_shim_generator_cache(cref):
+    """vdf_shim_set_cache: the same generator array on later calls is served from HBM (plain, then with its table);
+    results stay those of the uncached shim; a rewritten array (sampled point), another length and eviction are handled."""
+    import time
+    from vdf_amd._lib import lib
+    curve, n = o.CURVE_PALLAS, 1 << 16
+    pts = np.zeros((n, 8), dtype="<u8")
+    cref.lib().ref_synthetic_bases(curve, 3, 0, n, cref.p(pts))
+    rng = np.random.default_rng(21)
+    sm = o.curve_scalar_modulus(curve)
+    out = np.zeros(12, dtype="<u8")
+
+    def run(points, count, seed):
+        sc = rand_limbs(np.random.default_rng(seed), count)
+        t0 = time.perf_counter()
+        lib.mult_pippenger_pallas(out.ctypes.data, points.ctypes.data, count, sc.ctypes.data, False)
+        dt = time.perf_counter() - t0
+        return jac_to_affine(out, curve), ints(sc), dt
+
+    assert lib.vdf_shim_set_cache(65) != 0 and lib.vdf_shim_set_cache(-1) != 0
+    assert lib.vdf_shim_set_cache(2) == 0
+    try:
+        times = []
+        for call in range(4):                      # upload, cached + table build, cached table, cached table
+            got, sc, dt = run(pts, n, 100 + call)
+            assert got == o.msm_by_dlog(sc, curve, 3)
+            times.append(dt)
+        print("shim call times (ms):", [round(1e3 * t, 2) for t in times])
+        got, sc, _ = run(pts, 5000, 7)             # a prefix is another set
+        assert got == o.msm_by_dlog(sc, curve, 3)
+        # the array rewritten in place where the fingerprint looks: first generator doubled
+        g0 = o.synthetic_bases(curve, 3, 1)[0]
+        pts2 = pts.copy()
+        pts[0] = affine_array([o.pt_add(g0, g0, o.P)], curve)[0]
+        got, sc, _ = run(pts, n, 9)
+        want = o.pt_add(o.msm_by_dlog(sc, curve, 3), o.pt_mul(sc[0], g0, o.P), o.P)      # + one more s_0 * G_0
+        assert got == want
+        # eviction: two other sets push the first one out; it still computes correctly afterwards
+        for k, arr in enumerate((pts2, pts2[:30000].copy())):
+            got, sc, _ = run(arr, len(arr), 50 + k)
+            assert got == o.msm_by_dlog(sc, curve, 3)
+        got, sc, _ = run(pts, n, 10)
+        assert got == o.pt_add(o.msm_by_dlog(sc, curve, 3), o.pt_mul(sc[0], g0, o.P), o.P)
+    finally:
+        assert lib.vdf_shim_set_cache(0) == 0      # frees every cached set
+
+
 def test_error_paths(ctx):
     import vdf_amd
     bases = ctx.bases_generate(o.CURVE_PALLAS, 1, 16)

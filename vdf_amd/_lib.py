@@ -28,6 +28,7 @@ PROTOTYPES = {
     "vdf_ctx_get_async": (_i, [_vp, C.POINTER(_i)]),
     "vdf_ctx_sync": (_i, [_vp]),
     "vdf_ctx_wait": (_i, [_vp, _vp]),
+    "vdf_shim_set_cache": (_i, [_i]),
     "vdf_ctx_mark": (_i, [_vp, _i]),
     "vdf_ctx_sync_mark": (_i, [_vp, _i]),
     "vdf_ctx_device": (_i, [_vp]),

@@ -195,17 +195,80 @@ vdf_ctx* default_ctx() {
   return g_default_ctx;
 }
 
+// Generator cache of the shims (vdf_shim_set_cache).  nova-snark commits under the same CommitGens for the life of the
+// process; the upstream signature gives no handle to keep them resident, so the shim recognises a generator array by
+// (curve, address, length) and a fingerprint of 64 sampled points, keeps it in HBM, and from the second call on with
+// its fixed-base table.  The address is a key only: it is dereferenced in the call that passes it, never later.
+struct ShimEntry { int curve; const void* ptr; size_t n; uint64_t fp; vdf_bases* bases; uint64_t last_use; bool table; };
+std::mutex g_shim_mu;
+std::vector<ShimEntry> g_shim;
+int g_shim_cap = -1;                 // -1: not decided yet (environment), 0: off
+uint64_t g_shim_clock = 0;
+
+uint64_t shim_fingerprint(const vdf_affine* points, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+  const size_t samples = n < 64 ? n : 64;
+  for (size_t k = 0; k < samples; ++k) {
+    const size_t i = samples == n ? k : (k == samples - 1 ? n - 1 : k * (n / samples));
+    uint64_t w[8];
+    std::memcpy(w, &points[i], 64);
+    for (uint64_t v : w) { h ^= v; h *= 0x100000001b3ull; h ^= h >> 29; }
+  }
+  return h;
+}
+
+int shim_cache_capacity() {          // caller holds g_shim_mu
+  if (g_shim_cap < 0) {
+    const char* ov = std::getenv("VDF_SHIM_CACHE");
+    const long v = ov ? std::atol(ov) : 0;
+    g_shim_cap = v > 0 ? (v > 64 ? 64 : (int)v) : 0;
+  }
+  return g_shim_cap;
+}
+
 void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf_fe* scalars, bool is_mont) {
   if (out) std::memset(out, 0, sizeof(*out));
   vdf_ctx* ctx = default_ctx();
   if (!ctx || !out) return;
   vdf_bases* b = nullptr;
-  if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
+  bool cached = false, want_table = false;
+  {
+    std::lock_guard<std::mutex> lock(g_shim_mu);
+    if (shim_cache_capacity() > 0 && points && n) {
+      const uint64_t fp = shim_fingerprint(points, n);
+      for (ShimEntry& e : g_shim)
+        if (e.curve == curve && e.ptr == (const void*)points && e.n == n && e.fp == fp) {
+          b = e.bases; cached = true; e.last_use = ++g_shim_clock;
+          want_table = !e.table;                     // the second call for a set pays for its table
+          e.table = true;
+          break;
+        }
+    }
+  }
+  if (!cached) {
+    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
+  } else if (want_table && n >= 1024) {
+    (void)vdf_bases_precompute(ctx, b, 16, 1);       // failure (memory) leaves the plain path
+  }
   if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
     g_create_err = ctx->err;
     std::memset(out, 0, sizeof(*out));
   }
-  vdf_bases_free(b);
+  if (cached) return;
+  std::lock_guard<std::mutex> lock(g_shim_mu);
+  const int cap = shim_cache_capacity();
+  if (cap <= 0) { vdf_bases_free(b); return; }
+  // a stale entry for this address (same array, new contents or length) goes; then the least recently used
+  for (size_t i = 0; i < g_shim.size();)
+    if (g_shim[i].curve == curve && g_shim[i].ptr == (const void*)points && g_shim[i].n == n) { vdf_bases_free(g_shim[i].bases); g_shim.erase(g_shim.begin() + i); }
+    else ++i;
+  while ((int)g_shim.size() >= cap) {
+    size_t lru = 0;
+    for (size_t i = 1; i < g_shim.size(); ++i) if (g_shim[i].last_use < g_shim[lru].last_use) lru = i;
+    vdf_bases_free(g_shim[lru].bases);
+    g_shim.erase(g_shim.begin() + lru);
+  }
+  g_shim.push_back(ShimEntry{curve, (const void*)points, n, shim_fingerprint(points, n), b, ++g_shim_clock, false});
 }
 
 template <class P>
@@ -593,6 +656,14 @@ int vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls) {
     ctx->timed.clear();
     return Status{};
   });
+}
+
+int vdf_shim_set_cache(int entries) {
+  if (entries < 0 || entries > 64) return VDF_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lock(g_shim_mu);
+  g_shim_cap = entries;
+  while ((int)g_shim.size() > entries) { vdf_bases_free(g_shim.back().bases); g_shim.pop_back(); }
+  return VDF_OK;
 }
 
 void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont) {
