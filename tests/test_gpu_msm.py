@@ -179,6 +179,42 @@ def test_full_size_2_20_dlog_identity(ctx, mode):
     bases.free()
 
 
+def test_maximum_size_2_24_additivity(ctx):
+    """BASELINE config 4's total size on one GPU (2^24 Pallas points, 16 GiB fixed-base table): too large for any host
+    check, so the size-independent property -- MSM(all) equals the sum of the four quarter MSMs taken at offsets into the
+    same table -- plus the two-scalar-vector linearity on the first quarter."""
+    import torch
+    curve, n = o.CURVE_PALLAS, 1 << 24
+    bases = ctx.bases_generate(curve, 7, n)
+    bases.precompute(16, 1)
+    g = torch.Generator(device="cuda"); g.manual_seed(24)
+    sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    was = ctx.get_async()
+    ctx.set_async(False)
+    try:
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        ctx.msm(bases, sc, n=n, out=out)
+        q = n // 4
+        parts = torch.zeros((4, 12), dtype=torch.int64, device="cuda")
+        for k in range(4):
+            ctx.msm(bases, sc[k * q:(k + 1) * q], n=q, offset=k * q, out=parts[k])
+        tot = torch.zeros(12, dtype=torch.int64, device="cuda")
+        ctx.point_sum(curve, parts, 4, out=tot)
+        aff = lambda t: jac_to_affine(t.cpu().numpy().view("<u8"), curve)
+        assert aff(out) == aff(tot) and aff(out) is not None
+        # ragged split as well: 3 + (n - 3)
+        ctx.msm(bases, sc[:3], n=3, out=parts[0])
+        ctx.msm(bases, sc[3:], n=n - 3, offset=3, out=parts[1])
+        ctx.point_sum(curve, parts, 2, out=tot)
+        assert aff(out) == aff(tot)
+    finally:
+        ctx.set_async(was)
+        bases.free()
+        del sc
+        torch.cuda.empty_cache()
+
+
 def test_linearity_property(ctx):
     """msm(a + r*b) == msm(a) + r*msm(b): ties the MSM and axpy kernels together at 2^16."""
     n, curve = 1 << 16, o.CURVE_PALLAS
