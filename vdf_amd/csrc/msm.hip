@@ -24,7 +24,8 @@
 //   k_fixup       per bucket (one quad): add the heads of the slices it spans; buckets spanning many slices are
 //                 queued and reduced by a whole wavefront (k_fixup_heavy: strided partial sums, then
 //                 a butterfly of quad additions).
-//   k_reduce1/2   sum_b (b+1)*B_b per bucket set (running sums per segment + scalar offset, LDS tree)
+//   k_red_sums/weights/combine   sum_b (b+1)*B_b per bucket set: row and column sums of the bucket matrix, small
+//                 multiplications of those, one workgroup per set (k_reduce1/2: the first version, for tiny sets)
 //   k_final       per group: Horner over its bucket sets, XYZZ -> Jacobian
 // The tail kernels use the quad-cooperative group law of ecq.cuh.  msm_run with an external bucket array stops
 // after the fix-up; msm_tail then reduces the groups of an MSM job (vdf_msm_job_*) together.
@@ -90,6 +91,41 @@ static RedGeom red_geom(size_t nkeys, uint32_t nbk) {
   return r;
 }
 
+// Bucket reduction as a matrix (k_red_sums / k_red_weights / k_red_combine).  The nbk = 2^m buckets of a set form a
+// matrix of 2^H rows and 2^L columns (bucket b = h 2^L + l);  sum_b (b+1) B_b = sum_l (l+1) C_l + 2^L sum_h h R_h  with
+// the column sums C_l and row sums R_h: two additions per bucket and then only 2^H + 2^L small multiplications,
+// where one segment of buckets per quad (k_reduce1) multiplies every quad's running sum by its offset.
+struct MatGeom {
+  uint32_t Lb, nrows, ncols, nsums;      // columns = 2^Lb
+  uint32_t Q, sums_per_wg, wgs_per_set;  // phase 1: Q quads (a power of two <= 64) per sum
+  uint32_t bA, bB;                       // phase 2 workgroups per set: column part, row part
+  size_t sums_bytes, scratch_bytes;      // per call: sums of all sets, then the phase-2 partials
+};
+static MatGeom mat_geom(size_t gsets, uint32_t nbk) {
+  MatGeom g;
+  uint32_t m = 0;
+  while ((1u << m) < nbk) ++m;
+  g.Lb = (m + 1) / 2;
+  g.ncols = 1u << g.Lb;
+  g.nrows = nbk >> g.Lb;
+  g.nsums = g.nrows + g.ncols;
+  uint32_t q = g.nrows / 2;                                  // at least two points per quad in a column sum
+  if (q < 1) q = 1;
+  if (q > 64) q = 64;
+  g.Q = q;
+  g.sums_per_wg = 64 / g.Q;
+  g.wgs_per_set = (g.nsums + g.sums_per_wg - 1) / g.sums_per_wg;
+  g.bA = (g.ncols + 63) / 64;
+  g.bB = (g.nrows + 63) / 64;
+  g.sums_bytes = align_up(gsets * g.nsums * 128, 256);
+  g.scratch_bytes = g.sums_bytes + align_up(gsets * (g.bA + g.bB) * 128, 256);
+  return g;
+}
+static bool use_matrix_reduction(uint32_t nbk) {
+  static const int mode = [] { const char* ov = std::getenv("VDF_MSM_RED"); return ov ? std::atoi(ov) : 1; }();   // tuning override: 0 = segments
+  return mode != 0 && nbk >= 16;
+}
+
 static WsLayout ws_layout(const MsmPlan& p) {
   WsLayout w{};
   size_t off = 0;
@@ -110,7 +146,11 @@ static WsLayout ws_layout(const MsmPlan& p) {
   const RedGeom rg = red_geom(nkeys, p.nbk);
   w.red_seg = rg.seg; w.red_threads_per_set = rg.threads_per_set; w.red_block = rg.block;
   w.red_blocks_per_set = rg.blocks_per_set;
-  w.partials = take((size_t)p.gsets * w.red_blocks_per_set * 128);
+  {
+    const size_t seg_bytes = (size_t)p.gsets * w.red_blocks_per_set * 128;
+    const size_t mat_bytes = mat_geom(p.gsets, p.nbk).scratch_bytes;
+    w.partials = take(seg_bytes > mat_bytes ? seg_bytes : mat_bytes);
+  }
   w.wsum = take((size_t)p.gsets * 128);
   w.total = off;
   return w;
@@ -713,6 +753,99 @@ __global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partia
   if (lt == 0) qpoint_store<P>(wsum + (size_t)set * 128, acc);
 }
 
+// ---- bucket reduction as a matrix (mat_geom) ----
+// phase 1: every row sum and column sum of every set; Q quads share a sum (strided), LDS tree within the Q quads
+template <class P>
+__global__ __launch_bounds__(256) void k_red_sums(const char* __restrict__ bucket_acc, uint32_t nbk, uint32_t Lb, uint32_t Q,
+                                                  uint32_t wgs_per_set, char* __restrict__ sums) {
+  raise_wave_priority();
+  __shared__ __align__(16) char lds_raw[64 * 128];
+  const uint32_t ncols = 1u << Lb, nrows = nbk >> Lb, nsums = nrows + ncols;
+  const uint32_t set = blockIdx.x / wgs_per_set, blk = blockIdx.x % wgs_per_set;
+  const uint32_t lt = threadIdx.x >> 2, sub = lt / Q, qi = lt % Q;
+  const uint32_t sidx = blk * (64 / Q) + sub;                      // which sum of the set
+  const char* bp = bucket_acc + (size_t)set * nbk * 128;
+  QPoint<P> acc = qpoint_identity<P>();
+  if (sidx < nrows) {
+    for (uint32_t l = qi; l < ncols; l += Q) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(bp + ((size_t)sidx * ncols + l) * 128));
+  } else if (sidx < nsums) {
+    const uint32_t l = sidx - nrows;
+    for (uint32_t h = qi; h < nrows; h += Q) acc = qpoint_add<P>(acc, qpoint_load_lazy<P>(bp + ((size_t)h * ncols + l) * 128));
+  }
+  qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+  __syncthreads();
+  for (uint32_t stride = Q >> 1; stride >= 1; stride >>= 1) {
+    if (qi < stride) {
+      acc = qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)(lt + stride) * 128));
+      qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+    }
+    __syncthreads();
+  }
+  if (qi == 0 && sidx < nsums) qpoint_store<P>(sums + ((size_t)set * nsums + sidx) * 128, acc);
+}
+
+// phase 2: one quad per sum: (l+1) C_l or h R_h by double-and-add, then an LDS tree; a workgroup holds sums of one
+// kind of one set, so the two kinds come out as separate partials (the rows still lack their common factor 2^Lb)
+template <class P>
+__global__ __launch_bounds__(256) void k_red_weights(const char* __restrict__ sums, uint32_t nbk, uint32_t Lb, uint32_t bA,
+                                                     uint32_t bB, char* __restrict__ partials) {
+  raise_wave_priority();
+  __shared__ __align__(16) char lds_raw[64 * 128];
+  const uint32_t ncols = 1u << Lb, nrows = nbk >> Lb, nsums = nrows + ncols;
+  const uint32_t set = blockIdx.x / (bA + bB), blk = blockIdx.x % (bA + bB);
+  const uint32_t lt = threadIdx.x >> 2;
+  const bool col = blk < bA;
+  const uint32_t idx = (col ? blk : blk - bA) * 64 + lt;           // column l or row h
+  const uint32_t weight = col ? idx + 1 : idx;
+  QPoint<P> tot = qpoint_identity<P>();
+  if (idx < (col ? ncols : nrows) && weight) {
+    const QPoint<P> pt = qpoint_load<P>(sums + ((size_t)set * nsums + (col ? nrows + idx : idx)) * 128);
+    for (int bit = 31 - __builtin_clz(weight); bit >= 0; --bit) {
+      tot = qpoint_dbl<P>(tot);
+      if ((weight >> bit) & 1u) tot = qpoint_add<P>(tot, pt);
+    }
+  }
+  qpoint_store<P>(lds_raw + (size_t)lt * 128, tot);
+  __syncthreads();
+  for (uint32_t stride = 32; stride >= 1; stride >>= 1) {
+    if (lt < stride) {
+      tot = qpoint_add<P>(tot, qpoint_load<P>(lds_raw + (size_t)(lt + stride) * 128));
+      qpoint_store<P>(lds_raw + (size_t)lt * 128, tot);
+    }
+    __syncthreads();
+  }
+  if (lt == 0) qpoint_store<P>(partials + ((size_t)set * (bA + bB) + blk) * 128, tot);
+}
+
+// phase 3: per set, the column partials + 2^Lb * the row partials (quads 0..31 / 32..63, a tree in each half)
+template <class P>
+__global__ __launch_bounds__(256) void k_red_combine(const char* __restrict__ partials, uint32_t Lb, uint32_t bA, uint32_t bB,
+                                                     char* __restrict__ wsum) {
+  raise_wave_priority();
+  __shared__ __align__(16) char lds_raw[64 * 128];
+  const uint32_t set = blockIdx.x;
+  const uint32_t lt = threadIdx.x >> 2, half = lt >> 5, qi = lt & 31u;
+  const char* base = partials + (size_t)set * (bA + bB) * 128 + (half ? (size_t)bA * 128 : 0);
+  const uint32_t count = half ? bB : bA;
+  QPoint<P> acc = qpoint_identity<P>();
+  for (uint32_t i = qi; i < count; i += 32) acc = qpoint_add<P>(acc, qpoint_load<P>(base + (size_t)i * 128));
+  qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+  __syncthreads();
+  for (uint32_t stride = 16; stride >= 1; stride >>= 1) {
+    if (qi < stride) {
+      acc = qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)(lt + stride) * 128));
+      qpoint_store<P>(lds_raw + (size_t)lt * 128, acc);
+    }
+    __syncthreads();
+  }
+  if (lt == 32) {
+    for (uint32_t k = 0; k < Lb; ++k) acc = qpoint_dbl<P>(acc);
+    qpoint_store<P>(lds_raw + (size_t)32 * 128, acc);
+  }
+  __syncthreads();
+  if (lt == 0) qpoint_store<P>(wsum + (size_t)set * 128, qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)32 * 128)));
+}
+
 // Horner over a group's bucket sets (one quad per group, one workgroup each), XYZZ -> Jacobian
 template <class P>
 __global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum_all, int sets, int c, char* __restrict__ out_all) {
@@ -869,10 +1002,19 @@ template <class P>
 static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* bucket_acc, char* partials, char* wsum,
                          void* d_out, hipStream_t st) {
   const uint32_t gsets = (uint32_t)(groups * sets);
-  const RedGeom rg = red_geom((size_t)gsets * nbk, nbk);
-  hipLaunchKernelGGL((k_reduce1<P>), dim3(gsets * rg.blocks_per_set), dim3(rg.block * 4), (size_t)rg.block * 128, st,
-                     bucket_acc, nbk, rg.seg, rg.threads_per_set, rg.blocks_per_set, partials);
-  hipLaunchKernelGGL((k_reduce2<P>), dim3(gsets), dim3(256), 0, st, partials, rg.blocks_per_set, wsum);
+  if (use_matrix_reduction(nbk)) {
+    const MatGeom g = mat_geom(gsets, nbk);
+    char* sums = partials;
+    char* parts = partials + g.sums_bytes;
+    hipLaunchKernelGGL((k_red_sums<P>), dim3(gsets * g.wgs_per_set), dim3(256), 0, st, bucket_acc, nbk, g.Lb, g.Q, g.wgs_per_set, sums);
+    hipLaunchKernelGGL((k_red_weights<P>), dim3(gsets * (g.bA + g.bB)), dim3(256), 0, st, sums, nbk, g.Lb, g.bA, g.bB, parts);
+    hipLaunchKernelGGL((k_red_combine<P>), dim3(gsets), dim3(256), 0, st, parts, g.Lb, g.bA, g.bB, wsum);
+  } else {
+    const RedGeom rg = red_geom((size_t)gsets * nbk, nbk);
+    hipLaunchKernelGGL((k_reduce1<P>), dim3(gsets * rg.blocks_per_set), dim3(rg.block * 4), (size_t)rg.block * 128, st,
+                       bucket_acc, nbk, rg.seg, rg.threads_per_set, rg.blocks_per_set, partials);
+    hipLaunchKernelGGL((k_reduce2<P>), dim3(gsets), dim3(256), 0, st, partials, rg.blocks_per_set, wsum);
+  }
   hipLaunchKernelGGL((k_final<P>), dim3(groups), dim3(64), 0, st, wsum, sets, c, reinterpret_cast<char*>(d_out));
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
@@ -944,17 +1086,20 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
 
 // Stand-alone bucket reduction over `groups` x `sets` bucket sets laid out back to back (a job's shared array).
 // tail_ws: msm_tail_ws_bytes() bytes = the bucket array followed by the reduction scratch.
+static size_t tail_scratch_bytes(size_t gsets, uint32_t nbk) {
+  const RedGeom rg = red_geom(gsets * nbk, nbk);
+  const size_t seg = align_up(gsets * rg.blocks_per_set * 128, 256), mat = mat_geom(gsets, nbk).scratch_bytes;
+  return seg > mat ? seg : mat;
+}
 size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk) {
   const size_t gsets = (size_t)groups * sets;
-  const RedGeom rg = red_geom(gsets * nbk, nbk);
-  return align_up(gsets * nbk * 128, 256) + align_up(gsets * rg.blocks_per_set * 128, 256) + align_up(gsets * 128, 256);
+  return align_up(gsets * nbk * 128, 256) + tail_scratch_bytes(gsets, nbk) + align_up(gsets * 128, 256);
 }
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream) {
   const size_t gsets = (size_t)groups * sets;
-  const RedGeom rg = red_geom(gsets * nbk, nbk);
   char* bucket_acc = reinterpret_cast<char*>(tail_ws);
   char* partials = bucket_acc + align_up(gsets * nbk * 128, 256);
-  char* wsum = partials + align_up(gsets * rg.blocks_per_set * 128, 256);
+  char* wsum = partials + tail_scratch_bytes(gsets, nbk);
   if (curve == VDF_CURVE_PALLAS) return msm_tail_t<FpParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
   if (curve == VDF_CURVE_VESTA) return msm_tail_t<FqParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
