@@ -90,3 +90,21 @@ def test_c_example_builds_against_the_headers():
     """The plain-C client links against the two libraries (no GPU needed to build it)."""
     exe = os.path.join(ROOT, "examples", "prove_chain")
     assert os.path.exists(exe), "make -C vdf_amd/csrc"
+
+
+def test_rust_sys_bindings_are_complete_and_current():
+    """bindings/rust/vdf-hip-sys/src/lib.rs is generated from the two headers (tools/gen_rust_sys.py); it cannot be
+    compiled here (no Rust toolchain), so what is checked is that it is what the generator makes of today's headers and
+    that it declares every symbol the headers do."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    have = open(os.path.join(ROOT, "bindings", "rust", "vdf-hip-sys", "src", "lib.rs")).read()
+    assert have == gen.emit(), "run tools/gen_rust_sys.py"
+    declared = set(re.findall(r"pub fn (\w+)\(", have))
+    for header in ("vdf_hip.h", "vdf_nova.h"):
+        txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        for name in set(re.findall(r"\b((?:vdf_|mult_pippenger_)\w+)\s*\(", txt)):
+            assert name in declared, name
+    assert "*const *mut VdfFe" in have and "*mut *mut VdfCtx" in have      # pointer constness survives the translation
