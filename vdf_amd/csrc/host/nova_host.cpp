@@ -441,10 +441,10 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       m.y = neg(m.y, Fb);
       p->c_pt = pt_add(p->c_pt, pt_from_aff(m, Fb), Fb);                     // consecutive steps: C -= t S0
     } else {
-      const Fe k = from_mont(sub(c.result.i, one(F), F), F);
+      const Fe i0m1 = from_mont(sub(c.result.i, one(F), F), F);              // i_0 - 1 as an integer
       Aff s1 = pp->S1;
       s1.y = neg(s1.y, Fb);
-      p->c_pt = pt_add(pt_mul(pt_from_aff(pp->S0, Fb), k.l, 255, Fb), pt_from_aff(s1, Fb), Fb);
+      p->c_pt = pt_add(pt_mul(pt_from_aff(pp->S0, Fb), i0m1.l, 255, Fb), pt_from_aff(s1, Fb), Fb);
     }
     p->c_i0 = c.result.i;
     p->c_valid = true;
