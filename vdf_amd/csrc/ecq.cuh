@@ -70,6 +70,12 @@ template <class P> __device__ __forceinline__ QPoint<P> qpoint_scatter(const XYZ
   return r;
 }
 
+// -a: the y coordinate (lane 1) changes sign
+template <class P> __device__ __forceinline__ QPoint<P> qpoint_neg(QPoint<P> a) {
+  a.c = fe_select(quad_pos() == 1, fe_neg(a.c), a.c);
+  return a;
+}
+
 // 2 * a  (dbl-2008-s-1, a = 0) in four multiplication stages
 template <class P> __device__ __attribute__((noinline)) QPoint<P> qpoint_dbl(QPoint<P> a) {
   if (a.inf) return a;

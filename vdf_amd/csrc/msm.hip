@@ -799,10 +799,15 @@ __global__ __launch_bounds__(256) void k_red_weights(const char* __restrict__ su
   const uint32_t weight = col ? idx + 1 : idx;
   QPoint<P> tot = qpoint_identity<P>();
   if (idx < (col ? ncols : nrows) && weight) {
+    // signed double-and-add (non-adjacent form, read off 3w and w): at most one addition per two doublings, and the
+    // slowest quad of the workgroup sets the pace
     const QPoint<P> pt = qpoint_load<P>(sums + ((size_t)set * nsums + (col ? nrows + idx : idx)) * 128);
-    for (int bit = 31 - __builtin_clz(weight); bit >= 0; --bit) {
+    const QPoint<P> mpt = qpoint_neg<P>(pt);
+    const uint32_t h3 = 3u * weight;
+    for (int bit = 31 - __builtin_clz(h3); bit >= 1; --bit) {
       tot = qpoint_dbl<P>(tot);
-      if ((weight >> bit) & 1u) tot = qpoint_add<P>(tot, pt);
+      const uint32_t hb = (h3 >> bit) & 1u, wb = (weight >> bit) & 1u;
+      if (hb != wb) tot = qpoint_add<P>(tot, hb ? pt : mpt);
     }
   }
   qpoint_store<P>(lds_raw + (size_t)lt * 128, tot);
@@ -818,9 +823,11 @@ __global__ __launch_bounds__(256) void k_red_weights(const char* __restrict__ su
 }
 
 // phase 3: per set, the column partials + 2^Lb * the row partials (quads 0..31 / 32..63, a tree in each half)
+// out_jac != nullptr (one bucket set per group): the set's sum is the group's result and leaves as a Jacobian point,
+// k_final's work for that case
 template <class P>
 __global__ __launch_bounds__(256) void k_red_combine(const char* __restrict__ partials, uint32_t Lb, uint32_t bA, uint32_t bB,
-                                                     char* __restrict__ wsum) {
+                                                     char* __restrict__ wsum, char* __restrict__ out_jac) {
   raise_wave_priority();
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t set = blockIdx.x;
@@ -843,7 +850,19 @@ __global__ __launch_bounds__(256) void k_red_combine(const char* __restrict__ pa
     qpoint_store<P>(lds_raw + (size_t)32 * 128, acc);
   }
   __syncthreads();
-  if (lt == 0) qpoint_store<P>(wsum + (size_t)set * 128, qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)32 * 128)));
+  if (lt == 0) {
+    const QPoint<P> res = qpoint_add<P>(acc, qpoint_load<P>(lds_raw + (size_t)32 * 128));
+    if (!out_jac) {
+      qpoint_store<P>(wsum + (size_t)set * 128, res);
+    } else {
+      const Jac<P> j = xyzz_to_jac(qpoint_gather(res));
+      if (threadIdx.x == 0) {
+        fe_store<P>(out_jac + (size_t)set * 96, j.x);
+        fe_store<P>(out_jac + (size_t)set * 96 + 32, j.y);
+        fe_store<P>(out_jac + (size_t)set * 96 + 64, j.z);
+      }
+    }
+  }
 }
 
 // Horner over a group's bucket sets (one quad per group, one workgroup each), XYZZ -> Jacobian
@@ -1008,7 +1027,12 @@ static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* 
     char* parts = partials + g.sums_bytes;
     hipLaunchKernelGGL((k_red_sums<P>), dim3(gsets * g.wgs_per_set), dim3(256), 0, st, bucket_acc, nbk, g.Lb, g.Q, g.wgs_per_set, sums);
     hipLaunchKernelGGL((k_red_weights<P>), dim3(gsets * (g.bA + g.bB)), dim3(256), 0, st, sums, nbk, g.Lb, g.bA, g.bB, parts);
-    hipLaunchKernelGGL((k_red_combine<P>), dim3(gsets), dim3(256), 0, st, parts, g.Lb, g.bA, g.bB, wsum);
+    char* direct = sets == 1 ? reinterpret_cast<char*>(d_out) : nullptr;
+    hipLaunchKernelGGL((k_red_combine<P>), dim3(gsets), dim3(256), 0, st, parts, g.Lb, g.bA, g.bB, wsum, direct);
+    if (direct) {
+      VDF_TRY_HIP(hipGetLastError());
+      return Status{};
+    }
   } else {
     const RedGeom rg = red_geom((size_t)gsets * nbk, nbk);
     hipLaunchKernelGGL((k_reduce1<P>), dim3(gsets * rg.blocks_per_set), dim3(rg.block * 4), (size_t)rg.block * 128, st,
