@@ -984,8 +984,9 @@ int vdf_spmv3_t(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* eq, const vd
     if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
     if (!rho || ptr_is_device(rho)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
     if (!all_device({eq, out})) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    if (!ctx->reduce_scratch) VDF_TRY_HIP(hipMalloc(&ctx->reduce_scratch, vdf::snark_reduce_scratch_bytes()));
     VDF_TRY(vdf::snark_spmvt(shape->field, shape->d_t_colptr, shape->d_t_row, shape->d_t_cm, shape->d_t_heavy, shape->t_nheavy,
-                             shape->d_dict, eq, rho, shape->num_cols, out, ctx->stream));
+                             shape->d_dict, eq, rho, shape->num_cols, out, ctx->reduce_scratch, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });

@@ -175,7 +175,8 @@ size_t snark_reduce_scratch_bytes();
 Status snark_reduce(int field, int kind, const void* const tables[], const vdf_fe* u, size_t n, void* scratch, void* out,
                     hipStream_t s);
 Status snark_spmvt(int field, const uint32_t* colptr, const uint32_t* rows, const uint32_t* cm, const uint32_t* heavy,
-                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, hipStream_t s);
+                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, void* scratch,
+                   hipStream_t s);
 Status snark_ipa_scalars(int field, const void* a, const void* sv, size_t n, size_t nj, void* sL, void* sR, hipStream_t s);
 Status snark_scale_pattern(int field, void* sv, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi, hipStream_t s);
 

@@ -256,15 +256,63 @@ __global__ __launch_bounds__(256) void k_spmvt_heavy(const uint32_t* __restrict_
   if (threadIdx.x == 0) fe_store<P>(out + (size_t)c * 32, fe_load<P>(lds));
 }
 
+// a heavy column shared by SPMVT_PARTS workgroups (the constant column of the step circuit has ~3t entries: one
+// workgroup walking them was 0.5 ms): each sums a contiguous chunk into a partial, k_spmvt_heavy_sum adds the partials
+static constexpr uint32_t SPMVT_PARTS = 64;
+template <class P>
+__global__ __launch_bounds__(256) void k_spmvt_heavy_part(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ colptr,
+                                                          const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cm,
+                                                          const char* __restrict__ dict, const char* __restrict__ eq, FeArg rho,
+                                                          char* __restrict__ partials) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __align__(16) char lds[256 * 3 * 32];
+  const uint32_t item = blockIdx.x / SPMVT_PARTS, part = blockIdx.x % SPMVT_PARTS;
+  const uint32_t c = heavy[item];
+  const uint32_t lo = colptr[c], hi = colptr[c + 1];
+  const uint32_t chunk = (hi - lo + SPMVT_PARTS - 1) / SPMVT_PARTS;
+  const uint32_t k0 = lo + part * chunk, k1 = (k0 + chunk < hi) ? k0 + chunk : hi;
+  Fe<P> pw[3];
+  pw[0] = fe_one<P>(); pw[1] = arg_fe<P>(rho); pw[2] = fe_mul(pw[1], pw[1]);
+  Fe<P> acc[3] = {fe_zero<P>(), fe_zero<P>(), fe_zero<P>()};
+  for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) acc[0] = fe_add(acc[0], spmvt_entry<P>(rows, cm, dict, eq, pw, k));
+  block_tree<P, 1>(acc, lds);
+  if (threadIdx.x == 0) fe_store<P>(partials + (size_t)blockIdx.x * 32, fe_load<P>(lds));
+}
+template <class P>
+__global__ __launch_bounds__(64) void k_spmvt_heavy_sum(const uint32_t* __restrict__ heavy, const char* __restrict__ partials,
+                                                        char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __align__(16) char lds[64 * 32];
+  fe_store<P>(lds + (size_t)threadIdx.x * 32, fe_load<P>(partials + ((size_t)blockIdx.x * SPMVT_PARTS + threadIdx.x) * 32));
+  __syncthreads();
+  for (int stride = 32; stride >= 1; stride >>= 1) {
+    if ((int)threadIdx.x < stride) {
+      char* p = lds + (size_t)threadIdx.x * 32;
+      fe_store<P>(p, fe_add(fe_load<P>(p), fe_load<P>(p + (size_t)stride * 32)));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fe_store<P>(out + (size_t)heavy[blockIdx.x] * 32, fe_load<P>(lds));
+}
+
+// scratch: snark_reduce_scratch_bytes() bytes (the context's reduction scratch), or nullptr
 Status snark_spmvt(int field, const uint32_t* colptr, const uint32_t* rows, const uint32_t* cm, const uint32_t* heavy,
-                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, hipStream_t s) {
+                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, void* scratch,
+                   hipStream_t s) {
   if (ncols == 0) return Status{};
   const FeArg r = to_arg(rho);
   SNARK_DISPATCH(field, k_spmvt, grid_for(ncols), dim3(256), 0, s, colptr, rows, cm, reinterpret_cast<const char*>(dict),
                  reinterpret_cast<const char*>(eq), r, ncols, reinterpret_cast<char*>(out));
-  if (nheavy)
+  if (!nheavy) return Status{};
+  if (scratch && nheavy * SPMVT_PARTS * 32 <= snark_reduce_scratch_bytes()) {
+    SNARK_DISPATCH(field, k_spmvt_heavy_part, dim3((unsigned)(nheavy * SPMVT_PARTS)), dim3(256), 0, s, heavy, colptr, rows, cm,
+                   reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(scratch));
+    SNARK_DISPATCH(field, k_spmvt_heavy_sum, dim3((unsigned)nheavy), dim3(64), 0, s, heavy, reinterpret_cast<const char*>(scratch),
+                   reinterpret_cast<char*>(out));
+  } else {
     SNARK_DISPATCH(field, k_spmvt_heavy, dim3((unsigned)nheavy), dim3(256), 0, s, heavy, colptr, rows, cm,
                    reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(out));
+  }
   return Status{};
 }
 
