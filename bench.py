@@ -86,7 +86,7 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     }
 
 
-def prove_step_leg(ctx, log2t, nsteps, chains=2):
+def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset=0):
     """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU (folding-only
     stage, see include/vdf_nova.h).  Forward evaluation and public parameters are outside the timed region
     (benches/nova.rs:28-59); step 0 (base case) is reported apart from the steady-state steps."""
@@ -94,7 +94,7 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2):
     from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
     t = 1 << log2t
     pp = public_params(ctx, t)
-    initial = State.from_ints(FIELD_FQ, 0x1234567890ABCDEF1234567890ABCDEF, 0, 0)   # y = 0, i = 0: benches/nova.rs:24-26
+    initial = State.from_ints(FIELD_FQ, 0x1234567890ABCDEF1234567890ABCDEF + (seed_offset << 64), 0, 0)   # y = 0, i = 0: benches/nova.rs:24-26
     t0 = time.perf_counter()
     z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(
         PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, nsteps, initial)
@@ -136,6 +136,9 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2):
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes,
            "forward_eval_s_per_step_host": eval_s / nsteps,
            "stage": "folding-only (step circuit + NIFS on the primary curve; no augmented circuit / secondary curve)"}
+    if not with_compress:
+        proof.free()
+        return out
     # compress (src/nova/proof.rs:360-368) and verification of the compressed proof, once, outside `value`
     a = time.perf_counter()
     snark = proof.compress(pp)
@@ -296,6 +299,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # prove_step across GPUs: one chain does not shard (each step needs the previous challenge), so N GPUs prove N
+    # independent chains -- replicas, no collective on the data path; only the rates are combined here
+    replicas = None
+    if (world > 1 or args.rehearse_collective) and not args.no_prove:
+        ctx.set_async(False)
+        mine = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, chains=1, with_compress=False, seed_offset=rank)
+        r = torch.tensor([mine["value"], -mine["value"], mine["value"], 1.0 if mine["verified"] else 0.0],
+                         dtype=torch.float64, device="cuda")
+        agg = r.clone()
+        dist.all_reduce(agg[0:1], op=dist.ReduceOp.SUM)
+        mx = r[1:3].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        ok = r[3:4].clone()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        replicas = {"metric": mine["metric"], "value": float(agg[0].item()), "unit": "prove_step/s", "n_gpus": world,
+                    "per_gpu_min": float(-mx[0].item()), "per_gpu_max": float(mx[1].item()), "verified": bool(ok.item() > 0.5),
+                    "steady_state_steps_per_gpu": mine["steady_state_steps"], "scaling": "weak",
+                    "what": "independent chains, one per GPU (replicas; a single chain does not shard); rank 0's stage times follow",
+                    "stage_ms": mine["stage_ms"]}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -344,7 +366,9 @@ def main():
                                  "waits for the other in-flight step's workgroups to retire; isolated_launch_ms (one step at "
                                  "a time) is the kernel itself and valu_issue_frac is computed from it (DESIGN.md 4.1, 4.2)"},
         }
-        if world == 1 and not args.no_prove:
+        if replicas is not None:
+            line["prove_step_replicas"] = replicas
+        if world == 1 and not args.no_prove and not args.rehearse_collective:
             ctx.set_async(False)
             line["prove_step"] = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, args.prove_chains)
         if world == 1 and not args.no_cpu:
