@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU (2^k)")
-    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--window", type=int, default=0, help="fixed-base window bits; 0 = the library's recommendation for this size")
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
     ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
                     help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
@@ -326,7 +326,8 @@ def main():
         acc_iso_ms = iso["accumulate"] if iso else acc_avg_ms
         alg_bytes = 96.0 * n
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
-        windows_eff = (256 + args.window - 1) // args.window          # entries per point (zero digits are rare)
+        window = shs[0].bases.window or args.window or 16
+        windows_eff = (255 + window - 1) // window                    # entries per point: scalars are below 2^255, zero digits are rare
         ctx_num_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -342,9 +343,9 @@ def main():
             "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU ({'seeded try-and-increment' if args.bases == 'tai' else '[k_i]G'} "
                                    f"generators, seed 7), uniform 254-bit scalars (torch Philox, seed 1234+rank) resident in HBM, "
-                                   f"fixed-base table c={args.window} sets={args.sets}; {depth} independent steps in flight on {depth} streams; "
+                                   f"fixed-base table c={window} sets={args.sets}; {depth} independent steps in flight on {depth} streams; "
                                    f"N>1: point-chunk shards + all-gather of 96-B partials",
-                       "points_per_gpu": n, "window_bits": args.window, "bucket_sets": args.sets, "steps_in_flight": depth},
+                       "points_per_gpu": n, "window_bits": window, "bucket_sets": args.sets, "steps_in_flight": depth},
             "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),
                          "pipeline": total_ms / max(calls, 1)},
             "stage_ms_one_step_at_a_time": iso,

@@ -96,8 +96,11 @@ int  vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t sta
 enum { VDF_GENS_KNOWN_DLOG = 0, VDF_GENS_TRY_AND_INCREMENT = 1 };
 int  vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed, size_t start, size_t n, vdf_bases** out);
 /* Build the fixed-base table  2^(window_bits*sets*j) * P_i, j = 0..tables-1, so that an MSM
- * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table). */
+ * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table).  window_bits == 0: the
+ * recommended window for this many generators (16 below 2^19 generators, 17 from there on).  A table serves MSMs over
+ * any sub-range of its generators; for MSMs much shorter than the table choose the window by their length. */
 int  vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets);
+int  vdf_bases_window(const vdf_bases* bases);            /* window of the current table, 0 without one */
 int  vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out);
 size_t vdf_bases_len(const vdf_bases* bases);
 const void* vdf_bases_device_ptr(const vdf_bases* bases);

@@ -471,7 +471,8 @@ int vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed
 int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets) {
   return guarded(ctx, [&]() -> Status {
     if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
-    if (window_bits < 4 || window_bits > 20) return Status{VDF_ERR_BAD_ARG, "window_bits must be 4..20"};
+    if (window_bits == 0) window_bits = bases->n >= ((size_t)1 << 19) ? 17 : 16;      // measured: DESIGN.md 4.2
+    if (window_bits < 4 || window_bits > 20) return Status{VDF_ERR_BAD_ARG, "window_bits must be 0 (recommended) or 4..20"};
     const int windows = (256 + window_bits - 1) / window_bits;
     if (sets <= 0) sets = 1;
     if (sets > windows) sets = windows;
@@ -488,6 +489,8 @@ int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int se
     return Status{};
   });
 }
+
+int vdf_bases_window(const vdf_bases* bases) { return bases && bases->d_table ? bases->tbl_c : 0; }
 
 int vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out) {
   return guarded(ctx, [&]() -> Status {

@@ -70,6 +70,11 @@ class Bases:
     def precompute(self, window_bits: int = 16, sets: int = 1) -> None:
         self.ctx._check(lib.vdf_bases_precompute(self.ctx.handle, self.handle, window_bits, sets))
 
+    @property
+    def window(self) -> int:
+        """Window of the fixed-base table (0 without one)."""
+        return lib.vdf_bases_window(self.handle)
+
     def download(self, offset: int = 0, n: Optional[int] = None) -> np.ndarray:
         n = len(self) - offset if n is None else n
         out = np.zeros((n, 8), dtype="<u8")
