@@ -160,7 +160,7 @@ def test_heavy_bucket_path(ctx, curve):
     bases.free()
 
 
-@pytest.mark.parametrize("mode", ["plain", "table"])
+@pytest.mark.parametrize("mode", ["plain", "table", "table_recommended"])
 def test_full_size_2_20_dlog_identity(ctx, mode):
     """BASELINE config 2 (2^20 Pallas points), device-resident scalars, checked bit-exactly
     through sum s_i*[k_i]G = [sum s_i*k_i]G."""
@@ -169,6 +169,11 @@ def test_full_size_2_20_dlog_identity(ctx, mode):
     bases = ctx.bases_generate(curve, 7, n)
     if mode == "table":
         bases.precompute(16, 1)
+    elif mode == "table_recommended":                 # the bench's configuration: window 0 = the library's choice
+        bases.precompute(0, 1)
+        assert bases.window == 17
+    else:
+        assert bases.window == 0
     sc = rand_limbs(np.random.default_rng(2020), n)
     d = torch.from_numpy(sc.view(np.int64)).cuda()
     out = torch.zeros(12, dtype=torch.int64, device="cuda")
@@ -186,7 +191,7 @@ def test_maximum_size_2_24_additivity(ctx):
     import torch
     curve, n = o.CURVE_PALLAS, 1 << 24
     bases = ctx.bases_generate(curve, 7, n)
-    bases.precompute(16, 1)
+    bases.precompute(0, 1)
     g = torch.Generator(device="cuda"); g.manual_seed(24)
     sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
     sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
