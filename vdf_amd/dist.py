@@ -55,8 +55,9 @@ class ShardedMsm:
             always_gather: bool = False):
         """One sharded MSM.  all_gather(dst, src) fills dst (world x 12) from every rank's src (12).
         always_gather: take the collective path even for world == 1 (rehearsal of the N > 1 code on one GPU)."""
-        self.local_partial(scalars_local, partial_buf, is_mont=is_mont)
         if self.world == 1 and not always_gather:
-            return self.combine(partial_buf, out=out)
+            # one rank: its partial is the result (nothing to gather, nothing to sum)
+            return self.local_partial(scalars_local, partial_buf if out is None else out, is_mont=is_mont)
+        self.local_partial(scalars_local, partial_buf, is_mont=is_mont)
         all_gather(gathered_buf, partial_buf)
         return self.combine(gathered_buf, out=out)
