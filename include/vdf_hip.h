@@ -133,7 +133,9 @@ int  vdf_msm_job_begin(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t
                        vdf_msm_job** out);
 int  vdf_msm_job_push(vdf_msm_job* job, int g, const vdf_fe* scalars);
 int  vdf_msm_job_finish(vdf_msm_job* job, vdf_jac out[]);
-/* Window size override for tuning (0 = automatic). */
+/* Window size override for tuning (0 = automatic).  It applies to calls without a fixed-base table (a table fixes its own
+ * window); a batch too wide for the requested window -- bucket sets x 2^(window - 11) sort partitions, at most 8192 --
+ * runs at the largest window that fits. */
 int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
 /* out = sum of n Jacobian points (the combine step of a point-chunk-sharded MSM: each GPU
  * contributes one 96-byte partial, exchanged with an RCCL all-gather). */

@@ -301,6 +301,27 @@ def test_pippenger_shim_generator_cache(cref):
         assert lib.vdf_shim_set_cache(0) == 0      # frees every cached set
 
 
+def test_wide_batch_with_a_large_tableless_window(ctx, cref):
+    """Found by tools/gpu_msm_fuzz.py: a table-less batch of 3 at window 19 is 42 bucket sets of 2^18 buckets -- more sort
+    partitions than the pipeline has, which used to run pass B with 11 fine bits (out-of-bounds writes).  The window of a
+    table-less call is now lowered to what fits; results are unchanged."""
+    curve = o.CURVE_PALLAS
+    bases = ctx.bases_generate(curve, 5, 14524)
+    pts = bases.download()
+    rng = np.random.default_rng(23)
+    offs, lens = [5473, 10447, 12204], [6006, 3444, 1067]
+    scs = [rand_limbs(rng, n) for n in lens]
+    try:
+        for w in (19, 20):
+            ctx.set_msm_window(w)
+            out = ctx.msm_batch(bases, scs, lens, offs)
+            for g in range(3):
+                assert jac_to_affine(out[g], curve) == cpu_msm(cref, curve, pts[offs[g]:offs[g] + lens[g]], scs[g])
+    finally:
+        ctx.set_msm_window(0)
+        bases.free()
+
+
 def test_error_paths(ctx):
     import vdf_amd
     bases = ctx.bases_generate(o.CURVE_PALLAS, 1, 16)

@@ -160,11 +160,14 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
   vdf::MsmPlan plan;
   const char* pts;
   if (bases->d_table && (ctx->msm_window == 0 || ctx->msm_window == bases->tbl_c)) {
+    if (!vdf::msm_plan_feasible(groups, bases->tbl_c, bases->tbl_sets))
+      return Status{VDF_ERR_BAD_ARG, "a batch this wide does not fit the sort under this table's window and bucket sets: fewer MSMs per call"};
     plan = vdf::msm_make_plan(groups, n, offset, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus);
     plan.tstride = (uint32_t)bases->n;
     pts = reinterpret_cast<const char*>(bases->d_table);
   } else {
     int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(nmax);
+    while (c > 4 && !vdf::msm_plan_feasible(groups, c, 0)) --c;     // a table-less window is a tuning knob: lowered to what fits
     plan = vdf::msm_make_plan(groups, n, offset, c, 0, 0, ctx->num_cus);
     plan.tstride = 0;
     pts = reinterpret_cast<const char*>(bases->d_pts);

@@ -131,6 +131,7 @@ inline MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus)
   return msm_make_plan(1, &n, &zero, c, sets, tables, num_cus);
 }
 int msm_auto_window(size_t n);
+bool msm_plan_feasible(int groups, int c, int sets);       // sets <= 0: one bucket set per window (no table)
 // d_points: table (tables*tstride affine) or plain bases (tables == 1).  d_scalars[g]: gn[g] x 32 B device.
 // d_out: groups x 96 B device (Jacobian).  Enqueues on `stream`; no synchronisation.
 // ev (optional): 4 events recorded at start / before accumulate / after accumulate / end.

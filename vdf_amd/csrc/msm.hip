@@ -165,6 +165,15 @@ int msm_auto_window(size_t n) {
   return c;
 }
 
+// The two-level sort needs  bucket sets x 2^(bucket bits - 10)  partitions (pass B sorts at most 10 bits) and has at
+// most 8192 (pass A keeps a cursor per partition in LDS): large windows with many bucket sets do not fit.
+bool msm_plan_feasible(int groups, int c, int sets) {
+  const int windows = (256 + c - 1) / c;
+  if (sets <= 0) sets = windows;
+  const int over = c - 1 - 10;
+  return ((uint64_t)groups * sets << (over > 0 ? over : 0)) <= 8192u;
+}
+
 MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus) {
   MsmPlan p;
   p.groups = groups;
