@@ -301,6 +301,42 @@ def test_pippenger_shim_generator_cache(cref):
         assert lib.vdf_shim_set_cache(0) == 0      # frees every cached set
 
 
+def test_pippenger_shim_cache_under_concurrent_callers(cref):
+    """Four threads, four generator arrays, a cache of two: entries are evicted while other threads compute.  rayon
+    workers call pasta-msm concurrently (SURVEY.md 8b threading), so the shim must stay correct under exactly this."""
+    import threading
+    from vdf_amd._lib import lib
+    curve = o.CURVE_PALLAS
+    sets = []
+    for k in range(4):
+        n = 3000 + 500 * k
+        pts = np.zeros((n, 8), dtype="<u8")
+        cref.lib().ref_synthetic_bases(curve, 40 + k, 0, n, cref.p(pts))
+        sets.append((pts, n, 40 + k))
+    assert lib.vdf_shim_set_cache(2) == 0
+    failures = []
+
+    def worker(k):
+        pts, n, seed = sets[k]
+        rng = np.random.default_rng(k)
+        for rep in range(12):
+            sc = rand_limbs(rng, n)
+            out = np.zeros(12, dtype="<u8")
+            lib.mult_pippenger_pallas(out.ctypes.data, pts.ctypes.data, n, sc.ctypes.data, False)
+            if jac_to_affine(out, curve) != o.msm_by_dlog(ints(sc), curve, seed):
+                failures.append((k, rep))
+
+    try:
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not failures
+    finally:
+        assert lib.vdf_shim_set_cache(0) == 0
+
+
 def test_wide_batch_with_a_large_tableless_window(ctx, cref):
     """Found by tools/gpu_msm_fuzz.py: a table-less batch of 3 at window 19 is 42 bucket sets of 2^18 buckets -- more sort
     partitions than the pipeline has, which used to run pass B with 11 fine bits (out-of-bounds writes).  The window of a

@@ -233,45 +233,50 @@ void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf
   if (out) std::memset(out, 0, sizeof(*out));
   vdf_ctx* ctx = default_ctx();
   if (!ctx || !out) return;
-  vdf_bases* b = nullptr;
-  bool cached = false, want_table = false;
-  {
-    std::lock_guard<std::mutex> lock(g_shim_mu);
-    if (shim_cache_capacity() > 0 && points && n) {
-      const uint64_t fp = shim_fingerprint(points, n);
-      for (ShimEntry& e : g_shim)
-        if (e.curve == curve && e.ptr == (const void*)points && e.n == n && e.fp == fp) {
-          b = e.bases; cached = true; e.last_use = ++g_shim_clock;
-          want_table = !e.table;                     // the second call for a set pays for its table
-          e.table = true;
-          break;
-        }
-    }
-  }
-  if (!cached) {
+  // With the cache on, a call holds the cache lock from lookup to the end of its MSM: an entry must not be evicted (and
+  // its generators freed) by another thread while this one computes with it.  Nothing is lost -- the shims share one
+  // default context, whose calls are serialised anyway.
+  std::unique_lock<std::mutex> lock(g_shim_mu);
+  const int cap = shim_cache_capacity();
+  if (cap <= 0 || !points || !n) {
+    lock.unlock();
+    vdf_bases* b = nullptr;
     if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
-  } else if (want_table && n >= 1024) {
-    (void)vdf_bases_precompute(ctx, b, 16, 1);       // failure (memory) leaves the plain path
+    if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
+      g_create_err = ctx->err;
+      std::memset(out, 0, sizeof(*out));
+    }
+    vdf_bases_free(b);
+    return;
   }
-  if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
+  const uint64_t fp = shim_fingerprint(points, n);
+  ShimEntry* hit = nullptr;
+  for (ShimEntry& e : g_shim)
+    if (e.curve == curve && e.ptr == (const void*)points && e.n == n && e.fp == fp) { hit = &e; break; }
+  if (!hit) {
+    // a stale entry for this address (same array, new contents) goes; then the least recently used
+    for (size_t i = 0; i < g_shim.size();)
+      if (g_shim[i].curve == curve && g_shim[i].ptr == (const void*)points && g_shim[i].n == n) { vdf_bases_free(g_shim[i].bases); g_shim.erase(g_shim.begin() + i); }
+      else ++i;
+    while ((int)g_shim.size() >= cap) {
+      size_t lru = 0;
+      for (size_t i = 1; i < g_shim.size(); ++i) if (g_shim[i].last_use < g_shim[lru].last_use) lru = i;
+      vdf_bases_free(g_shim[lru].bases);
+      g_shim.erase(g_shim.begin() + lru);
+    }
+    vdf_bases* b = nullptr;
+    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
+    g_shim.push_back(ShimEntry{curve, (const void*)points, n, fp, b, 0, false});
+    hit = &g_shim.back();
+  } else if (!hit->table) {
+    if (n >= 1024) (void)vdf_bases_precompute(ctx, hit->bases, 16, 1);   // the second call for a set pays for its table;
+    hit->table = true;                                                   // failure (memory) leaves the plain path
+  }
+  hit->last_use = ++g_shim_clock;
+  if (vdf_msm(ctx, hit->bases, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
     g_create_err = ctx->err;
     std::memset(out, 0, sizeof(*out));
   }
-  if (cached) return;
-  std::lock_guard<std::mutex> lock(g_shim_mu);
-  const int cap = shim_cache_capacity();
-  if (cap <= 0) { vdf_bases_free(b); return; }
-  // a stale entry for this address (same array, new contents or length) goes; then the least recently used
-  for (size_t i = 0; i < g_shim.size();)
-    if (g_shim[i].curve == curve && g_shim[i].ptr == (const void*)points && g_shim[i].n == n) { vdf_bases_free(g_shim[i].bases); g_shim.erase(g_shim.begin() + i); }
-    else ++i;
-  while ((int)g_shim.size() >= cap) {
-    size_t lru = 0;
-    for (size_t i = 1; i < g_shim.size(); ++i) if (g_shim[i].last_use < g_shim[lru].last_use) lru = i;
-    vdf_bases_free(g_shim[lru].bases);
-    g_shim.erase(g_shim.begin() + lru);
-  }
-  g_shim.push_back(ShimEntry{curve, (const void*)points, n, shim_fingerprint(points, n), b, ++g_shim_clock, false});
 }
 
 template <class P>
