@@ -240,6 +240,11 @@ int  vdf_ctx_sync_mark(vdf_ctx* ctx, int slot);
 /* out[i] = prod_j (bit_j(i) ? hi[j] : lo[j]), i < 2^k, k <= 24: eq(r, .) with lo = 1 - r, hi = r; the inner-product
  * argument's generator coefficients with lo = x^-1, hi = x. */
 int  vdf_pair_table(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, int k, vdf_fe* out);
+/* out[i] = (prod_j (bit_j(i >> log_m) ? hi[j] : lo[j])) * pattern[i mod 2^log_m], i < 2^(k + log_m), log_m <= 4: the table over
+ * the top k index bits times a vector of 2^log_m values over the low bits (host memory) -- the generator coefficients of an
+ * inner-product argument that stopped at a vector of 2^log_m elements instead of halving down to one. */
+int  vdf_pair_table_pattern(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, int k, const vdf_fe* pattern, int log_m,
+                            vdf_fe* out);
 /* v[t][i] <- c_lo[t] * v[t][i] + c_hi[t] * v[t][i + n/2], i < n/2, for t < k <= 8 vectors of length n (power of two)
  * in one launch: a sum-check binding (1 - r, r); the argument's folds (x, x^-1) / (x^-1, x). */
 int  vdf_fold_halves(vdf_ctx* ctx, int field, int k, vdf_fe* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n);

@@ -106,7 +106,7 @@ int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 
 /* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
  * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS
- * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v1" (oracle/spartan.py): a
+ * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v2" (oracle/spartan.py): a
  * Spartan-style sum-check argument with inner-product-argument openings under the same Pedersen generators; the
  * extra generator of the openings is generator number num_gens of the same family.  Like the rest of this layer it is
  * self-consistent, not interchangeable with nova-snark (whose constants are unpinned); in the
@@ -132,7 +132,7 @@ int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
  *
  *   chain  = magic[8] | t u64 | num_steps u64 | digest of the public parameters [32] | z_0 [96]
  *            | per step k: z_{k+1} [96], commitment of the fresh witness [32], (k >= 1) cross-term commitment [32]
- *   "VDFSNK01" compressed proof = chain | the argument of vdf_nova_snark_bytes with 32-byte points
+ *   "VDFSNK02" compressed proof = chain | the argument of vdf_nova_snark_bytes with 32-byte points
  *   "VDFRSK01" running proof    = chain | W [num_vars x 32] | E [num_cons x 32]
  *
  * Challenges and the folded instance are not stored: deserialisation replays the folds (as verification does), so a
@@ -141,7 +141,7 @@ int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
  * VDF_ERR_NONCANONICAL for an out-of-range field element or bytes that decode to no curve point.
  *
  * The compressed proof is what a prover ships to a verifier in another process: 56 + 96 + 160 n - 32 bytes of chain
- * plus 5.5 KB of argument at t = 2^16.  The running proof is a checkpoint: vdf_nova_proof_deserialize rebuilds the
+ * plus 5.9 KB of argument at t = 2^16.  The running proof is a checkpoint: vdf_nova_proof_deserialize rebuilds the
  * device-resident state (including A z, B z, C z of the running instance), refuses a witness that does not open the
  * commitments its records fold to, and vdf_nova_prove_step continues from it. */
 /* The 32-byte point encoding by itself (host arithmetic only, no device): commitments are points of Pallas, in

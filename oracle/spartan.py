@@ -6,7 +6,7 @@ for relaxed R1CS with inner-product-argument openings, the shape of nova-snark 0
 and every constant below (transcript, challenge width, padding) is this build's own.  What pins it is mathematics:
 completeness and soundness checks in tests/, and bit-exact agreement between this restatement and the product.
 
-Protocol "vdf-spartan-v1" for an instance (comm_W, comm_E, u, X) of shape (A, B, C) with witness (W, E),
+Protocol "vdf-spartan-v2" for an instance (comm_W, comm_E, u, X) of shape (A, B, C) with witness (W, E),
 (A z) o (B z) = u (C z) + E,  z = (W, u, X):
 
   transcript   hash chain over SHAKE256: state' = H(state | label | ':' | data); a challenge is the first 16 bytes
@@ -40,7 +40,7 @@ def _h(data: bytes, n: int) -> bytes:
 
 class Transcript:
     def __init__(self, label: bytes):
-        self.state = _h(b"vdf-spartan-v1|" + label, 32)
+        self.state = _h(b"vdf-spartan-v2|" + label, 32)
 
     def absorb(self, label: bytes, data: bytes) -> None:
         self.state = _h(self.state + label + b":" + data, 32)
@@ -128,11 +128,14 @@ def sumcheck_verify(tr: Transcript, label: bytes, claim: int, msgs: Sequence[Seq
 
 
 # ---- inner-product argument -----------------------------------------------------------------------------
+IPA_STOP = 16      # the halving stops at this length: the prover sends the remaining vector instead of four more rounds
+
+
 @dataclass
 class IpaProof:
     L: List[Point] = field(default_factory=list)
     R: List[Point] = field(default_factory=list)
-    a: int = 0
+    a: List[int] = field(default_factory=list)     # the folded vector, min(n, IPA_STOP) elements
 
 
 def _msm(s: Sequence[int], G: Sequence[Point], curve: int) -> Point:
@@ -146,7 +149,7 @@ def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Seq
     Q = o.pt_mul(tr.challenge(label), U, pm)
     a, b, G = list(a), list(b), list(G)
     proof = IpaProof()
-    while len(a) > 1:
+    while len(a) > IPA_STOP:
         h = len(a) // 2
         cL = sum(x * y for x, y in zip(a[:h], b[h:])) % q
         cR = sum(x * y for x, y in zip(a[h:], b[:h])) % q
@@ -159,7 +162,7 @@ def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Seq
         b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
         G = [o.pt_add(o.pt_mul(xi, G[i], pm), o.pt_mul(x, G[h + i], pm), pm) for i in range(h)]
         proof.L.append(L); proof.R.append(R)
-    proof.a = a[0]
+    proof.a = list(a)
     return proof
 
 
@@ -167,7 +170,8 @@ def ipa_verify(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, b: Se
                proof: IpaProof, curve: int) -> bool:
     q, pm = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve)
     n = len(G)
-    if 1 << len(proof.L) != n or len(proof.L) != len(proof.R):
+    m = min(n, IPA_STOP)
+    if (m << len(proof.L)) != n or len(proof.L) != len(proof.R) or len(proof.a) != m:
         return False
     tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
     Q = o.pt_mul(tr.challenge(label), U, pm)
@@ -187,7 +191,9 @@ def ipa_verify(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, b: Se
             s[t] = s[t] * (x if (t % size) >= h else xi) % q
         b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
         size = h
-    rhs = o.pt_add(o.pt_mul(proof.a, _msm(s, G, curve), pm), o.pt_mul(proof.a * b[0] % q, Q, pm), pm)
+    # the folded generators are G'_i = sum over t = i (mod m) of s_t G_t, the folded b is what is left of it
+    ab = sum(x * y for x, y in zip(proof.a, b)) % q
+    rhs = o.pt_add(_msm([s[t] * proof.a[t % m] % q for t in range(n)], G, curve), o.pt_mul(ab, Q, pm), pm)
     return acc == rhs
 
 

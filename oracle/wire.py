@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- never imported by the product (vdf_amd/).
 
-Python restatement of the wire formats of include/vdf_nova.h ("VDFSNK01" compressed proof, "VDFRSK01" running
+Python restatement of the wire formats of include/vdf_nova.h ("VDFSNK02" compressed proof, "VDFRSK01" running
 proof) and of the 32-byte point encoding.  The reference serialises nothing (src/nova/proof.rs:52-55 keeps
 proofs in memory), so there are no reference vectors for these: parity is product bytes == these bytes, plus the
 round trips and the rejection cases in tests/test_wire.py and tests/test_gpu_wire.py.  Parity unpinned against the
@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 from . import pasta as o
 
 Point = Optional[Tuple[int, int]]
-MAGIC_SNARK = b"VDFSNK01"
+MAGIC_SNARK = b"VDFSNK02"
 MAGIC_PROOF = b"VDFRSK01"
 
 
@@ -65,13 +65,13 @@ def encode_chain(magic: bytes, t: int, digest: bytes, z: Sequence[Sequence[int]]
 
 
 def encode_argument(proof) -> bytes:
-    """oracle.spartan.SpartanProof with 32-byte points (the argument section of "VDFSNK01")."""
+    """oracle.spartan.SpartanProof with 32-byte points (the argument section of "VDFSNK02")."""
     out = b"".join(fe(v) for ev in proof.outer for v in ev)
     out += b"".join(fe(v) for v in proof.claims)
     out += b"".join(fe(v) for ev in proof.inner for v in ev)
     out += fe(proof.w_eval)
     for ipa in (proof.ipa_W, proof.ipa_E):
-        out += b"".join(compress_point(L) + compress_point(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
+        out += b"".join(compress_point(L) + compress_point(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
     return out
 
 

@@ -91,7 +91,7 @@ out["tai_bases_seed7"] = {str(c): [[H(p[0]), H(p[1])] for p in o.tai_bases(c, 7,
 
 # --- compression SNARK on a folded t = 3 instance (oracle/spartan.py); same construction as tests/test_oracle_spartan.py --
 from oracle import spartan as sp  # noqa: E402
-t3 = 3
+t3 = 6          # 32 padded variables / constraints: one halving round of each inner-product argument, then its 16-vector
 sh3 = o.step_circuit_shape(t3, o.FIELD_FQ)
 def fresh(x0, i0):
     st = o.State(x0 % o.Q, 0, i0)
@@ -114,14 +114,14 @@ pt = lambda q: b"\0" * 64 if q is None else fe(q[0]) + fe(q[1])
 enc = b"".join(fe(v) for ev in pf.outer for v in ev) + b"".join(fe(v) for v in pf.claims)
 enc += b"".join(fe(v) for ev in pf.inner for v in ev) + fe(pf.w_eval)
 for ipa in (pf.ipa_W, pf.ipa_E):
-    enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
-out["spartan_t3"] = {"comm_W": [H(cW3[0]), H(cW3[1])], "comm_E": [H(cE3[0]), H(cE3[1])], "u": H(uf), "X": [H(v) for v in Xf],
+    enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
+out["spartan_t6"] = {"comm_W": [H(cW3[0]), H(cW3[1])], "comm_E": [H(cE3[0]), H(cE3[1])], "u": H(uf), "X": [H(v) for v in Xf],
                      "argument_hex": enc.hex()}
 
 # --- a whole proof on the wire: folding chain (oracle/nifs.py) + argument (oracle/spartan.py) + encoding (oracle/wire.py) --
 import hashlib  # noqa: E402
 from oracle import nifs, wire  # noqa: E402
-wt, wn = 3, 2
+wt, wn = 6, 2
 winit = o.State(o.rand_fe(31, 0, o.Q), 0, 1)
 wproof, wsh, wdig = nifs.prove_chain(winit, wt, wn)
 wN = 1
@@ -134,7 +134,7 @@ wcw = [nifs._pt(s.comm_w) for s in wproof.steps]
 wcT = [nifs._pt(s.comm_T) for s in wproof.steps]
 wire_snark = wire.encode_compressed_proof(wt, wdig, wz, wcw, wcT, warg)
 wire_running = wire.encode_running_proof(wt, wdig, wz, wcw, wcT, wproof.W, wproof.E)
-out["wire_t3"] = {"t": wt, "steps": wn, "seed": 31, "i0": 1, "digest": wdig.hex(), "compressed_proof_hex": wire_snark.hex(),
+out["wire_t6"] = {"t": wt, "steps": wn, "seed": 31, "i0": 1, "digest": wdig.hex(), "compressed_proof_hex": wire_snark.hex(),
                   "running_proof_sha256": hashlib.sha256(wire_running).hexdigest(), "running_proof_len": len(wire_running)}
 
 path = os.path.join(os.path.dirname(__file__), "vectors.json")

@@ -24,7 +24,7 @@ def _encode(proof: sp.SpartanProof) -> bytes:
     out += b"".join(fe(v) for ev in proof.inner for v in ev)
     out += fe(proof.w_eval)
     for ipa in (proof.ipa_W, proof.ipa_E):
-        out += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
+        out += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
     return out
 
 
@@ -37,7 +37,7 @@ def _pt(a):
     return None if a == (0, 0) else a
 
 
-@pytest.mark.parametrize("t,n", [(3, 3), (5, 2)])
+@pytest.mark.parametrize("t,n", [(3, 3), (5, 2), (12, 2)])       # 0, 1 and 2 halving rounds before the 16-vector
 def test_compressed_argument_equals_the_oracles(ctx, t, n):
     pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=31)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
@@ -73,14 +73,16 @@ def test_compress_and_verify_at_t_1024_and_tampering(ctx):
     sizes = pp.sizes()
     s = (sizes["num_cons"] - 1).bit_length()
     l1 = (sizes["num_vars"] - 1).bit_length() + 1
-    assert len(good) == 32 * (3 * s + 4 + 2 * l1 + 1 + 2) + 128 * ((l1 - 1) + s)
+    kW, kE = (l1 - 1) - 4, s - 4                       # halving rounds: the arguments stop at 16 elements
+    assert len(good) == 32 * (3 * s + 4 + 2 * l1 + 1 + 16 + 16) + 128 * (kW + kE)
     # wrong statement
     assert not snark.verify(pp, n, z0, [zi[1], zi[0], zi[2]])
     assert not snark.verify(pp, n - 1, z0, zi)
     # every section of the encoding: one flipped low bit must be rejected (or refused as non-canonical)
+    head = 32 * (3 * s + 4 + 2 * l1 + 1)
     offsets = {"outer": 40, "claims": 32 * 3 * s + 33, "inner": 32 * (3 * s + 4) + 64 + 1, "w_eval": 32 * (3 * s + 4 + 2 * l1),
-               "ipaW.L": 32 * (3 * s + 4 + 2 * l1 + 1) + 3, "ipaW.a": 32 * (3 * s + 4 + 2 * l1 + 1) + 128 * (l1 - 1),
-               "ipaE.R": 32 * (3 * s + 4 + 2 * l1 + 2) + 128 * (l1 - 1) + 64 + 5, "ipaE.a": len(good) - 32}
+               "ipaW.L": head + 3, "ipaW.a[0]": head + 128 * kW, "ipaW.a[9]": head + 128 * kW + 32 * 9 + 2,
+               "ipaE.R": head + 128 * kW + 32 * 16 + 64 + 5, "ipaE.a[15]": len(good) - 32}
     for name, off in offsets.items():
         bad = bytearray(good)
         bad[off] ^= 1

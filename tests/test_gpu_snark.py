@@ -135,3 +135,28 @@ def test_scalar_and_vector_placement_is_checked(ctx):
         ctx.fold_halves(F, [np.zeros((8, 4), dtype="<u8")], one, one, 8)      # vectors must be device memory
     with pytest.raises(Exception):
         ctx.fold_halves(F, [v], one, one, 6)                          # power of two
+
+
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+@pytest.mark.parametrize("k,log_m", [(0, 0), (0, 4), (3, 2), (9, 4), (14, 4)])
+def test_pair_table_pattern(ctx, field, k, log_m):
+    """out[i] = (pair table over the top k bits of i) * pattern[low log_m bits of i]."""
+    import torch
+    m = o.modulus(field)
+    rng = np.random.default_rng(100 * k + log_m)
+    lo, hi = [int(x) % m for x in ints(rand_limbs(rng, max(k, 1)))], [int(x) % m for x in ints(rand_limbs(rng, max(k, 1)))]
+    pat = [int(x) % m for x in ints(rand_limbs(rng, 1 << log_m))]
+    n = 1 << (k + log_m)
+    out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    ctx.pair_table_pattern(field, mont(lo, m), mont(hi, m), k, mont(pat, m), log_m, out)
+    ctx.sync()
+    got = unmont(out.cpu().numpy().view("<u8"), m)
+    idx = sorted(i for i in set([0, 1, n - 1, n // 2, n // 3] + [int(x) for x in rng.integers(0, n, size=40)]) if i < n)
+    for i in idx:
+        e = pat[i & ((1 << log_m) - 1)]
+        top = i >> log_m
+        for j in range(k):
+            e = e * (hi[j] if (top >> (k - 1 - j)) & 1 else lo[j]) % m
+        assert got[i] == e, i
+    with pytest.raises(Exception):
+        ctx.pair_table_pattern(field, mont(lo, m), mont(hi, m), k, mont(pat + [1] * 16, m), 5, out)      # pattern too long

@@ -1,4 +1,4 @@
-"""GPU: the wire formats of include/vdf_nova.h.  "VDFSNK01" -- the compressed proof a prover ships to a verifier in
+"""GPU: the wire formats of include/vdf_nova.h.  "VDFSNK02" -- the compressed proof a prover ships to a verifier in
 another process; "VDFRSK01" -- the running proof as a checkpoint that prove_step resumes from.  The reference keeps
 proofs in memory only (src/nova/proof.rs:52-55): the expected bytes are those of the restatement oracle/wire.py,
 and the behaviour asked of a decoded proof is the reference's own test flow (:403-451)."""
@@ -55,9 +55,9 @@ def test_compressed_proof_bytes_equal_the_oracles(ctx, t, n):
 
 
 def test_product_bytes_equal_the_committed_vector(ctx, golden):
-    """tests/golden/vectors.json "wire_t3" (made on the CPU by the oracle alone): the product's bytes for the same chain."""
+    """tests/golden/vectors.json "wire_t6" (made on the CPU by the oracle alone): the product's bytes for the same chain."""
     import hashlib
-    g = golden["wire_t3"]
+    g = golden["wire_t6"]
     t, n = g["t"], g["steps"]
     pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=g["seed"], i0=g["i0"])
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
@@ -83,7 +83,7 @@ def test_a_verifier_in_its_own_context_accepts_the_bytes_and_nothing_else(ctx):
         chain = w.chain_size(n)
         offsets = {"magic": 3, "t": 8, "steps": 16, "digest": 30, "z0": 56 + 40, "z1": 56 + 96 + 5, "comm_w0": 56 + 96 + 96 + 7,
                    "z2": 56 + 96 + 128 + 64, "comm_T1": 56 + 96 + 128 + 128 + 1, "sign bit": 56 + 96 + 96 + 31,
-                   "outer": chain + 33, "ipa point": len(good) - 32 - 64 + 9, "ipa a": len(good) - 1}
+                   "outer": chain + 33, "ipa point": len(good) - 32 * 16 - 64 + 9, "ipa a": len(good) - 1}
         for name, off in offsets.items():
             bad = bytearray(good)
             bad[off] ^= 0x80 if name == "sign bit" else 1

@@ -1,5 +1,5 @@
 """CPU: the folding layer's restatement (oracle/nifs.py) -- completeness, the verifier's rejections, and the committed
-wire-format vector (tests/golden/vectors.json "wire_t3": chain by oracle/nifs.py, argument by oracle/spartan.py, bytes by
+wire-format vector (tests/golden/vectors.json "wire_t6": chain by oracle/nifs.py, argument by oracle/spartan.py, bytes by
 oracle/wire.py).  The flow is the reference's test_nova_proof (src/nova/proof.rs:403-451) at t = 3."""
 import copy
 import hashlib
@@ -72,7 +72,7 @@ def test_new_x_is_an_affine_image_of_another_witness_value():
 
 
 def test_wire_golden_vector(golden):
-    g = golden["wire_t3"]
+    g = golden["wire_t6"]
     init = o.State(o.rand_fe(g["seed"], 0, o.Q), 0, g["i0"])
     proof, sh, digest = nifs.prove_chain(init, g["t"], g["steps"])
     assert digest.hex() == g["digest"]

@@ -21,7 +21,7 @@ def _fresh(shape, t, x0, i0):
 
 @pytest.fixture(scope="module")
 def relaxed():
-    t = 3
+    t = 6                                    # 32 padded variables / constraints: a halving round, then the 16-vector
     shape = o.step_circuit_shape(t, o.FIELD_FQ)
     N = 1
     while N < max(shape.num_vars, shape.num_cons):
@@ -84,9 +84,15 @@ def test_complete_and_sound_against_tampering(relaxed):
     assert not _verify(relaxed, bad)
     bad = copy.deepcopy(proof); bad.w_eval = (bad.w_eval + 1) % Q
     assert not _verify(relaxed, bad)
-    bad = copy.deepcopy(proof); bad.ipa_W.a = (bad.ipa_W.a + 1) % Q
+    assert len(proof.ipa_W.L) == 1 and len(proof.ipa_W.a) == sp.IPA_STOP == len(proof.ipa_E.a)
+    for k in (0, 7, 15):
+        bad = copy.deepcopy(proof); bad.ipa_W.a[k] = (bad.ipa_W.a[k] + 1) % Q
+        assert not _verify(relaxed, bad)
+    bad = copy.deepcopy(proof); bad.ipa_E.a = bad.ipa_E.a[:-1]
     assert not _verify(relaxed, bad)
     bad = copy.deepcopy(proof); bad.ipa_E.L[0] = relaxed["U"]
+    assert not _verify(relaxed, bad)
+    bad = copy.deepcopy(proof); bad.ipa_E.L.append(relaxed["U"]); bad.ipa_E.R.append(relaxed["U"])     # one round too many
     assert not _verify(relaxed, bad)
     # a different instance: u, X, commitments
     assert not _verify(relaxed, proof, u=(relaxed["u"] + 1) % Q)
@@ -109,7 +115,7 @@ def test_against_the_committed_golden_argument():
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "vectors.json")))
     for c in (o.CURVE_PALLAS, o.CURVE_VESTA):
         assert [[("%064x" % p[0]), ("%064x" % p[1])] for p in o.tai_bases(c, 7, 4)] == g["tai_bases_seed7"][str(c)]
-    t = 3
+    t = 6
     shape = o.step_circuit_shape(t, o.FIELD_FQ)
     W1, X1 = _fresh(shape, t, 123456789, 5)
     W2, X2 = _fresh(shape, t, 987654321, 9)
@@ -120,7 +126,7 @@ def test_against_the_committed_golden_argument():
     G = o.tai_bases(o.CURVE_PALLAS, 0x4E6F7661, 32)
     U = o.tai_base(o.CURVE_PALLAS, 0x4E6F7661, 32)
     cW, cE = o.msm_naive(W, G[:len(W)], o.CURVE_PALLAS), o.msm_naive(E, G[:len(E)], o.CURVE_PALLAS)
-    gs = g["spartan_t3"]
+    gs = g["spartan_t6"]
     assert ["%064x" % cW[0], "%064x" % cW[1]] == gs["comm_W"] and "%064x" % u == gs["u"]
     pf = sp.prove(shape, b"\x07" * 32, G, U, cW, cE, u, X, W, E)
     fe = lambda v: int(v).to_bytes(32, "little")
@@ -128,5 +134,6 @@ def test_against_the_committed_golden_argument():
     enc = b"".join(fe(v) for ev in pf.outer for v in ev) + b"".join(fe(v) for v in pf.claims)
     enc += b"".join(fe(v) for ev in pf.inner for v in ev) + fe(pf.w_eval)
     for ipa in (pf.ipa_W, pf.ipa_E):
-        enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + fe(ipa.a)
+        enc += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
+        assert len(ipa.L) == 1 and len(ipa.a) == sp.IPA_STOP
     assert enc.hex() == gs["argument_hex"]

@@ -1,5 +1,5 @@
 """Mutated wire bytes: every decode must end in an error or in a proof that does not verify -- never in a crash, a hang
-or an accepted forgery.  Both formats ("VDFSNK01" compressed proof, "VDFRSK01" running proof)."""
+or an accepted forgery.  Both formats ("VDFSNK02" compressed proof, "VDFRSK01" running proof)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "vdf_pair_table_pattern": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "vdf_fold_halves": (_i, [_vp, _i, _i, C.POINTER(_vp), _vp, _vp, _sz]),
     "vdf_reduce": (_i, [_vp, _i, _i, C.POINTER(_vp), _vp, _sz, _vp]),
     "vdf_spmv3_t": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -961,6 +961,19 @@ int vdf_pair_table(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, 
   });
 }
 
+int vdf_pair_table_pattern(vdf_ctx* ctx, int field, const vdf_fe* lo, const vdf_fe* hi, int k, const vdf_fe* pattern, int log_m,
+                           vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (k < 0 || log_m < 0 || log_m > 4 || k + log_m > 24) return Status{VDF_ERR_BAD_LENGTH, "0..24 variables in all, pattern of 1..16"};
+    if (k && (!lo || !hi || ptr_is_device(lo) || ptr_is_device(hi))) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    if (!pattern || ptr_is_device(pattern)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
+    if (!ptr_is_device(out)) return Status{VDF_ERR_BAD_ARG, kDevVec};
+    VDF_TRY(vdf::snark_pair_table_pattern(field, lo, hi, k, pattern, log_m, out, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
 int vdf_fold_halves(vdf_ctx* ctx, int field, int k, vdf_fe* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n) {
   return guarded(ctx, [&]() -> Status {
     if (k < 0 || k > 8) return Status{VDF_ERR_BAD_ARG, "k must be 0..8"};

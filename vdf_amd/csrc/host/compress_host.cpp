@@ -5,7 +5,7 @@ using namespace vdfnova;
 
 // =============================================================================================================
 // Compression SNARK: NovaVDFProof::compress / verification of the compressed proof (src/nova/proof.rs:360-368, :383).
-// Protocol "vdf-spartan-v1", restated line by line by the test oracle (spartan.py: prove / verify); every pass over a vector is
+// Protocol "vdf-spartan-v2", restated line by line by the test oracle (spartan.py: prove / verify); every pass over a vector is
 // a call through include/vdf_hip.h, the host keeps the transcript, O(log n) field work and O(log n) point work.
 // =============================================================================================================
 namespace {
@@ -14,7 +14,7 @@ struct Transcript {
   uint8_t state[32];
   explicit Transcript(const char* label) {
     Shake256 h;
-    h.absorb("vdf-spartan-v1|", 15);
+    h.absorb("vdf-spartan-v2|", 15);
     h.absorb(label, strlen(label));
     h.squeeze(state, 32);
   }
@@ -58,7 +58,12 @@ struct Transcript {
   }
 };
 
-struct Ipa { std::vector<Aff> L, R; Fe a; };
+// The halving of an inner-product argument stops at IPA_STOP elements: the prover sends that vector instead of four more
+// rounds (each a pair of MSMs over all generators for the prover; the verifier's one MSM is the same either way).
+constexpr size_t IPA_STOP = 16;
+inline size_t ipa_final(size_t n) { return n < IPA_STOP ? n : IPA_STOP; }
+inline size_t ipa_rounds(size_t n) { size_t k = 0; for (size_t m = n; m > IPA_STOP; m >>= 1) ++k; return k; }
+struct Ipa { std::vector<Aff> L, R; std::vector<Fe> a; };
 struct Spartan {
   std::vector<std::array<Fe, 3>> outer;
   Fe claims[4];
@@ -181,7 +186,9 @@ int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a
   const Pt Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
   const FixedBase Qtab(Qp);
   out->L.clear(); out->R.clear();
-  for (size_t nj = n; nj > 1; nj >>= 1) {
+  size_t left = n;
+  for (size_t nj = n; nj > IPA_STOP; nj >>= 1) {
+    left = nj >> 1;
     Fe cross[2];
     const vdf_fe* ab[2] = {(const vdf_fe*)d_a, (const vdf_fe*)d_b};
     HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_IPA_CROSS, ab, nullptr, nj, (vdf_fe*)cross));
@@ -205,7 +212,8 @@ int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a
     out->L.push_back(Lp); out->R.push_back(Rp);
   }
   HIPCALL(ctx, vdf_ctx_sync(ctx));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, &out->a, d_a, 32));
+  out->a.resize(left);
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, out->a.data(), d_a, left * 32));
   return VDF_OK;
 }
 
@@ -216,8 +224,13 @@ int ipa_verify(vdf_pp* pp, Transcript& tr, const char* label, size_t n, const st
   const Field& F = field(PRIMARY_FIELD);
   const Field& Fb = field_fp();
   *ok = false;
-  const size_t k = proof.L.size();
-  if (((size_t)1 << k) != n || proof.R.size() != k || rb.size() != k) return VDF_OK;
+  const size_t k = proof.L.size();                 // rounds performed; rb has one entry per variable of the full vector
+  const size_t m = ipa_final(n);
+  int log_m = 0, log_n = 0;
+  while (((size_t)1 << log_m) < m) ++log_m;
+  while (((size_t)1 << log_n) < n) ++log_n;
+  if (((size_t)1 << log_n) != n || k != ipa_rounds(n) || proof.R.size() != k || proof.a.size() != m || rb.size() != (size_t)log_n)
+    return VDF_OK;
   tr.absorb_pt(label, &P, 1);
   tr.absorb_fe(label, &v, 1, F);
   uint64_t raw[4];
@@ -252,11 +265,23 @@ int ipa_verify(vdf_pp* pp, Transcript& tr, const char* label, size_t n, const st
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     acc = pt_add(acc, pt_from_aff(jac_to_aff(jlr, Fb), Fb), Fb);
   }
-  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)xis.data(), (const vdf_fe*)xs.data(), (int)k, (vdf_fe*)d_s));
+  // coefficients of the original generators in sum_i a_i G'_i, G'_i the folded generators: the table of the performed
+  // rounds over the top index bits times the sent vector over the low ones; b folded in closed form: bfin (the rounds)
+  // times eq over the remaining variables
+  HIPCALL(ctx, vdf_pair_table_pattern(ctx, PRIMARY_FIELD, (const vdf_fe*)xis.data(), (const vdf_fe*)xs.data(), (int)k,
+                                      (const vdf_fe*)proof.a.data(), log_m, (vdf_fe*)d_s));
   vdf_jac jg;
   HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)d_s, n, 1, &jg));
-  const Pt gf = pt_from_aff(jac_to_aff(jg, Fb), Fb);
-  const Pt rhs = pt_add(pt_mul_fe(gf, proof.a, F), pt_mul_fe(Qp, mul(proof.a, bfin, F), F), Fb);
+  Fe ab = zero();
+  for (size_t i = 0; i < m; ++i) {
+    Fe bi = bfin;
+    for (int j = 0; j < log_m; ++j) {
+      const Fe& r = rb[k + j];
+      bi = mul(bi, ((i >> (log_m - 1 - j)) & 1) ? r : sub(one(F), r, F), F);
+    }
+    ab = add(ab, mul(proof.a[i], bi, F), F);
+  }
+  const Pt rhs = pt_add(pt_from_aff(jac_to_aff(jg, Fb), Fb), pt_mul_fe(Qp, ab, F), Fb);
   const Aff a1 = pt_to_aff(acc, Fb), a2 = pt_to_aff(rhs, Fb);
   *ok = memcmp(&a1, &a2, sizeof(Aff)) == 0;
   return VDF_OK;
@@ -467,11 +492,12 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
 void vdf_nova_snark_free(vdf_snark* s) { delete s; }
 
 // flat canonical encoding of the argument (little-endian, non-Montgomery): outer rounds (3 each), 4 claims, inner
-// rounds (2 each), w, then per opening: (L, R) per round as affine (x, y), the final scalar
+// rounds (2 each), w, then per opening: (L, R) per round as affine (x, y), the final vector (at most 16 elements)
 size_t vdf_nova_snark_size(const vdf_snark* s) {
   if (!s) return 0;
   const Spartan& p = s->sp;
-  return 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + 2) + 128 * (p.ipaW.L.size() + p.ipaE.L.size());
+  return 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) +
+         128 * (p.ipaW.L.size() + p.ipaE.L.size());
 }
 
 int vdf_nova_snark_bytes(const vdf_snark* s, uint8_t* out, size_t cap) {
@@ -488,7 +514,7 @@ int vdf_nova_snark_bytes(const vdf_snark* s, uint8_t* out, size_t cap) {
   put(s->sp.w_eval, F);
   for (const Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
     for (size_t j = 0; j < ip->L.size(); ++j) { put_pt(ip->L[j]); put_pt(ip->R[j]); }
-    put(ip->a, F);
+    for (const Fe& v : ip->a) put(v, F);
   }
   return VDF_OK;
 }
@@ -509,7 +535,7 @@ int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
   get(s->sp.w_eval, F);
   for (Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
     for (size_t j = 0; j < ip->L.size(); ++j) { get_pt(ip->L[j]); get_pt(ip->R[j]); }
-    get(ip->a, F);
+    for (Fe& v : ip->a) get(v, F);
   }
   if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
   return VDF_OK;
@@ -517,13 +543,14 @@ int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
 
 // ---- the whole compressed proof as one byte string: chain (wire_host.cpp) | argument with 32-byte points --------
 static size_t argument_wire_size(const Layout& L) {
-  return 32 * (3 * (size_t)L.s + 4 + 2 * (size_t)L.l1 + 1 + 2) + 64 * ((size_t)(L.l1 - 1) + (size_t)L.s);
+  return 32 * (3 * (size_t)L.s + 4 + 2 * (size_t)L.l1 + 1 + ipa_final(L.NW) + ipa_final(L.M)) +
+         64 * (ipa_rounds(L.NW) + ipa_rounds(L.M));
 }
 
 size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
   if (!s) return 0;
   const Spartan& p = s->sp;
-  return wire_chain_size(s->steps.size()) + 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + 2) +
+  return wire_chain_size(s->steps.size()) + 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) +
          64 * (p.ipaW.L.size() + p.ipaE.L.size());
 }
 
@@ -539,7 +566,7 @@ int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
   o = wire_put_fe(o, s->sp.w_eval, F);
   for (const Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
     for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
-    o = wire_put_fe(o, ip->a, F);
+    for (const Fe& v : ip->a) o = wire_put_fe(o, v, F);
   }
   return VDF_OK;
 }
@@ -560,8 +587,8 @@ int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_sn
   if (len != argument_wire_size(L)) return fail(VDF_ERR_BAD_LENGTH, "argument section has the wrong length for this shape");
   Spartan& p = s->sp;
   p.outer.resize(L.s); p.inner.resize(L.l1);
-  p.ipaW.L.resize(L.l1 - 1); p.ipaW.R.resize(L.l1 - 1);
-  p.ipaE.L.resize(L.s); p.ipaE.R.resize(L.s);
+  p.ipaW.L.resize(ipa_rounds(L.NW)); p.ipaW.R.resize(ipa_rounds(L.NW)); p.ipaW.a.resize(ipa_final(L.NW));
+  p.ipaE.L.resize(ipa_rounds(L.M)); p.ipaE.R.resize(ipa_rounds(L.M)); p.ipaE.a.resize(ipa_final(L.M));
   bool canonical = true, on_curve = true;
   auto get = [&](Fe& v) { canonical &= wire_get_fe(in, F, &v); in += 32; };
   for (auto& ev : p.outer) for (Fe& v : ev) get(v);
@@ -574,7 +601,7 @@ int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_sn
       on_curve &= pt_decompress(in + 32, Fb, &ip->R[j]);
       in += 64;
     }
-    get(ip->a);
+    for (Fe& v : ip->a) get(v);
   }
   if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the argument is not canonical");
   if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the argument does not decode to a curve point");

@@ -129,7 +129,7 @@ bool fold_replay(const vdf_pp* pp, const std::vector<StepRecord>& steps, Fe* r_o
 int alloc_proof_buffers(vdf_proof* p);
 
 // ---- wire formats (wire_host.cpp; layout in include/vdf_nova.h) --------------------------------------------
-constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK01";      // compressed proof
+constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK02";      // compressed proof
 constexpr char WIRE_MAGIC_PROOF[9] = "VDFRSK01";      // running proof (checkpoint)
 size_t wire_chain_size(size_t num_steps);
 uint8_t* wire_put_chain(uint8_t* o, const char magic[8], uint64_t t, const uint8_t digest[32], const std::vector<StepRecord>& steps);

@@ -171,6 +171,8 @@ Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, h
 // ---- snark.hip -------------------------------------------------------------------------
 // vdf_fe* arguments are HOST pointers whose values travel as kernel arguments; void* are device vectors
 Status snark_pair_table(int field, const vdf_fe* lo, const vdf_fe* hi, int k, void* out, hipStream_t s);
+Status snark_pair_table_pattern(int field, const vdf_fe* lo, const vdf_fe* hi, int k, const vdf_fe* pattern, int log_m, void* out,
+                                hipStream_t s);
 Status snark_fold_halves(int field, int k, void* const v[], const vdf_fe c_lo[], const vdf_fe c_hi[], size_t n, hipStream_t s);
 size_t snark_reduce_scratch_bytes();
 Status snark_reduce(int field, int kind, const void* const tables[], const vdf_fe* u, size_t n, void* scratch, void* out,

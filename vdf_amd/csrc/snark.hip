@@ -1,4 +1,4 @@
-// Kernels of the compression SNARK (protocol "vdf-spartan-v1", restated by the test oracle, spartan.py): a Spartan-style
+// Kernels of the compression SNARK (protocol "vdf-spartan-v2", restated by the test oracle, spartan.py): a Spartan-style
 // argument for the folded relaxed R1CS instance with inner-product-argument openings -- the work behind
 // `NovaVDFProof::compress` / verification of the compressed proof (/root/reference/src/nova/proof.rs:360-368, :383;
 // nova-snark 0.8.0 `CompressedSNARK`).
@@ -64,6 +64,37 @@ Status snark_pair_table(int field, const vdf_fe* lo, const vdf_fe* hi, int k, vo
   for (int j = 0; j < k; ++j) { a.lo[j] = to_arg(&lo[j]); a.hi[j] = to_arg(&hi[j]); }
   const size_t n = (size_t)1 << k;
   SNARK_DISPATCH(field, k_eq_table, grid_for(n), dim3(256), 0, s, a, n, reinterpret_cast<char*>(out));
+  return Status{};
+}
+
+// out[i] = (pair table over the top k bits of i) * pattern[low log_m bits of i]: the coefficient of generator i in the
+// verifier's check of an inner-product argument that stopped at a vector of 2^log_m elements
+struct PatternArgs { FeArg p[16]; int log_m; };
+template <class P>
+__global__ __launch_bounds__(256) void k_eq_table_pattern(PairArgs a, PatternArgs pat, size_t n, char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t hi_idx = i >> pat.log_m;
+  Fe<P> acc = arg_fe<P>(pat.p[i & (((size_t)1 << pat.log_m) - 1)]);
+  for (int j = 0; j < a.k; ++j) {
+    const bool bit = (hi_idx >> (a.k - 1 - j)) & 1;
+    acc = fe_mul(acc, arg_fe<P>(bit ? a.hi[j] : a.lo[j]));
+  }
+  fe_store<P>(out + i * 32, acc);
+}
+
+Status snark_pair_table_pattern(int field, const vdf_fe* lo, const vdf_fe* hi, int k, const vdf_fe* pattern, int log_m, void* out,
+                                hipStream_t s) {
+  if (k < 0 || log_m < 0 || log_m > 4 || k + log_m > 24) return Status{VDF_ERR_BAD_LENGTH, "at most 24 variables, pattern of at most 16"};
+  PairArgs a{};
+  a.k = k;
+  for (int j = 0; j < k; ++j) { a.lo[j] = to_arg(&lo[j]); a.hi[j] = to_arg(&hi[j]); }
+  PatternArgs pa{};
+  pa.log_m = log_m;
+  for (int j = 0; j < (1 << log_m); ++j) pa.p[j] = to_arg(&pattern[j]);
+  const size_t n = (size_t)1 << (k + log_m);
+  SNARK_DISPATCH(field, k_eq_table_pattern, grid_for(n), dim3(256), 0, s, a, pa, n, reinterpret_cast<char*>(out));
   return Status{};
 }
 

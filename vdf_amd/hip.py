@@ -303,6 +303,9 @@ class Context:
     def pair_table(self, field, lo, hi, k, out) -> None:
         self._check(lib.vdf_pair_table(self.handle, field, _ptr(lo), _ptr(hi), k, _ptr(out)))
 
+    def pair_table_pattern(self, field, lo, hi, k, pattern, log_m, out) -> None:
+        self._check(lib.vdf_pair_table_pattern(self.handle, field, _ptr(lo), _ptr(hi), k, _ptr(pattern), log_m, _ptr(out)))
+
     def fold_halves(self, field, vectors, c_lo, c_hi, n) -> None:
         k = len(vectors)
         v = (C.c_void_p * k)(*[_ptr(x) for x in vectors])
