@@ -106,7 +106,7 @@ int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 
 /* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
  * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS
- * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v2" (oracle/spartan.py): a
+ * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v3" (oracle/spartan.py): a
  * Spartan-style sum-check argument with inner-product-argument openings under the same Pedersen generators; the
  * extra generator of the openings is generator number num_gens of the same family.  Like the rest of this layer it is
  * self-consistent, not interchangeable with nova-snark (whose constants are unpinned); in the

@@ -6,7 +6,7 @@ for relaxed R1CS with inner-product-argument openings, the shape of nova-snark 0
 and every constant below (transcript, challenge width, padding) is this build's own.  What pins it is mathematics:
 completeness and soundness checks in tests/, and bit-exact agreement between this restatement and the product.
 
-Protocol "vdf-spartan-v2" for an instance (comm_W, comm_E, u, X) of shape (A, B, C) with witness (W, E),
+Protocol "vdf-spartan-v3" for an instance (comm_W, comm_E, u, X) of shape (A, B, C) with witness (W, E),
 (A z) o (B z) = u (C z) + E,  z = (W, u, X):
 
   transcript   hash chain over SHAKE256: state' = H(state | label | ':' | data); a challenge is the first 16 bytes
@@ -40,7 +40,7 @@ def _h(data: bytes, n: int) -> bytes:
 
 class Transcript:
     def __init__(self, label: bytes):
-        self.state = _h(b"vdf-spartan-v2|" + label, 32)
+        self.state = _h(b"vdf-spartan-v3|" + label, 32)
 
     def absorb(self, label: bytes, data: bytes) -> None:
         self.state = _h(self.state + label + b":" + data, 32)
@@ -142,59 +142,119 @@ def _msm(s: Sequence[int], G: Sequence[Point], curve: int) -> Point:
     return o.msm_naive(list(s), list(G), curve)
 
 
-def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Sequence[int], b: Sequence[int], v: int,
-              P: Point, curve: int) -> IpaProof:
-    q, pm = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve)
-    tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
-    Q = o.pt_mul(tr.challenge(label), U, pm)
-    a, b, G = list(a), list(b), list(G)
-    proof = IpaProof()
-    while len(a) > IPA_STOP:
+class _IpaProver:
+    """One inner-product argument as a state machine, so that several can advance in lockstep: a round of all of them
+    is one batch of MSMs for the product (ipa_prove_many)."""
+
+    def __init__(self, tr, label, G, U, a, b, v, P, curve):
+        self.q, self.pm, self.curve, self.label = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve), curve, label
+        tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
+        self.Q = o.pt_mul(tr.challenge(label), U, self.pm)
+        self.a, self.b, self.G = list(a), list(b), list(G)
+        self.proof = IpaProof()
+
+    def active(self) -> bool:
+        return len(self.a) > IPA_STOP
+
+    def round_points(self) -> None:
+        a, b, G, q, pm = self.a, self.b, self.G, self.q, self.pm
         h = len(a) // 2
         cL = sum(x * y for x, y in zip(a[:h], b[h:])) % q
         cR = sum(x * y for x, y in zip(a[h:], b[:h])) % q
-        L = o.pt_add(_msm(a[:h], G[h:], curve), o.pt_mul(cL, Q, pm), pm)
-        R = o.pt_add(_msm(a[h:], G[:h], curve), o.pt_mul(cR, Q, pm), pm)
-        tr.absorb_pt(label, [L, R])
-        x = tr.challenge(label)
+        self.L = o.pt_add(_msm(a[:h], G[h:], self.curve), o.pt_mul(cL, self.Q, pm), pm)
+        self.R = o.pt_add(_msm(a[h:], G[:h], self.curve), o.pt_mul(cR, self.Q, pm), pm)
+
+    def round_fold(self, tr) -> None:
+        a, b, G, q, pm = self.a, self.b, self.G, self.q, self.pm
+        h = len(a) // 2
+        tr.absorb_pt(self.label, [self.L, self.R])
+        x = tr.challenge(self.label)
         xi = pow(x, -1, q)
-        a = [(a[i] * x + a[h + i] * xi) % q for i in range(h)]
-        b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
-        G = [o.pt_add(o.pt_mul(xi, G[i], pm), o.pt_mul(x, G[h + i], pm), pm) for i in range(h)]
-        proof.L.append(L); proof.R.append(R)
-    proof.a = list(a)
-    return proof
+        self.a = [(a[i] * x + a[h + i] * xi) % q for i in range(h)]
+        self.b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
+        self.G = [o.pt_add(o.pt_mul(xi, G[i], pm), o.pt_mul(x, G[h + i], pm), pm) for i in range(h)]
+        self.proof.L.append(self.L); self.proof.R.append(self.R)
+
+    def finish(self) -> IpaProof:
+        self.proof.a = list(self.a)
+        return self.proof
+
+
+def ipa_prove_many(tr: Transcript, jobs, curve: int) -> List[IpaProof]:
+    """jobs: (label, G, U, a, b, v, P) each.  Statements and values are absorbed job by job; then the arguments advance
+    in lockstep: every round, all still-active jobs compute their (L, R) -- before any challenge of that round is drawn --
+    and then, job by job, absorb them, draw their challenge and fold.  A shorter vector simply finishes earlier."""
+    ps = [_IpaProver(tr, *job, curve) for job in jobs]
+    while any(p.active() for p in ps):
+        act = [p for p in ps if p.active()]
+        for p in act:
+            p.round_points()
+        for p in act:
+            p.round_fold(tr)
+    return [p.finish() for p in ps]
+
+
+def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Sequence[int], b: Sequence[int], v: int,
+              P: Point, curve: int) -> IpaProof:
+    return ipa_prove_many(tr, [(label, G, U, a, b, v, P)], curve)[0]
+
+
+class _IpaVerifier:
+    def __init__(self, tr, label, G, U, b, v, P, proof, curve):
+        self.q, self.pm, self.curve, self.label = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve), curve, label
+        self.G, self.proof, self.n = list(G), proof, len(G)
+        self.m = min(self.n, IPA_STOP)
+        self.ok = (self.m << len(proof.L)) == self.n and len(proof.L) == len(proof.R) and len(proof.a) == self.m
+        tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
+        self.Q = o.pt_mul(tr.challenge(label), U, self.pm)
+        self.acc = o.pt_add(P, o.pt_mul(v, self.Q, self.pm), self.pm)
+        self.s = [1] * self.n             # G'_i = sum over t = i (mod m) of s_t G_t
+        self.b = list(b)
+        self.size, self.idx = self.n, 0
+
+    def active(self) -> bool:
+        return self.ok and self.idx < len(self.proof.L)
+
+    def round(self, tr) -> None:
+        q, pm = self.q, self.pm
+        L, R = self.proof.L[self.idx], self.proof.R[self.idx]
+        tr.absorb_pt(self.label, [L, R])
+        x = tr.challenge(self.label)
+        if x == 0:
+            self.ok = False
+            return
+        xi = pow(x, -1, q)
+        self.acc = o.pt_add(self.acc, o.pt_add(o.pt_mul(x * x % q, L, pm), o.pt_mul(xi * xi % q, R, pm), pm), pm)
+        h = self.size // 2
+        for t in range(self.n):
+            self.s[t] = self.s[t] * (x if (t % self.size) >= h else xi) % q
+        self.b = [(self.b[i] * xi + self.b[h + i] * x) % q for i in range(h)]
+        self.size, self.idx = h, self.idx + 1
+
+    def final(self) -> bool:
+        if not self.ok:
+            return False
+        q, pm, m = self.q, self.pm, self.m
+        ab = sum(x * y for x, y in zip(self.proof.a, self.b)) % q
+        rhs = o.pt_add(_msm([self.s[t] * self.proof.a[t % m] % q for t in range(self.n)], self.G, self.curve),
+                       o.pt_mul(ab, self.Q, pm), pm)
+        return self.acc == rhs
+
+
+def ipa_verify_many(tr: Transcript, jobs, curve: int) -> bool:
+    """jobs: (label, G, U, b, v, P, proof) each; the transcript order of ipa_prove_many."""
+    vs = [_IpaVerifier(tr, *job, curve) for job in jobs]
+    if not all(v.ok for v in vs):
+        return False
+    while any(v.active() for v in vs):
+        for v in [v for v in vs if v.active()]:
+            v.round(tr)
+    return all(v.final() for v in vs)
 
 
 def ipa_verify(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, b: Sequence[int], v: int, P: Point,
                proof: IpaProof, curve: int) -> bool:
-    q, pm = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve)
-    n = len(G)
-    m = min(n, IPA_STOP)
-    if (m << len(proof.L)) != n or len(proof.L) != len(proof.R) or len(proof.a) != m:
-        return False
-    tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
-    Q = o.pt_mul(tr.challenge(label), U, pm)
-    acc = o.pt_add(P, o.pt_mul(v, Q, pm), pm)
-    s = [1] * n                       # G_final = sum s_t G_t
-    b = list(b)
-    size = n
-    for L, R in zip(proof.L, proof.R):
-        tr.absorb_pt(label, [L, R])
-        x = tr.challenge(label)
-        if x == 0:
-            return False
-        xi = pow(x, -1, q)
-        acc = o.pt_add(acc, o.pt_add(o.pt_mul(x * x % q, L, pm), o.pt_mul(xi * xi % q, R, pm), pm), pm)
-        h = size // 2
-        for t in range(n):
-            s[t] = s[t] * (x if (t % size) >= h else xi) % q
-        b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
-        size = h
-    # the folded generators are G'_i = sum over t = i (mod m) of s_t G_t, the folded b is what is left of it
-    ab = sum(x * y for x, y in zip(proof.a, b)) % q
-    rhs = o.pt_add(_msm([s[t] * proof.a[t % m] % q for t in range(n)], G, curve), o.pt_mul(ab, Q, pm), pm)
-    return acc == rhs
+    return ipa_verify_many(tr, [(label, G, U, b, v, P, proof)], curve)
 
 
 # ---- the SNARK ---------------------------------------------------------------------------------------------
@@ -261,8 +321,8 @@ def prove(shape: o.R1CSShape, digest: bytes, G: Sequence[Point], U: Point, comm_
     eq_ry = eq_table(ry[1:], q)
     w_eval = sum(x * y for x, y in zip(pad(W, NW), eq_ry)) % q
     tr.absorb_fe(b"weval", [w_eval])
-    ipa_W = ipa_prove(tr, b"ipaW", G[:NW], U, pad(W, NW), eq_ry, w_eval, comm_W, curve)
-    ipa_E = ipa_prove(tr, b"ipaE", G[:M], U, pad(E, M), eq_rx, claims[3], comm_E, curve)
+    ipa_W, ipa_E = ipa_prove_many(tr, [(b"ipaW", G[:NW], U, pad(W, NW), eq_ry, w_eval, comm_W),
+                                       (b"ipaE", G[:M], U, pad(E, M), eq_rx, claims[3], comm_E)], curve)
     return SpartanProof(outer, claims, inner, w_eval, ipa_W, ipa_E)
 
 
@@ -297,6 +357,5 @@ def verify(shape: o.R1CSShape, digest: bytes, G: Sequence[Point], U: Point, comm
     if claim != m_ry * z_ry % q:
         return False
     tr.absorb_fe(b"weval", [proof.w_eval])
-    if not ipa_verify(tr, b"ipaW", G[:NW], U, eq_rest, proof.w_eval, comm_W, proof.ipa_W, curve):
-        return False
-    return ipa_verify(tr, b"ipaE", G[:M], U, eq_rx, e, comm_E, proof.ipa_E, curve)
+    return ipa_verify_many(tr, [(b"ipaW", G[:NW], U, eq_rest, proof.w_eval, comm_W, proof.ipa_W),
+                                (b"ipaE", G[:M], U, eq_rx, e, comm_E, proof.ipa_E)], curve)

@@ -5,7 +5,7 @@ using namespace vdfnova;
 
 // =============================================================================================================
 // Compression SNARK: NovaVDFProof::compress / verification of the compressed proof (src/nova/proof.rs:360-368, :383).
-// Protocol "vdf-spartan-v2", restated line by line by the test oracle (spartan.py: prove / verify); every pass over a vector is
+// Protocol "vdf-spartan-v3", restated line by line by the test oracle (spartan.py: prove / verify); every pass over a vector is
 // a call through include/vdf_hip.h, the host keeps the transcript, O(log n) field work and O(log n) point work.
 // =============================================================================================================
 namespace {
@@ -14,7 +14,7 @@ struct Transcript {
   uint8_t state[32];
   explicit Transcript(const char* label) {
     Shake256 h;
-    h.absorb("vdf-spartan-v2|", 15);
+    h.absorb("vdf-spartan-v3|", 15);
     h.absorb(label, strlen(label));
     h.squeeze(state, 32);
   }
@@ -173,117 +173,193 @@ struct FixedBase {
   }
 };
 
-// <a, b> = v under P = <a, G[0..n)>; a, b, s: device vectors of length n that this function consumes (s = all ones)
-int ipa_prove(vdf_pp* pp, Transcript& tr, const char* label, size_t n, void* d_a, void* d_b, void* d_s, void* d_sL, void* d_sR,
-              const Fe& v, const Aff& P, vdf_jac* h_lr, Ipa* out) {
+// One opening <a, b> = v under P = <a, G[0..n)>: a, b, s are device vectors of length n that the argument consumes
+// (s = all ones), sL / sR scratch of the same length.
+struct IpaJob {
+  const char* label;
+  size_t n;
+  void *d_a, *d_b, *d_s, *d_sL, *d_sR;
+  Fe v;
+  Aff P;
+  Ipa* out;
+  // state
+  size_t nj = 0;
+  Pt Qp;
+  std::unique_ptr<FixedBase> Qtab;
+  Fe cross[2];
+};
+
+// Several inner-product arguments in lockstep (the test oracle's ipa_prove_many): statements and values are absorbed job
+// by job; then every round ALL still-active jobs put their L and R into ONE batched MSM (up to four groups: one sort, one
+// accumulate grid, one bucket reduction) before any challenge of the round is drawn, and job by job absorb them, draw
+// their challenge and fold.  h_lr: 2 * jobs pinned result slots.
+int ipa_prove_many(vdf_pp* pp, Transcript& tr, IpaJob* jobs, int njobs, vdf_jac* h_lr) {
   vdf_ctx* ctx = pp->ctx;
   const Field& F = field(PRIMARY_FIELD);
   const Field& Fb = field_fp();
-  tr.absorb_pt(label, &P, 1);
-  tr.absorb_fe(label, &v, 1, F);
   uint64_t raw[4];
-  tr.challenge(label, F, raw);
-  const Pt Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
-  const FixedBase Qtab(Qp);
-  out->L.clear(); out->R.clear();
-  size_t left = n;
-  for (size_t nj = n; nj > IPA_STOP; nj >>= 1) {
-    left = nj >> 1;
-    Fe cross[2];
-    const vdf_fe* ab[2] = {(const vdf_fe*)d_a, (const vdf_fe*)d_b};
-    HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_IPA_CROSS, ab, nullptr, nj, (vdf_fe*)cross));
-    HIPCALL(ctx, vdf_ipa_scalars(ctx, PRIMARY_FIELD, (const vdf_fe*)d_a, (const vdf_fe*)d_s, n, nj, (vdf_fe*)d_sL, (vdf_fe*)d_sR));
-    const size_t off[2] = {0, 0}, len[2] = {n, n};
-    const vdf_fe* sc[2] = {(const vdf_fe*)d_sL, (const vdf_fe*)d_sR};
-    HIPCALL(ctx, vdf_msm_batch(ctx, pp->gens, 2, off, sc, len, 1, h_lr));
+  if (njobs < 1 || njobs > 2) return fail(VDF_ERR_BAD_ARG, "one or two openings at a time (four MSMs per batch)");
+  for (int q = 0; q < njobs; ++q) {
+    IpaJob& jb = jobs[q];
+    tr.absorb_pt(jb.label, &jb.P, 1);
+    tr.absorb_fe(jb.label, &jb.v, 1, F);
+    tr.challenge(jb.label, F, raw);
+    jb.Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
+    jb.Qtab.reset(new FixedBase(jb.Qp));
+    jb.nj = jb.n;
+    jb.out->L.clear(); jb.out->R.clear();
+  }
+  for (;;) {
+    IpaJob* act[2];
+    int na = 0;
+    for (int q = 0; q < njobs; ++q) if (jobs[q].nj > IPA_STOP) act[na++] = &jobs[q];
+    if (!na) break;
+    size_t off[4] = {0, 0, 0, 0}, len[4];
+    const vdf_fe* sc[4];
+    for (int q = 0; q < na; ++q) {
+      IpaJob& jb = *act[q];
+      const vdf_fe* ab[2] = {(const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_b};
+      HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));
+      HIPCALL(ctx, vdf_ipa_scalars(ctx, PRIMARY_FIELD, (const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_s, jb.n, jb.nj, (vdf_fe*)jb.d_sL,
+                                   (vdf_fe*)jb.d_sR));
+      sc[2 * q] = (const vdf_fe*)jb.d_sL; sc[2 * q + 1] = (const vdf_fe*)jb.d_sR;
+      len[2 * q] = len[2 * q + 1] = jb.n;
+    }
+    HIPCALL(ctx, vdf_msm_batch(ctx, pp->gens, 2 * na, off, sc, len, 1, h_lr));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
-    Aff l0, r0;
-    jac_to_aff2(h_lr[0], h_lr[1], Fb, &l0, &r0);
-    const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), Qtab.mul(cross[0], F), Fb), Fb);
-    const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), Qtab.mul(cross[1], F), Fb), Fb);
-    const Aff lr[2] = {Lp, Rp};
-    tr.absorb_pt(label, lr, 2);
-    const Fe x = tr.challenge(label, F, raw);
-    const Fe xi = inverse(x, F);
-    vdf_fe* vecs[2] = {(vdf_fe*)d_a, (vdf_fe*)d_b};
-    const Fe c_lo[2] = {x, xi}, c_hi[2] = {xi, x};
-    HIPCALL(ctx, vdf_fold_halves(ctx, PRIMARY_FIELD, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, nj));
-    HIPCALL(ctx, vdf_scale_pattern(ctx, PRIMARY_FIELD, (vdf_fe*)d_s, n, nj, (const vdf_fe*)&xi, (const vdf_fe*)&x));
-    out->L.push_back(Lp); out->R.push_back(Rp);
+    for (int q = 0; q < na; ++q) {
+      IpaJob& jb = *act[q];
+      Aff l0, r0;
+      jac_to_aff2(h_lr[2 * q], h_lr[2 * q + 1], Fb, &l0, &r0);
+      const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), jb.Qtab->mul(jb.cross[0], F), Fb), Fb);
+      const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), jb.Qtab->mul(jb.cross[1], F), Fb), Fb);
+      const Aff lr[2] = {Lp, Rp};
+      tr.absorb_pt(jb.label, lr, 2);
+      const Fe x = tr.challenge(jb.label, F, raw);
+      const Fe xi = inverse(x, F);
+      vdf_fe* vecs[2] = {(vdf_fe*)jb.d_a, (vdf_fe*)jb.d_b};
+      const Fe c_lo[2] = {x, xi}, c_hi[2] = {xi, x};
+      HIPCALL(ctx, vdf_fold_halves(ctx, PRIMARY_FIELD, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, jb.nj));
+      HIPCALL(ctx, vdf_scale_pattern(ctx, PRIMARY_FIELD, (vdf_fe*)jb.d_s, jb.n, jb.nj, (const vdf_fe*)&xi, (const vdf_fe*)&x));
+      jb.out->L.push_back(Lp); jb.out->R.push_back(Rp);
+      jb.nj >>= 1;
+    }
   }
   HIPCALL(ctx, vdf_ctx_sync(ctx));
-  out->a.resize(left);
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, out->a.data(), d_a, left * 32));
+  for (int q = 0; q < njobs; ++q) {
+    jobs[q].out->a.resize(jobs[q].nj);
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, jobs[q].out->a.data(), jobs[q].d_a, jobs[q].nj * 32));
+  }
   return VDF_OK;
 }
 
-// b is eq(rb, .): its fold is a closed form; the coefficient vector of the folded generator is a tensor-product table
-int ipa_verify(vdf_pp* pp, Transcript& tr, const char* label, size_t n, const std::vector<Fe>& rb, const Fe& v, const Aff& P,
-               const Ipa& proof, void* d_s, bool* ok) {
+// b is eq(rb, .): its fold is a closed form; the coefficient vector of the folded generators is a tensor-product table
+struct IpaCheck {
+  const char* label;
+  size_t n;
+  const std::vector<Fe>* rb;       // one entry per variable of the full vector
+  Fe v;
+  Aff P;
+  const Ipa* proof;
+  // state
+  size_t k = 0, m = 0, idx = 0;
+  int log_m = 0;
+  Pt Qp, acc;
+  Fe bfin;
+  std::vector<Fe> xs, xis;
+};
+
+// The transcript order of ipa_prove_many; then, per opening, two device MSMs: sum_j x_j^2 L_j + x_j^-2 R_j (2k
+// multiplications by full-size scalars: on the host they were the whole cost of verification, 0.25 ms each) and the
+// folded generators against the sent vector.
+int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void* d_s, bool* ok) {
   vdf_ctx* ctx = pp->ctx;
   const Field& F = field(PRIMARY_FIELD);
   const Field& Fb = field_fp();
   *ok = false;
-  const size_t k = proof.L.size();                 // rounds performed; rb has one entry per variable of the full vector
-  const size_t m = ipa_final(n);
-  int log_m = 0, log_n = 0;
-  while (((size_t)1 << log_m) < m) ++log_m;
-  while (((size_t)1 << log_n) < n) ++log_n;
-  if (((size_t)1 << log_n) != n || k != ipa_rounds(n) || proof.R.size() != k || proof.a.size() != m || rb.size() != (size_t)log_n)
-    return VDF_OK;
-  tr.absorb_pt(label, &P, 1);
-  tr.absorb_fe(label, &v, 1, F);
   uint64_t raw[4];
-  tr.challenge(label, F, raw);
-  const Pt Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
-  Pt acc = pt_add(pt_from_aff(P, Fb), pt_mul_fe(Qp, v, F), Fb);
-  std::vector<Fe> xs(k), xis(k);
-  Fe bfin = one(F);
-  // sum_j x_j^2 L_j + x_j^-2 R_j: 2k scalar multiplications by full-size scalars -- on the host they were the whole
-  // cost of verification (0.25 ms each); as one small MSM on the device they are one call
-  std::vector<Aff> lr_pts(2 * k);
-  std::vector<Fe> lr_sc(2 * k);
-  for (size_t j = 0; j < k; ++j) {
-    const Aff lr[2] = {proof.L[j], proof.R[j]};
-    tr.absorb_pt(label, lr, 2);
-    const Fe x = tr.challenge(label, F, raw);
-    if (x.is_zero()) return VDF_OK;
-    const Fe xi = inverse(x, F);
-    lr_pts[2 * j] = proof.L[j]; lr_sc[2 * j] = sqr(x, F);
-    lr_pts[2 * j + 1] = proof.R[j]; lr_sc[2 * j + 1] = sqr(xi, F);
-    bfin = mul(bfin, add(mul(sub(one(F), rb[j], F), xi, F), mul(rb[j], x, F), F), F);
-    xs[j] = x; xis[j] = xi;
+  for (int q = 0; q < njobs; ++q) {
+    IpaCheck& c = jobs[q];
+    c.k = c.proof->L.size();
+    c.m = ipa_final(c.n);
+    int log_n = 0;
+    while (((size_t)1 << c.log_m) < c.m) ++c.log_m;
+    while (((size_t)1 << log_n) < c.n) ++log_n;
+    if (((size_t)1 << log_n) != c.n || c.k != ipa_rounds(c.n) || c.proof->R.size() != c.k || c.proof->a.size() != c.m ||
+        c.rb->size() != (size_t)log_n)
+      return VDF_OK;
   }
-  if (k) {
-    vdf_bases* lrb = nullptr;
-    HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)lr_pts.data(), 2 * k, &lrb));
-    vdf_jac jlr;
-    const int rc = vdf_msm(ctx, lrb, 0, (const vdf_fe*)lr_sc.data(), 2 * k, 1, &jlr);
-    const std::string err = rc == VDF_OK ? "" : vdf_last_error(ctx);
-    vdf_bases_free(lrb);
-    if (rc != VDF_OK) return fail(rc, "vdf_msm (L, R): " + err);
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
-    acc = pt_add(acc, pt_from_aff(jac_to_aff(jlr, Fb), Fb), Fb);
+  for (int q = 0; q < njobs; ++q) {
+    IpaCheck& c = jobs[q];
+    tr.absorb_pt(c.label, &c.P, 1);
+    tr.absorb_fe(c.label, &c.v, 1, F);
+    tr.challenge(c.label, F, raw);
+    c.Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
+    c.acc = pt_add(pt_from_aff(c.P, Fb), pt_mul_fe(c.Qp, c.v, F), Fb);
+    c.bfin = one(F);
+    c.xs.resize(c.k); c.xis.resize(c.k);
   }
-  // coefficients of the original generators in sum_i a_i G'_i, G'_i the folded generators: the table of the performed
-  // rounds over the top index bits times the sent vector over the low ones; b folded in closed form: bfin (the rounds)
-  // times eq over the remaining variables
-  HIPCALL(ctx, vdf_pair_table_pattern(ctx, PRIMARY_FIELD, (const vdf_fe*)xis.data(), (const vdf_fe*)xs.data(), (int)k,
-                                      (const vdf_fe*)proof.a.data(), log_m, (vdf_fe*)d_s));
-  vdf_jac jg;
-  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)d_s, n, 1, &jg));
-  Fe ab = zero();
-  for (size_t i = 0; i < m; ++i) {
-    Fe bi = bfin;
-    for (int j = 0; j < log_m; ++j) {
-      const Fe& r = rb[k + j];
-      bi = mul(bi, ((i >> (log_m - 1 - j)) & 1) ? r : sub(one(F), r, F), F);
+  for (;;) {
+    bool any = false;
+    for (int q = 0; q < njobs; ++q) {
+      IpaCheck& c = jobs[q];
+      if (c.idx >= c.k) continue;
+      any = true;
+      const size_t j = c.idx++;
+      const Aff lr[2] = {c.proof->L[j], c.proof->R[j]};
+      tr.absorb_pt(c.label, lr, 2);
+      const Fe x = tr.challenge(c.label, F, raw);
+      if (x.is_zero()) return VDF_OK;
+      const Fe xi = inverse(x, F);
+      const Fe& r = (*c.rb)[j];
+      c.bfin = mul(c.bfin, add(mul(sub(one(F), r, F), xi, F), mul(r, x, F), F), F);
+      c.xs[j] = x; c.xis[j] = xi;
     }
-    ab = add(ab, mul(proof.a[i], bi, F), F);
+    if (!any) break;
   }
-  const Pt rhs = pt_add(pt_from_aff(jac_to_aff(jg, Fb), Fb), pt_mul_fe(Qp, ab, F), Fb);
-  const Aff a1 = pt_to_aff(acc, Fb), a2 = pt_to_aff(rhs, Fb);
-  *ok = memcmp(&a1, &a2, sizeof(Aff)) == 0;
+  bool all = true;
+  for (int q = 0; q < njobs; ++q) {
+    IpaCheck& c = jobs[q];
+    const size_t k = c.k, m = c.m;
+    if (k) {
+      std::vector<Aff> lr_pts(2 * k);
+      std::vector<Fe> lr_sc(2 * k);
+      for (size_t j = 0; j < k; ++j) {
+        lr_pts[2 * j] = c.proof->L[j]; lr_sc[2 * j] = sqr(c.xs[j], F);
+        lr_pts[2 * j + 1] = c.proof->R[j]; lr_sc[2 * j + 1] = sqr(c.xis[j], F);
+      }
+      vdf_bases* lrb = nullptr;
+      HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)lr_pts.data(), 2 * k, &lrb));
+      vdf_jac jlr;
+      const int rc = vdf_msm(ctx, lrb, 0, (const vdf_fe*)lr_sc.data(), 2 * k, 1, &jlr);
+      const std::string err = rc == VDF_OK ? "" : vdf_last_error(ctx);
+      vdf_bases_free(lrb);
+      if (rc != VDF_OK) return fail(rc, "vdf_msm (L, R): " + err);
+      HIPCALL(ctx, vdf_ctx_sync(ctx));
+      c.acc = pt_add(c.acc, pt_from_aff(jac_to_aff(jlr, Fb), Fb), Fb);
+    }
+    // coefficients of the original generators in sum_i a_i G'_i, G'_i the folded generators: the table of the performed
+    // rounds over the top index bits times the sent vector over the low ones; b folded in closed form: bfin (the
+    // rounds) times eq over the remaining variables
+    HIPCALL(ctx, vdf_pair_table_pattern(ctx, PRIMARY_FIELD, (const vdf_fe*)c.xis.data(), (const vdf_fe*)c.xs.data(), (int)k,
+                                        (const vdf_fe*)c.proof->a.data(), c.log_m, (vdf_fe*)d_s));
+    vdf_jac jg;
+    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)d_s, c.n, 1, &jg));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    Fe ab = zero();
+    for (size_t i = 0; i < m; ++i) {
+      Fe bi = c.bfin;
+      for (int j = 0; j < c.log_m; ++j) {
+        const Fe& r = (*c.rb)[k + j];
+        bi = mul(bi, ((i >> (c.log_m - 1 - j)) & 1) ? r : sub(one(F), r, F), F);
+      }
+      ab = add(ab, mul(c.proof->a[i], bi, F), F);
+    }
+    const Pt rhs = pt_add(pt_from_aff(jac_to_aff(jg, Fb), Fb), pt_mul_fe(c.Qp, ab, F), Fb);
+    const Aff a1 = pt_to_aff(c.acc, Fb), a2 = pt_to_aff(rhs, Fb);
+    all = all && memcmp(&a1, &a2, sizeof(Aff)) == 0;
+  }
+  *ok = all;
   return VDF_OK;
 }
 
@@ -302,7 +378,7 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
   for (void** p : {&d_w, &d_s, &d_sL, &d_sR}) { int rc = bufs.zeros(L.NW, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   { int rc = bufs.zeros(pp->ncols, &d_cols); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   vdf_jac* h_lr = nullptr;
-  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * sizeof(vdf_jac), (void**)&h_lr));
+  HIPCALL(ctx, vdf_host_alloc(ctx, 4 * sizeof(vdf_jac), (void**)&h_lr));
   struct HostFree { vdf_ctx* c; void* p; ~HostFree() { vdf_host_free(c, p); } } hf{ctx, h_lr};
 
   Transcript tr("compress");
@@ -370,15 +446,21 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
     HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_DOT, tabs, nullptr, L.NW, (vdf_fe*)&out->w_eval));
   }
   tr.absorb_fe("weval", &out->w_eval, 1, F);
+  // the two openings advance in lockstep (one four-group MSM per round).  W: a = W padded, b = eq(r_y[1:], .);
+  // E: a = E padded to M (fresh copy: d_e was folded by the sum-check), b = eq(r_x, .).  Each needs its own coefficient
+  // and scalar vectors: the E opening's live in buffers the sum-checks are done with.
   std::vector<Fe> ones_lo(24, one(F));
   HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.l1 - 1, (vdf_fe*)d_s));
-  { int rc = ipa_prove(pp, tr, "ipaW", L.NW, d_w, d_eq_ry, d_s, d_sL, d_sR, out->w_eval, cW, h_lr, &out->ipaW); if (rc != VDF_OK) return rc; }
-  // E: a = E padded to M (fresh copy: d_e was folded), b = eq(r_x, .)
   HIPCALL(ctx, vdf_dev_memset(ctx, d_e, 0, L.M * 32));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_e, d_E, nc * 32));
-  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.s, (vdf_fe*)d_s));
-  { int rc = ipa_prove(pp, tr, "ipaE", L.M, d_e, d_eq_rx, d_s, d_sL, d_sR, out->claims[3], cE, h_lr, &out->ipaE); if (rc != VDF_OK) return rc; }
-  return VDF_OK;
+  void *d_sE = d_eq, *d_sLE = d_bz, *d_sRE = d_cz;            // M entries each, spent by the outer sum-check (d_az holds eq(r_x, .))
+  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.s, (vdf_fe*)d_sE));
+  IpaJob jobs[2];
+  jobs[0].label = "ipaW"; jobs[0].n = L.NW; jobs[0].d_a = d_w; jobs[0].d_b = d_eq_ry; jobs[0].d_s = d_s; jobs[0].d_sL = d_sL;
+  jobs[0].d_sR = d_sR; jobs[0].v = out->w_eval; jobs[0].P = cW; jobs[0].out = &out->ipaW;
+  jobs[1].label = "ipaE"; jobs[1].n = L.M; jobs[1].d_a = d_e; jobs[1].d_b = d_eq_rx; jobs[1].d_s = d_sE; jobs[1].d_sL = d_sLE;
+  jobs[1].d_sR = d_sRE; jobs[1].v = out->claims[3]; jobs[1].P = cE; jobs[1].out = &out->ipaE;
+  return ipa_prove_many(pp, tr, jobs, 2, h_lr);
 }
 
 int spartan_verify(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Spartan& pf, bool* ok) {
@@ -444,12 +526,10 @@ int spartan_verify(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const 
   const Fe z_ry = add(mul(sub(one(F), ry[0], F), pf.w_eval, F), mul(ry[0], pub, F), F);
   if (claim != mul(m_ry, z_ry, F)) return VDF_OK;
   tr.absorb_fe("weval", &pf.w_eval, 1, F);
-  bool ok1 = false, ok2 = false;
-  { int rc = ipa_verify(pp, tr, "ipaW", L.NW, rest, pf.w_eval, cW, pf.ipaW, d_s, &ok1); if (rc != VDF_OK) return rc; }
-  if (!ok1) return VDF_OK;
-  { int rc = ipa_verify(pp, tr, "ipaE", L.M, rx, e, cE, pf.ipaE, d_s, &ok2); if (rc != VDF_OK) return rc; }
-  *ok = ok2;
-  return VDF_OK;
+  IpaCheck checks[2];
+  checks[0].label = "ipaW"; checks[0].n = L.NW; checks[0].rb = &rest; checks[0].v = pf.w_eval; checks[0].P = cW; checks[0].proof = &pf.ipaW;
+  checks[1].label = "ipaE"; checks[1].n = L.M; checks[1].rb = &rx; checks[1].v = e; checks[1].P = cE; checks[1].proof = &pf.ipaE;
+  return ipa_verify_many(pp, tr, checks, 2, d_s, ok);
 }
 
 }  // namespace

@@ -1,4 +1,4 @@
-// Kernels of the compression SNARK (protocol "vdf-spartan-v2", restated by the test oracle, spartan.py): a Spartan-style
+// Kernels of the compression SNARK (protocol "vdf-spartan-v3", restated by the test oracle, spartan.py): a Spartan-style
 // argument for the folded relaxed R1CS instance with inner-product-argument openings -- the work behind
 // `NovaVDFProof::compress` / verification of the compressed proof (/root/reference/src/nova/proof.rs:360-368, :383;
 // nova-snark 0.8.0 `CompressedSNARK`).
