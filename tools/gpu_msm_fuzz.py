@@ -13,6 +13,7 @@ from util import jac_to_affine, rand_limbs, limbs
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # run just this configuration (the others only advance the RNG)
+BIG = bool(os.environ.get("FUZZ_BIG"))                         # production-like: 2^17 .. 1.1 M points, table windows 16 / 17, one set
 rng = np.random.default_rng(seed)
 ctx = v.Context(0)
 L = cref.lib()
@@ -43,13 +44,17 @@ for it in range(iters):
     sm = o.curve_scalar_modulus(curve)
     nmax = int(rng.choice([7, 60, 500, 3000, 20000, 20000, 300000]))
     ntot = int(rng.integers(1, nmax + 1))
+    if BIG:
+        ntot = int(rng.integers(1 << 17, 1100000))
     bseed = int(rng.integers(1, 1000))
     c = int(rng.integers(4, 21))
     table = rng.random() < 0.6
+    if BIG:
+        c, table = int(rng.choice([16, 17, 0])), True
     sets, win = 0, 0
     if table:
-        windows = (256 + c - 1) // c
-        sets = int(rng.choice([1, 1, 2, windows]))
+        windows = (256 + c - 1) // c if c else 16
+        sets = 1 if BIG else int(rng.choice([1, 1, 2, windows]))
     else:
         win = c if rng.random() < 0.7 else 0
     k = int(rng.integers(1, 5))
