@@ -1,4 +1,4 @@
-"""Large single-GPU MSMs (2^22, 2^24 points, fixed-base table c = 16): timing, and parity through
+"""Large single-GPU MSMs (2^22, 2^24 points, fixed-base table, recommended window): timing, and parity through
 size-independent identities -- the discrete-log identity of the [k_i]G family at 2^22, and at 2^24
 MSM(all) == sum of the four quarter MSMs (offsets into the same table) via vdf_point_sum."""
 import sys, time, os
@@ -11,7 +11,7 @@ ctx = v.Context(0)
 curve = v.CURVE_PALLAS
 for lg in [int(a) for a in sys.argv[1:]] or [22, 24]:
     n = 1 << lg
-    t0 = time.time(); bases = ctx.bases_generate(curve, 7, n); bases.precompute(16, 1)
+    t0 = time.time(); bases = ctx.bases_generate(curve, 7, n); bases.precompute(0, 1)
     print(f"2^{lg}: bases + table {time.time() - t0:.1f} s ({16 * n * 64 / 2**30:.1f} GiB table)", flush=True)
     g = torch.Generator(device="cuda"); g.manual_seed(lg)
     sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
