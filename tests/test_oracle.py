@@ -260,3 +260,13 @@ def test_try_and_increment_generators_are_curve_points_with_even_y():
     for a in (0, 1, 4, 5, 12345678901234567890):
         r = o.sqrt_mod(a * a, o.P)
         assert r in (a % o.P, (-a) % o.P)
+
+
+def test_vectorised_dlog_identity_equals_the_plain_one():
+    """msm_by_dlog_limbs (what the 2^24 GPU test is checked against) is the same function as msm_by_dlog."""
+    import numpy as np
+    from util import rand_limbs, ints
+    rng = np.random.default_rng(11)
+    for curve, seed, start, n in ((o.CURVE_PALLAS, 7, 0, 1000), (o.CURVE_VESTA, 3, 12345, 257), (o.CURVE_PALLAS, 9, 1 << 23, 1)):
+        sc = rand_limbs(rng, n)
+        assert o.msm_by_dlog_limbs(sc, curve, seed, start) == o.msm_by_dlog(ints(sc), curve, seed, start)
