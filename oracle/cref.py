@@ -46,7 +46,7 @@ def lib() -> C.CDLL:
             "ref_forward_step": [i, i, vp, vp], "ref_forward_step_pow": [i, vp, vp],
             "ref_minroot_eval": [i, i, vp, u64, vp, vp], "ref_minroot_inverse_eval": [i, vp, u64, vp],
             "ref_step_witness": [i, vp, u64, vp],
-            "ref_jac_to_affine": [i, vp, vp], "ref_synthetic_bases": [i, u64, sz, sz, vp],
+            "ref_jac_to_affine": [i, vp, vp], "ref_synthetic_bases": [i, u64, sz, sz, vp], "ref_tai_bases": [i, u64, sz, sz, vp],
             "ref_msm": [i, vp, vp, sz, i, i, i, vp], "ref_msm_naive": [i, vp, vp, sz, i, vp],
         }
         for name, args in sig.items():

@@ -494,6 +494,82 @@ void ref_synthetic_bases(int curve, uint64_t seed, size_t start, size_t n, affin
   }
 }
 
+/* Tonelli-Shanks square root (2-adicity 32 in both fields); returns 0 for a non-residue */
+static int fe_sqrt(fe* r, const fe* a, const field* F) {
+  if (fe_is_zero(a)) { *r = *a; return 1; }
+  /* m - 1 = 2^32 * t */
+  uint64_t t[4], e[4];
+  memcpy(t, F->m, 32);
+  t[0] -= 1;
+  for (int i = 0; i < 4; ++i) e[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0);        /* (m - 1) / 2 */
+  fe one, leg;
+  fe_set_one(&one, F);
+  fe_pow(&leg, a, e, F);
+  if (!fe_eq(&leg, &one)) return 0;
+  uint64_t tt[4], th[4];
+  for (int i = 0; i < 4; ++i) tt[i] = (t[i] >> 32) | (i < 3 ? t[i + 1] << 32 : 0);        /* t = (m - 1) >> 32, odd */
+  /* (t + 1) / 2 */
+  { u128 c = (u128)tt[0] + 1; th[0] = (uint64_t)c; c >>= 64; for (int i = 1; i < 4; ++i) { c += tt[i]; th[i] = (uint64_t)c; c >>= 64; } }
+  for (int i = 0; i < 4; ++i) th[i] = (th[i] >> 1) | (i < 3 ? th[i + 1] << 63 : 0);
+  fe z, c, x, b, mone;
+  fe_neg(&mone, &one, F);
+  for (uint64_t k = 2;; ++k) {                        /* smallest non-residue, as oracle/pasta.py sqrt_mod */
+    fe_set_u64(&z, k, F);
+    fe_pow(&leg, &z, e, F);
+    if (fe_eq(&leg, &mone)) break;
+  }
+  fe_pow(&c, &z, tt, F);
+  fe_pow(&x, a, th, F);
+  fe_pow(&b, a, tt, F);
+  int s = 32;
+  while (!fe_eq(&b, &one)) {
+    int k = 0;
+    fe q = b;
+    while (!fe_eq(&q, &one)) { fe_sqr(&q, &q, F); ++k; }
+    fe g = c;
+    for (int i = 0; i < s - k - 1; ++i) fe_sqr(&g, &g, F);
+    fe_mul(&x, &x, &g, F);
+    fe_sqr(&c, &g, F);
+    fe_mul(&b, &b, &c, F);
+    s = k;
+  }
+  *r = x;
+  return 1;
+}
+static uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+/* generator family 1 (oracle/pasta.py tai_base): seeded try-and-increment, even y */
+void ref_tai_bases(int curve, uint64_t seed, size_t start, size_t n, affine* out) {
+  const field* F = curve_field(curve);
+  fe five;
+  fe_set_u64(&five, 5, F);
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t sm = seed * 0xD1342543DE82EF95ull + (uint64_t)(start + i) * 0x9E3779B97F4A7C15ull, st[4];
+    for (int k = 0; k < 4; ++k) { st[k] = splitmix64(sm); sm += 0x9E3779B97F4A7C15ull; }
+    for (;;) {
+      uint64_t w[4];
+      for (int k = 0; k < 4; ++k) {
+        w[k] = rotl64(st[1] * 5, 7) * 9;
+        const uint64_t t = st[1] << 17;
+        st[2] ^= st[0]; st[3] ^= st[1]; st[1] ^= st[2]; st[0] ^= st[3];
+        st[2] ^= t;
+        st[3] = rotl64(st[3], 45);
+      }
+      while (geq_m(w, F)) sub_m(w, F);
+      fe xc, x, rhs, y, yc;
+      memcpy(xc.l, w, 32);
+      fe_to_mont(&x, &xc, F);
+      fe_sqr(&rhs, &x, F);
+      fe_mul(&rhs, &rhs, &x, F);
+      fe_add(&rhs, &rhs, &five, F);
+      if (!fe_sqrt(&y, &rhs, F)) continue;
+      fe_from_mont(&yc, &y, F);
+      if (yc.l[0] & 1) fe_neg(&y, &y, F);
+      out[i].x = x; out[i].y = y;
+      break;
+    }
+  }
+}
+
 /* ---- Pippenger MSM (pasta-msm 0.1.1's published algorithm: signed windows, XYZZ buckets with
  * mixed addition, running-sum bucket reduction, windows spread over a thread pool) ------------ */
 typedef struct {
