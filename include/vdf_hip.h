@@ -212,6 +212,12 @@ int  vdf_minroot_step_z(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_
  * and is an MSM over 3t + 4 instead of 4t + 4 points, with the same value (libvdf_nova.so uses this). */
 int  vdf_minroot_step_z_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe z_in[3],
                                const vdf_fe* i0, const vdf_fe* u, const vdf_fe X[6], vdf_fe* z, vdf_fe* w_packed);
+/* Only the variables `InverseMinRootCircuit::synthesize` allocates (src/nova/proof.rs:107-126), for a step circuit that
+ * sits inside an augmented circuit: vars_per_round = 4: new_x, tmp1, tmp2, new_y per round (the reference's allocation,
+ * as vdf_minroot_witness) ; vars_per_round = 3: tmp1, tmp2, new_y (the bound form, where new_x is the linear
+ * combination y - i + 1 and no variable); then final_i = i0.  out has vars_per_round * t + 1 elements.  i0: host memory. */
+int  vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe* i0, int vars_per_round,
+                              vdf_fe* out);
 /* vdf_spmv3(shape, z2) followed by vdf_cross_term(Az1, Bz1, Cz1, Az2, Bz2, Cz2, u1): writes Az2, Bz2, Cz2
  * (num_cons each) and T.  u1: host memory.  (nova-snark NIFS::prove -> commit_T, K4 + K5.) */
 int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,

@@ -3,18 +3,23 @@
  *
  * The reference is Rust (/root/reference/src/minroot.rs, src/nova/proof.rs); no Rust toolchain
  * exists in the build image, so the host side is C++ and mirrors the reference's names, argument
- * meaning and error behaviour.  Every heavy operation is a call through include/vdf_hip.h; this
+ * meaning and error behaviour.  Every pass over a vector is a call through include/vdf_hip.h; this
  * library contains no kernel and no CPU fallback for one.  What stays on the host is what the
  * reference also keeps sequential or O(1): the forward MinRoot evaluation (src/minroot.rs:329-359,
- * the "delay" itself), transcript hashing, and the two scalar multiplications of an instance fold.
+ * the "delay" itself), and the synthesis of the ~10^4 variables of an augmented circuit that are not
+ * MinRoot rounds (hashes, in-circuit group arithmetic: strictly sequential field work).
  *
- * STAGE: folding-only, plus the compression SNARK over the folded instance.  A step is the reference's step circuit
- * (InverseMinRootCircuit::synthesize, src/nova/proof.rs:87-140) wrapped so that z_in / z_out are
- * public (the "exposed-IO wrapper", oracle/pasta.py step_circuit_shape) and folded with NIFS
- * (SURVEY.md Appendix C).  The in-circuit verifier (augmented circuit), the secondary curve and
- * Poseidon are not built: the proof is therefore linear in the number of steps (the verifier
- * replays the folds) instead of constant-size.  The transcript hash is SHAKE256, squeezed to 128
- * bits; nova-snark's Poseidon transcript is implementation-defined and unpinned.
+ * What a proof is: Nova IVC on the Pallas / Vesta cycle (src/nova/proof.rs:26-43), protocol
+ * "vdf-nova-ivc-v1", specified in oracle/nova.py.  prove_step (:342-349) folds the previous secondary
+ * instance, synthesises the PRIMARY augmented circuit (in-circuit check of the previous output hash,
+ * in-circuit NIFS verifier for the secondary curve, the MinRoot step circuit, the next output hash)
+ * commits and folds it, then does the same for the SECONDARY augmented circuit around
+ * TrivialTestCircuit (:258-260).  A proof has constant size in the number of steps and verify
+ * (:370-392) recomputes two hashes and checks three satisfiability claims, `zi_secondary == [0]`
+ * included.  nova-snark 0.8.0's own constants (Poseidon parameters, allocation order, transcript,
+ * generator derivation) are not in /root/reference and pinned by none of its tests:
+ * proofs are self-consistent and bit-exact against oracle/nova.py, not interchangeable with
+ * nova-snark's -- parity unpinned.
  */
 #ifndef VDF_NOVA_H
 #define VDF_NOVA_H
@@ -51,14 +56,28 @@ typedef struct vdf_circuits vdf_circuits; /* Vec<InverseMinRootCircuit<G1>>, :57
 typedef struct vdf_proof vdf_proof;       /* NovaVDFProof::Recursive, :51-55 */
 typedef struct vdf_snark vdf_snark;       /* NovaVDFProof::Compressed, :54 */
 
-/* public_params(num_iters_per_step), :232-237: R1CS shape of the wrapped step circuit, Pedersen
- * generators (next_pow2(max(vars, cons)) of them by seeded try-and-increment -- unknown discrete logarithms,
- * VDF_GENS_TRY_AND_INCREMENT; nova-snark's own label -> hash derivation is unpinned) with their fixed-base table,
- * shape digest.  One-time; outside every timed region (benches/nova.rs:51-58). */
+/* The primary step circuit (the seam of :79-153).  BOUND (the default): InverseMinRootCircuit with new_x carried as
+ * the linear combination y - i + 1 instead of a variable -- 3 variables and 3 constraints per round.  REFERENCE: the
+ * circuit exactly as the reference writes it (4 variables per round; new_x allocated at :167-173 and used by no
+ * constraint, :219-227 takes y - i + 1 directly), kept for shape / witness parity; a prover may set its new_x freely,
+ * so a proof over it does not attest the VDF (tests/test_oracle_nova.py shows the forgery). */
+enum { VDF_CIRCUIT_MINROOT_BOUND = 0, VDF_CIRCUIT_MINROOT_REFERENCE = 1 };
+enum { VDF_SIDE_PRIMARY = 0, VDF_SIDE_SECONDARY = 1 };
+
+/* public_params(num_iters_per_step), :232-237: both augmented circuits synthesised once for their R1CS shapes,
+ * Pedersen generators per curve (next_pow2(max(vars, cons)) of them, seeded try-and-increment -- unknown discrete
+ * logarithms; nova-snark's own label -> hash derivation is unpinned) with their fixed-base tables, and the digest of
+ * all of it that every hash of the protocol absorbs.  One-time; outside every timed region (benches/nova.rs:51-58). */
 int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** out);
+/* The same with the step circuit and the generator family chosen.  gens_family = VDF_GENS_KNOWN_DLOG is for tests only
+ * (commitments checkable by the discrete-log identity at full size; such commitments are not binding). */
+int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, vdf_pp** out);
 void vdf_nova_pp_free(vdf_pp* pp);
-int  vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
+int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
                        uint64_t* num_gens);
+/* the 250-bit digest of the parameters (little-endian), and the run of primary variables the GPU fills (MinRoot rounds) */
+int  vdf_nova_pp_digest(const vdf_pp* pp, uint8_t out[32]);
+int  vdf_nova_pp_segment(const vdf_pp* pp, uint64_t* begin, uint64_t* len);
 
 /* InverseMinRootCircuit::eval_and_make_circuits, :262-299: num_steps forward evaluations of
  * num_iters_per_step rounds each from initial_state (host, sequential), one circuit per step
@@ -78,31 +97,53 @@ void vdf_nova_circuits_free(vdf_circuits* c);
  * per circuit.  Returns VDF_ERR_* (the reference asserts success, :353). */
 int  vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_t num_iters_per_step,
                                 const vdf_fe z0[3], vdf_proof** out);
-/* One RecursiveSNARK::prove_step (:342-349): *proof == NULL starts a new proof (the `None` case).
- * What a step computes that does not depend on the chain -- the fresh witness of circuit k and its commitment -- is
- * enqueued one call early, for circuit k + 1 of the same `circuits`, on a second context the proof owns; a call for any
- * other step simply finds no such work waiting and does it then.  The results are those of a prover without lookahead,
- * and no call returns while anything in flight still reads the circuits' memory (they may be freed right after).
- * The fresh commitment is an MSM over 3t + 4 merged generators (vdf_minroot_step_z_packed, include/vdf_hip.h): the
- * same point as the commitment to all 4t + 4 witness values. */
+/* One RecursiveSNARK::prove_step (:342-349): *proof == NULL starts a new proof (the `None` case).  z0_secondary is
+ * [0] (:310, :389-391).  What a step computes that does not depend on the chain -- the MinRoot rounds of circuit k and
+ * their share of the commitment -- is enqueued one call early, for circuit k + 1 of the same `circuits`, on a second
+ * context the proof owns; a call for any other step finds no such work waiting and does it then.  The results are
+ * those of a prover without lookahead, and no call returns while anything in flight still reads the circuits' memory. */
 int  vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]);
-/* NovaVDFProof::verify(pp, num_steps, z0, zi), :370-387: *ok = 1 iff the proof is valid for
- * num_steps steps from z0 AND the verified zi_primary equals zi (the Ok(bool) of :386). */
+/* NovaVDFProof::verify(pp, num_steps, z0, zi), :370-387: *ok = 1 iff the proof is valid for num_steps steps from z0
+ * (two output hashes, three satisfiability claims), the verified zi_primary equals zi, and zi_secondary == [0]
+ * (the Ok(bool) of :386). */
 int  vdf_nova_verify(const vdf_proof* proof, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok);
 void vdf_nova_proof_free(vdf_proof* proof);
 size_t vdf_nova_proof_num_steps(const vdf_proof* proof);
-/* Introspection for parity tests: running relaxed instance (commitments as affine points, u, X[6])
- * and device pointers of the running witness W (num_vars) and error vector E (num_cons). */
-int  vdf_nova_proof_instance(const vdf_proof* proof, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[6]);
-int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, const void** d_W, const void** d_E);
-/* per-step record k: fresh commitment, cross-term commitment, challenge, public IO */
-int  vdf_nova_proof_step_record(const vdf_proof* proof, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]);
-/* host wall-clock of the last prove_step, milliseconds.  A step is enqueued asynchronously, so the slots are
- * launch times except [3] and [4]: fresh witness + its commitment (zero when the previous step looked ahead),
- * launch of the commitment of T, cross-term launch, wait for the fresh commitment + launch of the next step's
- * lookahead, wait (previous step's host instance fold, then the commitment of T), transcript + fold launch,
- * bookkeeping, total. */
+/* Introspection for the parity tests.  Instances: commitments as affine points, u and X[2] in Montgomery form of the
+ * instance's own scalar field (Fq on the primary side, Fp on the secondary).  Witness pointers: device memory,
+ * z = [W | u | X] (W = the first num_vars elements) and E (NULL for the fresh instance). */
+enum { VDF_INST_RUNNING_PRIMARY = 0, VDF_INST_RUNNING_SECONDARY = 1, VDF_INST_FRESH_SECONDARY = 2 };
+int  vdf_nova_proof_instance(const vdf_proof* proof, int which, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[2]);
+int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, int which, const void** d_z, const void** d_E);
+int  vdf_nova_proof_zi(const vdf_proof* proof, vdf_fe zi_primary[3], vdf_fe zi_secondary[1]);
+/* by-products of the last prove_step: the fresh primary instance, both cross-term commitments (identity in the base
+ * step) and both fold challenges (canonical 128-bit integers, little-endian limbs) */
+typedef struct { vdf_affine comm_W1; vdf_fe X1[2]; vdf_affine comm_T1, comm_T2; uint64_t r1[4], r2[4]; } vdf_nova_step_info;
+int  vdf_nova_proof_last_step(const vdf_proof* proof, vdf_nova_step_info* out);
+/* host wall-clock of the last prove_step, milliseconds: [0] enqueue + wait of the secondary cross term and commitments,
+ * [1] synthesis of the primary augmented circuit, [2] upload + enqueue of the primary cross term and commitments,
+ * [3] wait for them, [4] synthesis of the secondary augmented circuit, [5] upload + fold launches, [6] lookahead
+ * launch, [7] total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
+
+/* ---- host-only entry points (no device): what the CPU tests pin against oracle/nova.py ------------------------- */
+/* the random oracle: lane 1 of the sponge after absorbing xs under `tag` (a full field element, Montgomery in and out) */
+int  vdf_nova_ro_hash(int field, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out);
+/* digest of the parameters public_params would make (both shapes synthesised on the host), and the sizes per side:
+ * sizes[side] = {num_cons, num_vars, nnz(A) + nnz(B) + nnz(C)} */
+int  vdf_nova_shape_digest(uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]);
+/* One augmented circuit synthesised on the host with every variable computed there (small t only).  The inputs that
+ * belong to the folded side (U_u, U_X, u_X) are in Montgomery form of THAT side's scalar field, everything else in the
+ * circuit's own field.  result / input: the MinRoot step's states (side 0; ignored for side 1).  arity = 3 / 1. */
+typedef struct {
+  vdf_fe params, i, z0[3], zi[3];
+  vdf_affine U_comm_W, U_comm_E; vdf_fe U_u, U_X[2];
+  vdf_affine u_comm_W; vdf_fe u_X[2];
+  vdf_affine T;
+} vdf_nova_aug_inputs;
+int  vdf_nova_aug_synthesize(int side, uint64_t num_iters_per_step, int circuit_kind, const vdf_nova_aug_inputs* in,
+                             const vdf_state* result, const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars,
+                             size_t* num_cons, vdf_fe X[2], vdf_fe z_next[3]);
 
 /* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
  * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS

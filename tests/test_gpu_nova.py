@@ -1,50 +1,73 @@
-"""GPU tests of the Nova proof layer (vdf_amd/nova.py over libvdf_nova.so + libvdf_hip.so):
-the reference's test_nova_proof (src/nova/proof.rs:403-451) at its own size, BASELINE config 1
-(t = 1024, 3 steps), and a full replay of the folds by the oracle (witness, error vector,
-instance, commitments through the discrete-log identity, SHAKE256 transcript)."""
+"""GPU tests of the Nova proof layer (vdf_amd/nova.py over libvdf_nova.so + libvdf_hip.so): the reference's
+test_nova_proof (src/nova/proof.rs:403-451) at its own size, every quantity of every step against the oracle
+(oracle/nova.py), BASELINE config 1 (t = 1024, 3 steps) and config 3 (t = 2^16) checked by the C restatement and the
+discrete-log identity, and negative cases."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
-from oracle import pasta as o
-from oracle import nifs
-from util import ints, unmont
-from vdf_amd.minroot import PallasVDF, State, FIELD_FQ
-from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+from oracle import nova as nv, pasta as o
+from util import ints, unmont, limbs
+from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode
+from vdf_amd.nova import (InverseMinRootCircuit, NovaVDFProof, public_params, CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE,
+                          GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT, INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY,
+                          INST_FRESH_SECONDARY)
 
 pytestmark = pytest.mark.gpu
-# the oracle side of the proof layer lives in oracle/nifs.py; these names are what the other GPU tests import
-GENS_SEED, GENS_FAMILY = nifs.GENS_SEED, nifs.GENS_FAMILY
-gens, commit, le32, shape_digest, challenge = nifs.gens, nifs.commit, nifs.le32, nifs.shape_digest, nifs.challenge
+BASE = (o.P, o.Q)                      # coordinate modulus of side 0 / 1 commitments
+SCAL = (o.Q, o.P)                      # scalar modulus of side 0 / 1 instances
 
 
-def aff_ints(arr):
-    x, y = unmont(np.asarray(arr).reshape(2, 4), o.P)
-    return (x, y)
+def aff_ints(arr, side):
+    return tuple(unmont(np.asarray(arr).reshape(2, 4), BASE[side]))
 
 
-def make(ctx, t, n, seed=42, i0=1):
+def make(ctx, t, n, seed=42, i0=1, kind=CIRCUIT_MINROOT_BOUND, family=GENS_TRY_AND_INCREMENT, mode=None):
     x = o.rand_fe(seed, 0, o.Q)
     initial = State.from_ints(FIELD_FQ, x, 0, i0)             # y = 0, i = 1: src/nova/proof.rs:417-421
-    pp = public_params(ctx, t)
-    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    pp = public_params(ctx, t, kind, family)
+    vdf = PallasVDF.new() if mode is None else PallasVDF.new_with_mode(mode)
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(vdf, t, n, initial)
     return pp, z0, circuits, initial, (x, 0, i0)
 
 
+def check_instance(proof, which, side, want):
+    """instance + witness of the product against an oracle Relaxed / Fresh."""
+    m = SCAL[side]
+    inst = proof.instance(which)
+    z, E = proof.witness(which)
+    assert aff_ints(inst["comm_W"], side) == tuple(want.comm_W)
+    assert unmont(inst["X"], m) == list(want.X)
+    zz = unmont(z, m)
+    nvars = len(want.W)
+    assert zz[:nvars] == list(want.W)
+    if which == INST_FRESH_SECONDARY:
+        assert zz[nvars:] == [1] + list(want.X) and E is None
+        assert unmont(inst["u"].reshape(1, 4), m) == [1] and aff_ints(inst["comm_E"], side) == (0, 0)
+    else:
+        assert aff_ints(inst["comm_E"], side) == tuple(want.comm_E)
+        assert unmont(inst["u"].reshape(1, 4), m) == [want.u]
+        assert zz[nvars:] == [want.u] + list(want.X)
+        assert unmont(E, m) == list(want.E)
+
+
 def test_nova_proof(ctx):
-    """test_nova_proof_aux(5, 3), src/nova/proof.rs:403-451, including its compress leg (:446-450)."""
+    """test_nova_proof_aux(5, 3), src/nova/proof.rs:403-451 (its compress leg: tests/test_gpu_compress.py)."""
     t, n = 5, 3
     pp, z0, circuits, initial, init_ints = make(ctx, t, n)
     zi = [initial.x, initial.y, initial.i]
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.num_steps() == n
     assert proof.verify(pp, n, z0, zi) is True
-    # Ok(false) legs: wrong expected z_i, wrong step count
+    # Ok(false) legs: wrong expected z_i, wrong step count, another z0
     wrong = [initial.y, initial.x, initial.i]
     assert proof.verify(pp, n, z0, wrong) is False
     assert proof.verify(pp, n + 1, z0, zi) is False
     assert proof.verify(pp, n, zi, zi) is False
-    compressed = proof.compress(pp)                              # :446-448
-    assert compressed.verify(pp, n, z0, zi) is True              # :449-450
-    assert compressed.verify(pp, n, z0, wrong) is False
+    # zi_secondary == [0] (:386, :389-391)
+    zp, zs = proof.zi()
+    assert unmont(zs, o.P) == [0] and [bytes(zp[k]) for k in range(3)] == zi
 
 
 def test_eval_and_make_circuits_order(ctx):
@@ -66,42 +89,43 @@ def test_eval_and_make_circuits_order(ctx):
         InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, 0, initial)
 
 
-@pytest.mark.parametrize("t,n", [(5, 3), (24, 3)])
-def test_prove_steps_replayed_by_the_oracle(ctx, t, n):
-    """Every quantity of every fold, bit-exact against the Python oracle."""
-    m = o.Q
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
-    sh = o.step_circuit_shape(t, o.FIELD_FQ)
-    sizes = pp.sizes()
-    assert (sizes["num_cons"], sizes["num_vars"], sizes["num_io"]) == (sh.num_cons, sh.num_vars, 6)
-    assert sizes["nnz"] == len(sh.A) + len(sh.B) + len(sh.C)
-    digest = shape_digest(sh, t)
-    # the whole chain by the oracle, then the product step by step against its prefixes
-    states = nifs.forward_states(o.State(*init_ints), t, n)
-    proof = None
+@pytest.mark.parametrize("t,n,kind", [(5, 3, CIRCUIT_MINROOT_BOUND), (24, 3, CIRCUIT_MINROOT_BOUND), (7, 2, CIRCUIT_MINROOT_REFERENCE)])
+def test_prove_steps_replayed_by_the_oracle(ctx, t, n, kind):
+    """Every quantity of every step, bit-exact against oracle/nova.py: parameters digest, the fresh primary instance,
+    both cross-term commitments, both challenges, the three instances a proof carries and their witnesses."""
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77, kind=kind)
+    com = nv.CCommit()
+    opp = nv.public_params(t, com, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=(kind == CIRCUIT_MINROOT_BOUND))
+    assert pp.digest() == opp.params
+    for side in (0, 1):
+        sz, sh = pp.sizes(side), opp.shapes[side]
+        assert (sz["num_cons"], sz["num_vars"], sz["num_io"], sz["nnz"]) == (sh.num_cons, sh.num_vars, 2, len(sh.A) + len(sh.B) + len(sh.C))
+    states = [o.State(*init_ints)]
+    for _ in range(n):
+        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    z0i = [states[n].x, states[n].y, states[n].i]
+    assert [State(*z0).to_ints(FIELD_FQ)[k] for k in range(3)] == z0i
+    proof, want = None, None
     for k in range(n):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
-        want, sh2, dg = nifs.prove_chain(states[n - k - 1], t, k + 1)      # the first k + 1 steps end at states[n-k-1]
-        assert dg == digest
-        for j in range(k + 1):
-            rec, ws = proof.step_record(j), want.steps[j]
-            assert aff_ints(rec["comm_w"]) == ws.comm_w and aff_ints(rec["comm_T"]) == ws.comm_T
-            assert unmont(rec["r"].reshape(1, 4), m) == [ws.r] and unmont(rec["X"], m) == ws.X
-        inst = proof.instance()
-        gW, gE = proof.witness()
-        assert unmont(gW, m) == want.W
-        assert unmont(gE, m) == want.E
-        assert unmont(inst["u"].reshape(1, 4), m) == [want.u]
-        assert unmont(inst["X"], m) == want.X
-        assert aff_ints(inst["comm_W"]) == want.comm_W and aff_ints(inst["comm_E"]) == want.comm_E
-        assert o.is_sat_relaxed(sh, want.W, want.E, want.u, want.X, m)
-    zi = [State.from_ints(FIELD_FQ, *init_ints).x, State.from_ints(FIELD_FQ, *init_ints).y, State.from_ints(FIELD_FQ, *init_ints).i]
+        want = nv.prove_step(opp, want, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1], kind == CIRCUIT_MINROOT_BOUND), z0i)
+        tr, ls = want.trace[-1], proof.last_step()
+        assert aff_ints(ls["comm_W1"], 0) == tuple(tr["l1"].comm_W) and unmont(ls["X1"], o.Q) == tr["l1"].X
+        if k:
+            assert aff_ints(ls["comm_T1"], 0) == tuple(tr["T1"]) and aff_ints(ls["comm_T2"], 1) == tuple(tr["T2"])
+            assert (ls["r1"], ls["r2"]) == (tr["r1"], tr["r2"])
+        check_instance(proof, INST_RUNNING_PRIMARY, 0, want.r[0])
+        check_instance(proof, INST_RUNNING_SECONDARY, 1, want.r[1])
+        check_instance(proof, INST_FRESH_SECONDARY, 1, want.l2)
+        zp, zs = proof.zi()
+        assert unmont(zp, o.Q) == want.zi[0] and unmont(zs, o.P) == want.zi[1]
+        assert nv.verify(opp, want, k + 1, z0i) is not None
+    zi = [initial.x, initial.y, initial.i]
     assert proof.verify(pp, n, z0, zi)
 
 
 def test_tampered_witness_is_rejected(ctx):
-    """Corrupting one word of the running witness on the device must fail verification."""
-    import ctypes as C
+    """Corrupting one word of any of the five witness vectors on the device must fail verification."""
     from vdf_amd._lib import lib
     from vdf_amd.nova import nova_lib
     t, n = 8, 2
@@ -109,103 +133,43 @@ def test_tampered_witness_is_rejected(ctx):
     zi = [initial.x, initial.y, initial.i]
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
     assert proof.verify(pp, n, z0, zi)
-    dW, dE = C.c_void_p(), C.c_void_p()
-    nova_lib.vdf_nova_proof_witness_ptrs(proof.handle, C.byref(dW), C.byref(dE))
-    word = np.zeros(4, dtype="<u8")
-    ctx._check(lib.vdf_dev_memcpy(ctx.handle, word.ctypes.data, dW.value + 7 * 32, 32))
-    bad = word.copy(); bad[0] ^= 1
-    ctx._check(lib.vdf_dev_memcpy(ctx.handle, dW.value + 7 * 32, bad.ctypes.data, 32))
-    assert proof.verify(pp, n, z0, zi) is False
-    ctx._check(lib.vdf_dev_memcpy(ctx.handle, dW.value + 7 * 32, word.ctypes.data, 32))
-    assert proof.verify(pp, n, z0, zi) is True
-
-
-def _same_proof(a, b, n):
-    ia, ib = a.instance(), b.instance()
-    assert all(np.array_equal(ia[k], ib[k]) for k in ia)
-    for k in range(n):
-        ra, rb = a.step_record(k), b.step_record(k)
-        assert all(np.array_equal(ra[f], rb[f]) for f in ra)
-    (wa, ea), (wb, eb) = a.witness(), b.witness()
-    assert np.array_equal(wa, wb) and np.array_equal(ea, eb)
-
-
-def test_lookahead_is_invisible(ctx):
-    """prove_step enqueues the next step's fresh witness and commitment ahead of time (include/vdf_nova.h).  Whatever
-    the caller does next -- the expected step, the same step from another circuits object, a refused call in between,
-    a second proof interleaved -- the proofs are the ones a step-at-a-time prover makes."""
-    t, n = 32, 5
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
-    zi = [initial.x, initial.y, initial.i]
-    ref = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
-    assert ref.verify(pp, n, z0, zi)
-    # (a) the same states from a second circuits object: every lookahead is for the wrong object and is dropped
-    _, twin = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
-    p = None
-    for k in range(n):
-        p = NovaVDFProof.prove_step(pp, p, circuits if k % 2 == 0 else twin, k, z0)
-    _same_proof(ref, p, n)
-    assert p.verify(pp, n, z0, zi)
-    # (b) a refused call (wrong step) between two good ones leaves the proof and its lookahead intact
-    q = None
-    for k in range(n):
-        q = NovaVDFProof.prove_step(pp, q, circuits, k, z0)
-        if k == 1:
-            with pytest.raises(Exception):
-                NovaVDFProof.prove_step(pp, q, circuits, 4, z0)
-            with pytest.raises(Exception):
-                NovaVDFProof.prove_step(pp, q, circuits, n, z0)
-    _same_proof(ref, q, n)
-    # (c) two proofs advanced in turns over the same circuits
-    a = b = None
-    for k in range(n):
-        a = NovaVDFProof.prove_step(pp, a, circuits, k, z0)
-        b = NovaVDFProof.prove_step(pp, b, circuits, k, z0)
-    _same_proof(ref, a, n)
-    _same_proof(ref, b, n)
-    # (d) circuits whose traces were never uploaded (staged per step) and uploaded ones give the same proof
-    twin.upload(ctx)
-    u = NovaVDFProof.prove_recursively(pp, twin, t, z0)
-    _same_proof(ref, u, n)
-    # (e) freeing the circuits right after the last call is safe: nothing in flight reads them
-    _, gone = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
-    gone.upload(ctx)
-    g = None
-    for k in range(3):
-        g = NovaVDFProof.prove_step(pp, g, gone, k, z0)
-    gone.free()
-    g.free()
-    assert ref.compress(pp).verify(pp, n, z0, zi)
+    for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+        dz, dE = C.c_void_p(), C.c_void_p()
+        assert nova_lib.vdf_nova_proof_witness_ptrs(proof.handle, which, C.byref(dz), C.byref(dE)) == 0
+        for base, off in ((dz.value, 32 * 40), (dE.value, 32 * 11)):
+            if not base:
+                continue
+            word = np.zeros(1, dtype="<u8")
+            ctx._check(lib.vdf_dev_memcpy(ctx.handle, word.ctypes.data, base + off, 8))
+            bad = word ^ np.uint64(1)
+            ctx._check(lib.vdf_dev_memcpy(ctx.handle, base + off, bad.ctypes.data, 8))
+            assert proof.verify(pp, n, z0, zi) is False
+            ctx._check(lib.vdf_dev_memcpy(ctx.handle, base + off, word.ctypes.data, 8))
+            assert proof.verify(pp, n, z0, zi) is True
 
 
 def test_mismatched_z0_is_an_error(ctx):
-    import vdf_amd
-    t, n = 4, 2
-    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=6)
-    with pytest.raises(vdf_amd.VdfError):
-        NovaVDFProof.prove_recursively(pp, circuits, t, [initial.x, initial.y, initial.i])   # not the final state
-    with pytest.raises(vdf_amd.VdfError):
-        NovaVDFProof.prove_recursively(pp, circuits, t + 1, z0)
+    """StepCircuit::output's assertion (src/nova/proof.rs:147-149): z_i must be the circuit's result."""
+    from vdf_amd.hip import VdfError
+    t = 4
+    pp, z0, circuits, initial, _ = make(ctx, t, 2, seed=3)
+    with pytest.raises(VdfError):
+        NovaVDFProof.prove_step(pp, None, circuits, 0, [initial.x, initial.y, initial.i])
+    with pytest.raises(VdfError):
+        NovaVDFProof.prove_step(pp, None, circuits, 1, z0)          # step 1's circuit first: result != z0
 
 
-def test_config1_t1024_three_steps(ctx):
-    """BASELINE config 1: 1024 iterations per step, 3 recursive steps; both i = 0 (benches/nova.rs:24-26)
-    and i = 1 (src/nova/proof.rs:419)."""
-    for i0 in (0, 1):
-        t, n = 1024, 3
-        pp, z0, circuits, initial, _ = make(ctx, t, n, seed=11, i0=i0)
-        proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
-        assert proof.num_steps() == n
-        assert proof.verify(pp, n, z0, [initial.x, initial.y, initial.i])
-        ms = proof.last_step_ms()
-        assert ms["total"] > 0
-
-
-def test_plain_c_client_of_both_abis():
-    """examples/prove_chain.c: eval -> prove -> verify -> compress -> verify, from C, in a process of its own."""
-    import os, subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "prove_chain")
-    assert os.path.exists(exe), "build it with `make -C vdf_amd/csrc` (part of __graft_entry__.build())"
-    r = subprocess.run([exe, "8", "3"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "verify: true" in r.stdout and "verify (compressed): true" in r.stdout
+def test_lookahead_is_invisible(ctx):
+    """Steps proven out of the order the lookahead expected, and from another circuits object, give the same proof."""
+    t, n = 16, 4
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=11)
+    a = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    z0b, circuits_b = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    b = None
+    for k in range(n):
+        b = NovaVDFProof.prove_step(pp, b, circuits_b if k % 2 else circuits, k, z0)     # alternate the source
+    for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+        ia, ib = a.instance(which), b.instance(which)
+        for key in ia:
+            assert np.array_equal(ia[key], ib[key]), (which, key)
+    assert b.verify(pp, n, z0, [initial.x, initial.y, initial.i])

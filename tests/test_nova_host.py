@@ -1,0 +1,129 @@
+"""CPU tests of the host side of the Nova layer (libvdf_nova.so: random oracle, R1CS shapes, augmented-circuit synthesis)
+against its specification, oracle/nova.py.  No device call is made: these entry points are host arithmetic only.
+Reference anchors: src/nova/proof.rs:79-153 (step circuit), :232-237 (setup), :342-349 (prove_step)."""
+import copy
+import random
+
+import numpy as np
+import pytest
+
+from oracle import nova as nv, pasta as o, poseidon as ps
+from util import limbs, ints
+
+import vdf_amd.nova as vn
+from vdf_amd.minroot import State
+
+
+def mont(vals, field):
+    return limbs([o.to_mont(v % o.modulus(field), o.modulus(field)) for v in vals])
+
+
+def unmont(arr, field):
+    m = o.modulus(field)
+    return [o.from_mont(v, m) for v in ints(arr)]
+
+
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+def test_random_oracle_equals_the_restatement(field):
+    rng = random.Random(field)
+    m = o.modulus(field)
+    for n in (0, 1, 2, 3, 4, 7, 16, 17):
+        xs = [rng.randrange(m) for _ in range(n)]
+        for tag in (1, 2, 99):
+            got = unmont(vn.ro_hash(field, tag, mont(xs, field) if n else np.zeros((0, 4), dtype="<u8")), field)[0]
+            assert got == ps.hash_elements(tag, xs, field)
+
+
+@pytest.mark.parametrize("t,kind", [(1, 0), (5, 0), (5, 1), (64, 0)])
+def test_shape_digest_equals_the_restatement(t, kind):
+    """Both R1CS shapes (every triple of A, B, C on both sides) hash to the oracle's `params`."""
+    pp = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=(kind == 0))
+    digest, sizes = vn.shape_digest(t, kind, 1)
+    assert digest == pp.params
+    for s in (0, 1):
+        sh = pp.shapes[s]
+        assert sizes[s] == [sh.num_cons, sh.num_vars, len(sh.A) + len(sh.B) + len(sh.C)]
+    # the generator family is part of the digest
+    assert vn.shape_digest(t, kind, 0)[0] != digest
+
+
+def c_inputs(side, inp):
+    """oracle AugInputs -> vdf_nova_aug_inputs (the folded side's scalars in that side's Montgomery form)."""
+    f, pf = nv.SIDE_FIELD[side], nv.SIDE_FIELD[1 - side]
+    a = vn.AugInputs()
+
+    def put(dst, vals, field):
+        arr = mont(vals, field)
+        if isinstance(dst, vn._Fe):
+            C = __import__("ctypes")
+            C.memmove(C.addressof(dst), arr.ctypes.data, 32)
+        else:
+            C = __import__("ctypes")
+            C.memmove(C.addressof(dst), arr.ctypes.data, 32 * len(vals))
+    put(a.params, [inp.params], f); put(a.i, [inp.i], f)
+    put(a.z0, list(inp.z0) + [0] * (3 - len(inp.z0)), f); put(a.zi, list(inp.zi) + [0] * (3 - len(inp.zi)), f)
+    put(a.U_comm_W, inp.U.comm_W, f); put(a.U_comm_E, inp.U.comm_E, f)
+    put(a.U_u, [inp.U.u], pf); put(a.U_X, inp.U.X, pf)
+    put(a.u_comm_W, inp.u_W, f); put(a.u_X, inp.u_X, pf); put(a.T, inp.T, f)
+    return a
+
+
+def st(s, field=o.FIELD_FQ):
+    return State.from_ints(field, s.x, s.y, s.i)
+
+
+@pytest.fixture(scope="module")
+def oracle_run():
+    """Three oracle steps at t = 5 with every circuit's inputs and outputs recorded."""
+    t, n = 5, 3
+    com = nv.CCommit()
+    rec = []
+    orig = nv.synth_fresh
+
+    def spy(pp, side, inp, step):
+        fresh, z = orig(pp, side, inp, step)
+        rec.append((side, copy.deepcopy(inp), step, fresh, z))
+        return fresh, z
+    nv.synth_fresh = spy
+    try:
+        pp = nv.public_params(t, com, nv.GENS_SEED, 1)
+        init = o.State(0x1234, 0, 1)
+        states = [init]
+        for _ in range(n):
+            states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+        z0 = [states[n].x, states[n].y, states[n].i]
+        s = None
+        for k in range(n):
+            s = nv.prove_step(pp, s, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1]), z0)
+    finally:
+        nv.synth_fresh = orig
+    return t, pp, rec
+
+
+def test_augmented_circuit_witness_equals_the_restatement(oracle_run):
+    """Every variable of both augmented circuits, base step and two folding steps: W, X and z_{i+1} bit for bit."""
+    t, pp, rec = oracle_run
+    assert len(rec) == 6
+    for side, inp, step, fresh, z_next in rec:
+        f = nv.SIDE_FIELD[side]
+        res = st(step.result) if side == 0 else None
+        inn = st(step.input) if side == 0 else None
+        W, X, zn, nc = vn.aug_synthesize(side, t, 0, c_inputs(side, inp), res, inn)
+        assert nc == pp.shapes[side].num_cons and W.shape[0] == pp.shapes[side].num_vars
+        assert unmont(X, f) == fresh.X
+        assert unmont(zn, f) == z_next
+        got = unmont(W, f)
+        bad = [k for k in range(len(got)) if got[k] != fresh.W[k]]
+        assert not bad, (side, inp.i, bad[:5])
+
+
+def test_reference_circuit_witness(oracle_run):
+    """The reference's own allocation (4 variables per round, src/nova/proof.rs:167-181) through the same seam."""
+    t, pp, rec = oracle_run
+    side, inp, step, fresh, z_next = rec[2]                     # a folding step of the primary side
+    ref_step = nv.InverseMinRootCircuit(t, step.result, step.input, bound=False)
+    cs = nv.CS(nv.SIDE_FIELD[0])
+    z = nv.synthesize_augmented(cs, 0, inp, ref_step)
+    W, X, zn, nc = vn.aug_synthesize(0, t, 1, c_inputs(0, inp), st(step.result), st(step.input))
+    assert unmont(W, o.FIELD_FQ) == cs.W and unmont(zn, o.FIELD_FQ) == z and nc == cs.rows
+    assert len(cs.W) == len(fresh.W) + t

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "vdf_minroot_witness": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
     "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "vdf_minroot_step_z_packed": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_minroot_step_segment": (_i, [_vp, _i, _vp, _u64, _vp, _i, _vp]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),

@@ -872,6 +872,20 @@ int vdf_minroot_step_z_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, u
   return step_z_impl(ctx, field, trace_xy, t, z_in, i0, u, X, z, w_packed);
 }
 
+int vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe* i0, int vars_per_round,
+                             vdf_fe* out) {
+  return guarded(ctx, [&]() -> Status {
+    if (t == 0 || t >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
+    if (vars_per_round != 3 && vars_per_round != 4) return Status{VDF_ERR_BAD_ARG, "vars_per_round is 3 (bound) or 4 (reference)"};
+    if (!i0 || ptr_is_device(i0)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    if (!ptr_is_device(trace_xy) || !ptr_is_device(out))
+      return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    VDF_TRY(vdf::vec_step_segment(field, trace_xy, t, i0, vars_per_round, out, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
 int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
                         const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T) {
   return guarded(ctx, [&]() -> Status {

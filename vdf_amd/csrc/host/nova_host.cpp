@@ -1,6 +1,6 @@
-// libvdf_nova.so, part 2: the reference's Nova proof surface (src/nova/proof.rs) on top of the kernel ABI
-// (include/vdf_hip.h): public parameters, circuits, prove_step / prove_recursively, verify.  See include/vdf_nova.h
-// for the stage this implements.
+// libvdf_nova.so, part 2: the reference's Nova proof surface (src/nova/proof.rs:232-392) on top of the kernel ABI
+// (include/vdf_hip.h): public parameters, circuits, prove_step / prove_recursively, verify.  Protocol
+// "vdf-nova-ivc-v1", specified by oracle/nova.py; see include/vdf_nova.h.
 #include "nova_internal.hpp"
 
 using namespace vdfnova;
@@ -8,268 +8,356 @@ using namespace vdfnova;
 namespace vdfnova {
 static thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+RelaxedInst to_relaxed(const Inst& in, const Field& own) {
+  RelaxedInst r;
+  r.comm_W = in.comm_W; r.comm_E = in.comm_E;
+  fe_to_int(in.u, own, r.u);
+  for (int k = 0; k < NUM_IO; ++k) fe_to_int(in.X[k], own, r.X[k]);
+  return r;
+}
+
+std::unique_ptr<StepCircuit> make_primary_circuit(const vdf_pp* pp, const Circuit* c, bool device_rounds) {
+  std::unique_ptr<InverseMinRootCircuit> m(new InverseMinRootCircuit());
+  m->t = pp->t;
+  m->bound = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND;
+  m->device_rounds = device_rounds;
+  m->blank = c == nullptr;                                              // blank circuit of the setup (:249-256)
+  if (c) {
+    m->result = MinRootState{c->result.x, c->result.y, c->result.i};
+    m->input = MinRootState{c->input.x, c->input.y, c->input.i};
+  } else {
+    m->result = m->input = MinRootState{zero(), zero(), zero()};
+  }
+  return std::unique_ptr<StepCircuit>(m.release());
+}
 }  // namespace vdfnova
 
 namespace {
 
-
-void absorb_fe(Shake256& h, const Fe& a, const Field& F) { Fe c = from_mont(a, F); h.absorb(c.l, 32); }
-void absorb_aff(Shake256& h, const Aff& p) {
-  const Field& F = field_fp();    // Pallas coordinates live in Fp
-  absorb_fe(h, p.x, F);
-  absorb_fe(h, p.y, F);
+AugInputs blank_inputs(size_t arity) {
+  AugInputs in;
+  in.params = in.i = zero();
+  in.z0.assign(arity, zero());
+  in.zi.assign(arity, zero());
+  memset(&in.U, 0, sizeof(in.U));
+  memset(&in.u_W, 0, sizeof(in.u_W));
+  memset(in.u_X, 0, sizeof(in.u_X));
+  memset(&in.T, 0, sizeof(in.T));
+  return in;
 }
 
-// Builds the COO triples of the wrapped step circuit; same layout as the test oracle (step_circuit_shape)
-// (constraint order of src/nova/proof.rs:176-178, :219-227, :128-133, then the six IO-binding rows).
-struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
-void build_shape(uint64_t t, Coo m[3], size_t* num_cons, size_t* num_vars) {
-  const Field& F = field(PRIMARY_FIELD);
-  const Fe ONE = one(F), MINUS_ONE = neg(ONE, F);
-  const uint32_t nv = (uint32_t)(3 + 4 * t + 1), one_col = nv, io = nv + 1;
-  auto push = [](Coo& c, uint32_t r, uint32_t col, const Fe& v) { c.rows.push_back(r); c.cols.push_back(col); c.vals.push_back(v); };
-  uint32_t xv = 0, yv = 1, iv = 2, row = 0;
-  for (uint64_t j = 0; j < t; ++j) {
-    const uint32_t base = (uint32_t)(3 + 4 * j), new_x = base, tmp1 = base + 1, tmp2 = base + 2, new_y = base + 3;
-    push(m[0], row, xv, ONE); push(m[1], row, xv, ONE); push(m[2], row, tmp1, ONE); ++row;          // x*x = tmp1
-    push(m[0], row, tmp1, ONE); push(m[1], row, tmp1, ONE); push(m[2], row, tmp2, ONE); ++row;      // tmp1*tmp1 = tmp2
-    push(m[0], row, tmp2, ONE); push(m[1], row, xv, ONE);                                           // tmp2*x = new_y + y - i + 1
-    push(m[2], row, new_y, ONE); push(m[2], row, yv, ONE); push(m[2], row, iv, MINUS_ONE);
-    push(m[2], row, one_col, from_u64(j + 1, F)); ++row;                                            // i = z_in.i - j
-    xv = new_x; yv = new_y;
-  }
-  const uint32_t final_i = (uint32_t)(3 + 4 * t);
-  push(m[0], row, final_i, ONE); push(m[1], row, one_col, ONE);                                     // final_i*1 = i - t
-  push(m[2], row, iv, ONE); push(m[2], row, one_col, neg(from_u64(t, F), F)); ++row;
-  const uint32_t outs[6] = {0, 1, 2, xv, yv, final_i};
-  for (int k = 0; k < 6; ++k) {
-    push(m[0], row, outs[k], ONE); push(m[1], row, one_col, ONE); push(m[2], row, io + k, ONE); ++row;
-  }
-  *num_cons = row;
-  *num_vars = nv;
-}
+struct HostShape { Coo m[3]; size_t num_cons = 0, num_vars = 0, step_begin = 0, step_end = 0; };
 
-
-
-
-// a[i] + b[i] for affine points with one shared inversion (Montgomery's trick); identities and equal abscissae take
-// the general formulas
-void batch_add_affine(const std::vector<Aff>& a, const std::vector<Aff>& b, std::vector<Aff>* out) {
-  const Field& F = field_fp();
-  const size_t n = a.size();
-  out->resize(n);
-  std::vector<Fe> d(n), pre(n);
-  std::vector<char> special(n, 0);
-  Fe run = one(F);
-  for (size_t i = 0; i < n; ++i) {
-    d[i] = sub(b[i].x, a[i].x, F);
-    if (a[i].is_id() || b[i].is_id() || d[i].is_zero()) { special[i] = 1; d[i] = one(F); }
-    pre[i] = run;
-    run = mul(run, d[i], F);
-  }
-  Fe inv = inverse(run, F);
-  for (size_t i = n; i-- > 0;) {
-    const Fe di = mul(inv, pre[i], F);           // 1 / d[i]
-    inv = mul(inv, d[i], F);
-    if (special[i]) { (*out)[i] = pt_to_aff(pt_add(pt_from_aff(a[i], F), pt_from_aff(b[i], F), F), F); continue; }
-    const Fe lam = mul(sub(b[i].y, a[i].y, F), di, F);
-    const Fe x3 = sub(sub(sqr(lam, F), a[i].x, F), b[i].x, F);
-    (*out)[i].x = x3;
-    (*out)[i].y = sub(mul(lam, sub(a[i].x, x3, F), F), a[i].y, F);
+// both augmented circuits in shape mode (PublicParams::setup, src/nova/proof.rs:236)
+void build_shapes(uint64_t t, int circuit_kind, HostShape out[2]) {
+  vdf_pp tmp;
+  tmp.t = t;
+  tmp.circuit_kind = circuit_kind;
+  for (int side = 0; side < 2; ++side) {
+    CS cs(side_field(side), true);
+    std::unique_ptr<StepCircuit> step;
+    if (side == PRIMARY) step = make_primary_circuit(&tmp, nullptr, false);
+    else step.reset(new TrivialTestCircuit());
+    // the step circuit's variables are one contiguous run: find it by synthesising the wrapper once around an empty step
+    synthesize_augmented(cs, side, blank_inputs(step->arity()), *step);
+    cs.finish(out[side].m);
+    out[side].num_cons = cs.rows;
+    out[side].num_vars = cs.W.size();
+    out[side].step_begin = cs.step_begin;
+    out[side].step_end = cs.step_end;
   }
 }
 
-// generators of the packed witness [z_in(3) | tmp1, tmp2, new_y per round | final_i] and the two fixed points of the
-// correction (nova_internal.hpp)
-int setup_packed_generators(vdf_pp* pp) {
-  vdf_ctx* ctx = pp->ctx;
-  const size_t t = pp->t, nv = pp->num_vars;
-  std::vector<Aff> G(nv);
-  HIPCALL(ctx, vdf_bases_download(ctx, pp->gens, 0, nv, (vdf_affine*)G.data()));
-  pp->num_w = 3 * t + 4;
-  std::vector<Aff> Gw(pp->num_w), a, b, sum, Gx(t);
-  for (size_t j = 0; j < t; ++j) Gx[j] = G[3 + 4 * j];
-  a.push_back(G[1]); b.push_back(G[3]);                                     // y_0 = z_in.y carries round 0's new_x
-  for (size_t j = 0; j + 1 < t; ++j) { a.push_back(G[6 + 4 * j]); b.push_back(G[3 + 4 * (j + 1)]); }
-  batch_add_affine(a, b, &sum);
-  Gw[0] = G[0]; Gw[1] = sum[0]; Gw[2] = G[2];
-  for (size_t j = 0; j < t; ++j) {
-    Gw[3 + 3 * j] = G[4 + 4 * j];
-    Gw[4 + 3 * j] = G[5 + 4 * j];
-    Gw[5 + 3 * j] = (j + 1 < t) ? sum[1 + j] : G[6 + 4 * j];
+// oracle/nova.py digest_shapes
+void digest_shapes(uint64_t t, int gens_family, const HostShape sh[2], uint8_t out[32]) {
+  Shake256 h;
+  h.absorb("vdf-nova-ivc-v1", 15);
+  h.absorb("vdf-poseidon2-v1", 16);
+  const uint64_t hdr[3] = {t, GENS_SEED, (uint64_t)gens_family};
+  h.absorb(hdr, sizeof(hdr));
+  for (int side = 0; side < 2; ++side) {
+    const Field& F = field(side_field(side));
+    const uint64_t sz[3] = {(uint64_t)sh[side].num_cons, (uint64_t)sh[side].num_vars, (uint64_t)NUM_IO};
+    h.absorb(sz, sizeof(sz));
+    for (int k = 0; k < 3; ++k) {
+      const Coo& m = sh[side].m[k];
+      const uint64_t n = m.rows.size();
+      h.absorb(&n, 8);
+      std::vector<uint8_t> buf(n * 40);
+      for (size_t e = 0; e < n; ++e) {
+        memcpy(&buf[e * 40], &m.rows[e], 4);
+        memcpy(&buf[e * 40 + 4], &m.cols[e], 4);
+        const Fe c = from_mont(m.vals[e], F);
+        memcpy(&buf[e * 40 + 8], c.l, 32);
+      }
+      h.absorb(buf.data(), buf.size());
+    }
   }
-  Gw[3 + 3 * t] = G[3 + 4 * t];
-  HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)Gw.data(), pp->num_w, &pp->gens_w));
-  HIPCALL(ctx, vdf_bases_precompute(ctx, pp->gens_w, 16, 1));
-  // S0 = sum_j G_{3+4j}, S1 = sum_j j G_{3+4j}: two MSMs with small scalars
-  vdf_bases* bx = nullptr;
-  HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)Gx.data(), t, &bx));
-  std::vector<Fe> ones(t), idx(t);
-  for (size_t j = 0; j < t; ++j) { ones[j] = Fe{{1, 0, 0, 0}}; idx[j] = Fe{{(uint64_t)j, 0, 0, 0}}; }
-  vdf_jac j0, j1;
-  int rc = vdf_msm(ctx, bx, 0, (const vdf_fe*)ones.data(), t, 0, &j0);
-  if (rc == VDF_OK) rc = vdf_msm(ctx, bx, 0, (const vdf_fe*)idx.data(), t, 0, &j1);
-  if (rc == VDF_OK) rc = vdf_ctx_sync(ctx);
-  const std::string err = rc == VDF_OK ? "" : vdf_last_error(ctx);
-  vdf_bases_free(bx);
-  if (rc != VDF_OK) return fail(rc, "packed generators: " + err);
-  const Field& Fb = field_fp();
-  pp->S0 = jac_to_aff(j0, Fb);
-  pp->S1 = jac_to_aff(j1, Fb);
-  const uint64_t tk[4] = {t, 0, 0, 0};
-  pp->tS0 = pt_to_aff(pt_mul(pt_from_aff(pp->S0, Fb), tk, 64, Fb), Fb);
-  return VDF_OK;
+  h.squeeze(out, 32);
+  out[31] &= 0x03;                                 // 250 bits
+}
+
+Aff jac_aff(const vdf_jac& j, const Field& Fb) { return jac_to_aff(j, Fb); }
+Aff aff_add(const Aff& a, const Aff& b, const Field& Fb) { return pt_to_aff(pt_add(pt_from_aff(a, Fb), pt_from_aff(b, Fb), Fb), Fb); }
+
+// the running instance a circuit hands back: nine native values -> (commitments, u, X) in the instance's own field
+Inst inst_from_elements(const Fe e[9], const Field& circuit_field, const Field& own) {
+  Inst in;
+  in.comm_W = Aff{e[0], e[1]};
+  in.comm_E = Aff{e[2], e[3]};
+  uint64_t v[4];
+  fe_to_int(e[4], circuit_field, v);
+  in.u = int_to_fe(v, own);
+  for (int k = 0; k < 2; ++k) {
+    uint64_t lo[4], hi[4], x[4] = {0, 0, 0, 0};
+    fe_to_int(e[5 + 2 * k], circuit_field, lo);
+    fe_to_int(e[6 + 2 * k], circuit_field, hi);
+    // x = lo + hi * 2^126 (< 2^255)
+    x[0] = lo[0]; x[1] = lo[1] | (hi[0] << 62); x[2] = (hi[0] >> 2) | (hi[1] << 62); x[3] = (hi[1] >> 2) | (hi[2] << 62);
+    in.X[k] = int_to_fe(x, own);
+  }
+  return in;
 }
 
 }  // namespace
 
 namespace vdfnova {
-// r = SHAKE256(digest | U1 | u2 | comm_T) squeezed to 128 bits
-Fe challenge(const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Aff& cw2, const Fe* X2,
-             const Aff& cT, uint64_t r_raw[4]) {
-  const Field& F = field(PRIMARY_FIELD);
-  Shake256 h;
-  h.absorb("vdf-nova-fold-v1", 16);
-  h.absorb(pp->digest, 32);
-  absorb_aff(h, cW); absorb_aff(h, cE); absorb_fe(h, u, F);
-  for (int k = 0; k < NUM_IO; ++k) absorb_fe(h, X[k], F);
-  absorb_aff(h, cw2);
-  for (int k = 0; k < NUM_IO; ++k) absorb_fe(h, X2[k], F);
-  absorb_aff(h, cT);
-  r_raw[0] = r_raw[1] = r_raw[2] = r_raw[3] = 0;
-  h.squeeze(r_raw, 16);
-  Fe r;
-  memcpy(r.l, r_raw, 32);
-  return to_mont(r, F);
-}
-
-Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b) {      // a + r*b on Pallas
-  const Field& F = field_fp();
-  Pt rb = pt_mul(pt_from_aff(b, F), r_raw, 128, F);
-  return pt_to_aff(pt_add(pt_from_aff(a, F), rb, F), F);
-}
-
-bool fold_replay(const vdf_pp* pp, const std::vector<StepRecord>& steps, Fe* r_out, Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]) {
-  const Field& F = field(PRIMARY_FIELD);
-  *cW = steps[0].comm_w;
-  cE->x = cE->y = zero();
-  *u = one(F);
-  for (int j = 0; j < NUM_IO; ++j) X[j] = steps[0].X[j];
-  if (r_out) r_out[0] = zero();
-  for (size_t k = 1; k < steps.size(); ++k) {
-    const StepRecord& s = steps[k];
-    uint64_t r_raw[4];
-    const Fe r = challenge(pp, *cW, *cE, *u, X, s.comm_w, s.X, s.comm_T, r_raw);
-    if (r_out) r_out[k] = r;
-    else if (r != s.r) return false;
-    *cW = fold_commitment(*cW, r_raw, s.comm_w);
-    *cE = fold_commitment(*cE, r_raw, s.comm_T);
-    *u = add(*u, r, F);
-    for (int j = 0; j < NUM_IO; ++j) X[j] = add(X[j], mul(r, s.X[j], F), F);
-  }
-  return true;
-}
 
 int alloc_proof_buffers(vdf_proof* p) {
   vdf_pp* pp = p->pp;
   vdf_ctx* ctx = pp->ctx;
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z1));
-  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->ncols * 32, &p->d_z2s[k]));
-  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_w * 32, &p->d_wps[k]));
-  p->slot = 0;
-  p->d_z2 = p->d_z2s[0];
+  for (int s = 0; s < 2; ++s) {
+    const Side& sd = pp->s[s];
+    SideState& st = p->r[s];
+    HIPCALL(ctx, vdf_dev_alloc(ctx, sd.ncols * 32, &st.d_z));
+    HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &st.d_E));
+    HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &st.d_T));
+    for (int k = 0; k < 3; ++k) {
+      HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &st.d_abc[k]));
+      HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &st.d_abc2[k]));
+    }
+    HIPCALL(ctx, vdf_dev_memset(ctx, st.d_z, 0, sd.ncols * 32));
+    HIPCALL(ctx, vdf_dev_memset(ctx, st.d_E, 0, sd.num_cons * 32));
+    for (int k = 0; k < 3; ++k) HIPCALL(ctx, vdf_dev_memset(ctx, st.d_abc[k], 0, sd.num_cons * 32));
+    HIPCALL(ctx, vdf_host_alloc(ctx, (sd.ncols - (s == PRIMARY ? pp->seg_len : 0)) * 32, (void**)&p->h_stage[s]));
+  }
+  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->s[SECONDARY].ncols * 32, &p->d_l2z));
+  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->s[PRIMARY].ncols * 32, &p->d_z2s[k]));
   for (int k = 0; k < vdf_proof::DEPTH; ++k) {
     const int dev = vdf_ctx_device(ctx);
     if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
   }
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_E));
-  HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_T));
-  for (int k = 0; k < 6; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->num_cons * 32, &p->d_abc[k]));
-  HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 1) * sizeof(vdf_jac), (void**)&p->h_comm));
-  HIPCALL(ctx, vdf_dev_memset(ctx, p->d_E, 0, pp->num_cons * 32));
+  HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 4) * sizeof(vdf_jac), (void**)&p->h_pts));
+  memset(&p->last, 0, sizeof(p->last));
   return VDF_OK;
 }
-}  // namespace vdfnova
 
-void vdf_proof::join() const {
-  if (!pending.valid) return;
-  vdf_proof* self = const_cast<vdf_proof*>(this);
-  self->comm_W = fold_commitment(pending.cW0, pending.r, pending.cw);
-  self->comm_E = fold_commitment(pending.cE0, pending.r, pending.cT);
-  pending.valid = false;
+// commitment of the last secondary witness (its MSM normally rides in the next step's batch)
+int finalize_l2(const vdf_proof* cp) {
+  vdf_proof* p = const_cast<vdf_proof*>(cp);
+  if (p->l2_committed) return VDF_OK;
+  const Side& sd = p->pp->s[SECONDARY];
+  vdf_ctx* ctx = sd.ctx;
+  vdf_jac* slot = &p->h_pts[vdf_proof::RING];
+  HIPCALL(ctx, vdf_msm(ctx, sd.gens, 0, (const vdf_fe*)p->d_l2z, sd.num_vars, 1, slot));
+  HIPCALL(ctx, vdf_ctx_sync(ctx));
+  p->l2.comm_W = jac_to_aff(*slot, *sd.Fb);
+  p->l2_committed = true;
+  return VDF_OK;
 }
+
+int check_sat(const Side& sd, const Inst& in, const void* d_z, const void* d_E, void* d_abc[3], void* d_T, bool* ok) {
+  vdf_ctx* ctx = sd.ctx;
+  *ok = false;
+  vdf_jac j1, j2;
+  HIPCALL(ctx, vdf_msm(ctx, sd.gens, 0, (const vdf_fe*)d_z, sd.num_vars, 1, &j1));
+  const Aff a1 = jac_to_aff(j1, *sd.Fb);
+  if (memcmp(&a1, &in.comm_W, 64)) return VDF_OK;
+  if (d_E) {
+    HIPCALL(ctx, vdf_msm(ctx, sd.gens, 0, (const vdf_fe*)d_E, sd.num_cons, 1, &j2));
+    const Aff a2 = jac_to_aff(j2, *sd.Fb);
+    if (memcmp(&a2, &in.comm_E, 64)) return VDF_OK;
+  } else if (!in.comm_E.is_id()) return VDF_OK;
+  // z = (W, u, X) must carry the instance's u and X
+  std::vector<Fe> tail(1 + NUM_IO);
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, tail.data(), (const char*)d_z + sd.num_vars * 32, tail.size() * 32));
+  if (tail[0] != in.u || memcmp(&tail[1], in.X, 32 * NUM_IO)) return VDF_OK;
+  HIPCALL(ctx, vdf_spmv3(ctx, sd.shape, (const vdf_fe*)d_z, (vdf_fe*)d_abc[0], (vdf_fe*)d_abc[1], (vdf_fe*)d_abc[2]));
+  // residual Az*Bz - u*Cz - E through the cross-term kernel with Az2 = Bz1 = 0 and "Cz1" = E
+  HIPCALL(ctx, vdf_cross_term(ctx, sd.field, (const vdf_fe*)d_abc[0], (const vdf_fe*)sd.d_zero, (const vdf_fe*)(d_E ? d_E : sd.d_zero),
+                              (const vdf_fe*)sd.d_zero, (const vdf_fe*)d_abc[1], (const vdf_fe*)d_abc[2], (const vdf_fe*)&in.u,
+                              sd.num_cons, (vdf_fe*)d_T));
+  std::vector<uint64_t> res(sd.num_cons * 4);
+  HIPCALL(ctx, vdf_dev_memcpy(ctx, res.data(), d_T, sd.num_cons * 32));
+  uint64_t any = 0;
+  for (uint64_t w : res) any |= w;
+  *ok = any == 0;
+  return VDF_OK;
+}
+
+}  // namespace vdfnova
 
 extern "C" {
 
 const char* vdf_nova_last_error(void) { return vdfnova::g_err.c_str(); }
 
+// ---- host-only entry points ------------------------------------------------------------------------------------
+int vdf_nova_ro_hash(int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) {
+  if (!valid_field(f) || (!xs && n) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  const Fe r = ro_hash(f, tag, (const Fe*)xs, n);
+  memcpy(out, &r, 32);
+  return VDF_OK;
+}
+
+int vdf_nova_shape_digest(uint64_t t, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
+  if (t == 0 || t > (1ull << 24) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  HostShape sh[2];
+  build_shapes(t, circuit_kind, sh);
+  digest_shapes(t, gens_family, sh, out);
+  if (sizes)
+    for (int s = 0; s < 2; ++s) {
+      sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
+      sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
+    }
+  return VDF_OK;
+}
+
+static AugInputs aug_from_abi(int side, const vdf_nova_aug_inputs* a) {
+  const Field& own = field(side_field(1 - side));                       // the folded side's scalar field
+  const size_t arity = side == PRIMARY ? 3 : 1;
+  AugInputs in;
+  memcpy(&in.params, &a->params, 32);
+  memcpy(&in.i, &a->i, 32);
+  in.z0.resize(arity); in.zi.resize(arity);
+  memcpy(in.z0.data(), a->z0, 32 * arity);
+  memcpy(in.zi.data(), a->zi, 32 * arity);
+  Inst U;
+  memcpy(&U.comm_W, &a->U_comm_W, 64); memcpy(&U.comm_E, &a->U_comm_E, 64);
+  memcpy(&U.u, &a->U_u, 32); memcpy(U.X, a->U_X, 64);
+  in.U = to_relaxed(U, own);
+  memcpy(&in.u_W, &a->u_comm_W, 64);
+  for (int k = 0; k < 2; ++k) { Fe x; memcpy(&x, &a->u_X[k], 32); fe_to_int(x, own, in.u_X[k]); }
+  memcpy(&in.T, &a->T, 64);
+  return in;
+}
+
+int vdf_nova_aug_synthesize(int side, uint64_t t, int circuit_kind, const vdf_nova_aug_inputs* a, const vdf_state* result,
+                            const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars, size_t* num_cons, vdf_fe X[2],
+                            vdf_fe z_next[3]) {
+  if ((side != PRIMARY && side != SECONDARY) || !a || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  vdf_pp tmp;
+  tmp.t = t;
+  tmp.circuit_kind = circuit_kind;
+  std::unique_ptr<StepCircuit> step;
+  Circuit c;
+  if (side == PRIMARY) {
+    if (!result || !input) return fail(VDF_ERR_BAD_ARG, "the primary circuit needs the step's states");
+    c.result = load_state(result); c.input = load_state(input); c.t = t;
+    step = make_primary_circuit(&tmp, &c, false);
+  } else step.reset(new TrivialTestCircuit());
+  CS cs(side_field(side), false);
+  const std::vector<Fe> zn = synthesize_augmented(cs, side, aug_from_abi(side, a), *step);
+  if (num_vars) *num_vars = cs.W.size();
+  if (num_cons) *num_cons = cs.rows;
+  if (W) {
+    if (w_cap < cs.W.size()) return fail(VDF_ERR_BAD_LENGTH, "W buffer too small");
+    memcpy(W, cs.W.data(), cs.W.size() * 32);
+  }
+  if (X) memcpy(X, cs.X.data(), 64);
+  if (z_next) memcpy(z_next, zn.data(), zn.size() * 32);
+  return VDF_OK;
+}
+
 // ---- public parameters -------------------------------------------------------------------------------
 int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
+  return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);
+}
+
+int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
   if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
+    return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
+  if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG) return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
-  vdf_pp* pp = new vdf_pp();
+  std::unique_ptr<vdf_pp, void (*)(vdf_pp*)> pp(new vdf_pp(), vdf_nova_pp_free);
   pp->ctx = ctx;
   pp->t = t;
-  Coo m[3];
-  build_shape(t, m, &pp->num_cons, &pp->num_vars);
-  pp->ncols = pp->num_vars + 1 + NUM_IO;
-  pp->nnz3 = m[0].rows.size() + m[1].rows.size() + m[2].rows.size();
-  const uint32_t* rows[3] = {m[0].rows.data(), m[1].rows.data(), m[2].rows.data()};
-  const uint32_t* cols[3] = {m[0].cols.data(), m[1].cols.data(), m[2].cols.data()};
-  const vdf_fe* vals[3] = {(const vdf_fe*)m[0].vals.data(), (const vdf_fe*)m[1].vals.data(), (const vdf_fe*)m[2].vals.data()};
-  const size_t nnz[3] = {m[0].rows.size(), m[1].rows.size(), m[2].rows.size()};
-  int rc = vdf_shape_create(ctx, PRIMARY_FIELD, pp->num_cons, pp->ncols, rows, cols, vals, nnz, &pp->shape);
-  if (rc != VDF_OK) { std::string e = vdf_last_error(ctx); delete pp; return fail(rc, "vdf_shape_create: " + e); }
-  size_t need = pp->num_vars > pp->num_cons ? pp->num_vars : pp->num_cons;
-  size_t g = 1;
-  while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
-  pp->num_gens = g;
-  rc = vdf_bases_generate_family(ctx, PRIMARY_CURVE, GENS_FAMILY, GENS_SEED, 0, g, &pp->gens);
-  if (rc == VDF_OK) rc = vdf_bases_precompute(ctx, pp->gens, 16, 1);
-  if (rc == VDF_OK) {
+  pp->circuit_kind = circuit_kind;
+  pp->gens_family = gens_family;
+  HostShape sh[2];
+  build_shapes(t, circuit_kind, sh);
+  digest_shapes(t, gens_family, sh, pp->digest);
+  pp->seg_begin = sh[PRIMARY].step_begin;
+  pp->seg_len = sh[PRIMARY].step_end - sh[PRIMARY].step_begin;
+  for (int s = 0; s < 2; ++s) {
+    Side& sd = pp->s[s];
+    sd.side = s; sd.field = side_field(s); sd.curve = side_curve(s);
+    sd.F = &field(sd.field);
+    sd.Fb = &field(s == PRIMARY ? VDF_FIELD_FP : VDF_FIELD_FQ);
+    sd.ctx = ctx;
+    sd.num_cons = sh[s].num_cons; sd.num_vars = sh[s].num_vars;
+    sd.ncols = sd.num_vars + 1 + NUM_IO;
+    memcpy(sd.digest, pp->digest, 32);
+    const Coo* m = sh[s].m;
+    sd.nnz3 = m[0].rows.size() + m[1].rows.size() + m[2].rows.size();
+    const uint32_t* rows[3] = {m[0].rows.data(), m[1].rows.data(), m[2].rows.data()};
+    const uint32_t* cols[3] = {m[0].cols.data(), m[1].cols.data(), m[2].cols.data()};
+    const vdf_fe* vals[3] = {(const vdf_fe*)m[0].vals.data(), (const vdf_fe*)m[1].vals.data(), (const vdf_fe*)m[2].vals.data()};
+    const size_t nnz[3] = {m[0].rows.size(), m[1].rows.size(), m[2].rows.size()};
+    HIPCALL(ctx, vdf_shape_create(ctx, sd.field, sd.num_cons, sd.ncols, rows, cols, vals, nnz, &sd.shape));
+    size_t need = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons, g = 1;
+    while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
+    sd.num_gens = g;
+    HIPCALL(ctx, vdf_bases_generate_family(ctx, sd.curve, gens_family, GENS_SEED, 0, g, &sd.gens));
+    // window of the fixed-base table by the size of the MSMs taken over it: 2^17 terms and more -> 16 bits, the
+    // ~10^4-term witnesses of an augmented circuit -> 13
+    HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? 16 : 13, 1));
     vdf_bases* ub = nullptr;
-    rc = vdf_bases_generate_family(ctx, PRIMARY_CURVE, GENS_FAMILY, GENS_SEED, g, 1, &ub);
-    if (rc == VDF_OK) rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&pp->gen_u);
-    if (ub) vdf_bases_free(ub);
+    HIPCALL(ctx, vdf_bases_generate_family(ctx, sd.curve, gens_family, GENS_SEED, g, 1, &ub));
+    const int rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&sd.gen_u);
+    vdf_bases_free(ub);
+    if (rc != VDF_OK) return fail(rc, std::string("generator download: ") + vdf_last_error(ctx));
+    HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &sd.d_zero));
+    HIPCALL(ctx, vdf_dev_memset(ctx, sd.d_zero, 0, sd.num_cons * 32));
+    uint64_t dv[4];
+    memcpy(dv, pp->digest, 32);
+    pp->params[s] = int_to_fe(dv, *sd.F);
   }
-  if (rc == VDF_OK) rc = setup_packed_generators(pp);
-  if (rc == VDF_OK) rc = vdf_dev_alloc(ctx, pp->num_cons * 32, &pp->d_zero);
-  if (rc == VDF_OK) rc = vdf_dev_memset(ctx, pp->d_zero, 0, pp->num_cons * 32);
-  if (rc != VDF_OK) { std::string e = vdf_last_error(ctx); vdf_nova_pp_free(pp); return fail(rc, "generator setup: " + e); }
-  // shape digest: sizes, every COO triple in canonical form, generator family
-  Shake256 h;
-  h.absorb("vdf-nova-shape-v1", 17);
-  uint64_t hdr[6] = {t, (uint64_t)pp->num_cons, (uint64_t)pp->num_vars, (uint64_t)NUM_IO, GENS_SEED, (uint64_t)GENS_FAMILY};
-  h.absorb(hdr, sizeof(hdr));
-  const Field& F = field(PRIMARY_FIELD);
-  for (int k = 0; k < 3; ++k)
-    for (size_t e = 0; e < m[k].rows.size(); ++e) {
-      uint32_t rc2[2] = {m[k].rows[e], m[k].cols[e]};
-      h.absorb(rc2, 8);
-      absorb_fe(h, m[k].vals[e], F);
-    }
-  h.squeeze(pp->digest, 32);
-  *out = pp;
+  *out = pp.release();
   return VDF_OK;
 }
 void vdf_nova_pp_free(vdf_pp* pp) {
   if (!pp) return;
-  if (pp->d_zero) vdf_dev_free(pp->ctx, pp->d_zero);
-  if (pp->shape) vdf_shape_free(pp->shape);
-  if (pp->gens) vdf_bases_free(pp->gens);
-  if (pp->gens_w) vdf_bases_free(pp->gens_w);
+  for (Side& sd : pp->s) {
+    if (sd.d_zero) vdf_dev_free(pp->ctx, sd.d_zero);
+    if (sd.shape) vdf_shape_free(sd.shape);
+    if (sd.gens) vdf_bases_free(sd.gens);
+  }
   delete pp;
 }
-int vdf_nova_pp_sizes(const vdf_pp* pp, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
+int vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
                       uint64_t* num_gens) {
-  if (!pp) return fail(VDF_ERR_BAD_ARG, "null pp");
-  if (num_cons) *num_cons = pp->num_cons;
-  if (num_vars) *num_vars = pp->num_vars;
+  if (!pp || (side != PRIMARY && side != SECONDARY)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  const Side& sd = pp->s[side];
+  if (num_cons) *num_cons = sd.num_cons;
+  if (num_vars) *num_vars = sd.num_vars;
   if (num_io) *num_io = NUM_IO;
-  if (nnz3) *nnz3 = pp->nnz3;
-  if (num_gens) *num_gens = pp->num_gens;
+  if (nnz3) *nnz3 = sd.nnz3;
+  if (num_gens) *num_gens = sd.num_gens;
+  return VDF_OK;
+}
+int vdf_nova_pp_digest(const vdf_pp* pp, uint8_t out[32]) {
+  if (!pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  memcpy(out, pp->digest, 32);
+  return VDF_OK;
+}
+int vdf_nova_pp_segment(const vdf_pp* pp, uint64_t* begin, uint64_t* len) {
+  if (!pp) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (begin) *begin = pp->seg_begin;
+  if (len) *len = pp->seg_len;
   return VDF_OK;
 }
 
@@ -288,7 +376,7 @@ int vdf_nova_eval_and_make_circuits(int mode, uint64_t t, size_t num_steps, cons
     vdf_state res;
     vdf_state in;
     store_state(&in, state);
-    vdf_minroot_eval(PRIMARY_FIELD, mode, &in, t, &res, (vdf_fe*)c.trace_xy.data());
+    vdf_minroot_eval(VDF_FIELD_FQ, mode, &in, t, &res, (vdf_fe*)c.trace_xy.data());
     c.result = load_state(&res);
     state = c.result;
     cs->v.push_back(std::move(c));
@@ -333,6 +421,24 @@ int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circu
   return rc;
 }
 
+// host-synthesised part of a witness into its device vector [W | 1 | X] through pinned memory; the variables
+// [cs.dev_begin, cs.dev_begin + cs.dev_len) are already there (the GPU made them), cs.W holds the others packed
+static int upload_fresh(vdf_ctx* ctx, const Side& sd, const CS& cs, Fe* stage, void* d_z) {
+  const size_t nv = sd.num_vars, nh = cs.W.size();
+  if (cs.num_vars() != nv || cs.rows != sd.num_cons) return fail(VDF_ERR_DEVICE, "augmented circuit does not match its shape");
+  memcpy(stage, cs.W.data(), nh * 32);
+  stage[nh] = one(*sd.F);
+  stage[nh + 1] = cs.X[0]; stage[nh + 2] = cs.X[1];
+  if (cs.dev_len == 0) {
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, d_z, stage, (nh + 3) * 32));
+  } else {
+    const size_t b = cs.dev_begin, e = cs.dev_begin + cs.dev_len;
+    if (b) HIPCALL(ctx, vdf_dev_memcpy(ctx, d_z, stage, b * 32));
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)d_z + e * 32, stage + b, (nh + 3 - b) * 32));
+  }
+  return VDF_OK;
+}
+
 static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3],
                            vdf_proof** fresh) {
   if (!pp || !proof || !circuits || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
@@ -340,38 +446,40 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   const Circuit& c = circuits->v[k];
   if (c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
   vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
+  const Side& S1 = pp->s[PRIMARY];
+  const Side& S2 = pp->s[SECONDARY];
+  const Field& F1 = *S1.F;
+  const Field& F2 = *S2.F;
   vdf_proof* p = *proof;
   const bool first = (p == nullptr);
   if (first) {
     p = new vdf_proof();
     *fresh = p;
     p->pp = pp;
-    memcpy(p->zi, z0, 96);
+    p->z0[PRIMARY].assign((const Fe*)z0, (const Fe*)z0 + 3);
+    p->z0[SECONDARY].assign(1, zero());                              // z0_secondary = [0], :310, :389-391
+    p->zi[PRIMARY] = p->z0[PRIMARY];
+    p->zi[SECONDARY] = p->z0[SECONDARY];
     int rc = alloc_proof_buffers(p);
     if (rc != VDF_OK) return rc;
+  } else if (memcmp(p->z0[PRIMARY].data(), z0, 96) != 0) {
+    return fail(VDF_ERR_BAD_ARG, "z0 differs from the one this proof was started with");
   }
   // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
-  if (memcmp(p->zi, &c.result, 96) != 0)
+  if (memcmp(p->zi[PRIMARY].data(), &c.result, 96) != 0)
     return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
   const double t0 = now_ms();
-  const size_t nc = pp->num_cons;
-  // The step is enqueued asynchronously: every call below is stream-ordered, and the host waits only for the
-  // two commitments the transcript needs.  The caller's synchronisation mode is restored on the way out.
   int was_async = 0;
   HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
-  // --- fresh z2 = [z_in | per-round new_x, tmp1, tmp2, new_y | final_i | 1 | X2] in one launch, and its
-  // commitment: both depend on the trace only.  Steady state: an earlier step already enqueued them on a lookahead
-  // context; otherwise they are enqueued here, the same way.
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
-  Fe X2[NUM_IO] = {c.result.x, c.result.y, c.result.i, c.input.x, c.input.y, c.input.i};
-  enum { MARK_Z = 0, MARK_W = 1 };                // marks on a lookahead context: z2 written / its commitment landed
-  bool touched[D] = {};                           // lookahead contexts that were given work by this call
-  // enqueues z2 of step j into ring slot s on that step's lookahead context, makes the first context wait for z2
-  // (not for the commitment: vdf_ctx_wait covers what is enqueued so far), then the commitment
-  auto enqueue_fresh = [&](size_t j, int s, bool cold) -> int {
+  enum { MARK_Z = 0, MARK_W = 1 };                // marks on a lookahead context: segment written / its commitment landed
+  bool touched[D] = {};
+  const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
+  const int per = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
+  // the MinRoot rounds of step j into ring slot s on that step's lookahead context, and their share of the commitment
+  auto enqueue_segment = [&](size_t j, int s, bool cold) -> int {
     const Circuit& cc = circuits->v[j];
     vdf_ctx* q = p->ctx2[j % D];
     if (cold) HIPCALL(q, vdf_ctx_wait(q, ctx));   // outside the steady state the ring slot may still be read by a fold
@@ -382,15 +490,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       HIPCALL(q, vdf_dev_memcpy(q, stage, cc.trace_xy.data(), (pp->t + 1) * 64));
       d_trace = stage;
     }
-    const Fe Xf[NUM_IO] = {cc.result.x, cc.result.y, cc.result.i, cc.input.x, cc.input.y, cc.input.i};
-    const Fe u2 = one(F);
-    HIPCALL(q, vdf_minroot_step_z_packed(q, PRIMARY_FIELD, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)Xf,
-                                         (const vdf_fe*)&cc.input.i, (const vdf_fe*)&u2, (const vdf_fe*)Xf, (vdf_fe*)p->d_z2s[s],
-                                         (vdf_fe*)p->d_wps[s]));
+    char* seg = (char*)p->d_z2s[s] + seg_b * 32;
+    HIPCALL(q, vdf_minroot_step_segment(q, S1.field, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)&cc.input.i, per, (vdf_fe*)seg));
     HIPCALL(q, vdf_ctx_mark(q, MARK_Z));
-    HIPCALL(ctx, vdf_ctx_wait(ctx, q));
-    // the commitment over the packed witness and the merged generators: 3t + 4 terms instead of 4t + 4
-    HIPCALL(q, vdf_msm(q, pp->gens_w, 0, (const vdf_fe*)p->d_wps[s], pp->num_w, 1, &p->h_comm[s]));
+    HIPCALL(ctx, vdf_ctx_wait(ctx, q));          // the first context waits for the rounds only, not for their commitment
+    HIPCALL(q, vdf_msm(q, S1.gens, seg_b, (const vdf_fe*)seg, seg_n, 1, &p->h_pts[s]));
     HIPCALL(q, vdf_ctx_mark(q, MARK_W));
     touched[j % D] = true;
     vdf_proof::Ahead a;
@@ -405,22 +509,13 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->ahead.clear();
     p->ahead_circuits = circuits;
     p->ahead_k = k;
-    int rc = enqueue_fresh(k, first ? 0 : (p->slot + 1) % R, !first);
+    int rc = enqueue_segment(k, first ? 0 : (p->slot + 1) % R, !first);
     if (rc != VDF_OK) return rc;
   }
   const int slot = p->ahead[0].slot;
   vdf_ctx* cq = p->ctx2[k % D];
   p->slot = slot;
-  p->d_z2 = p->d_z2s[slot];
-  const double t1 = now_ms();
-  vdf_jac* jw = &p->h_comm[slot];
-  vdf_jac* jt = &p->h_comm[R];
-  Aff comm_w;
-  StepRecord rec;
-  for (int j = 0; j < NUM_IO; ++j) rec.X[j] = X2[j];
-  double t2 = t1, t3 = t1, t4 = t1, t5 = t1, t6 = t1;
-  // keeps the fresh work of the next D steps enqueued (called once this step's commitment has landed: its
-  // context is free again)
+  void* d_z2 = p->d_z2s[slot];
   auto look_ahead = [&]() -> int {
     p->ahead.erase(p->ahead.begin());
     p->ahead_k = k + 1;
@@ -428,111 +523,161 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const size_t j = p->ahead_k + p->ahead.size();
       if (j >= circuits->v.size() || circuits->v[j].t != pp->t) break;
       const int last = p->ahead.empty() ? slot : p->ahead.back().slot;
-      int rc = enqueue_fresh(j, (last + 1) % R, !hit);
+      int rc = enqueue_segment(j, (last + 1) % R, !hit);
       if (rc != VDF_OK) return rc;
     }
     return VDF_OK;
   };
-  // commitment of the fresh witness = (MSM over the packed witness) - ((i_0 - 1) S0 - S1), i_0 = the step's counter
-  auto fresh_commitment = [&](const vdf_jac& j) -> Aff {
-    const Field& Fb = field_fp();
-    if (p->c_valid && sub(p->c_i0, from_u64(pp->t, F), F) == c.result.i) {
-      Aff m = pp->tS0;
-      m.y = neg(m.y, Fb);
-      p->c_pt = pt_add(p->c_pt, pt_from_aff(m, Fb), Fb);                     // consecutive steps: C -= t S0
+  vdf_jac* hb = &p->h_pts[R];                     // four result slots of the batched commitments
+  double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
+  Aff comm_T2, comm_T1;
+  memset(&comm_T2, 0, sizeof(Aff)); memset(&comm_T1, 0, sizeof(Aff));
+  uint64_t r2[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+  const Fe i_fe1 = from_u64((uint64_t)p->i, F1), i_fe2 = from_u64((uint64_t)p->i, F2);
+
+  // ---- (a) NIFS on the secondary side: cross term of (running, l2), commitments of l2's witness and of T ----------
+  if (!first) {
+    SideState& s2 = p->r[SECONDARY];
+    HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
+                                     (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
+                                     (vdf_fe*)s2.d_abc2[2], (vdf_fe*)s2.d_T));
+    if (p->l2_committed) {
+      HIPCALL(ctx, vdf_msm(ctx, S2.gens, 0, (const vdf_fe*)s2.d_T, S2.num_cons, 1, &hb[1]));
     } else {
-      const Fe i0m1 = from_mont(sub(c.result.i, one(F), F), F);              // i_0 - 1 as an integer
-      Aff s1 = pp->S1;
-      s1.y = neg(s1.y, Fb);
-      p->c_pt = pt_add(pt_mul(pt_from_aff(pp->S0, Fb), i0m1.l, 255, Fb), pt_from_aff(s1, Fb), Fb);
+      const size_t off[2] = {0, 0}, len[2] = {S2.num_vars, S2.num_cons};
+      const vdf_fe* sc[2] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T};
+      HIPCALL(ctx, vdf_msm_batch(ctx, S2.gens, 2, off, sc, len, 1, hb));
     }
-    p->c_i0 = c.result.i;
-    p->c_valid = true;
-    Fe X, Y, Z;
-    memcpy(X.l, j.x.l, 32); memcpy(Y.l, j.y.l, 32); memcpy(Z.l, j.z.l, 32);
-    Pt w;
-    w.x = X; w.y = Y; w.zz = sqr(Z, Fb); w.zzz = mul(w.zz, Z, Fb);
-    Pt cneg = p->c_pt;
-    cneg.y = neg(cneg.y, Fb);
-    return pt_to_aff(pt_add(w, cneg, Fb), Fb);
-  };
-  if (first) {
-    // running := fresh as a relaxed instance (E = 0, u = 1); the `None` case of prove_step.  A z, B z, C z of
-    // the running instance are computed here once and folded from then on (they are linear in z).
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, p->d_z1, p->d_z2, pp->ncols * 32));
-    HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
-    HIPCALL(cq, vdf_ctx_sync(cq));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
+    if (!p->l2_committed) { p->l2.comm_W = jac_aff(hb[0], *S2.Fb); p->l2_committed = true; }
+    comm_T2 = jac_aff(hb[1], *S2.Fb);
+  }
+  t1 = now_ms();
+  // ---- (b) the primary augmented circuit -----------------------------------------------------------------------
+  Inst l1;
+  {
+    AugInputs in;
+    in.params = pp->params[PRIMARY];
+    in.i = i_fe1;
+    in.z0 = p->z0[PRIMARY];
+    in.zi = p->zi[PRIMARY];
+    if (first) {
+      const AugInputs b = blank_inputs(3);
+      in.U = b.U; in.u_W = b.u_W; memcpy(in.u_X, b.u_X, sizeof(in.u_X)); in.T = b.T;
+    } else {
+      in.U = to_relaxed(p->r[SECONDARY].inst, F2);
+      in.u_W = p->l2.comm_W;
+      for (int j = 0; j < 2; ++j) fe_to_int(p->l2.X[j], F2, in.u_X[j]);
+      in.T = comm_T2;
+    }
+    CS cs(S1.field, false);
+    const std::unique_ptr<StepCircuit> c1 = make_primary_circuit(pp, &c, true);
+    Fe unew[9];
+    const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2);
+    if (cs.dev_begin != seg_b || cs.dev_len != seg_n) return fail(VDF_ERR_DEVICE, "device segment moved");
     t2 = now_ms();
-    comm_w = fresh_commitment(*jw);
-    p->comm_W = comm_w;
-    p->comm_E.x = p->comm_E.y = zero();
-    p->u = one(F);
-    for (int j = 0; j < NUM_IO; ++j) p->X[j] = X2[j];
-    rec.comm_T.x = rec.comm_T.y = zero();
-    rec.r = zero();
+    if (!first) {
+      // fold the secondary witness on the device (z, E, A z, B z, C z += r2 * fresh), the instance from the circuit
+      SideState& s2 = p->r[SECONDARY];
+      const Fe rr = int_to_fe(r2, F2);
+      vdf_fe* acc[5] = {(vdf_fe*)s2.d_z, (vdf_fe*)s2.d_E, (vdf_fe*)s2.d_abc[0], (vdf_fe*)s2.d_abc[1], (vdf_fe*)s2.d_abc[2]};
+      const vdf_fe* addv[5] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T, (const vdf_fe*)s2.d_abc2[0], (const vdf_fe*)s2.d_abc2[1],
+                               (const vdf_fe*)s2.d_abc2[2]};
+      const size_t len[5] = {S2.ncols, S2.num_cons, S2.num_cons, S2.num_cons, S2.num_cons};
+      HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+    }
+    p->r[SECONDARY].inst = inst_from_elements(unew, F1, F2);       // base step: the default instance
+    // the host-made variables go next to the rounds the lookahead context has written (vdf_ctx_wait at their launch)
+    int rc = upload_fresh(ctx, S1, cs, p->h_stage[PRIMARY], d_z2);
+    if (rc != VDF_OK) return rc;
+    l1.X[0] = cs.X[0]; l1.X[1] = cs.X[1];
+    l1.u = one(F1);
+    memset(&l1.comm_E, 0, sizeof(Aff));
+    p->zi[PRIMARY] = z_next;
+  }
+  // ---- (c) NIFS on the primary side ----------------------------------------------------------------------------
+  {
+    SideState& s1 = p->r[PRIMARY];
+    const size_t off[3] = {0, seg_e, 0}, len[3] = {seg_b, S1.num_vars - seg_e, S1.num_cons};
+    const vdf_fe* sc[3] = {(const vdf_fe*)d_z2, (const vdf_fe*)((const char*)d_z2 + seg_e * 32), (const vdf_fe*)s1.d_T};
+    if (first) {
+      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, 2, off, sc, len, 1, hb));
+    } else {
+      HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
+                                       (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
+                                       (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, 3, off, sc, len, 1, hb));
+    }
+    t3 = now_ms();
+    HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    const Field& Fb = *S1.Fb;
+    l1.comm_W = pt_to_aff(pt_add(pt_add(pt_from_aff(jac_aff(p->h_pts[slot], Fb), Fb), pt_from_aff(jac_aff(hb[0], Fb), Fb), Fb),
+                                 pt_from_aff(jac_aff(hb[1], Fb), Fb), Fb), Fb);
+    if (!first) comm_T1 = jac_aff(hb[2], Fb);
+    if (first) {
+      // running primary := the fresh instance, relaxed; its A z, B z, C z once, folded from then on
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, s1.d_z, d_z2, S1.ncols * 32));
+      HIPCALL(ctx, vdf_spmv3(ctx, S1.shape, (const vdf_fe*)s1.d_z, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]));
+    }
+  }
+  t4 = now_ms();
+  // ---- (d) the secondary augmented circuit -----------------------------------------------------------------------
+  {
+    AugInputs in;
+    in.params = pp->params[SECONDARY];
+    in.i = i_fe2;
+    in.z0 = p->z0[SECONDARY];
+    in.zi = p->zi[SECONDARY];
+    if (first) { const AugInputs b = blank_inputs(1); in.U = b.U; }
+    else in.U = to_relaxed(p->r[PRIMARY].inst, F1);
+    in.u_W = l1.comm_W;
+    for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in.u_X[j]);
+    in.T = comm_T1;
+    CS cs(S2.field, false);
+    const TrivialTestCircuit c2;
+    Fe unew[9];
+    const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1);
+    t5 = now_ms();
+    if (!first) {
+      SideState& s1 = p->r[PRIMARY];
+      const Fe rr = int_to_fe(r1, F1);
+      vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
+      const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
+                               (const vdf_fe*)s1.d_abc2[2]};
+      const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
+      HIPCALL(ctx, vdf_fold_many(ctx, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+    }
+    p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
+    int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
+    if (rc != VDF_OK) return rc;
+    p->l2.X[0] = cs.X[0]; p->l2.X[1] = cs.X[1];
+    p->l2.u = one(F2);
+    memset(&p->l2.comm_E, 0, sizeof(Aff));
+    memset(&p->l2.comm_W, 0, sizeof(Aff));
+    p->l2_committed = false;
+    p->zi[SECONDARY] = z_next;
+  }
+  t6 = now_ms();
+  {
     int rc = look_ahead();
     if (rc != VDF_OK) return rc;
-    t6 = now_ms();
-  } else {
-    // --- NIFS.prove, the critical path of the chain: multiply_vec(z2) + cross term (one
-    // launch), the commitment to T into pinned host memory, the challenge, the fold.  While the GPU works the host
-    // finishes the previous step's instance fold.
-    HIPCALL(ctx, vdf_nifs_cross_term(ctx, pp->shape, (const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)p->d_abc[1],
-                                     (const vdf_fe*)p->d_abc[2], (const vdf_fe*)&p->u, (vdf_fe*)p->d_abc[3], (vdf_fe*)p->d_abc[4],
-                                     (vdf_fe*)p->d_abc[5], (vdf_fe*)p->d_T));
-    t2 = now_ms();
-    HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_T, nc, 1, jt));
-    t3 = now_ms();
-    // this step's fresh commitment has been in flight since an earlier step; once it has landed its context is
-    // free for a later step's
-    HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
-    {
-      int rc = look_ahead();
-      if (rc != VDF_OK) return rc;
-    }
-    t4 = now_ms();
-    comm_w = fresh_commitment(*jw);                              // host point work while the GPU commits to T
-    p->join();                                                   // the previous step's instance fold
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
-    t5 = now_ms();
-    const Aff comm_T = jac_to_aff(*jt, field_fp());
-    uint64_t r_raw[4];
-    const Fe r = challenge(pp, p->comm_W, p->comm_E, p->u, p->X, comm_w, X2, comm_T, r_raw);
-    // witness fold on the device, one launch: z1 += r*z2 (W, and with it u and X), E += r*T, and the running
-    // A z, B z, C z += r * (A z2, B z2, C z2)
-    {
-      vdf_fe* acc[5] = {(vdf_fe*)p->d_z1, (vdf_fe*)p->d_E, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]};
-      const vdf_fe* add[5] = {(const vdf_fe*)p->d_z2, (const vdf_fe*)p->d_T, (const vdf_fe*)p->d_abc[3],
-                              (const vdf_fe*)p->d_abc[4], (const vdf_fe*)p->d_abc[5]};
-      const size_t len[5] = {pp->ncols, nc, nc, nc, nc};
-      HIPCALL(ctx, vdf_fold_many(ctx, PRIMARY_FIELD, (const vdf_fe*)&r, 5, acc, add, len));
-    }
-    t6 = now_ms();
-    // instance fold on the host (O(1)): u and X now, the two commitments deferred (vdf_proof::join)
-    p->pending.cW0 = p->comm_W; p->pending.cE0 = p->comm_E;
-    p->pending.cw = comm_w; p->pending.cT = comm_T;
-    memcpy(p->pending.r, r_raw, 32);
-    p->pending.valid = true;
-    p->u = add(p->u, r, F);
-    for (int j = 0; j < NUM_IO; ++j) p->X[j] = add(p->X[j], mul(r, X2[j], F), F);
-    rec.comm_T = comm_T;
-    rec.r = r;
   }
-  // nothing in flight reads the circuits' memory once this call returns (a lookahead's z2 is long written)
+  // the staging buffers are rewritten by the next call: their copies must have left; and nothing in flight may read the
+  // circuits' memory once this call returns
+  HIPCALL(ctx, vdf_ctx_sync(ctx));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
-  rec.comm_w = comm_w;
-  p->steps.push_back(rec);
   p->i += 1;
-  p->zi[0] = c.input.x; p->zi[1] = c.input.y; p->zi[2] = c.input.i;   // c1.output(zi), src/nova/proof.rs:142-152
+  p->last.comm_W1 = *(const vdf_affine*)&l1.comm_W;
+  memcpy(p->last.X1, l1.X, 64);
+  memcpy(&p->last.comm_T1, &comm_T1, 64);
+  memcpy(&p->last.comm_T2, &comm_T2, 64);
+  memcpy(p->last.r1, r1, 32); memcpy(p->last.r2, r2, 32);
   const double t7 = now_ms();
-  // fresh witness (only without lookahead) | commitment-of-T launch | cross-term launch | wait for the fresh
-  // commitment + lookahead launch | host fold of the previous step + wait for T | transcript + fold launch |
-  // bookkeeping | total
-  p->ms[0] = t1 - t0; p->ms[1] = t3 - t2; p->ms[2] = t2 - t1; p->ms[3] = t4 - t3;
+  p->ms[0] = t1 - t0; p->ms[1] = t2 - t1; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3;
   p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
   *proof = p;
-  *fresh = nullptr;                               // handed over to the caller
+  *fresh = nullptr;
   return VDF_OK;
 }
 
@@ -546,52 +691,59 @@ int vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_
     int rc = vdf_nova_prove_step(pp, &p, circuits, k, z0);
     if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
   }
+  int rc = finalize_l2(p);
+  if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
   *out = p;
   return VDF_OK;
 }
 
 void vdf_nova_proof_free(vdf_proof* p) {
   if (!p) return;
-  p->join();
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_sync(q);                   // lookaheads may still be in flight
     vdf_ctx_sync(ctx);
-    void* bufs[] = {p->d_z1, p->d_E, p->d_T, p->d_abc[0], p->d_abc[1], p->d_abc[2], p->d_abc[3], p->d_abc[4], p->d_abc[5]};
-    for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
+    for (SideState& st : p->r) {
+      void* bufs[] = {st.d_z, st.d_E, st.d_T, st.d_abc[0], st.d_abc[1], st.d_abc[2], st.d_abc2[0], st.d_abc2[1], st.d_abc2[2]};
+      for (void* b : bufs) if (b) vdf_dev_free(ctx, b);
+    }
+    if (p->d_l2z) vdf_dev_free(ctx, p->d_l2z);
     for (void* b : p->d_z2s) if (b) vdf_dev_free(ctx, b);
-    for (void* b : p->d_wps) if (b) vdf_dev_free(ctx, b);
     for (void* b : p->d_traces) if (b) vdf_dev_free(ctx, b);
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_destroy(q);
-    if (p->h_comm) vdf_host_free(ctx, p->h_comm);
+    if (p->h_pts) vdf_host_free(ctx, p->h_pts);
+    for (Fe* h : p->h_stage) if (h) vdf_host_free(ctx, h);
   }
   delete p;
 }
 size_t vdf_nova_proof_num_steps(const vdf_proof* p) { return p ? p->i : 0; }
 
-int vdf_nova_proof_instance(const vdf_proof* p, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[6]) {
-  if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
-  p->join();
-  if (comm_W) memcpy(comm_W, &p->comm_W, 64);
-  if (comm_E) memcpy(comm_E, &p->comm_E, 64);
-  if (u) memcpy(u, &p->u, 32);
-  if (X) memcpy(X, p->X, 32 * NUM_IO);
+int vdf_nova_proof_instance(const vdf_proof* p, int which, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[2]) {
+  if (!p || which < 0 || which > 2) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  if (which == VDF_INST_FRESH_SECONDARY) { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
+  const Inst& in = which == VDF_INST_FRESH_SECONDARY ? p->l2 : p->r[which].inst;
+  if (comm_W) memcpy(comm_W, &in.comm_W, 64);
+  if (comm_E) memcpy(comm_E, &in.comm_E, 64);
+  if (u) memcpy(u, &in.u, 32);
+  if (X) memcpy(X, in.X, 32 * NUM_IO);
   return VDF_OK;
 }
-int vdf_nova_proof_witness_ptrs(const vdf_proof* p, const void** d_W, const void** d_E) {
-  if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+int vdf_nova_proof_witness_ptrs(const vdf_proof* p, int which, const void** d_z, const void** d_E) {
+  if (!p || which < 0 || which > 2) return fail(VDF_ERR_BAD_ARG, "bad argument");
   HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
-  if (d_W) *d_W = p->d_z1;
-  if (d_E) *d_E = p->d_E;
+  if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }
+  else { if (d_z) *d_z = p->r[which].d_z; if (d_E) *d_E = p->r[which].d_E; }
   return VDF_OK;
 }
-int vdf_nova_proof_step_record(const vdf_proof* p, size_t k, vdf_affine* comm_w, vdf_affine* comm_T, vdf_fe* r, vdf_fe X[6]) {
-  if (!p || k >= p->steps.size()) return fail(VDF_ERR_BAD_LENGTH, "step index out of range");
-  const StepRecord& s = p->steps[k];
-  if (comm_w) memcpy(comm_w, &s.comm_w, 64);
-  if (comm_T) memcpy(comm_T, &s.comm_T, 64);
-  if (r) memcpy(r, &s.r, 32);
-  if (X) memcpy(X, s.X, 32 * NUM_IO);
+int vdf_nova_proof_zi(const vdf_proof* p, vdf_fe zi_primary[3], vdf_fe zi_secondary[1]) {
+  if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
+  if (zi_primary) memcpy(zi_primary, p->zi[PRIMARY].data(), 96);
+  if (zi_secondary) memcpy(zi_secondary, p->zi[SECONDARY].data(), 32);
+  return VDF_OK;
+}
+int vdf_nova_proof_last_step(const vdf_proof* p, vdf_nova_step_info* out) {
+  if (!p || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  *out = p->last;
   return VDF_OK;
 }
 int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
@@ -601,50 +753,43 @@ int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
 }
 
 // ---- verify --------------------------------------------------------------------------------------------
+// RecursiveSNARK::verify(pp, num_steps, z0_primary, z0_secondary) -> (zi_primary, zi_secondary), then the comparison of
+// src/nova/proof.rs:386 with z0_secondary = [0] (:389-391)
 int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
   if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
   *ok = 0;
   if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
-  p->join();
+  if (num_steps == 0 || p->i != num_steps) return VDF_OK;                  // NovaError::ProofVerifyError
+  { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
+  const Side& S1 = pp->s[PRIMARY];
+  const Side& S2 = pp->s[SECONDARY];
+  const Field& F1 = *S1.F;
+  const Field& F2 = *S2.F;
+  // (1) the two output hashes the last secondary instance carries
+  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + 3), z0s(1, zero());
+  uint64_t hv[4];
+  hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv);
+  if (int_to_fe(hv, F2) != p->l2.X[0]) return VDF_OK;
+  hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, p->zi[SECONDARY], to_relaxed(p->r[PRIMARY].inst, F1), hv);
+  if (int_to_fe(hv, F2) != p->l2.X[1]) return VDF_OK;
+  // (2) three satisfiability claims
   vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
-  if (num_steps == 0 || p->steps.size() != num_steps || p->i != num_steps) return VDF_OK;   // NovaError::ProofVerifyError
-  // (1) public-IO chain: X_0.z_in = z0, X_k.z_out = X_{k+1}.z_in; the last z_out is the verified z_i
-  if (memcmp(p->steps[0].X, z0, 96) != 0) return VDF_OK;
-  for (size_t k = 0; k + 1 < num_steps; ++k)
-    if (memcmp(&p->steps[k].X[3], &p->steps[k + 1].X[0], 96) != 0) return VDF_OK;
-  // every step must move the counter by exactly t in the inverse direction
-  const Fe tfe = from_u64(pp->t, F);
-  for (size_t k = 0; k < num_steps; ++k)
-    if (sub(p->steps[k].X[2], p->steps[k].X[5], F) != tfe) return VDF_OK;
-  // (2) replay the folds of the instances
-  Aff cW, cE;
-  Fe u, X[NUM_IO];
-  if (!fold_replay(pp, p->steps, nullptr, &cW, &cE, &u, X)) return VDF_OK;
-  if (memcmp(&cW, &p->comm_W, 64) || memcmp(&cE, &p->comm_E, 64) || u != p->u || memcmp(X, p->X, sizeof(X))) return VDF_OK;
-  // (3) the running witness opens the folded instance: commitments and relaxed satisfiability
-  const size_t nv = pp->num_vars, nc = pp->num_cons;
-  vdf_jac j1, j2;
-  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_z1, nv, 1, &j1));
-  HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)p->d_E, nc, 1, &j2));
-  Aff a1 = jac_to_aff(j1, field_fp()), a2 = jac_to_aff(j2, field_fp());
-  if (memcmp(&a1, &p->comm_W, 64) || memcmp(&a2, &p->comm_E, 64)) return VDF_OK;
-  // z = (W, u, X) must carry the instance's u and X
-  std::vector<Fe> tail(1 + NUM_IO);
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, tail.data(), (const char*)p->d_z1 + nv * 32, tail.size() * 32));
-  if (tail[0] != p->u || memcmp(&tail[1], p->X, 32 * NUM_IO)) return VDF_OK;
-  HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)p->d_z1, (vdf_fe*)p->d_abc[0], (vdf_fe*)p->d_abc[1], (vdf_fe*)p->d_abc[2]));
-  // residual Az*Bz - u*Cz - E through the cross-term kernel with Az2 = Bz1 = 0
-  HIPCALL(ctx, vdf_cross_term(ctx, PRIMARY_FIELD, (const vdf_fe*)p->d_abc[0], (const vdf_fe*)pp->d_zero, (const vdf_fe*)p->d_E,
-                              (const vdf_fe*)pp->d_zero, (const vdf_fe*)p->d_abc[1], (const vdf_fe*)p->d_abc[2],
-                              (const vdf_fe*)&p->u, nc, (vdf_fe*)p->d_T));
-  std::vector<uint64_t> res(nc * 4);
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, res.data(), p->d_T, nc * 32));
-  uint64_t any = 0;
-  for (uint64_t w : res) any |= w;
-  if (any) return VDF_OK;
-  // Ok(zi_primary == zi_primary_verified), src/nova/proof.rs:386
-  *ok = memcmp(&p->steps[num_steps - 1].X[3], zi, 96) == 0 ? 1 : 0;
+  HIPCALL(ctx, vdf_ctx_sync(ctx));
+  vdf_proof* q = const_cast<vdf_proof*>(p);                                  // scratch buffers only
+  bool good = false;
+  for (int s = 0; s < 2; ++s) {
+    int rc = check_sat(pp->s[s], p->r[s].inst, p->r[s].d_z, p->r[s].d_E, q->r[s].d_abc2, q->r[s].d_T, &good);
+    if (rc != VDF_OK) return rc;
+    if (!good) return VDF_OK;
+  }
+  if (p->l2.u != one(F2)) return VDF_OK;
+  {
+    int rc = check_sat(S2, p->l2, p->d_l2z, nullptr, q->r[SECONDARY].d_abc2, q->r[SECONDARY].d_T, &good);
+    if (rc != VDF_OK) return rc;
+    if (!good) return VDF_OK;
+  }
+  // Ok(zi_primary == zi && zi_secondary == [0]), src/nova/proof.rs:386
+  *ok = (memcmp(p->zi[PRIMARY].data(), zi, 96) == 0 && p->zi[SECONDARY][0].is_zero()) ? 1 : 0;
   return VDF_OK;
 }
 

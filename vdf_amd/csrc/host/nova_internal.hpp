@@ -1,5 +1,5 @@
-// Shared declarations of the translation units of libvdf_nova.so (minroot_host.cpp, nova_host.cpp,
-// compress_host.cpp): error plumbing, the curve / field roles of the reference, the handle structs.
+// Shared declarations of the translation units of libvdf_nova.so (minroot_host.cpp, r1cs.cpp, nova_host.cpp,
+// compress_host.cpp, wire_host.cpp): error plumbing, the two sides of the curve cycle, the handle structs.
 #pragma once
 #include <array>
 #include <chrono>
@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../../include/vdf_nova.h"
 #include "host_math.hpp"
+#include "r1cs.hpp"
 
 namespace vdfnova {
 using namespace vdfhost;
@@ -34,19 +35,33 @@ inline bool valid_field(int f) { return f == VDF_FIELD_FP || f == VDF_FIELD_FQ; 
 inline bool valid_mode(int m) { return m >= 0 && m <= 3; }
 
 // ---- Nova (nova_host.cpp) ---------------------------------------------------------------------------------
-constexpr int NUM_IO = 6;                  // X = [z_in(3), z_out(3)]
-constexpr uint64_t GENS_SEED = 0x4e6f7661; // "Nova": label of the generator family
-// Generators by seeded try-and-increment (include/vdf_hip.h): nobody knows their discrete logarithms, which is what
-// makes the Pedersen commitments binding -- the [k_i]G family of the kernel tests would not do for a proof system.
-constexpr int GENS_FAMILY = VDF_GENS_TRY_AND_INCREMENT;
-constexpr int PRIMARY_FIELD = VDF_FIELD_FQ;   // S1 = pallas::Scalar, src/nova/proof.rs:29
-constexpr int PRIMARY_CURVE = VDF_CURVE_PALLAS;   // G1, src/nova/proof.rs:26
+constexpr int NUM_IO = AUG_IO;             // public IO of an augmented circuit
+constexpr uint64_t GENS_SEED = 0x4e6f7661; // "Nova": label of the generator families
+constexpr int PRIMARY = 0, SECONDARY = 1;  // G1 = Pallas / G2 = Vesta, src/nova/proof.rs:26-27
 
-struct StepRecord { Aff comm_w, comm_T; Fe r; Fe X[NUM_IO]; };
+// One side of the cycle: an augmented circuit over F (the scalar field of `curve`), its R1CS shape and the Pedersen
+// generators its witnesses are committed under -- everything the folding, the satisfiability check and the
+// compression argument need to know about "the instance's side".
+struct Side {
+  int side = 0, field = 0, curve = 0;
+  const Field* F = nullptr;                // scalars of this side's instances (= the circuit's field)
+  const Field* Fb = nullptr;               // coordinates of this side's commitments
+  vdf_ctx* ctx = nullptr;
+  size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
+  vdf_shape* shape = nullptr;
+  vdf_bases* gens = nullptr;
+  Aff gen_u;                               // the extra generator of the inner-product arguments: number num_gens of the family
+  void* d_zero = nullptr;                  // num_cons zero elements (satisfiability residual)
+  uint8_t digest[32];                      // the parameters' digest (same on both sides; bound into the argument's transcript)
+};
 
+// instance of one side; u and X in Montgomery form of that side's own field
+struct Inst { Aff comm_W, comm_E; Fe u; Fe X[NUM_IO]; };
+RelaxedInst to_relaxed(const Inst& in, const Field& own);
+// relaxed satisfiability of (inst, z = [W | u | X], E) on `sd`: commitments open and A z o B z = u C z + E
+int check_sat(const Side& sd, const Inst& in, const void* d_z, const void* d_E, void* d_scratch_abc[3], void* d_scratch_T, bool* ok);
 
 }  // namespace vdfnova
-
 
 using vdfhost::Aff; using vdfhost::Fe;
 using vdfnova::NUM_IO;
@@ -54,18 +69,12 @@ using vdfnova::NUM_IO;
 struct vdf_pp {
   vdf_ctx* ctx = nullptr;
   uint64_t t = 0;
-  size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
-  vdf_shape* shape = nullptr;
-  vdf_bases* gens = nullptr;
-  uint8_t digest[32];
-  // Commitment to a fresh witness over 3t + 4 instead of 4t + 4 generators (vdf_minroot_step_z_packed): new_x of round
-  // j is y_j - (i_0 - 1 - j), so its generator G_{3+4j} is merged into the generator of y_j, and what remains,
-  // sum_j (i_0 - 1 - j) G_{3+4j} = (i_0 - 1) S0 - S1, depends on the step's counter i_0 only.
-  vdf_bases* gens_w = nullptr;
-  size_t num_w = 0;
-  Aff S0, S1, tS0;          // S0 = sum_j G_{3+4j}, S1 = sum_j j G_{3+4j}, tS0 = t * S0
-  Aff gen_u;                // the extra generator U of the inner-product arguments: synthetic generator number num_gens
-  void* d_zero = nullptr;   // num_cons zero elements (satisfiability residual)
+  int circuit_kind = 0, gens_family = 0;
+  vdfnova::Side s[2];
+  uint8_t digest[32];                      // 250-bit little-endian integer
+  Fe params[2];                            // the digest as an element of each side's field
+  // variables of the primary witness that the GPU fills from the forward trace (the MinRoot rounds): [seg_begin, seg_begin + seg_len)
+  size_t seg_begin = 0, seg_len = 0;
 };
 
 struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-66, + the forward trace
@@ -77,65 +86,50 @@ struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-6
 };
 struct vdf_circuits { std::vector<Circuit> v; vdf_ctx* ctx = nullptr; };
 
+// NovaVDFProof::Recursive = nova-snark RecursiveSNARK: running instance + witness on both sides, the last secondary
+// instance unfolded, the step counter and both z_i.  Constant size in the number of steps.
+struct SideState {
+  vdfnova::Inst inst;        // running relaxed instance
+  void* d_z = nullptr;       // [W | u | X]
+  void* d_E = nullptr;
+  void* d_abc[3] = {};       // A z, B z, C z of the running instance, folded along (linear in z)
+  void* d_abc2[3] = {};      // the fresh instance's
+  void* d_T = nullptr;
+};
 struct vdf_proof {
   vdf_pp* pp = nullptr;
-  size_t i = 0;              // steps folded so far
-  Fe zi[3];                  // current z_i (starts at z0)
-  Aff comm_W, comm_E;        // running relaxed instance
-  Fe u, X[NUM_IO];
-  void* d_z1 = nullptr;      // [W | u | X] of the running instance (W aliases the front)
-  void* d_z2 = nullptr;      // [W | 1 | X] of the fresh instance: the ring slot of the current step
-  // Lookahead.  The fresh witness of a later step and its commitment depend on the trace only, not on the fold
-  // chain, so they are computed on further contexts of the same device while the critical path of the chain (cross
-  // term -> commitment of T -> challenge -> fold) runs on the first: step j's fresh work goes to context j mod DEPTH,
-  // enqueued DEPTH steps early.  DEPTH + 2 ring slots: the slot step j is written to was last read by step
-  // j - DEPTH - 2, whose fold is known complete (the host has synchronised the first context since).
+  size_t i = 0;
+  std::vector<Fe> zi[2], z0[2];
+  SideState r[2];
+  // fresh secondary instance (u = 1, E = 0)
+  vdfnova::Inst l2;
+  void* d_l2z = nullptr;
+  bool l2_committed = false;
+  // fresh primary z: ring of slots, the MinRoot segment of a later step is filled (and committed) ahead of time on ctx2
   static constexpr int DEPTH = 1, RING = DEPTH + 2;
   vdf_ctx* ctx2[DEPTH] = {};
   void* d_z2s[RING] = {};
-  void* d_wps[RING] = {};       // the same slots' packed witnesses (3t + 4 values, what the commitment is taken over)
-  // correction point of the packed commitment for the counter c_i0: (c_i0 - 1) S0 - S1; consecutive steps differ by t S0
-  bool c_valid = false;
-  Fe c_i0;
-  vdfhost::Pt c_pt;
-  void* d_traces[DEPTH] = {};   // staging for traces that are not device-resident, one per lookahead context
+  void* d_traces[DEPTH] = {};
   int slot = 0;
-  // steps [ahead_k, ahead_end) of `ahead_circuits` are in flight or landed; entry j lives in slot ahead_slot0 + (j - ahead_k)
   struct Ahead { vdfnova::St result, input; int slot; };
   const vdf_circuits* ahead_circuits = nullptr;
   size_t ahead_k = 0;
-  std::vector<Ahead> ahead;     // ahead[i] describes step ahead_k + i
-  void* d_E = nullptr;       // running error vector
-  void* d_T = nullptr;
-  void* d_abc[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // Az1,Bz1,Cz1,Az2,Bz2,Cz2
-  vdf_jac* h_comm = nullptr; // pinned, device-mapped result slots: [0..RING) = commitment of W2 per ring slot, [RING] = of T
-  std::vector<vdfnova::StepRecord> steps;
+  std::vector<Ahead> ahead;
+  vdf_jac* h_pts = nullptr;      // pinned result slots: [0, RING) segment commitments per ring slot, then 4 for the batches
+  Fe* h_stage[2] = {};           // pinned staging of a host-synthesised witness, one per side
+  // the last step's by-products, for the parity tests
+  vdf_nova_step_info last;
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // The O(1) instance fold of step k (two 128-bit scalar multiplications on the host) is deferred: step k+1
-  // performs it while the GPU works on its commitments; everything else that reads comm_W / comm_E joins first.
-  struct Deferred { bool valid = false; Aff cW0, cE0, cw, cT; uint64_t r[4]; };
-  mutable Deferred pending;
-  void join() const;
 };
 
 namespace vdfnova {
-// r = SHAKE256(digest | U1 | u2 | comm_T) squeezed to 128 bits
-Fe challenge(const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Aff& cw2, const Fe* X2,
-             const Aff& cT, uint64_t r_raw[4]);
-Aff fold_commitment(const Aff& a, const uint64_t r_raw[4], const Aff& b);      // a + r*b on Pallas
-// The verifier's replay of the instance folds over the step records (steps must not be empty).  r_out == nullptr:
-// every record's challenge must be the transcript's (false otherwise); else the challenges are written to r_out.
-bool fold_replay(const vdf_pp* pp, const std::vector<StepRecord>& steps, Fe* r_out, Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]);
 int alloc_proof_buffers(vdf_proof* p);
+int finalize_l2(const vdf_proof* p);      // commits to the last secondary witness if that is still pending
+std::unique_ptr<StepCircuit> make_primary_circuit(const vdf_pp* pp, const Circuit* c, bool device_rounds);
 
 // ---- wire formats (wire_host.cpp; layout in include/vdf_nova.h) --------------------------------------------
-constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK02";      // compressed proof
-constexpr char WIRE_MAGIC_PROOF[9] = "VDFRSK01";      // running proof (checkpoint)
-size_t wire_chain_size(size_t num_steps);
-uint8_t* wire_put_chain(uint8_t* o, const char magic[8], uint64_t t, const uint8_t digest[32], const std::vector<StepRecord>& steps);
-// parses the chain, replays the folds (filling every record's challenge and the folded instance), advances *in
-int wire_get_chain(const uint8_t** in, size_t* len, const char magic[8], const vdf_pp* pp, std::vector<StepRecord>* steps,
-                   Aff* cW, Aff* cE, Fe* u, Fe X[NUM_IO]);
+constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK03";      // compressed proof
+constexpr char WIRE_MAGIC_PROOF[9] = "VDFRSK02";      // running proof (checkpoint)
 inline uint8_t* wire_put_fe(uint8_t* o, const Fe& v, const Field& F) { const Fe c = from_mont(v, F); memcpy(o, c.l, 32); return o + 32; }
 inline bool wire_get_fe(const uint8_t* i, const Field& F, Fe* v) {
   Fe c;

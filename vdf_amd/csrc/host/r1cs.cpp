@@ -1,0 +1,696 @@
+// Constraint system, random oracle and gadgets of the Nova layer.  Specification: oracle/nova.py, oracle/poseidon.py
+// (see r1cs.hpp).  Host code only: O(10^4) sequential field operations per step, no kernel work.
+#include "r1cs.hpp"
+
+#include <mutex>
+
+namespace vdfnova {
+
+// =============================================================================================================
+// CS
+// =============================================================================================================
+CS::CS(int f, bool shape_mode) : field_id(f), F(field(f)), shape(shape_mode) {}
+
+Num CS::constant(const Fe& k) const {
+  Num n;
+  n.v = k;
+  if (shape && !k.is_zero()) n.lc.push_back(Term{KEY_ONE, k});
+  return n;
+}
+
+static LC lc_combine(const LC& a, const LC& b, bool negate_b, const Field& F) {
+  LC out;
+  out.reserve(a.size() + b.size());
+  size_t i = 0, j = 0;
+  while (i < a.size() || j < b.size()) {
+    if (j == b.size() || (i < a.size() && a[i].key < b[j].key)) out.push_back(a[i++]);
+    else if (i == a.size() || b[j].key < a[i].key) {
+      Term t = b[j++];
+      if (negate_b) t.c = neg(t.c, F);
+      out.push_back(t);
+    } else {
+      const Fe c = negate_b ? vdfhost::sub(a[i].c, b[j].c, F) : vdfhost::add(a[i].c, b[j].c, F);
+      if (!c.is_zero()) out.push_back(Term{a[i].key, c});
+      ++i; ++j;
+    }
+  }
+  return out;
+}
+
+Num CS::add(const Num& a, const Num& b) const {
+  Num n;
+  n.v = vdfhost::add(a.v, b.v, F);
+  if (shape) n.lc = lc_combine(a.lc, b.lc, false, F);
+  return n;
+}
+Num CS::sub(const Num& a, const Num& b) const {
+  Num n;
+  n.v = vdfhost::sub(a.v, b.v, F);
+  if (shape) n.lc = lc_combine(a.lc, b.lc, true, F);
+  return n;
+}
+Num CS::scale(const Num& a, const Fe& k) const {
+  Num n;
+  n.v = vdfhost::mul(a.v, k, F);
+  if (shape && !k.is_zero()) {
+    n.lc.reserve(a.lc.size());
+    for (const Term& t : a.lc) n.lc.push_back(Term{t.key, vdfhost::mul(t.c, k, F)});
+  }
+  return n;
+}
+Num CS::scale_small(const Num& a, unsigned k) const {
+  Num n;
+  Fe acc = vdfhost::zero(), base = a.v;
+  for (unsigned e = k; e; e >>= 1) {
+    if (e & 1) acc = vdfhost::add(acc, base, F);
+    base = vdfhost::add(base, base, F);
+  }
+  n.v = acc;
+  if (shape && k) {
+    const Fe kf = from_u64(k, F);
+    n.lc.reserve(a.lc.size());
+    for (const Term& t : a.lc) n.lc.push_back(Term{t.key, vdfhost::mul(t.c, kf, F)});
+  }
+  return n;
+}
+Num CS::alloc(const Fe& v) {
+  Num n;
+  n.v = v;
+  if (shape) n.lc.push_back(Term{(uint32_t)W.size(), one(F)});
+  W.push_back(v);
+  return n;
+}
+Num CS::alloc_io(const Fe& v) {
+  Num n;
+  n.v = v;
+  if (shape) n.lc.push_back(Term{KEY_ONE + 1 + (uint32_t)X.size(), one(F)});
+  X.push_back(v);
+  return n;
+}
+void CS::skip(size_t n, size_t cons) {
+  dev_begin = W.size();
+  dev_len = n;
+  rows += cons;
+}
+void CS::enforce(const Num& a, const Num& b, const Num& c) {
+  if (shape) cons_.push_back(Row{a.lc, b.lc, c.lc});
+  ++rows;
+}
+Num CS::mul(const Num& a, const Num& b) {
+  Num c = alloc(vdfhost::mul(a.v, b.v, F));
+  enforce(a, b, c);
+  return c;
+}
+void CS::enforce_equal(const Num& a, const Num& b) { enforce(sub(a, b), constant(one(F)), zero_num()); }
+
+void CS::finish(Coo out[3]) const {
+  const uint32_t nv = (uint32_t)W.size();
+  auto col = [&](uint32_t key) { return key < KEY_ONE ? key : nv + (key - KEY_ONE); };
+  for (size_t r = 0; r < cons_.size(); ++r) {
+    const LC* l[3] = {&cons_[r].a, &cons_[r].b, &cons_[r].c};
+    for (int k = 0; k < 3; ++k)
+      for (const Term& t : *l[k]) { out[k].rows.push_back((uint32_t)r); out[k].cols.push_back(col(t.key)); out[k].vals.push_back(t.c); }
+  }
+}
+
+// =============================================================================================================
+// Random oracle
+// =============================================================================================================
+static const int M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+
+static RoConstants make_ro(int f) {
+  const Field& F = field(f);
+  RoConstants rc;
+  const unsigned mu[4] = {2, 3, 6, 8};
+  for (int i = 0; i < 4; ++i) rc.mu_minus_1[i] = mu[i] - 1;
+  Shake256 h;
+  h.absorb("vdf-poseidon2-v1", 16);
+  const uint8_t hdr[4] = {(uint8_t)f, RO_T, RO_RF, RO_RP};
+  h.absorb(hdr, 4);
+  Fe r_mont;                                           // Montgomery form of 2^256 mod m
+  { Fe o; memcpy(o.l, F.one, 32); r_mont = to_mont(o, F); }
+  auto next = [&]() {
+    uint64_t w[8];
+    h.squeeze(w, 64);
+    return vdfhost::add(int_to_fe(w, F), vdfhost::mul(int_to_fe(w + 4, F), r_mont, F), F);
+  };
+  for (int r = 0; r < RO_RF + RO_RP; ++r) {
+    if (r < RO_RF / 2) for (int i = 0; i < RO_T; ++i) rc.ext[r][i] = next();
+    else if (r < RO_RF / 2 + RO_RP) rc.in[r - RO_RF / 2] = next();
+    else for (int i = 0; i < RO_T; ++i) rc.ext[r - RO_RP][i] = next();
+  }
+  return rc;
+}
+const RoConstants& ro_constants(int f) {
+  static const RoConstants fp = make_ro(VDF_FIELD_FP), fq = make_ro(VDF_FIELD_FQ);
+  return f == VDF_FIELD_FP ? fp : fq;
+}
+
+static inline Fe times_small(const Fe& a, unsigned k, const Field& F) {
+  Fe acc = vdfhost::zero(), base = a;
+  for (unsigned e = k; e; e >>= 1) {
+    if (e & 1) acc = vdfhost::add(acc, base, F);
+    base = vdfhost::add(base, base, F);
+  }
+  return acc;
+}
+static inline void ext_layer(Fe s[4], const Field& F) {
+  Fe o[4];
+  for (int i = 0; i < 4; ++i) {
+    Fe acc = vdfhost::zero();
+    for (int j = 0; j < 4; ++j) acc = vdfhost::add(acc, times_small(s[j], (unsigned)M4[i][j], F), F);
+    o[i] = acc;
+  }
+  for (int i = 0; i < 4; ++i) s[i] = o[i];
+}
+static inline Fe pow5(const Fe& x, const Field& F) { const Fe x2 = sqr(x, F); return vdfhost::mul(sqr(x2, F), x, F); }
+
+void ro_permute(Fe s[RO_T], int f) {
+  const Field& F = field(f);
+  const RoConstants& rc = ro_constants(f);
+  ext_layer(s, F);
+  for (int r = 0; r < RO_RF + RO_RP; ++r) {
+    if (r < RO_RF / 2 || r >= RO_RF / 2 + RO_RP) {
+      const Fe* k = rc.ext[r < RO_RF / 2 ? r : r - RO_RP];
+      for (int i = 0; i < 4; ++i) s[i] = pow5(vdfhost::add(s[i], k[i], F), F);
+      ext_layer(s, F);
+    } else {
+      s[0] = pow5(vdfhost::add(s[0], rc.in[r - RO_RF / 2], F), F);
+      const Fe tot = vdfhost::add(vdfhost::add(s[0], s[1], F), vdfhost::add(s[2], s[3], F), F);
+      for (int i = 0; i < 4; ++i) s[i] = vdfhost::add(tot, times_small(s[i], rc.mu_minus_1[i], F), F);
+    }
+  }
+}
+
+Fe ro_hash(int f, uint64_t tag, const Fe* xs, size_t n) {
+  const Field& F = field(f);
+  Fe s[4] = {from_u64(tag + ((uint64_t)n << 32), F), vdfhost::zero(), vdfhost::zero(), vdfhost::zero()};
+  for (size_t k = 0; k < n; k += RO_RATE) {
+    for (size_t j = 0; j < RO_RATE && k + j < n; ++j) s[1 + j] = vdfhost::add(s[1 + j], xs[k + j], F);
+    ro_permute(s, f);
+  }
+  return s[1];
+}
+
+// =============================================================================================================
+// Gadgets
+// =============================================================================================================
+Num is_zero(CS& cs, const Num& a) {
+  const Field& F = cs.F;
+  Num z = cs.alloc(a.v.is_zero() ? one(F) : vdfhost::zero());
+  Num inv = cs.alloc(inverse(a.v, F));                  // 0 for 0
+  cs.enforce(a, inv, cs.sub(cs.constant(one(F)), z));
+  cs.enforce(a, z, cs.zero_num());
+  return z;
+}
+
+Num select(CS& cs, const Num& cond, const Num& a, const Num& b) {
+  Num out = cs.alloc(cond.v.is_zero() ? b.v : a.v);
+  cs.enforce(cond, cs.sub(a, b), cs.sub(out, b));
+  return out;
+}
+
+std::vector<Num> alloc_bits(CS& cs, const uint64_t v[4], int n) {
+  const Field& F = cs.F;
+  const Fe o = one(F), z = vdfhost::zero();
+  const Num one_n = cs.constant(o);
+  std::vector<Num> bits;
+  bits.reserve(n);
+  for (int k = 0; k < n; ++k) {
+    Num b = cs.alloc(((v[k / 64] >> (k % 64)) & 1) ? o : z);
+    cs.enforce(b, cs.sub(one_n, b), cs.zero_num());
+    bits.push_back(std::move(b));
+  }
+  return bits;
+}
+
+static const Fe* pow2_table(const Field& F) {          // 2^k in Montgomery form, k < 256
+  static Fe tp[256], tq[256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (int f = 0; f < 2; ++f) {
+      const Field& G = field(f);
+      Fe* t = f == VDF_FIELD_FP ? tp : tq;
+      t[0] = one(G);
+      for (int k = 1; k < 256; ++k) t[k] = vdfhost::add(t[k - 1], t[k - 1], G);
+    }
+  });
+  return &F == &field(VDF_FIELD_FP) ? tp : tq;
+}
+
+// bits are single variables (0 / 1) with ascending keys, as alloc_bits makes them
+Num pack(const CS& cs, const Num* bits, size_t n) {
+  const Field& F = cs.F;
+  const Fe* p2 = pow2_table(F);
+  uint64_t v[4] = {0, 0, 0, 0};
+  for (size_t k = 0; k < n; ++k) if (!bits[k].v.is_zero()) v[k / 64] |= 1ull << (k % 64);
+  Num out;
+  out.v = int_to_fe(v, F);
+  if (cs.shape) {
+    out.lc.reserve(n);
+    for (size_t k = 0; k < n; ++k) out.lc.push_back(Term{bits[k].lc[0].key, p2[k]});
+  }
+  return out;
+}
+
+std::vector<Num> strict_bits(CS& cs, const Num& a) {
+  const Field& F = cs.F;
+  uint64_t av[4];
+  fe_to_int(a.v, F, av);
+  std::vector<Num> bits = alloc_bits(cs, av, 255);
+  cs.enforce_equal(pack(cs, bits.data(), 255), a);
+  Num mid = cs.zero_num();
+  {                                                     // sum of bits 126..253
+    uint64_t cnt = 0;
+    for (int k = 126; k < 254; ++k) cnt += bits[k].v.is_zero() ? 0 : 1;
+    mid.v = from_u64(cnt, F);
+    if (cs.shape) for (int k = 126; k < 254; ++k) mid.lc.push_back(Term{bits[k].lc[0].key, one(F)});
+  }
+  const Num mz = is_zero(cs, mid);
+  const Num low = pack(cs, bits.data(), 126);
+  // c = m - 2^254; v = low + (2^126 - c) < 2^127, bit 126 clear iff low < c
+  uint64_t k126[4] = {0, 1ull << 62, 0, 0}, c[4] = {F.m[0], F.m[1], F.m[2], F.m[3] - (1ull << 62)};
+  sub4(k126, c);
+  const Num v = cs.add(low, cs.constant(int_to_fe(k126, F)));
+  uint64_t vv[4];
+  fe_to_int(v.v, F, vv);
+  const std::vector<Num> d = alloc_bits(cs, vv, 127);
+  cs.enforce_equal(pack(cs, d.data(), 127), v);
+  const Num one_n = cs.constant(one(F));
+  const Num ok = cs.mul(mz, cs.sub(one_n, d[126]));
+  cs.enforce(bits[254], cs.sub(one_n, ok), cs.zero_num());
+  return bits;
+}
+
+static void ext_layer_num(CS& cs, std::vector<Num>& s) {
+  std::vector<Num> o(4);
+  for (int i = 0; i < 4; ++i) {
+    Num acc = cs.scale_small(s[0], (unsigned)M4[i][0]);
+    for (int j = 1; j < 4; ++j) acc = cs.add(acc, cs.scale_small(s[j], (unsigned)M4[i][j]));
+    o[i] = std::move(acc);
+  }
+  s.swap(o);
+}
+static Num sbox(CS& cs, const Num& x) {
+  const Num x2 = cs.mul(x, x);
+  const Num x4 = cs.mul(x2, x2);
+  return cs.mul(x4, x);
+}
+static void poseidon_permute(CS& cs, std::vector<Num>& s) {
+  const RoConstants& rc = ro_constants(cs.field_id);
+  ext_layer_num(cs, s);
+  for (int r = 0; r < RO_RF + RO_RP; ++r) {
+    if (r < RO_RF / 2 || r >= RO_RF / 2 + RO_RP) {
+      const Fe* k = rc.ext[r < RO_RF / 2 ? r : r - RO_RP];
+      for (int i = 0; i < 4; ++i) s[i] = sbox(cs, cs.add(s[i], cs.constant(k[i])));
+      ext_layer_num(cs, s);
+    } else {
+      s[0] = sbox(cs, cs.add(s[0], cs.constant(rc.in[r - RO_RF / 2])));
+      const Num tot = cs.add(cs.add(s[0], s[1]), cs.add(s[2], s[3]));
+      for (int i = 0; i < 4; ++i) s[i] = cs.add(tot, cs.scale_small(s[i], rc.mu_minus_1[i]));
+    }
+  }
+}
+Num poseidon_hash(CS& cs, uint64_t tag, const std::vector<Num>& xs) {
+  std::vector<Num> s(4);
+  s[0] = cs.constant_u64(tag + ((uint64_t)xs.size() << 32));
+  s[1] = s[2] = s[3] = cs.zero_num();
+  for (size_t k = 0; k < xs.size(); k += RO_RATE) {
+    for (size_t j = 0; j < RO_RATE && k + j < xs.size(); ++j) s[1 + j] = cs.add(s[1 + j], xs[k + j]);
+    poseidon_permute(cs, s);
+  }
+  return s[1];
+}
+
+// ---- curve y^2 = x^3 + 5, affine, identity = (0, 0) ------------------------------------------------------------
+void check_on_curve(CS& cs, const Num& x, const Num& y, const Num& inf) {
+  const Num x2 = cs.mul(x, x);
+  const Num x3 = cs.mul(x2, x);
+  const Num y2 = cs.mul(y, y);
+  cs.enforce(cs.sub(cs.constant(one(cs.F)), inf), cs.sub(y2, cs.add(x3, cs.constant_u64(5))), cs.zero_num());
+}
+
+static void ec_double_raw(CS& cs, const Num& x, const Num& y, Num* ox, Num* oy) {
+  const Field& F = cs.F;
+  const Num x2 = cs.mul(x, x);
+  const Num two_y = cs.scale_small(y, 2), three_x2 = cs.scale_small(x2, 3);
+  const Num lam = cs.alloc(vdfhost::mul(three_x2.v, inverse(two_y.v, F), F));
+  cs.enforce(lam, two_y, three_x2);
+  const Num two_x = cs.scale_small(x, 2);
+  const Num dx = cs.alloc(vdfhost::sub(sqr(lam.v, F), two_x.v, F));
+  cs.enforce(lam, lam, cs.add(dx, two_x));
+  const Num dy = cs.alloc(vdfhost::sub(vdfhost::mul(lam.v, vdfhost::sub(x.v, dx.v, F), F), y.v, F));
+  cs.enforce(lam, cs.sub(x, dx), cs.add(dy, y));
+  *ox = dx; *oy = dy;
+}
+static void ec_add_raw(CS& cs, const Num& x1, const Num& y1, const Num& x2, const Num& y2, Num* ox, Num* oy) {
+  const Field& F = cs.F;
+  const Num dxn = cs.sub(x2, x1), dyn = cs.sub(y2, y1);
+  const Num lam = cs.alloc(vdfhost::mul(dyn.v, inverse(dxn.v, F), F));
+  cs.enforce(lam, dxn, dyn);
+  const Num sx = cs.alloc(vdfhost::sub(vdfhost::sub(sqr(lam.v, F), x1.v, F), x2.v, F));
+  cs.enforce(lam, lam, cs.add(cs.add(sx, x1), x2));
+  const Num sy = cs.alloc(vdfhost::sub(vdfhost::mul(lam.v, vdfhost::sub(x1.v, sx.v, F), F), y1.v, F));
+  cs.enforce(lam, cs.sub(x1, sx), cs.add(sy, y1));
+  *ox = sx; *oy = sy;
+}
+
+void ec_scalar_mul(CS& cs, const std::vector<Num>& bits, const Num& px, const Num& py, const Num& p_inf, Num* rx, Num* ry) {
+  const Field& F = cs.F;
+  const Num one_n = cs.constant(one(F));
+  Num ax = cs.zero_num(), ay = cs.zero_num(), acc_inf = one_n, wx = px, wy = py;
+  for (size_t k = 0; k < bits.size(); ++k) {
+    Num sx, sy;
+    ec_add_raw(cs, ax, ay, wx, wy, &sx, &sy);
+    const Num cx = select(cs, acc_inf, wx, sx);
+    const Num cy = select(cs, acc_inf, wy, sy);
+    ax = select(cs, bits[k], cx, ax);
+    ay = select(cs, bits[k], cy, ay);
+    acc_inf = cs.mul(acc_inf, cs.sub(one_n, bits[k]));
+    if (k + 1 < bits.size()) {
+      Num nx, ny;
+      ec_double_raw(cs, wx, wy, &nx, &ny);
+      wx = nx; wy = ny;
+    }
+  }
+  const Num keep = cs.sub(one_n, p_inf);
+  *rx = cs.mul(keep, ax);
+  *ry = cs.mul(keep, ay);
+}
+
+void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const Num& y2, Num* ox, Num* oy) {
+  const Field& F = cs.F;
+  const Num one_n = cs.constant(one(F));
+  const Num i1 = is_zero(cs, x1);
+  const Num i2 = is_zero(cs, x2);
+  const Num same_x = is_zero(cs, cs.sub(x2, x1));
+  const Num same_y = is_zero(cs, cs.sub(y2, y1));
+  const Num x1sq = cs.mul(x1, x1);
+  const Num num = select(cs, same_x, cs.scale_small(x1sq, 3), cs.sub(y2, y1));
+  const Num den = select(cs, same_x, cs.scale_small(y1, 2), cs.sub(x2, x1));
+  const Num lam = cs.alloc(vdfhost::mul(num.v, inverse(den.v, F), F));
+  cs.enforce(lam, den, num);
+  const Num x3 = cs.alloc(vdfhost::sub(vdfhost::sub(sqr(lam.v, F), x1.v, F), x2.v, F));
+  cs.enforce(lam, lam, cs.add(cs.add(x3, x1), x2));
+  const Num y3 = cs.alloc(vdfhost::sub(vdfhost::mul(lam.v, vdfhost::sub(x1.v, x3.v, F), F), y1.v, F));
+  cs.enforce(lam, cs.sub(x1, x3), cs.add(y3, y1));
+  const Num is_neg = cs.mul(same_x, cs.sub(one_n, same_y));
+  const Num keep = cs.sub(one_n, is_neg);
+  const Num tx = cs.mul(keep, x3), ty = cs.mul(keep, y3);
+  const Num ux = select(cs, i2, x1, tx), uy = select(cs, i2, y1, ty);
+  *ox = select(cs, i1, x2, ux);
+  *oy = select(cs, i1, y2, uy);
+}
+
+// ---- multi-limb integers for the foreign fold (little-endian 64-bit limbs) ---------------------------------------
+namespace {
+struct Wide { uint64_t l[8]; };                        // up to 512 bits
+Wide wide_zero() { Wide w; memset(&w, 0, sizeof(w)); return w; }
+Wide wide_from4(const uint64_t v[4]) { Wide w = wide_zero(); memcpy(w.l, v, 32); return w; }
+Wide wide_mul(const uint64_t* a, int na, const uint64_t* b, int nb) {
+  Wide w = wide_zero();
+  for (int i = 0; i < na; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < nb && i + j < 8; ++j) {
+      c += (u128)a[i] * b[j] + w.l[i + j];
+      w.l[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    for (int k = i + nb; k < 8 && c; ++k) { c += w.l[k]; w.l[k] = (uint64_t)c; c >>= 64; }
+  }
+  return w;
+}
+Wide wide_add(const Wide& a, const Wide& b) {
+  Wide w;
+  u128 c = 0;
+  for (int i = 0; i < 8; ++i) { c += (u128)a.l[i] + b.l[i]; w.l[i] = (uint64_t)c; c >>= 64; }
+  return w;
+}
+bool wide_geq(const Wide& a, const Wide& b) {
+  for (int i = 7; i >= 0; --i) if (a.l[i] != b.l[i]) return a.l[i] > b.l[i];
+  return true;
+}
+Wide wide_sub(const Wide& a, const Wide& b) {
+  Wide w;
+  u128 br = 0;
+  for (int i = 0; i < 8; ++i) {
+    u128 d = (u128)a.l[i] - b.l[i] - (uint64_t)br;
+    w.l[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  return w;
+}
+Wide wide_shl(const Wide& a, int s) {
+  Wide w = wide_zero();
+  const int ls = s / 64, bs = s % 64;
+  for (int i = 7; i >= ls; --i) {
+    w.l[i] = a.l[i - ls] << bs;
+    if (bs && i - ls - 1 >= 0) w.l[i] |= a.l[i - ls - 1] >> (64 - bs);
+  }
+  return w;
+}
+Wide wide_shr(const Wide& a, int s) {
+  Wide w = wide_zero();
+  const int ls = s / 64, bs = s % 64;
+  for (int i = 0; i + ls < 8; ++i) {
+    w.l[i] = a.l[i + ls] >> bs;
+    if (bs && i + ls + 1 < 8) w.l[i] |= a.l[i + ls + 1] << (64 - bs);
+  }
+  return w;
+}
+// quotient (< 2^qbits) and remainder of a / d by shift and subtract
+void wide_divmod(const Wide& a, const Wide& d, int qbits, Wide* q, Wide* r) {
+  Wide rem = a, quo = wide_zero();
+  for (int b = qbits - 1; b >= 0; --b) {
+    const Wide ds = wide_shl(d, b);
+    if (wide_geq(rem, ds)) { rem = wide_sub(rem, ds); quo.l[b / 64] |= 1ull << (b % 64); }
+  }
+  *q = quo; *r = rem;
+}
+void low_bits(const uint64_t v[4], int n, uint64_t out[4]) {       // v mod 2^n, n < 256
+  for (int i = 0; i < 4; ++i) {
+    const int lo = 64 * i;
+    out[i] = n >= lo + 64 ? v[i] : (n > lo ? v[i] & ((1ull << (n - lo)) - 1) : 0);
+  }
+}
+}  // namespace
+
+void fold_foreign(CS& cs, const Num& a_lo, const Num& a_hi, const std::vector<Num>& b_bits, const std::vector<Num>& r_bits,
+                  const Field& PF, Num* out_lo, Num* out_hi) {
+  const Field& F = cs.F;
+  const int L = LIMB_BITS;
+  const Num b_lo = pack(cs, b_bits.data(), L), b_all = pack(cs, b_bits.data(), b_bits.size());
+  const Num r_lo = pack(cs, r_bits.data(), L), r_all = pack(cs, r_bits.data(), r_bits.size());
+  uint64_t alo[4], ahi[4], blo[4], ball[4], rlo[4], rall[4];
+  fe_to_int(a_lo.v, F, alo); fe_to_int(a_hi.v, F, ahi);
+  fe_to_int(b_lo.v, F, blo); fe_to_int(b_all.v, F, ball);
+  fe_to_int(r_lo.v, F, rlo); fe_to_int(r_all.v, F, rall);
+  // tot = A + r B, A = a_lo + 2^126 a_hi
+  const Wide A = wide_add(wide_from4(alo), wide_shl(wide_from4(ahi), L));
+  const Wide tot = wide_add(A, wide_mul(rall, 2, ball, 4));
+  Wide kq, R;
+  wide_divmod(tot, wide_from4(PF.m), 130, &kq, &R);
+  uint64_t Rlo[4], Rhi[4];
+  low_bits(R.l, L, Rlo);
+  { const Wide h = wide_shr(R, L); memcpy(Rhi, h.l, 32); }
+  const std::vector<Num> k_bits = alloc_bits(cs, kq.l, 125);
+  const std::vector<Num> rlo_bits = alloc_bits(cs, Rlo, L);
+  const std::vector<Num> rhi_bits = alloc_bits(cs, Rhi, 129);
+  const Num k = pack(cs, k_bits.data(), 125);
+  const Num R_lo = pack(cs, rlo_bits.data(), L), R_hi = pack(cs, rhi_bits.data(), 129);
+  // (1) modulo the native field: r B = k p' + R_lo + D R_hi - a_lo - D a_hi
+  const Fe D = pow2_table(F)[L];
+  const Fe pf_nat = int_to_fe(PF.m, F);
+  Num rhs = cs.add(cs.scale(k, pf_nat), R_lo);
+  rhs = cs.add(rhs, cs.scale(R_hi, D));
+  rhs = cs.sub(rhs, a_lo);
+  rhs = cs.sub(rhs, cs.scale(a_hi, D));
+  cs.enforce(r_all, b_all, rhs);
+  // (2) modulo 2^126: a_lo + r_lo b_lo - k (p' mod D) - R_lo = (c' - 2^127) D
+  const Num prod = cs.mul(r_lo, b_lo);
+  uint64_t pfl[4];
+  low_bits(PF.m, L, pfl);
+  Wide pos = wide_add(wide_from4(alo), wide_mul(rlo, 2, blo, 2));
+  { Wide off = wide_zero(); off.l[3] = 1ull << 61; pos = wide_add(pos, off); }        // + 2^127 * 2^126 = 2^253
+  const Wide negv = wide_add(wide_mul(kq.l, 2, pfl, 2), wide_from4(Rlo));
+  const Wide cp = wide_shr(wide_sub(pos, negv), L);
+  const std::vector<Num> c_bits = alloc_bits(cs, cp.l, 128);
+  Num lhs = cs.add(a_lo, prod);
+  lhs = cs.sub(lhs, cs.scale(k, int_to_fe(pfl, F)));
+  lhs = cs.sub(lhs, R_lo);
+  const Num cnum = cs.sub(pack(cs, c_bits.data(), 128), cs.constant(pow2_table(F)[127]));
+  cs.enforce_equal(lhs, cs.scale(cnum, D));
+  *out_lo = R_lo; *out_hi = R_hi;
+}
+
+// =============================================================================================================
+// Step circuits
+// =============================================================================================================
+std::vector<Num> InverseMinRootCircuit::synthesize(CS& cs, const std::vector<Num>& z) const {
+  const Field& F = cs.F;
+  Num x = z[0], y = z[1];
+  const Num& i_in = z[2];
+  if (!cs.shape && device_rounds) {
+    // witness mode with the rounds left to the GPU (vdf_minroot_step_segment fills these variables from the forward
+    // trace): the outputs are the stored previous state, as StepCircuit::output has them (src/nova/proof.rs:142-152)
+    cs.skip(vars_per_round() * t + 1, 3 * t + 1);
+    std::vector<Num> out(3);
+    out[0].v = input.x; out[1].v = input.y; out[2].v = input.i;
+    return out;
+  }
+  for (uint64_t j = 0; j < t; ++j) {
+    const Num new_x_lc = cs.add(cs.sub(y, i_in), cs.constant_u64(j + 1));       // y - (i - 1), i = i_in - j (:162-164)
+    Num new_x;
+    if (!bound) new_x = cs.alloc(new_x_lc.v);                                     // :167-173
+    const Num tmp1 = cs.mul(x, x);                                                // :176
+    const Num tmp2 = cs.mul(tmp1, tmp1);                                          // :178
+    const Num new_y = cs.alloc(vdfhost::sub(vdfhost::mul(tmp2.v, x.v, F), new_x_lc.v, F));   // :181-189
+    cs.enforce(tmp2, x, cs.add(new_y, new_x_lc));                                 // :219-227
+    x = bound ? new_x_lc : new_x;
+    y = new_y;
+  }
+  const Num tn = cs.constant_u64(t);
+  const Num final_i = cs.alloc(vdfhost::sub(i_in.v, tn.v, F));                    // :122-133
+  cs.enforce(final_i, cs.constant(one(F)), cs.sub(i_in, tn));
+  return {x, y, final_i};
+}
+void InverseMinRootCircuit::output(const Fe* z, Fe* out) const {
+  (void)z;
+  out[0] = input.x; out[1] = input.y; out[2] = input.i;
+}
+
+// =============================================================================================================
+// Instances, native hashes, the augmented circuit
+// =============================================================================================================
+static void split126(const uint64_t v[4], uint64_t lo[4], uint64_t hi[4]) {
+  low_bits(v, LIMB_BITS, lo);
+  const Wide h = wide_shr(wide_from4(v), LIMB_BITS);
+  memcpy(hi, h.l, 32);
+}
+
+void relaxed_elements(const RelaxedInst& U, const Field& F, Fe out[9]) {
+  out[0] = U.comm_W.x; out[1] = U.comm_W.y; out[2] = U.comm_E.x; out[3] = U.comm_E.y;
+  out[4] = int_to_fe(U.u, F);
+  for (int k = 0; k < 2; ++k) {
+    uint64_t lo[4], hi[4];
+    split126(U.X[k], lo, hi);
+    out[5 + 2 * k] = int_to_fe(lo, F);
+    out[6 + 2 * k] = int_to_fe(hi, F);
+  }
+}
+
+Fe hash_state(int f, const Fe& params, const Fe& i, const std::vector<Fe>& z0, const std::vector<Fe>& zi, const RelaxedInst& U,
+              uint64_t out_int[4]) {
+  const Field& F = field(f);
+  std::vector<Fe> xs = {params, i};
+  xs.insert(xs.end(), z0.begin(), z0.end());
+  xs.insert(xs.end(), zi.begin(), zi.end());
+  Fe ue[9];
+  relaxed_elements(U, F, ue);
+  xs.insert(xs.end(), ue, ue + 9);
+  uint64_t h[4];
+  fe_to_int(ro_hash(f, TAG_STATE, xs.data(), xs.size()), F, h);
+  low_bits(h, HASH_BITS, out_int);
+  return int_to_fe(out_int, F);
+}
+
+void hash_challenge(int f, const Fe& params, const RelaxedInst& U, const Aff& u_W, const uint64_t u_X[2][4], const Aff& T,
+                    uint64_t r_out[4]) {
+  const Field& F = field(f);
+  Fe xs[16];
+  xs[0] = params;
+  relaxed_elements(U, F, xs + 1);
+  xs[10] = u_W.x; xs[11] = u_W.y;
+  xs[12] = int_to_fe(u_X[0], F); xs[13] = int_to_fe(u_X[1], F);
+  xs[14] = T.x; xs[15] = T.y;
+  uint64_t h[4];
+  fe_to_int(ro_hash(f, TAG_CHAL, xs, 16), F, h);
+  low_bits(h, CHAL_BITS, r_out);
+}
+
+std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out, uint64_t* r_out) {
+  const Field& F = cs.F;
+  const Field& PF = field(side_field(1 - side));
+  const size_t a = step.arity();
+  const Num one_n = cs.constant(one(F));
+  const Num params = cs.alloc(in.params);
+  const Num i = cs.alloc(in.i);
+  std::vector<Num> z0, zi;
+  for (size_t k = 0; k < a; ++k) z0.push_back(cs.alloc(in.z0[k]));
+  for (size_t k = 0; k < a; ++k) zi.push_back(cs.alloc(in.zi[k]));
+  Fe ue[9];
+  relaxed_elements(in.U, F, ue);
+  std::vector<Num> U;
+  for (int k = 0; k < 9; ++k) U.push_back(cs.alloc(ue[k]));
+  const Num uWx = cs.alloc(in.u_W.x), uWy = cs.alloc(in.u_W.y);
+  const Num uX[2] = {cs.alloc(int_to_fe(in.u_X[0], F)), cs.alloc(int_to_fe(in.u_X[1], F))};
+  const Num Tx = cs.alloc(in.T.x), Ty = cs.alloc(in.T.y);
+  const Num is_base = is_zero(cs, i);
+  // the hash this step must have been handed (checked unless i = 0)
+  std::vector<Num> hin = {params, i};
+  hin.insert(hin.end(), z0.begin(), z0.end());
+  hin.insert(hin.end(), zi.begin(), zi.end());
+  hin.insert(hin.end(), U.begin(), U.end());
+  const std::vector<Num> h_in = strict_bits(cs, poseidon_hash(cs, TAG_STATE, hin));
+  cs.enforce(cs.sub(one_n, is_base), cs.sub(uX[0], pack(cs, h_in.data(), HASH_BITS)), cs.zero_num());
+  // fold challenge
+  std::vector<Num> hch = {params};
+  hch.insert(hch.end(), U.begin(), U.end());
+  hch.insert(hch.end(), {uWx, uWy, uX[0], uX[1], Tx, Ty});
+  std::vector<Num> r_bits = strict_bits(cs, poseidon_hash(cs, TAG_CHAL, hch));
+  r_bits.resize(CHAL_BITS);
+  const Num r = pack(cs, r_bits.data(), CHAL_BITS);
+  // the two fresh points are on the curve (or the identity)
+  const Num uW_inf = is_zero(cs, uWx);
+  check_on_curve(cs, uWx, uWy, uW_inf);
+  const Num T_inf = is_zero(cs, Tx);
+  check_on_curve(cs, Tx, Ty, T_inf);
+  // comm_W' = U.W + r u.W ; comm_E' = U.E + r T
+  Num rWx, rWy, fWx, fWy, rTx, rTy, fEx, fEy;
+  ec_scalar_mul(cs, r_bits, uWx, uWy, uW_inf, &rWx, &rWy);
+  ec_add_complete(cs, U[0], U[1], rWx, rWy, &fWx, &fWy);
+  ec_scalar_mul(cs, r_bits, Tx, Ty, T_inf, &rTx, &rTy);
+  ec_add_complete(cs, U[2], U[3], rTx, rTy, &fEx, &fEy);
+  const Num fu = cs.add(U[4], r);
+  // X' = X + r x in the other field
+  std::vector<Num> xb[2];
+  for (int k = 0; k < 2; ++k) xb[k] = alloc_bits(cs, in.u_X[k], HASH_BITS);
+  for (int k = 0; k < 2; ++k) cs.enforce_equal(pack(cs, xb[k].data(), HASH_BITS), uX[k]);
+  Num f0lo, f0hi, f1lo, f1hi;
+  fold_foreign(cs, U[5], U[6], xb[0], r_bits, PF, &f0lo, &f0hi);
+  fold_foreign(cs, U[7], U[8], xb[1], r_bits, PF, &f1lo, &f1hi);
+  const Num fold[9] = {fWx, fWy, fEx, fEy, fu, f0lo, f0hi, f1lo, f1hi};
+  Num base[9];
+  if (side == 0) {
+    for (int k = 0; k < 9; ++k) base[k] = cs.zero_num();
+  } else {
+    base[0] = uWx; base[1] = uWy; base[2] = cs.zero_num(); base[3] = cs.zero_num(); base[4] = one_n;
+    base[5] = pack(cs, xb[0].data(), LIMB_BITS); base[6] = pack(cs, xb[0].data() + LIMB_BITS, HASH_BITS - LIMB_BITS);
+    base[7] = pack(cs, xb[1].data(), LIMB_BITS); base[8] = pack(cs, xb[1].data() + LIMB_BITS, HASH_BITS - LIMB_BITS);
+  }
+  std::vector<Num> Unew;
+  for (int k = 0; k < 9; ++k) Unew.push_back(select(cs, is_base, base[k], fold[k]));
+  std::vector<Num> z_in;
+  for (size_t k = 0; k < a; ++k) z_in.push_back(select(cs, is_base, z0[k], zi[k]));
+  cs.step_begin = cs.num_vars();
+  const std::vector<Num> z_out = step.synthesize(cs, z_in);
+  cs.step_end = cs.num_vars();
+  if (unew_out) for (int k = 0; k < 9; ++k) unew_out[k] = Unew[k].v;
+  if (r_out) fe_to_int(r.v, F, r_out);
+  const Num i_new = cs.add(i, one_n);
+  std::vector<Num> hout = {params, i_new};
+  hout.insert(hout.end(), z0.begin(), z0.end());
+  hout.insert(hout.end(), z_out.begin(), z_out.end());
+  hout.insert(hout.end(), Unew.begin(), Unew.end());
+  const std::vector<Num> h_out = strict_bits(cs, poseidon_hash(cs, TAG_STATE, hout));
+  const Num x0 = cs.alloc_io(uX[1].v);
+  cs.enforce_equal(x0, uX[1]);
+  const Num hv = pack(cs, h_out.data(), HASH_BITS);
+  const Num x1 = cs.alloc_io(hv.v);
+  cs.enforce_equal(x1, hv);
+  std::vector<Fe> out;
+  for (const Num& n : z_out) out.push_back(n.v);
+  return out;
+}
+
+}  // namespace vdfnova

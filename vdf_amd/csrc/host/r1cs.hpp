@@ -1,0 +1,154 @@
+// Constraint system, gadgets and circuits of the Nova layer (libvdf_nova.so): the host-side counterpart of what the
+// reference reaches through bellperson 0.22 (ConstraintSystem / AllocatedNum / LinearCombination, src/nova/proof.rs:3-9)
+// and nova-snark 0.8.0's augmented circuit (Cargo.toml:15).  Neither crate's source is in /root/reference; the
+// specification this file implements line by line is oracle/nova.py (protocol "vdf-nova-ivc-v1", parity unpinned
+// against nova-snark, pinned bit-for-bit against that restatement by tests/test_nova_host.py and tests/test_gpu_nova.py).
+//
+// One code path serves both uses of a circuit: SHAPE mode records the R1CS matrices (public_params, once), WITNESS
+// mode only computes the variable assignment (every prove_step) -- linear combinations are then empty and cost nothing.
+#pragma once
+#include <functional>
+#include <memory>
+#include <vector>
+#include "host_math.hpp"
+
+namespace vdfnova {
+using namespace vdfhost;
+
+// variable keys: W index k -> k; the constant column -> KEY_ONE; public IO k -> KEY_ONE + 1 + k.  Ascending key order is
+// the column order of z = (W, u, X).
+constexpr uint32_t KEY_ONE = 0x40000000u;
+struct Term { uint32_t key; Fe c; };
+using LC = std::vector<Term>;
+struct Num { Fe v; LC lc; };
+
+struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
+
+class CS {
+ public:
+  CS(int field_id, bool shape_mode);
+  const int field_id;
+  const Field& F;
+  const bool shape;                      // true: record constraints; false: witness only
+  std::vector<Fe> W, X;
+  size_t rows = 0;
+  // Witness mode: a run of dev_len variables that some other party fills (the MinRoot rounds, on the GPU) starts at
+  // variable index dev_begin; W then holds only the host-made values, packed: W[0, dev_begin) are variables
+  // [0, dev_begin), W[dev_begin, ...) are variables [dev_begin + dev_len, ...).
+  size_t dev_begin = 0, dev_len = 0;
+  // variables [step_begin, step_end) are the step circuit's own (set by synthesize_augmented)
+  size_t step_begin = 0, step_end = 0;
+  size_t num_vars() const { return W.size() + dev_len; }
+
+  Num constant(const Fe& k) const;
+  Num constant_u64(uint64_t k) const { return constant(from_u64(k, F)); }
+  Num zero_num() const { Num n; n.v = vdfhost::zero(); return n; }
+  Num add(const Num& a, const Num& b) const;
+  Num sub(const Num& a, const Num& b) const;
+  Num scale(const Num& a, const Fe& k) const;
+  Num scale_small(const Num& a, unsigned k) const;          // k <= 16: the value by additions
+  Num alloc(const Fe& v);
+  Num alloc_io(const Fe& v);
+  void skip(size_t n, size_t cons);                          // n variables (with their `cons` constraints) left to the device (witness mode, once)
+  void enforce(const Num& a, const Num& b, const Num& c);
+  Num mul(const Num& a, const Num& b);
+  void enforce_equal(const Num& a, const Num& b);
+  // COO triples in the column numbering of z = (W, u, X); call once, after synthesis (shape mode)
+  void finish(Coo out[3]) const;
+
+ private:
+  struct Row { LC a, b, c; };
+  std::vector<Row> cons_;
+};
+
+// ---- the random oracle: Poseidon2-style permutation, width 4 (oracle/poseidon.py) -----------------------------------
+constexpr int RO_T = 4, RO_RATE = 3, RO_RF = 8, RO_RP = 56;
+struct RoConstants { Fe ext[RO_RF][RO_T]; Fe in[RO_RP]; unsigned mu_minus_1[RO_T]; };
+const RoConstants& ro_constants(int field_id);
+void ro_permute(Fe s[RO_T], int field_id);
+Fe ro_hash(int field_id, uint64_t tag, const Fe* xs, size_t n);       // full field element (lane 1)
+
+// ---- gadgets (allocation and constraint order as in oracle/nova.py) -------------------------------------------------
+Num is_zero(CS& cs, const Num& a);
+Num select(CS& cs, const Num& cond, const Num& a, const Num& b);
+std::vector<Num> alloc_bits(CS& cs, const uint64_t v[4], int n);      // v = the canonical integer, little-endian limbs
+Num pack(const CS& cs, const Num* bits, size_t n);
+std::vector<Num> strict_bits(CS& cs, const Num& a);
+Num poseidon_hash(CS& cs, uint64_t tag, const std::vector<Num>& xs);
+void check_on_curve(CS& cs, const Num& x, const Num& y, const Num& inf);
+void ec_scalar_mul(CS& cs, const std::vector<Num>& bits, const Num& px, const Num& py, const Num& p_inf, Num* rx, Num* ry);
+void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const Num& y2, Num* ox, Num* oy);
+void fold_foreign(CS& cs, const Num& a_lo, const Num& a_hi, const std::vector<Num>& b_bits, const std::vector<Num>& r_bits,
+                  const Field& foreign, Num* r_lo, Num* r_hi);
+
+// ---- step circuits: the seam of src/nova/proof.rs:79-153 (trait StepCircuit: arity / synthesize / output) ----------
+struct StepCircuit {
+  virtual ~StepCircuit() {}
+  virtual size_t arity() const = 0;
+  // allocates the circuit's variables and constraints over z_in, returns z_out (values valid in witness mode)
+  virtual std::vector<Num> synthesize(CS& cs, const std::vector<Num>& z) const = 0;
+  virtual void output(const Fe* z, Fe* out) const = 0;
+};
+
+struct MinRootState { Fe x, y, i; };
+// InverseMinRootCircuit (src/nova/proof.rs:57-230).  bound = false: the reference's circuit exactly (4 variables per
+// round, new_x allocated at :167-173 and used by no constraint); bound = true (what the product proves by default):
+// new_x is the linear combination y - i + 1 itself (3 variables per round, the same three constraints per round).
+struct InverseMinRootCircuit : StepCircuit {
+  uint64_t t = 0;
+  bool bound = true, blank = true;
+  bool device_rounds = false;            // witness mode: leave the per-round variables to the GPU kernel (cs.skip)
+  MinRootState result, input;
+  size_t arity() const override { return 3; }
+  std::vector<Num> synthesize(CS& cs, const std::vector<Num>& z) const override;
+  void output(const Fe* z, Fe* out) const override;
+  size_t vars_per_round() const { return bound ? 3 : 4; }
+};
+// nova-snark's TrivialTestCircuit (src/nova/proof.rs:258-260): arity 1, z_out = z_in
+struct TrivialTestCircuit : StepCircuit {
+  size_t arity() const override { return 1; }
+  std::vector<Num> synthesize(CS&, const std::vector<Num>& z) const override { return z; }
+  void output(const Fe* z, Fe* out) const override { out[0] = z[0]; }
+};
+
+// ---- instances and the augmented circuit ---------------------------------------------------------------------------
+constexpr int HASH_BITS = 250, CHAL_BITS = 128, LIMB_BITS = 126, AUG_IO = 2;
+constexpr uint64_t TAG_STATE = 1, TAG_CHAL = 2;
+
+// a running (relaxed) instance of one side, as the OTHER side's circuit sees it: everything native to that circuit's
+// field except u and X, which are integers below the instance's own scalar modulus
+struct RelaxedInst {
+  Aff comm_W, comm_E;                    // coordinates: Montgomery form in the base field of the instance's curve
+  uint64_t u[4], X[2][4];                // canonical integers (u stays far below both moduli)
+};
+struct AugInputs {
+  Fe params, i;                          // Montgomery form in the circuit's field
+  std::vector<Fe> z0, zi;
+  RelaxedInst U;
+  Aff u_W;
+  uint64_t u_X[2][4];                    // canonical integers (250-bit hashes)
+  Aff T;
+};
+void relaxed_elements(const RelaxedInst& U, const Field& F, Fe out[9]);       // what a running instance is hashed as
+Fe hash_state(int field_id, const Fe& params, const Fe& i, const std::vector<Fe>& z0, const std::vector<Fe>& zi,
+              const RelaxedInst& U, uint64_t out_int[4]);
+void hash_challenge(int field_id, const Fe& params, const RelaxedInst& U, const Aff& u_W, const uint64_t u_X[2][4], const Aff& T,
+                    uint64_t r_out[4]);
+// side 0 = primary (circuit over Fq, folds Vesta instances), side 1 = secondary; returns z_{i+1}
+// unew (optional): the nine elements of the running instance the circuit hands on (the folded one, or the base case's);
+// r (optional): the fold challenge it derived, a 128-bit integer
+std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew = nullptr,
+                                     uint64_t* r = nullptr);
+inline int side_field(int side) { return side == 0 ? VDF_FIELD_FQ : VDF_FIELD_FP; }
+inline int side_curve(int side) { return side == 0 ? VDF_CURVE_PALLAS : VDF_CURVE_VESTA; }
+
+// 256-bit helpers on canonical little-endian limbs
+inline void fe_to_int(const Fe& mont, const Field& F, uint64_t out[4]) { const Fe c = from_mont(mont, F); memcpy(out, c.l, 32); }
+inline Fe int_to_fe(const uint64_t v[4], const Field& F) {      // v < 2^256, reduced
+  Fe c;
+  memcpy(c.l, v, 32);
+  while (geq(c.l, F.m)) sub4(c.l, F.m);
+  return to_mont(c, F);
+}
+
+}  // namespace vdfnova

@@ -155,6 +155,7 @@ Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint
 Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const uint32_t* coef, const void* dict,
                 const void* z, size_t rows, void* out, hipStream_t s);
 // fused step kernels; vdf_fe* arguments are HOST pointers whose values travel as kernel arguments
+Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, hipStream_t s);
 Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
                   const vdf_fe X[6], void* z, void* packed, hipStream_t s);
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],

@@ -142,6 +142,29 @@ __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, 
   }
 }
 
+// The variables InverseMinRootCircuit::synthesize allocates inside an augmented circuit (no z_in, u, X around them):
+// per round [new_x,] tmp1, tmp2, new_y, then final_i.  per = 4 is the reference's allocation (src/nova/proof.rs:167-181),
+// per = 3 the bound form without new_x (oracle/nova.py InverseMinRootCircuit).
+template <class P>
+__global__ __launch_bounds__(256) void k_step_segment(const char* __restrict__ trace, FeVal i0, uint64_t t, int per,
+                                                      char* __restrict__ out) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > t) return;
+  if (j == t) {
+    fe_store<P>(out + (size_t)per * t * 32, fe_from_val<P>(i0));
+    return;
+  }
+  const Fe<P> x = fe_load<P>(trace + (t - j) * 64);
+  const Fe<P> t1 = fe_sqr(x);
+  const Fe<P> t2 = fe_sqr(t1);
+  char* o = out + j * (size_t)per * 32;
+  if (per == 4) { fe_store<P>(o, fe_load<P>(trace + (t - j - 1) * 64)); o += 32; }
+  fe_store<P>(o, t1);
+  fe_store<P>(o + 32, t2);
+  fe_store<P>(o + 64, fe_load<P>(trace + (t - j - 1) * 64 + 32));
+}
+
 struct Csr3 { const uint32_t* rowptr[3]; const uint32_t* col[3]; const uint32_t* coef[3]; };
 
 // One term of a sparse row: +-z[col] or coefficient * z[col] (dictionary index 0 = +1, 1 = -1).
@@ -283,6 +306,11 @@ Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in
   k.u = to_val(u);
   for (int i = 0; i < 6; ++i) k.X[i] = to_val(&X[i]);
   FIELD_DISPATCH(field, k_step_z, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), k, t, M(z), M(packed));
+  return Status{};
+}
+
+Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, hipStream_t s) {
+  FIELD_DISPATCH(field, k_step_segment, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), to_val(i0), t, per, M(out));
   return Status{};
 }
 

@@ -288,6 +288,9 @@ class Context:
         self._check(lib.vdf_minroot_step_z_packed(self.handle, field, _ptr(trace_xy), t, _ptr(z_in), _ptr(i0), _ptr(u),
                                                   _ptr(X), _ptr(z), _ptr(w_packed)))
 
+    def minroot_step_segment(self, field, trace_xy, t, i0, vars_per_round, out) -> None:
+        self._check(lib.vdf_minroot_step_segment(self.handle, field, _ptr(trace_xy), t, _ptr(i0), vars_per_round, _ptr(out)))
+
     def nifs_cross_term(self, shape: Shape, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
         self._check(lib.vdf_nifs_cross_term(self.handle, shape.handle, _ptr(z2), _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(u1),
                                             _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))

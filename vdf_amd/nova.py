@@ -1,7 +1,7 @@
 """Python mirror of the reference's Nova proof API (/root/reference/src/nova/proof.rs:232-392) over
 libvdf_nova.so: `public_params`, `InverseMinRootCircuit.{circuits, eval_and_make_circuits}`,
 `NovaVDFProof.{prove_recursively, verify, compress}`.  Every heavy step runs as HIP kernels through
-the C ABI of libvdf_hip.so; see include/vdf_nova.h for the stage implemented (folding-only)."""
+the C ABI of libvdf_hip.so; see include/vdf_nova.h (Nova IVC on the Pallas / Vesta cycle, protocol "vdf-nova-ivc-v1")."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,8 +16,11 @@ from .minroot import State, _State, _Fe, nova_lib, EvalMode, MinRootVDF, PallasV
 _vp, _i, _u64, _sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
 for _name, _res, _args in [
     ("vdf_nova_public_params", _i, [_vp, _u64, C.POINTER(_vp)]),
+    ("vdf_nova_public_params_ex", _i, [_vp, _u64, _i, _i, C.POINTER(_vp)]),
     ("vdf_nova_pp_free", None, [_vp]),
-    ("vdf_nova_pp_sizes", _i, [_vp] + [C.POINTER(_u64)] * 5),
+    ("vdf_nova_pp_sizes", _i, [_vp, _i] + [C.POINTER(_u64)] * 5),
+    ("vdf_nova_pp_digest", _i, [_vp, _vp]),
+    ("vdf_nova_pp_segment", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_eval_and_make_circuits", _i, [_i, _u64, _sz, C.POINTER(_State), C.POINTER(_Fe * 3), C.POINTER(_vp)]),
     ("vdf_nova_circuits_len", _sz, [_vp]),
     ("vdf_nova_circuits_upload", _i, [_vp, _vp]),
@@ -28,18 +31,22 @@ for _name, _res, _args in [
     ("vdf_nova_verify", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
     ("vdf_nova_proof_free", None, [_vp]),
     ("vdf_nova_proof_num_steps", _sz, [_vp]),
-    ("vdf_nova_proof_instance", _i, [_vp, _vp, _vp, _vp, _vp]),
-    ("vdf_nova_proof_witness_ptrs", _i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
-    ("vdf_nova_proof_step_record", _i, [_vp, _sz, _vp, _vp, _vp, _vp]),
+    ("vdf_nova_proof_instance", _i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    ("vdf_nova_proof_witness_ptrs", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("vdf_nova_proof_zi", _i, [_vp, _vp, _vp]),
+    ("vdf_nova_proof_last_step", _i, [_vp, _vp]),
     ("vdf_nova_last_step_ms", _i, [_vp, C.POINTER(C.c_double * 8)]),
+    ("vdf_nova_ro_hash", _i, [_i, _u64, _vp, _sz, _vp]),
+    ("vdf_nova_shape_digest", _i, [_u64, _i, _i, _vp, _vp]),
+    ("vdf_nova_aug_synthesize", _i, [_i, _u64, _i, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp, _vp]),
     ("vdf_nova_compress", _i, [_vp, _vp, C.POINTER(_vp)]),
     ("vdf_nova_verify_compressed", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
     ("vdf_nova_snark_free", None, [_vp]),
     ("vdf_nova_snark_size", _sz, [_vp]),
     ("vdf_nova_snark_bytes", _i, [_vp, _vp, _sz]),
     ("vdf_nova_snark_set_bytes", _i, [_vp, _vp, _sz]),
-    ("vdf_nova_point_compress", _i, [_vp, _vp]),
-    ("vdf_nova_point_decompress", _i, [_vp, _vp]),
+    ("vdf_nova_point_compress", _i, [_i, _vp, _vp]),
+    ("vdf_nova_point_decompress", _i, [_i, _vp, _vp]),
     ("vdf_nova_snark_serialized_size", _sz, [_vp]),
     ("vdf_nova_snark_serialize", _i, [_vp, _vp, _sz]),
     ("vdf_nova_snark_deserialize", _i, [_vp, _vp, _sz, C.POINTER(_vp)]),
@@ -47,8 +54,15 @@ for _name, _res, _args in [
     ("vdf_nova_proof_serialize", _i, [_vp, _vp, _sz]),
     ("vdf_nova_proof_deserialize", _i, [_vp, _vp, _sz, C.POINTER(_vp)]),
 ]:
+    if not hasattr(nova_lib, _name):          # AttributeError at call time names the missing entry point
+        continue
     getattr(nova_lib, _name).argtypes = _args
     getattr(nova_lib, _name).restype = _res
+
+CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE = 0, 1
+SIDE_PRIMARY, SIDE_SECONDARY = 0, 1
+INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY = 0, 1, 2
+GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT = 0, 1
 
 
 def _check(rc: int) -> None:
@@ -56,20 +70,55 @@ def _check(rc: int) -> None:
         raise VdfError(rc, (nova_lib.vdf_nova_last_error() or b"").decode())
 
 
-def point_compress(aff: np.ndarray) -> bytes:
-    """32-byte encoding of a Pallas point given as 8 Montgomery words (x, y); host arithmetic only."""
+def point_compress(aff: np.ndarray, curve: int = 0) -> bytes:
+    """32-byte encoding of a point of `curve` given as 8 Montgomery words (x, y); host arithmetic only."""
     a = np.ascontiguousarray(aff, dtype="<u8").reshape(8)
     out = (C.c_uint8 * 32)()
-    _check(nova_lib.vdf_nova_point_compress(a.ctypes.data, out))
+    _check(nova_lib.vdf_nova_point_compress(curve, a.ctypes.data, out))
     return bytes(out)
 
 
-def point_decompress(data: bytes) -> np.ndarray:
+def point_decompress(data: bytes, curve: int = 0) -> np.ndarray:
     if len(data) != 32:
         raise ValueError("32 bytes")
     out = np.zeros(8, dtype="<u8")
-    _check(nova_lib.vdf_nova_point_decompress((C.c_uint8 * 32).from_buffer_copy(data), out.ctypes.data))
+    _check(nova_lib.vdf_nova_point_decompress(curve, (C.c_uint8 * 32).from_buffer_copy(data), out.ctypes.data))
     return out
+
+
+def ro_hash(field: int, tag: int, xs: np.ndarray) -> np.ndarray:
+    """The random oracle's sponge (host only): lane 1 after absorbing xs (Montgomery limbs in and out)."""
+    xs = np.ascontiguousarray(xs, dtype="<u8").reshape(-1, 4)
+    out = np.zeros(4, dtype="<u8")
+    _check(nova_lib.vdf_nova_ro_hash(field, tag, xs.ctypes.data, xs.shape[0], out.ctypes.data))
+    return out
+
+
+def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
+    """(digest as an integer, sizes[side] = (num_cons, num_vars, nnz)) of the parameters public_params(t) would make."""
+    d = (C.c_uint8 * 32)()
+    sizes = np.zeros((2, 3), dtype="<u8")
+    _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
+    return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+class AugInputs(C.Structure):     # vdf_nova_aug_inputs
+    _fields_ = [("params", _Fe), ("i", _Fe), ("z0", _Fe * 3), ("zi", _Fe * 3),
+                ("U_comm_W", _Fe * 2), ("U_comm_E", _Fe * 2), ("U_u", _Fe), ("U_X", _Fe * 2),
+                ("u_comm_W", _Fe * 2), ("u_X", _Fe * 2), ("T", _Fe * 2)]
+
+
+def aug_synthesize(side: int, t: int, circuit_kind: int, inputs: AugInputs, result=None, inp=None, cap: int = 1 << 16):
+    """One augmented circuit synthesised on the host: (W, X, z_next, num_cons)."""
+    W = np.zeros((cap, 4), dtype="<u8")
+    X, zn = np.zeros((2, 4), dtype="<u8"), np.zeros((3, 4), dtype="<u8")
+    nv, nc = C.c_size_t(), C.c_size_t()
+    r = C.byref(result._c()) if result is not None else None
+    i = C.byref(inp._c()) if inp is not None else None
+    _check(nova_lib.vdf_nova_aug_synthesize(side, t, circuit_kind, C.addressof(inputs), C.cast(r, _vp) if r else None,
+                                            C.cast(i, _vp) if i else None, W.ctypes.data, cap, C.byref(nv), C.byref(nc),
+                                            X.ctypes.data, zn.ctypes.data))
+    return W[:nv.value].copy(), X, zn[:3 if side == 0 else 1].copy(), nc.value
 
 
 def _z(vals: Sequence[bytes]):
@@ -82,10 +131,21 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         self._proofs = weakref.WeakSet()         # proofs made under these parameters: freed before them
         ctx._children.add(self)
 
-    def sizes(self) -> dict:
+    def sizes(self, side: int = 0) -> dict:
         v = [C.c_uint64() for _ in range(5)]
-        _check(nova_lib.vdf_nova_pp_sizes(self.handle, *[C.byref(x) for x in v]))
+        _check(nova_lib.vdf_nova_pp_sizes(self.handle, side, *[C.byref(x) for x in v]))
         return dict(zip(("num_cons", "num_vars", "num_io", "nnz", "num_gens"), [x.value for x in v]))
+
+    def digest(self) -> int:
+        d = (C.c_uint8 * 32)()
+        _check(nova_lib.vdf_nova_pp_digest(self.handle, d))
+        return int.from_bytes(bytes(d), "little")
+
+    def segment(self) -> Tuple[int, int]:
+        """(first variable, count) of the primary witness's run that the GPU fills: the MinRoot rounds."""
+        b, n = C.c_uint64(), C.c_uint64()
+        _check(nova_lib.vdf_nova_pp_segment(self.handle, C.byref(b), C.byref(n)))
+        return b.value, n.value
 
     def free(self) -> None:
         if self.handle and self.ctx.handle:      # a dead context took the device memory with it (see hip.Bases.free)
@@ -101,9 +161,10 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
             pass
 
 
-def public_params(ctx: Context, num_iters_per_step: int) -> NovaVDFPublicParams:      # :232-237
+def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_BOUND,
+                  gens_family: int = GENS_TRY_AND_INCREMENT) -> NovaVDFPublicParams:      # :232-237
     h = C.c_void_p()
-    _check(nova_lib.vdf_nova_public_params(ctx.handle, num_iters_per_step, C.byref(h)))
+    _check(nova_lib.vdf_nova_public_params_ex(ctx.handle, num_iters_per_step, circuit_kind, gens_family, C.byref(h)))
     return NovaVDFPublicParams(ctx, h.value, num_iters_per_step)
 
 
@@ -207,34 +268,42 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
     def num_steps(self) -> int:
         return nova_lib.vdf_nova_proof_num_steps(self.handle)
 
-    def instance(self) -> dict:
+    def instance(self, which: int = INST_RUNNING_PRIMARY) -> dict:
         cw, ce = np.zeros(8, dtype="<u8"), np.zeros(8, dtype="<u8")
-        u, X = np.zeros(4, dtype="<u8"), np.zeros((6, 4), dtype="<u8")
-        _check(nova_lib.vdf_nova_proof_instance(self.handle, cw.ctypes.data, ce.ctypes.data, u.ctypes.data, X.ctypes.data))
+        u, X = np.zeros(4, dtype="<u8"), np.zeros((2, 4), dtype="<u8")
+        _check(nova_lib.vdf_nova_proof_instance(self.handle, which, cw.ctypes.data, ce.ctypes.data, u.ctypes.data, X.ctypes.data))
         return {"comm_W": cw, "comm_E": ce, "u": u, "X": X}
 
-    def witness(self) -> Tuple[np.ndarray, np.ndarray]:
-        """Downloads the running (W, E) for parity checks."""
+    def witness(self, which: int = INST_RUNNING_PRIMARY) -> Tuple[np.ndarray, np.ndarray]:
+        """Downloads (z = [W | u | X], E) of one of the three instances for parity checks (E is None for the fresh one)."""
         from ._lib import lib
-        s = self.pp.sizes()
-        dW, dE = C.c_void_p(), C.c_void_p()
-        _check(nova_lib.vdf_nova_proof_witness_ptrs(self.handle, C.byref(dW), C.byref(dE)))
-        W = np.zeros((s["num_vars"], 4), dtype="<u8")
-        E = np.zeros((s["num_cons"], 4), dtype="<u8")
-        self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, W.ctypes.data, dW.value, W.nbytes))
-        self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, E.ctypes.data, dE.value, E.nbytes))
-        return W, E
+        s = self.pp.sizes(0 if which == INST_RUNNING_PRIMARY else 1)
+        dz, dE = C.c_void_p(), C.c_void_p()
+        _check(nova_lib.vdf_nova_proof_witness_ptrs(self.handle, which, C.byref(dz), C.byref(dE)))
+        z = np.zeros((s["num_vars"] + 3, 4), dtype="<u8")
+        self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, z.ctypes.data, dz.value, z.nbytes))
+        E = None
+        if dE.value:
+            E = np.zeros((s["num_cons"], 4), dtype="<u8")
+            self.pp.ctx._check(lib.vdf_dev_memcpy(self.pp.ctx.handle, E.ctypes.data, dE.value, E.nbytes))
+        return z, E
 
-    def step_record(self, k: int) -> dict:
-        cw, ct = np.zeros(8, dtype="<u8"), np.zeros(8, dtype="<u8")
-        r, X = np.zeros(4, dtype="<u8"), np.zeros((6, 4), dtype="<u8")
-        _check(nova_lib.vdf_nova_proof_step_record(self.handle, k, cw.ctypes.data, ct.ctypes.data, r.ctypes.data, X.ctypes.data))
-        return {"comm_w": cw, "comm_T": ct, "r": r, "X": X}
+    def zi(self) -> Tuple[np.ndarray, np.ndarray]:
+        a, b = np.zeros((3, 4), dtype="<u8"), np.zeros((1, 4), dtype="<u8")
+        _check(nova_lib.vdf_nova_proof_zi(self.handle, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def last_step(self) -> dict:
+        """By-products of the last prove_step: fresh primary instance, cross-term commitments, fold challenges."""
+        raw = np.zeros(8 + 8 + 8 + 8 + 4 + 4, dtype="<u8")
+        _check(nova_lib.vdf_nova_proof_last_step(self.handle, raw.ctypes.data))
+        return {"comm_W1": raw[0:8], "X1": raw[8:16].reshape(2, 4), "comm_T1": raw[16:24], "comm_T2": raw[24:32],
+                "r1": int.from_bytes(raw[32:36].tobytes(), "little"), "r2": int.from_bytes(raw[36:40].tobytes(), "little")}
 
     def last_step_ms(self) -> dict:
         ms = (C.c_double * 8)()
         _check(nova_lib.vdf_nova_last_step_ms(self.handle, C.byref(ms)))
-        return dict(zip(("witness_launch", "commit_launch", "cross_term_launch", "lookahead", "wait", "fold", "host", "total"), list(ms)))
+        return dict(zip(("secondary_nifs", "primary_synthesis", "primary_launch", "primary_wait", "secondary_synthesis", "secondary_launch", "lookahead", "total"), list(ms)))
 
     def free(self) -> None:
         if self.handle and self.pp.handle and self.pp.ctx.handle:      # needs live parameters and a live context
