@@ -146,22 +146,22 @@ int  vdf_nova_aug_synthesize(int side, uint64_t num_iters_per_step, int circuit_
                              size_t* num_cons, vdf_fe X[2], vdf_fe z_next[3]);
 
 /* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
- * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: a succinct argument that the folded relaxed R1CS
- * instance is satisfiable, instead of its 14 MB witness.  Protocol "vdf-spartan-v3" (oracle/spartan.py): a
- * Spartan-style sum-check argument with inner-product-argument openings under the same Pedersen generators; the
- * extra generator of the openings is generator number num_gens of the same family.  Like the rest of this layer it is
- * self-consistent, not interchangeable with nova-snark (whose constants are unpinned); in the
- * folding-only stage the compressed proof still carries the per-step records the verifier replays.  Every pass
- * over a vector runs on the GPU through include/vdf_hip.h. */
+ * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: the last secondary instance is folded into the running
+ * one, then one succinct argument PER SIDE (SS1 / SS2 of :32-33) that the running primary instance and the folded
+ * secondary instance are satisfiable, instead of their witnesses.  Protocol "vdf-spartan-v3" (oracle/spartan.py): a
+ * Spartan-style sum-check argument with inner-product-argument openings under the side's own Pedersen generators; the
+ * extra generator of the openings is generator number num_gens of the same family.  Self-consistent, bit-exact against
+ * the oracle, not interchangeable with nova-snark (unpinned).  Every pass over a vector runs on the GPU. */
 int  vdf_nova_compress(const vdf_proof* proof, vdf_pp* pp, vdf_snark** out);
-/* NovaVDFProof::verify for the Compressed variant: *ok = 1 iff the step records chain from z0 to zi over num_steps
- * steps, fold to the stated instance, and the argument for that instance verifies. */
+/* NovaVDFProof::verify for the Compressed variant (:383): *ok = 1 iff the two output hashes match the carried
+ * instances for num_steps steps from z0, both arguments verify (the secondary one for the instance the verifier
+ * folds itself), the carried zi_primary equals zi and zi_secondary == [0]. */
 int  vdf_nova_verify_compressed(const vdf_snark* snark, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3],
                                 int* ok);
 void vdf_nova_snark_free(vdf_snark* snark);
-/* Flat canonical encoding of the argument (little-endian, non-Montgomery; layout in the implementation and in
- * tests/test_gpu_compress.py): size, export, and import -- which replaces the argument of `snark` and returns
- * VDF_ERR_NONCANONICAL for out-of-range field elements. */
+/* Flat canonical encoding of the two arguments, primary then secondary (little-endian, non-Montgomery, 64-byte points;
+ * layout in the implementation and in oracle/wire.py): size, export, and import -- which replaces the arguments of
+ * `snark` and returns VDF_ERR_NONCANONICAL for an out-of-range field element or a point off its curve. */
 size_t vdf_nova_snark_size(const vdf_snark* snark);
 int  vdf_nova_snark_bytes(const vdf_snark* snark, uint8_t* out, size_t cap);
 int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
@@ -171,25 +171,24 @@ int  vdf_nova_snark_set_bytes(vdf_snark* snark, const uint8_t* in, size_t len);
  * are this library's own, versioned by their magic.  Field elements: 32 bytes, canonical, little-endian.  Points:
  * 32 bytes, canonical little-endian x with the parity of y in bit 255, the identity as 32 zero bytes.
  *
- *   chain  = magic[8] | t u64 | num_steps u64 | digest of the public parameters [32] | z_0 [96]
- *            | per step k: z_{k+1} [96], commitment of the fresh witness [32], (k >= 1) cross-term commitment [32]
- *   "VDFSNK02" compressed proof = chain | the argument of vdf_nova_snark_bytes with 32-byte points
- *   "VDFRSK01" running proof    = chain | W [num_vars x 32] | E [num_cons x 32]
+ *   relaxed instance = comm_W [32] | comm_E [32] | u [32] | X [2 x 32];   strict instance = comm_W [32] | X [2 x 32]
+ *   "VDFSNK03" compressed proof = magic[8] | t u64 | digest of the public parameters [32]
+ *        | running primary instance | running secondary instance | last secondary instance (strict)
+ *        | cross-term commitment of the last fold [32] | z_i primary [96] | z_i secondary [32]
+ *        | argument of the primary side | argument of the secondary side   (as vdf_nova_snark_bytes, 32-byte points)
+ *   "VDFRSK02" running proof    = magic[8] | t u64 | steps u64 | digest [32] | z_0 [96] | z_i primary [96] | z_i secondary [32]
+ *        | the same three instances | W1 | E1 | W2 | E2 | w2
  *
- * Challenges and the folded instance are not stored: deserialisation replays the folds (as verification does), so a
- * decoded proof states nothing the reader did not derive.  Deserialisation fails with VDF_ERR_BAD_ARG for a foreign
- * magic or other public parameters, VDF_ERR_BAD_LENGTH for a length that does not fit the shape, and
- * VDF_ERR_NONCANONICAL for an out-of-range field element or bytes that decode to no curve point.
- *
- * The compressed proof is what a prover ships to a verifier in another process: 56 + 96 + 160 n - 32 bytes of chain
- * plus 5.9 KB of argument at t = 2^16.  The running proof is a checkpoint: vdf_nova_proof_deserialize rebuilds the
- * device-resident state (including A z, B z, C z of the running instance), refuses a witness that does not open the
- * commitments its records fold to, and vdf_nova_prove_step continues from it. */
-/* The 32-byte point encoding by itself (host arithmetic only, no device): commitments are points of Pallas, in
- * Montgomery coordinates like everywhere in this ABI.  decompress: VDF_ERR_NONCANONICAL unless the bytes are exactly
- * what compress writes for some point. */
-int  vdf_nova_point_compress(const vdf_affine* p, uint8_t out[32]);
-int  vdf_nova_point_decompress(const uint8_t in[32], vdf_affine* out);
+ * Both are constant-size in the number of steps.  Deserialisation fails with VDF_ERR_BAD_ARG for a foreign magic or
+ * other public parameters, VDF_ERR_BAD_LENGTH for a length that does not fit the shapes, and VDF_ERR_NONCANONICAL for
+ * an out-of-range field element or bytes that decode to no curve point.  The running proof is a checkpoint:
+ * vdf_nova_proof_deserialize rebuilds the device-resident state (including A z, B z, C z of the running instances),
+ * refuses witnesses that do not open their commitments, and vdf_nova_prove_step continues from it. */
+/* The 32-byte point encoding by itself (host arithmetic only, no device); curve = VDF_CURVE_PALLAS / VDF_CURVE_VESTA,
+ * coordinates in Montgomery form like everywhere in this ABI.  decompress: VDF_ERR_NONCANONICAL unless the bytes are
+ * exactly what compress writes for some point. */
+int  vdf_nova_point_compress(int curve, const vdf_affine* p, uint8_t out[32]);
+int  vdf_nova_point_decompress(int curve, const uint8_t in[32], vdf_affine* out);
 size_t vdf_nova_snark_serialized_size(const vdf_snark* snark);
 int  vdf_nova_snark_serialize(const vdf_snark* snark, uint8_t* out, size_t cap);
 int  vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out);

@@ -662,3 +662,81 @@ class CCommit:
         bm = o.curve_base_modulus(SIDE_CURVE[side])
         raw = aff.tobytes()
         return (o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:], "little"), bm))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CompressedSNARK (src/nova/proof.rs:360-368 compress, :383 verify): fold the last secondary instance, then one
+# Spartan-style argument per curve (oracle/spartan.py, "vdf-spartan-v3") that the two running instances are satisfiable
+# ---------------------------------------------------------------------------------------------------------------
+def num_gens(sh: o.R1CSShape) -> int:
+    g = 1
+    while g < max(sh.num_vars, sh.num_cons):
+        g <<= 1
+    return g
+
+
+def spartan_setup(pp: PublicParams, side: int):
+    """(generator table, the extra generator U = generator number num_gens of the family) of one side."""
+    from . import spartan
+    import numpy as np
+    com = pp.commit
+    g = num_gens(pp.shapes[side])
+    arr = com._gens(side, g)[:g]
+    one = np.zeros((1, 8), dtype="<u8")
+    fn = com.L.ref_tai_bases if com.family == FAMILY_TRY_AND_INCREMENT else com.L.ref_synthetic_bases
+    fn(SIDE_CURVE[side], com.seed, g, 1, com.cref.p(one))
+    bm = o.curve_base_modulus(SIDE_CURVE[side])
+    raw = one.tobytes()
+    U = (o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:64], "little"), bm))
+    return spartan.Gens(arr, SIDE_CURVE[side]), U
+
+
+@dataclass
+class CompressedSNARK:
+    r_U1: Relaxed              # instances only (W, E empty)
+    r_U2: Relaxed              # the running secondary instance BEFORE the last fold
+    l_u2: Fresh
+    T2: Aff
+    snark1: object             # spartan.SpartanProof for r_U1
+    snark2: object             # for fold(r_U2, l_u2)
+    zi: List[List[int]]
+
+
+def _inst_only(R: Relaxed) -> Relaxed:
+    return Relaxed(R.comm_W, R.comm_E, R.u, list(R.X), [], [])
+
+
+def _pt(a: Aff):
+    return None if a == (0, 0) else a
+
+
+def compress(pp: PublicParams, s: RecursiveSNARK) -> CompressedSNARK:
+    from . import spartan
+    f2, T2, _ = nifs_fold(pp, 1, s.r[1], s.l2)
+    digest = int(pp.params).to_bytes(32, "little")
+    proofs = []
+    for side, R in ((0, s.r[0]), (1, f2)):
+        G, U = spartan_setup(pp, side)
+        proofs.append(spartan.prove(pp.shapes[side], digest, G, U, _pt(R.comm_W), _pt(R.comm_E), R.u, R.X, R.W, R.E, SIDE_CURVE[side]))
+    return CompressedSNARK(_inst_only(s.r[0]), _inst_only(s.r[1]), Fresh(s.l2.comm_W, list(s.l2.X), []), T2, proofs[0], proofs[1],
+                           [list(s.zi[0]), list(s.zi[1])])
+
+
+def verify_compressed(pp: PublicParams, c: CompressedSNARK, num_steps: int, z0_1: Sequence[int], z0_2: Sequence[int] = (0,)):
+    from . import spartan
+    if num_steps == 0:
+        return None
+    if c.l_u2.X[0] != hash_state(SIDE_FIELD[0], pp.params, num_steps, z0_1, c.zi[0], c.r_U2):
+        return None
+    if c.l_u2.X[1] != hash_state(SIDE_FIELD[1], pp.params, num_steps, z0_2, c.zi[1], c.r_U1):
+        return None
+    m2 = o.modulus(SIDE_FIELD[1])
+    r = hash_challenge(SIDE_FIELD[0], pp.params, c.r_U2, c.l_u2.comm_W, c.l_u2.X, c.T2)
+    f2 = Relaxed(ec_fold(1, c.r_U2.comm_W, r, c.l_u2.comm_W), ec_fold(1, c.r_U2.comm_E, r, c.T2), (c.r_U2.u + r) % m2,
+                 o.axpy(c.r_U2.X, r, c.l_u2.X, m2), [], [])
+    digest = int(pp.params).to_bytes(32, "little")
+    for side, R, pf in ((0, c.r_U1, c.snark1), (1, f2, c.snark2)):
+        G, U = spartan_setup(pp, side)
+        if not spartan.verify(pp.shapes[side], digest, G, U, _pt(R.comm_W), _pt(R.comm_E), R.u, R.X, pf, SIDE_CURVE[side]):
+            return None
+    return c.zi[0], c.zi[1]

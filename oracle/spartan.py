@@ -138,41 +138,82 @@ class IpaProof:
     a: List[int] = field(default_factory=list)     # the folded vector, min(n, IPA_STOP) elements
 
 
-def _msm(s: Sequence[int], G: Sequence[Point], curve: int) -> Point:
+class Gens:
+    """A generator table held as the C restatement's array (uint64[n, 8], Montgomery affine): sliceable, and its MSMs
+    run in oracle/pasta_ref.c -- the augmented circuits have ~10^4 variables, far beyond msm_naive."""
+
+    def __init__(self, arr, curve: int):
+        self.arr, self.curve = arr, curve
+
+    def __len__(self) -> int:
+        return self.arr.shape[0]
+
+    def __getitem__(self, sl) -> "Gens":
+        assert isinstance(sl, slice)
+        return Gens(self.arr[sl], self.curve)
+
+    def msm(self, scalars: Sequence[int]) -> Point:
+        import numpy as np
+        from . import cref
+        L = cref.lib()
+        n = len(scalars)
+        assert n == len(self)
+        pts = np.ascontiguousarray(self.arr)
+        sc = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in scalars), dtype="<u8").reshape(n, 4).copy()
+        out, aff = np.zeros(12, dtype="<u8"), np.zeros(8, dtype="<u8")
+        L.ref_msm(self.curve, cref.p(pts), cref.p(sc), n, 0, 4, 0, cref.p(out))
+        L.ref_jac_to_affine(self.curve, cref.p(out), cref.p(aff))
+        bm = o.curve_base_modulus(self.curve)
+        raw = aff.tobytes()
+        x, y = o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:], "little"), bm)
+        return None if (x, y) == (0, 0) else (x, y)
+
+
+def _msm(s: Sequence[int], G, curve: int) -> Point:
+    if isinstance(G, Gens):
+        return G.msm(s)
     return o.msm_naive(list(s), list(G), curve)
 
 
 class _IpaProver:
     """One inner-product argument as a state machine, so that several can advance in lockstep: a round of all of them
-    is one batch of MSMs for the product (ipa_prove_many)."""
+    is one batch of MSMs for the product (ipa_prove_many).  The folded generators G' = G_lo x^-1 + G_hi x are never
+    formed: s[t] is the coefficient of original generator t in its folded generator G'_(t mod size), and a round's
+    <a_lo, G'_hi>, <a_hi, G'_lo> are MSMs over the ORIGINAL generators with scalars s[t] a[...] (as the product does it)."""
 
     def __init__(self, tr, label, G, U, a, b, v, P, curve):
         self.q, self.pm, self.curve, self.label = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve), curve, label
         tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])
         self.Q = o.pt_mul(tr.challenge(label), U, self.pm)
-        self.a, self.b, self.G = list(a), list(b), list(G)
+        self.a, self.b, self.G = list(a), list(b), G
+        self.n = len(self.a)
+        self.s = [1] * self.n
         self.proof = IpaProof()
 
     def active(self) -> bool:
         return len(self.a) > IPA_STOP
 
     def round_points(self) -> None:
-        a, b, G, q, pm = self.a, self.b, self.G, self.q, self.pm
-        h = len(a) // 2
+        a, b, q, pm, s = self.a, self.b, self.q, self.pm, self.s
+        size = len(a)
+        h = size // 2
         cL = sum(x * y for x, y in zip(a[:h], b[h:])) % q
         cR = sum(x * y for x, y in zip(a[h:], b[:h])) % q
-        self.L = o.pt_add(_msm(a[:h], G[h:], self.curve), o.pt_mul(cL, self.Q, pm), pm)
-        self.R = o.pt_add(_msm(a[h:], G[:h], self.curve), o.pt_mul(cR, self.Q, pm), pm)
+        sL = [s[t] * a[(t % size) - h] % q if (t % size) >= h else 0 for t in range(self.n)]
+        sR = [s[t] * a[(t % size) + h] % q if (t % size) < h else 0 for t in range(self.n)]
+        self.L = o.pt_add(_msm(sL, self.G, self.curve), o.pt_mul(cL, self.Q, pm), pm)
+        self.R = o.pt_add(_msm(sR, self.G, self.curve), o.pt_mul(cR, self.Q, pm), pm)
 
     def round_fold(self, tr) -> None:
-        a, b, G, q, pm = self.a, self.b, self.G, self.q, self.pm
-        h = len(a) // 2
+        a, b, q = self.a, self.b, self.q
+        size = len(a)
+        h = size // 2
         tr.absorb_pt(self.label, [self.L, self.R])
         x = tr.challenge(self.label)
         xi = pow(x, -1, q)
         self.a = [(a[i] * x + a[h + i] * xi) % q for i in range(h)]
         self.b = [(b[i] * xi + b[h + i] * x) % q for i in range(h)]
-        self.G = [o.pt_add(o.pt_mul(xi, G[i], pm), o.pt_mul(x, G[h + i], pm), pm) for i in range(h)]
+        self.s = [self.s[t] * (x if (t % size) >= h else xi) % q for t in range(self.n)]
         self.proof.L.append(self.L); self.proof.R.append(self.R)
 
     def finish(self) -> IpaProof:
@@ -202,7 +243,7 @@ def ipa_prove(tr: Transcript, label: bytes, G: Sequence[Point], U: Point, a: Seq
 class _IpaVerifier:
     def __init__(self, tr, label, G, U, b, v, P, proof, curve):
         self.q, self.pm, self.curve, self.label = o.curve_scalar_modulus(curve), o.curve_base_modulus(curve), curve, label
-        self.G, self.proof, self.n = list(G), proof, len(G)
+        self.G, self.proof, self.n = G, proof, len(G)
         self.m = min(self.n, IPA_STOP)
         self.ok = (self.m << len(proof.L)) == self.n and len(proof.L) == len(proof.R) and len(proof.a) == self.m
         tr.absorb_pt(label, [P]); tr.absorb_fe(label, [v])

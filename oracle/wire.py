@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- never imported by the product (vdf_amd/).
 
-Python restatement of the wire formats of include/vdf_nova.h ("VDFSNK02" compressed proof, "VDFRSK01" running
+Python restatement of the wire formats of include/vdf_nova.h ("VDFSNK03" compressed proof, "VDFRSK02" running
 proof) and of the 32-byte point encoding.  The reference serialises nothing (src/nova/proof.rs:52-55 keeps
 proofs in memory), so there are no reference vectors for these: parity is product bytes == these bytes, plus the
 round trips and the rejection cases in tests/test_wire.py and tests/test_gpu_wire.py.  Parity unpinned against the
@@ -13,8 +13,8 @@ from typing import List, Optional, Sequence, Tuple
 from . import pasta as o
 
 Point = Optional[Tuple[int, int]]
-MAGIC_SNARK = b"VDFSNK02"
-MAGIC_PROOF = b"VDFRSK01"
+MAGIC_SNARK = b"VDFSNK03"
+MAGIC_PROOF = b"VDFRSK02"
 
 
 def fe(v: int) -> bytes:
@@ -50,38 +50,50 @@ def decompress_point(data: bytes, curve: int = o.CURVE_PALLAS) -> Point:
     return (x, y)
 
 
-def encode_chain(magic: bytes, t: int, digest: bytes, z: Sequence[Sequence[int]], comm_w: Sequence[Point],
-                 comm_T: Sequence[Point]) -> bytes:
-    """z: the n + 1 states z_0 .. z_n (3 integers each); comm_w: n points; comm_T: n points, [0] ignored."""
-    n = len(comm_w)
-    assert len(z) == n + 1 and len(comm_T) == n and len(digest) == 32 and len(magic) == 8
-    out = magic + t.to_bytes(8, "little") + n.to_bytes(8, "little") + digest
-    out += b"".join(fe(v) for v in z[0])
-    for k in range(n):
-        out += b"".join(fe(v) for v in z[k + 1]) + compress_point(comm_w[k])
-        if k:
-            out += compress_point(comm_T[k])
-    return out
-
-
-def encode_argument(proof) -> bytes:
-    """oracle.spartan.SpartanProof with 32-byte points (the argument section of "VDFSNK02")."""
+def encode_argument(proof, points=None) -> bytes:
+    """oracle.spartan.SpartanProof; points = compress_point for the wire (32 bytes), None for the flat encoding (64)."""
+    flat = lambda p: b"\0" * 64 if p is None else fe(p[0]) + fe(p[1])
+    pt = points or flat
     out = b"".join(fe(v) for ev in proof.outer for v in ev)
     out += b"".join(fe(v) for v in proof.claims)
     out += b"".join(fe(v) for ev in proof.inner for v in ev)
     out += fe(proof.w_eval)
     for ipa in (proof.ipa_W, proof.ipa_E):
-        out += b"".join(compress_point(L) + compress_point(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
+        out += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
     return out
 
 
-def encode_compressed_proof(t, digest, z, comm_w, comm_T, proof) -> bytes:
-    return encode_chain(MAGIC_SNARK, t, digest, z, comm_w, comm_T) + encode_argument(proof)
+def _pt(a):
+    return None if tuple(a) == (0, 0) else tuple(a)
 
 
-def encode_running_proof(t, digest, z, comm_w, comm_T, W: Sequence[int], E: Sequence[int]) -> bytes:
-    return encode_chain(MAGIC_PROOF, t, digest, z, comm_w, comm_T) + b"".join(fe(v) for v in W) + b"".join(fe(v) for v in E)
+def encode_instance(inst, relaxed: bool) -> bytes:
+    """oracle.nova.Relaxed / Fresh: comm_W [, comm_E, u], X."""
+    out = compress_point(_pt(inst.comm_W))
+    if relaxed:
+        out += compress_point(_pt(inst.comm_E)) + fe(inst.u)
+    return out + b"".join(fe(v) for v in inst.X)
 
 
-def chain_size(n: int) -> int:
-    return 8 + 8 + 8 + 32 + 96 + n * 128 + (n - 1) * 32
+def encode_flat_arguments(c) -> bytes:
+    """vdf_nova_snark_bytes: both arguments of an oracle.nova.CompressedSNARK, 64-byte points."""
+    return encode_argument(c.snark1) + encode_argument(c.snark2)
+
+
+def encode_compressed_proof(t: int, params: int, c) -> bytes:
+    """ "VDFSNK03" (include/vdf_nova.h) for an oracle.nova.CompressedSNARK."""
+    out = MAGIC_SNARK + int(t).to_bytes(8, "little") + int(params).to_bytes(32, "little")
+    out += encode_instance(c.r_U1, True) + encode_instance(c.r_U2, True) + encode_instance(c.l_u2, False)
+    out += compress_point(_pt(c.T2))
+    out += b"".join(fe(v) for v in c.zi[0]) + b"".join(fe(v) for v in c.zi[1])
+    return out + encode_argument(c.snark1, compress_point) + encode_argument(c.snark2, compress_point)
+
+
+def encode_running_proof(t: int, params: int, s, z0) -> bytes:
+    """ "VDFRSK02" for an oracle.nova.RecursiveSNARK."""
+    out = MAGIC_PROOF + int(t).to_bytes(8, "little") + int(s.i).to_bytes(8, "little") + int(params).to_bytes(32, "little")
+    out += b"".join(fe(v) for v in z0) + b"".join(fe(v) for v in s.zi[0]) + b"".join(fe(v) for v in s.zi[1])
+    out += encode_instance(s.r[0], True) + encode_instance(s.r[1], True) + encode_instance(s.l2, False)
+    for vec in (s.r[0].W, s.r[0].E, s.r[1].W, s.r[1].E, s.l2.W):
+        out += b"".join(fe(v) for v in vec)
+    return out

@@ -76,14 +76,25 @@ def test_cpu_backend_request_is_refused():
 
 
 def test_product_does_not_import_the_oracle():
-    """vdf_amd/ (the product) must never import oracle/ (test infrastructure)."""
+    """vdf_amd/ (the product) must never import, link, load or execute anything of oracle/ (test infrastructure).  Its
+    sources may NAME the restatement in comments (it is their specification); outside comments and docstrings the word
+    must not occur at all."""
     pkg = os.path.join(ROOT, "vdf_amd")
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp")):
-                src = open(os.path.join(dirpath, fn)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
-                assert "pasta_ref" not in src and "oracle/" not in src.replace("oracle/pasta.py base_dlog", ""), fn
+            if not fn.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp", ".inc")) and fn != "Makefile":
+                continue
+            src = open(os.path.join(dirpath, fn)).read()
+            if fn.endswith(".py"):
+                code = re.sub(r'"""".*?"""|\'\'\'.*?\'\'\'', "", src, flags=re.S)
+                code = re.sub(r'""".*?"""', "", code, flags=re.S)
+                code = re.sub(r"#.*", "", code)
+            elif fn == "Makefile":
+                code = re.sub(r"#.*", "", src)
+            else:
+                code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+                code = re.sub(r"//.*", "", code)
+            assert "oracle" not in code and "pasta_ref" not in code and "cref" not in code, fn
 
 
 def test_c_example_builds_against_the_headers():

@@ -1,31 +1,18 @@
 """GPU: NovaVDFProof::compress and verification of the compressed proof (src/nova/proof.rs:360-368, :383; the
-reference's own test at :446-450).  The argument produced by the product must equal, byte for byte, the one the
-Python restatement (oracle/spartan.py) produces for the same folded instance and witness; at larger sizes it must
-verify, and every kind of tampering must be rejected."""
+reference's own test at :446-450): one argument per side of the curve cycle (SS1, SS2 of :32-33).  The arguments the
+product makes must equal, byte for byte, the ones the Python restatement (oracle/nova.py compress over
+oracle/spartan.py) makes for the same proof; at larger sizes they must verify, and tampering must be rejected."""
+import time
+
 import numpy as np
 import pytest
 
-from oracle import pasta as o
-from oracle import spartan as sp
-from util import unmont
-from test_gpu_nova import make, shape_digest, aff_ints, gens
+from oracle import nova as nv, pasta as o, wire as w
+from test_gpu_nova import make
 from vdf_amd.minroot import State, FIELD_FQ
-from vdf_amd.nova import NovaVDFProof
+from vdf_amd.nova import NovaVDFProof, CIRCUIT_MINROOT_BOUND
 
 pytestmark = pytest.mark.gpu
-Q = o.Q
-
-
-def _encode(proof: sp.SpartanProof) -> bytes:
-    fe = lambda v: int(v).to_bytes(32, "little")
-    pt = lambda p: b"\0" * 64 if p is None else fe(p[0]) + fe(p[1])
-    out = b"".join(fe(v) for ev in proof.outer for v in ev)
-    out += b"".join(fe(v) for v in proof.claims)
-    out += b"".join(fe(v) for ev in proof.inner for v in ev)
-    out += fe(proof.w_eval)
-    for ipa in (proof.ipa_W, proof.ipa_E):
-        out += b"".join(pt(L) + pt(R) for L, R in zip(ipa.L, ipa.R)) + b"".join(fe(v) for v in ipa.a)
-    return out
 
 
 def _zi(init_ints):
@@ -33,31 +20,44 @@ def _zi(init_ints):
     return [s.x, s.y, s.i]
 
 
-def _pt(a):
-    return None if a == (0, 0) else a
+def oracle_proof(t, n, init_ints):
+    """The same chain proven by the oracle: (public parameters, RecursiveSNARK, z0 as integers)."""
+    opp = nv.public_params(t, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
+    states = [o.State(*init_ints)]
+    for _ in range(n):
+        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    z0 = [states[n].x, states[n].y, states[n].i]
+    s = None
+    for k in range(n):
+        s = nv.prove_step(opp, s, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1]), z0)
+    return opp, s, z0
 
 
-@pytest.mark.parametrize("t,n", [(3, 3), (5, 2), (12, 2)])       # 0, 1 and 2 halving rounds before the 16-vector
-def test_compressed_argument_equals_the_oracles(ctx, t, n):
+@pytest.mark.parametrize("t,n", [(3, 2), (5, 3)])
+def test_compressed_arguments_equal_the_oracles(ctx, t, n):
     pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=31)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
-    sh = o.step_circuit_shape(t, o.FIELD_FQ)
-    inst = proof.instance()
-    gW, gE = proof.witness()
-    W, E = unmont(gW, Q), unmont(gE, Q)
-    u, X = unmont(inst["u"].reshape(1, 4), Q)[0], unmont(inst["X"], Q)
-    cW, cE = _pt(aff_ints(inst["comm_W"])), _pt(aff_ints(inst["comm_E"]))
-    assert o.is_sat_relaxed(sh, W, E, u, X, Q)
-    N = pp.sizes()["num_gens"]
-    G = gens(N)
-    U = gens(1, start=N)[0]
-    digest = shape_digest(sh, t)
-    want = sp.prove(sh, digest, G, U, cW, cE, u, X, W, E)
-    assert sp.verify(sh, digest, G, U, cW, cE, u, X, want)
+    opp, want_s, z0i = oracle_proof(t, n, init_ints)
+    want = nv.compress(opp, want_s)
+    assert nv.verify_compressed(opp, want, n, z0i) is not None
     snark = proof.compress(pp)
-    got = snark.to_bytes()
-    assert got == _encode(want)
+    assert snark.to_bytes() == w.encode_flat_arguments(want)
+    assert snark.serialize() == w.encode_compressed_proof(t, opp.params, want)
     assert snark.verify(pp, n, z0, _zi(init_ints))
+    # compressing does not disturb the running proof
+    assert proof.verify(pp, n, z0, _zi(init_ints))
+    assert proof.compress(pp).serialize() == snark.serialize()
+
+
+def test_nova_proof_compress_leg(ctx):
+    """test_nova_proof_aux(5, 3), src/nova/proof.rs:446-450: compress succeeds and the compressed proof verifies."""
+    t, n = 5, 3
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n)
+    zi = _zi(init_ints)
+    compressed = NovaVDFProof.prove_recursively(pp, circuits, t, z0).compress(pp)
+    assert compressed.verify(pp, n, z0, zi) is True
+    assert compressed.verify(pp, n, z0, [zi[1], zi[0], zi[2]]) is False
+    assert compressed.verify(pp, n + 1, z0, zi) is False
 
 
 def test_compress_and_verify_at_t_1024_and_tampering(ctx):
@@ -70,27 +70,33 @@ def test_compress_and_verify_at_t_1024_and_tampering(ctx):
     snark = proof.compress(pp)
     assert snark.verify(pp, n, z0, zi)
     good = snark.to_bytes()
-    sizes = pp.sizes()
-    s = (sizes["num_cons"] - 1).bit_length()
-    l1 = (sizes["num_vars"] - 1).bit_length() + 1
-    kW, kE = (l1 - 1) - 4, s - 4                       # halving rounds: the arguments stop at 16 elements
-    assert len(good) == 32 * (3 * s + 4 + 2 * l1 + 1 + 16 + 16) + 128 * (kW + kE)
-    # wrong statement
+    size = 0
+    sect = []
+    for side in (0, 1):
+        sz = pp.sizes(side)
+        s = (sz["num_cons"] - 1).bit_length()
+        l1 = (sz["num_vars"] - 1).bit_length() + 1
+        kW, kE = (l1 - 1) - 4, s - 4                   # halving rounds: the arguments stop at 16 elements
+        sect.append((size, s, l1, kW, kE))
+        size += 32 * (3 * s + 4 + 2 * l1 + 1 + 16 + 16) + 128 * (kW + kE)
+    assert len(good) == size
     assert not snark.verify(pp, n, z0, [zi[1], zi[0], zi[2]])
     assert not snark.verify(pp, n - 1, z0, zi)
-    # every section of the encoding: one flipped low bit must be rejected (or refused as non-canonical)
-    head = 32 * (3 * s + 4 + 2 * l1 + 1)
-    offsets = {"outer": 40, "claims": 32 * 3 * s + 33, "inner": 32 * (3 * s + 4) + 64 + 1, "w_eval": 32 * (3 * s + 4 + 2 * l1),
-               "ipaW.L": head + 3, "ipaW.a[0]": head + 128 * kW, "ipaW.a[9]": head + 128 * kW + 32 * 9 + 2,
-               "ipaE.R": head + 128 * kW + 32 * 16 + 64 + 5, "ipaE.a[15]": len(good) - 32}
-    for name, off in offsets.items():
-        bad = bytearray(good)
-        bad[off] ^= 1
-        try:
-            snark.set_bytes(bytes(bad))
-        except Exception:
-            continue
-        assert not snark.verify(pp, n, z0, zi), name
+    # every section of both arguments: one flipped low bit must be rejected (or refused as non-canonical / off the curve)
+    for side, (base, s, l1, kW, kE) in enumerate(sect):
+        head = base + 32 * (3 * s + 4 + 2 * l1 + 1)
+        offsets = {"outer": base + 40, "claims": base + 32 * 3 * s + 33, "inner": base + 32 * (3 * s + 4) + 64 + 1,
+                   "w_eval": base + 32 * (3 * s + 4 + 2 * l1), "ipaW.L": head + 3, "ipaW.a[0]": head + 128 * kW,
+                   "ipaW.a[9]": head + 128 * kW + 32 * 9 + 2, "ipaE.R": head + 128 * kW + 32 * 16 + 64 + 5,
+                   "ipaE.a[15]": head + 128 * (kW + kE) + 32 * 31}
+        for name, off in offsets.items():
+            bad = bytearray(good)
+            bad[off] ^= 1
+            try:
+                snark.set_bytes(bytes(bad))
+            except Exception:
+                continue
+            assert not snark.verify(pp, n, z0, zi), (side, name)
     snark.set_bytes(good)
     assert snark.verify(pp, n, z0, zi)
     with pytest.raises(Exception):
@@ -100,8 +106,7 @@ def test_compress_and_verify_at_t_1024_and_tampering(ctx):
 
 
 def test_compress_full_size_t_2_16(ctx):
-    """t = 2^16 (BASELINE config 3 shape: 2^18 constraints, 2^19 padded variables): completes and verifies."""
-    import time
+    """t = 2^16 (BASELINE config 3 shape: 2^18 constraints and variables on the primary side): completes and verifies."""
     t, n = 1 << 16, 2
     pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=5)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
@@ -110,7 +115,8 @@ def test_compress_full_size_t_2_16(ctx):
     t1 = time.perf_counter()
     assert snark.verify(pp, n, z0, _zi(init_ints))
     t2 = time.perf_counter()
-    print(f"compress {1e3 * (t1 - t0):.1f} ms, verify {1e3 * (t2 - t1):.1f} ms, argument {len(snark.to_bytes())} bytes")
+    print(f"compress {1e3 * (t1 - t0):.1f} ms, verify {1e3 * (t2 - t1):.1f} ms, arguments {len(snark.to_bytes())} bytes, "
+          f"on the wire {len(snark.serialize())} bytes")
     bad = bytearray(snark.to_bytes())
     bad[100] ^= 1
     snark.set_bytes(bytes(bad))

@@ -127,3 +127,12 @@ def test_reference_circuit_witness(oracle_run):
     W, X, zn, nc = vn.aug_synthesize(0, t, 1, c_inputs(0, inp), st(step.result), st(step.input))
     assert unmont(W, o.FIELD_FQ) == cs.W and unmont(zn, o.FIELD_FQ) == z and nc == cs.rows
     assert len(cs.W) == len(fresh.W) + t
+
+
+def test_committed_known_answers(golden):
+    """tests/golden/vectors.json: the random oracle on (1..5) in both fields and the parameters digest at t = 1."""
+    for field in (o.FIELD_FP, o.FIELD_FQ):
+        want = int(golden["ro"][str(field)], 16)
+        assert ps.hash_elements(1, [1, 2, 3, 4, 5], field) == want
+        assert unmont(vn.ro_hash(field, 1, mont([1, 2, 3, 4, 5], field)), field)[0] == want
+    assert vn.shape_digest(1, 0, 1)[0] == int(golden["params_t1"], 16)

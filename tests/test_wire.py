@@ -64,6 +64,18 @@ def test_decompress_rejects_everything_that_is_not_an_encoding():
         point_decompress(b"\0" * 31)
 
 
+def test_vesta_points_use_the_other_coordinate_field():
+    """Commitments of the secondary side are Vesta points (coordinates in Fq)."""
+    pts = o.tai_bases(o.CURVE_VESTA, 4, 6) + [None]
+    arr = affine_array(pts, o.CURVE_VESTA)
+    for p, a in zip(pts, arr):
+        enc = point_compress(a, o.CURVE_VESTA)
+        assert enc == w.compress_point(p) and w.decompress_point(enc, o.CURVE_VESTA) == p
+        got = point_decompress(enc, o.CURVE_VESTA)
+        x, y = unmont(got.reshape(2, 4), o.Q)
+        assert ((x, y) == (0, 0) and p is None) or (x, y) == p
+
+
 def test_both_roots_are_reachable():
     """The sign bit selects the root: flipping it negates the point."""
     p = o.tai_bases(o.CURVE_PALLAS, 2, 1)[0]

@@ -1,4 +1,5 @@
-// libvdf_nova.so, part 3: NovaVDFProof::compress and verification of the compressed proof.
+// libvdf_nova.so, part 3: NovaVDFProof::compress and verification of the compressed proof: one Spartan-style argument
+// per side of the curve cycle (SS1 / SS2 of src/nova/proof.rs:32-33), after the last secondary instance is folded.
 #include "nova_internal.hpp"
 
 using namespace vdfnova;
@@ -31,8 +32,7 @@ struct Transcript {
     for (size_t i = 0; i < k; ++i) { const Fe c = from_mont(v[i], F); memcpy(&b[i * 32], c.l, 32); }
     absorb(label, b.data(), b.size());
   }
-  void absorb_pt(const char* label, const Aff* p, size_t k) {
-    const Field& F = field_fp();
+  void absorb_pt(const char* label, const Aff* p, size_t k, const Field& F) {      // F: the points' coordinate field
     std::vector<uint8_t> b(k * 64, 0);
     for (size_t i = 0; i < k; ++i)
       if (!p[i].is_id()) {
@@ -76,7 +76,8 @@ size_t pow2_at_least(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; 
 int log2_exact(size_t n) { int k = 0; while (((size_t)1 << k) < n) ++k; return k; }
 
 struct Layout { size_t M, NW, Z; int s, l1; };
-Layout layout_of(const vdf_pp* pp) {
+Layout layout_of(const Side& pp_) {
+  const Side* pp = &pp_;
   Layout l;
   l.M = pow2_at_least(pp->num_cons); l.NW = pow2_at_least(pp->num_vars); l.Z = 2 * l.NW;
   l.s = log2_exact(l.M); l.l1 = log2_exact(l.Z);
@@ -113,11 +114,11 @@ Fe interpolate(const Fe* y, int npts, const Fe& r, const Field& F) {
   return acc;
 }
 
-void instance_bytes(Transcript& tr, const vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X) {
-  const Field& F = field(PRIMARY_FIELD);
-  tr.absorb("shape", pp->digest, 32);
+void instance_bytes(Transcript& tr, const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X) {
+  const Field& F = *sd.F;
+  tr.absorb("shape", sd.digest, 32);
   const Aff pts[2] = {cW, cE};
-  tr.absorb_pt("inst", pts, 2);
+  tr.absorb_pt("inst", pts, 2, *sd.Fb);
   Fe v[1 + NUM_IO];
   v[0] = u;
   for (int j = 0; j < NUM_IO; ++j) v[1 + j] = X[j];
@@ -125,17 +126,19 @@ void instance_bytes(Transcript& tr, const vdf_pp* pp, const Aff& cW, const Aff& 
 }
 
 // lo = 1 - r, hi = r table of eq(r, .) on the device
-int eq_table_dev(vdf_ctx* ctx, const std::vector<Fe>& r, void* out) {
-  const Field& F = field(PRIMARY_FIELD);
+int eq_table_dev(const Side& sd, const std::vector<Fe>& r, void* out) {
+  vdf_ctx* ctx = sd.ctx;
+  const Field& F = *sd.F;
   std::vector<Fe> lo(r.size());
   for (size_t j = 0; j < r.size(); ++j) lo[j] = sub(one(F), r[j], F);
-  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)lo.data(), (const vdf_fe*)r.data(), (int)r.size(), (vdf_fe*)out));
+  HIPCALL(ctx, vdf_pair_table(ctx, sd.field, (const vdf_fe*)lo.data(), (const vdf_fe*)r.data(), (int)r.size(), (vdf_fe*)out));
   return VDF_OK;
 }
 
 // M(y) in the padded layout (W at [0, NW), u at NW, X after it) from eq(r_x, .)
-int m_vector_dev(vdf_pp* pp, const Layout& L, const void* d_eq_rx, const Fe& rho, void* d_cols, void* d_mvec) {
-  vdf_ctx* ctx = pp->ctx;
+int m_vector_dev(const Side& sd, const Layout& L, const void* d_eq_rx, const Fe& rho, void* d_cols, void* d_mvec) {
+  const Side* pp = &sd;
+  vdf_ctx* ctx = sd.ctx;
   HIPCALL(ctx, vdf_spmv3_t(ctx, pp->shape, (const vdf_fe*)d_eq_rx, (const vdf_fe*)&rho, (vdf_fe*)d_cols));
   HIPCALL(ctx, vdf_dev_memset(ctx, d_mvec, 0, L.Z * 32));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_mvec, d_cols, pp->num_vars * 32));
@@ -143,17 +146,17 @@ int m_vector_dev(vdf_pp* pp, const Layout& L, const void* d_eq_rx, const Fe& rho
   return VDF_OK;
 }
 
-Pt pt_mul_fe(const Pt& p, const Fe& k_mont, const Field& Fscalar) {       // k in Montgomery form of the scalar field
+Pt pt_mul_fe(const Pt& p, const Fe& k_mont, const Field& Fscalar, const Field& Fb) {       // k in Montgomery form of the scalar field
   const Fe k = from_mont(k_mont, Fscalar);
-  return pt_mul(p, k.l, 255, field_fp());
+  return pt_mul(p, k.l, 255, Fb);
 }
 
 // Fixed-base multiples of one point (the Q of an inner-product argument is multiplied by two fresh scalars per
 // round): 4-bit windows, d * 16^w * Q for d = 1..15, so a product is 64 additions and no doubling.
 struct FixedBase {
   std::vector<Pt> tab;            // [w * 15 + (d - 1)]
-  explicit FixedBase(const Pt& q) : tab(64 * 15) {
-    const Field& Fb = field_fp();
+  const Field& Fb;
+  FixedBase(const Pt& q, const Field& fb) : tab(64 * 15), Fb(fb) {
     Pt base = q;
     for (int w = 0; w < 64; ++w) {
       Pt acc = base;
@@ -162,7 +165,6 @@ struct FixedBase {
     }
   }
   Pt mul(const Fe& k_mont, const Field& Fscalar) const {
-    const Field& Fb = field_fp();
     const Fe k = from_mont(k_mont, Fscalar);
     Pt r = pt_identity();
     for (int w = 0; w < 64; ++w) {
@@ -193,19 +195,20 @@ struct IpaJob {
 // by job; then every round ALL still-active jobs put their L and R into ONE batched MSM (up to four groups: one sort, one
 // accumulate grid, one bucket reduction) before any challenge of the round is drawn, and job by job absorb them, draw
 // their challenge and fold.  h_lr: 2 * jobs pinned result slots.
-int ipa_prove_many(vdf_pp* pp, Transcript& tr, IpaJob* jobs, int njobs, vdf_jac* h_lr) {
-  vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
+int ipa_prove_many(const Side& sd, Transcript& tr, IpaJob* jobs, int njobs, vdf_jac* h_lr) {
+  const Side* pp = &sd;
+  vdf_ctx* ctx = sd.ctx;
+  const Field& F = *sd.F;
+  const Field& Fb = *sd.Fb;
   uint64_t raw[4];
   if (njobs < 1 || njobs > 2) return fail(VDF_ERR_BAD_ARG, "one or two openings at a time (four MSMs per batch)");
   for (int q = 0; q < njobs; ++q) {
     IpaJob& jb = jobs[q];
-    tr.absorb_pt(jb.label, &jb.P, 1);
+    tr.absorb_pt(jb.label, &jb.P, 1, Fb);
     tr.absorb_fe(jb.label, &jb.v, 1, F);
     tr.challenge(jb.label, F, raw);
     jb.Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
-    jb.Qtab.reset(new FixedBase(jb.Qp));
+    jb.Qtab.reset(new FixedBase(jb.Qp, Fb));
     jb.nj = jb.n;
     jb.out->L.clear(); jb.out->R.clear();
   }
@@ -219,8 +222,8 @@ int ipa_prove_many(vdf_pp* pp, Transcript& tr, IpaJob* jobs, int njobs, vdf_jac*
     for (int q = 0; q < na; ++q) {
       IpaJob& jb = *act[q];
       const vdf_fe* ab[2] = {(const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_b};
-      HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));
-      HIPCALL(ctx, vdf_ipa_scalars(ctx, PRIMARY_FIELD, (const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_s, jb.n, jb.nj, (vdf_fe*)jb.d_sL,
+      HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));
+      HIPCALL(ctx, vdf_ipa_scalars(ctx, sd.field, (const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_s, jb.n, jb.nj, (vdf_fe*)jb.d_sL,
                                    (vdf_fe*)jb.d_sR));
       sc[2 * q] = (const vdf_fe*)jb.d_sL; sc[2 * q + 1] = (const vdf_fe*)jb.d_sR;
       len[2 * q] = len[2 * q + 1] = jb.n;
@@ -234,13 +237,13 @@ int ipa_prove_many(vdf_pp* pp, Transcript& tr, IpaJob* jobs, int njobs, vdf_jac*
       const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), jb.Qtab->mul(jb.cross[0], F), Fb), Fb);
       const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), jb.Qtab->mul(jb.cross[1], F), Fb), Fb);
       const Aff lr[2] = {Lp, Rp};
-      tr.absorb_pt(jb.label, lr, 2);
+      tr.absorb_pt(jb.label, lr, 2, Fb);
       const Fe x = tr.challenge(jb.label, F, raw);
       const Fe xi = inverse(x, F);
       vdf_fe* vecs[2] = {(vdf_fe*)jb.d_a, (vdf_fe*)jb.d_b};
       const Fe c_lo[2] = {x, xi}, c_hi[2] = {xi, x};
-      HIPCALL(ctx, vdf_fold_halves(ctx, PRIMARY_FIELD, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, jb.nj));
-      HIPCALL(ctx, vdf_scale_pattern(ctx, PRIMARY_FIELD, (vdf_fe*)jb.d_s, jb.n, jb.nj, (const vdf_fe*)&xi, (const vdf_fe*)&x));
+      HIPCALL(ctx, vdf_fold_halves(ctx, sd.field, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, jb.nj));
+      HIPCALL(ctx, vdf_scale_pattern(ctx, sd.field, (vdf_fe*)jb.d_s, jb.n, jb.nj, (const vdf_fe*)&xi, (const vdf_fe*)&x));
       jb.out->L.push_back(Lp); jb.out->R.push_back(Rp);
       jb.nj >>= 1;
     }
@@ -272,10 +275,11 @@ struct IpaCheck {
 // The transcript order of ipa_prove_many; then, per opening, two device MSMs: sum_j x_j^2 L_j + x_j^-2 R_j (2k
 // multiplications by full-size scalars: on the host they were the whole cost of verification, 0.25 ms each) and the
 // folded generators against the sent vector.
-int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void* d_s, bool* ok) {
-  vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
+int ipa_verify_many(const Side& sd, Transcript& tr, IpaCheck* jobs, int njobs, void* d_s, bool* ok) {
+  const Side* pp = &sd;
+  vdf_ctx* ctx = sd.ctx;
+  const Field& F = *sd.F;
+  const Field& Fb = *sd.Fb;
   *ok = false;
   uint64_t raw[4];
   for (int q = 0; q < njobs; ++q) {
@@ -291,11 +295,11 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
   }
   for (int q = 0; q < njobs; ++q) {
     IpaCheck& c = jobs[q];
-    tr.absorb_pt(c.label, &c.P, 1);
+    tr.absorb_pt(c.label, &c.P, 1, Fb);
     tr.absorb_fe(c.label, &c.v, 1, F);
     tr.challenge(c.label, F, raw);
     c.Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
-    c.acc = pt_add(pt_from_aff(c.P, Fb), pt_mul_fe(c.Qp, c.v, F), Fb);
+    c.acc = pt_add(pt_from_aff(c.P, Fb), pt_mul_fe(c.Qp, c.v, F, Fb), Fb);
     c.bfin = one(F);
     c.xs.resize(c.k); c.xis.resize(c.k);
   }
@@ -307,7 +311,7 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
       any = true;
       const size_t j = c.idx++;
       const Aff lr[2] = {c.proof->L[j], c.proof->R[j]};
-      tr.absorb_pt(c.label, lr, 2);
+      tr.absorb_pt(c.label, lr, 2, Fb);
       const Fe x = tr.challenge(c.label, F, raw);
       if (x.is_zero()) return VDF_OK;
       const Fe xi = inverse(x, F);
@@ -329,7 +333,7 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
         lr_pts[2 * j + 1] = c.proof->R[j]; lr_sc[2 * j + 1] = sqr(c.xis[j], F);
       }
       vdf_bases* lrb = nullptr;
-      HIPCALL(ctx, vdf_bases_upload(ctx, PRIMARY_CURVE, (const vdf_affine*)lr_pts.data(), 2 * k, &lrb));
+      HIPCALL(ctx, vdf_bases_upload(ctx, sd.curve, (const vdf_affine*)lr_pts.data(), 2 * k, &lrb));
       vdf_jac jlr;
       const int rc = vdf_msm(ctx, lrb, 0, (const vdf_fe*)lr_sc.data(), 2 * k, 1, &jlr);
       const std::string err = rc == VDF_OK ? "" : vdf_last_error(ctx);
@@ -341,7 +345,7 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
     // coefficients of the original generators in sum_i a_i G'_i, G'_i the folded generators: the table of the performed
     // rounds over the top index bits times the sent vector over the low ones; b folded in closed form: bfin (the
     // rounds) times eq over the remaining variables
-    HIPCALL(ctx, vdf_pair_table_pattern(ctx, PRIMARY_FIELD, (const vdf_fe*)c.xis.data(), (const vdf_fe*)c.xs.data(), (int)k,
+    HIPCALL(ctx, vdf_pair_table_pattern(ctx, sd.field, (const vdf_fe*)c.xis.data(), (const vdf_fe*)c.xs.data(), (int)k,
                                         (const vdf_fe*)c.proof->a.data(), c.log_m, (vdf_fe*)d_s));
     vdf_jac jg;
     HIPCALL(ctx, vdf_msm(ctx, pp->gens, 0, (const vdf_fe*)d_s, c.n, 1, &jg));
@@ -355,7 +359,7 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
       }
       ab = add(ab, mul(c.proof->a[i], bi, F), F);
     }
-    const Pt rhs = pt_add(pt_from_aff(jac_to_aff(jg, Fb), Fb), pt_mul_fe(c.Qp, ab, F), Fb);
+    const Pt rhs = pt_add(pt_from_aff(jac_to_aff(jg, Fb), Fb), pt_mul_fe(c.Qp, ab, F, Fb), Fb);
     const Aff a1 = pt_to_aff(c.acc, Fb), a2 = pt_to_aff(rhs, Fb);
     all = all && memcmp(&a1, &a2, sizeof(Aff)) == 0;
   }
@@ -363,11 +367,12 @@ int ipa_verify_many(vdf_pp* pp, Transcript& tr, IpaCheck* jobs, int njobs, void*
   return VDF_OK;
 }
 
-int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const void* d_z, const void* d_E,
+int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const void* d_z, const void* d_E,
                   Spartan* out) {
-  vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
-  const Layout L = layout_of(pp);
+  const Side* pp = &sd;
+  vdf_ctx* ctx = sd.ctx;
+  const Field& F = *sd.F;
+  const Layout L = layout_of(sd);
   if (L.l1 > 24 || L.s > 24) return fail(VDF_ERR_BAD_LENGTH, "shape too large for the compression SNARK (2^24 entries)");
   if (L.NW > pp->num_gens) return fail(VDF_ERR_BAD_LENGTH, "not enough generators");
   const size_t nv = pp->num_vars, nc = pp->num_cons;
@@ -382,13 +387,13 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
   struct HostFree { vdf_ctx* c; void* p; ~HostFree() { vdf_host_free(c, p); } } hf{ctx, h_lr};
 
   Transcript tr("compress");
-  instance_bytes(tr, pp, cW, cE, u, X);
+  instance_bytes(tr, sd, cW, cE, u, X);
   HIPCALL(ctx, vdf_spmv3(ctx, pp->shape, (const vdf_fe*)d_z, (vdf_fe*)d_az, (vdf_fe*)d_bz, (vdf_fe*)d_cz));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_e, d_E, nc * 32));
   uint64_t raw[4];
   std::vector<Fe> tau(L.s);
   for (int j = 0; j < L.s; ++j) tau[j] = tr.challenge("tau", F, raw);
-  { int rc = eq_table_dev(ctx, tau, d_eq); if (rc != VDF_OK) return rc; }
+  { int rc = eq_table_dev(sd, tau, d_eq); if (rc != VDF_OK) return rc; }
   // ---- outer sum-check -----------------------------------------------------------------------------------
   std::vector<Fe> rx;
   out->outer.clear();
@@ -397,12 +402,12 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
     vdf_fe* vecs[5] = {(vdf_fe*)d_eq, (vdf_fe*)d_az, (vdf_fe*)d_bz, (vdf_fe*)d_cz, (vdf_fe*)d_e};
     for (size_t n = L.M; n > 1; n >>= 1) {
       std::array<Fe, 3> ev;
-      HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_R1CS_ROUND, tabs, (const vdf_fe*)&u, n, (vdf_fe*)ev.data()));
+      HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_R1CS_ROUND, tabs, (const vdf_fe*)&u, n, (vdf_fe*)ev.data()));
       tr.absorb_fe("outer", ev.data(), 3, F);
       const Fe r = tr.challenge("outer", F, raw);
       const Fe omr = sub(one(F), r, F);
       const Fe c_lo[5] = {omr, omr, omr, omr, omr}, c_hi[5] = {r, r, r, r, r};
-      HIPCALL(ctx, vdf_fold_halves(ctx, PRIMARY_FIELD, 5, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, n));
+      HIPCALL(ctx, vdf_fold_halves(ctx, sd.field, 5, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, n));
       out->outer.push_back(ev);
       rx.push_back(r);
     }
@@ -416,8 +421,8 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
   const Fe rho = tr.challenge("rho", F, raw);
   // ---- inner sum-check -----------------------------------------------------------------------------------
   void* d_eq_rx = d_az;                                       // the outer tables are spent: reuse one as eq(r_x, .)
-  { int rc = eq_table_dev(ctx, rx, d_eq_rx); if (rc != VDF_OK) return rc; }
-  { int rc = m_vector_dev(pp, L, d_eq_rx, rho, d_cols, d_mvec); if (rc != VDF_OK) return rc; }
+  { int rc = eq_table_dev(sd, rx, d_eq_rx); if (rc != VDF_OK) return rc; }
+  { int rc = m_vector_dev(sd, L, d_eq_rx, rho, d_cols, d_mvec); if (rc != VDF_OK) return rc; }
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_zpad, d_z, nv * 32));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)d_zpad + L.NW * 32, (const char*)d_z + nv * 32, (1 + NUM_IO) * 32));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_w, d_z, nv * 32));
@@ -428,49 +433,50 @@ int spartan_prove(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const F
     vdf_fe* vecs[2] = {(vdf_fe*)d_mvec, (vdf_fe*)d_zpad};
     for (size_t n = L.Z; n > 1; n >>= 1) {
       std::array<Fe, 2> ev;
-      HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_QUADRATIC_ROUND, tabs, nullptr, n, (vdf_fe*)ev.data()));
+      HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_QUADRATIC_ROUND, tabs, nullptr, n, (vdf_fe*)ev.data()));
       tr.absorb_fe("inner", ev.data(), 2, F);
       const Fe r = tr.challenge("inner", F, raw);
       const Fe omr = sub(one(F), r, F);
       const Fe c_lo[2] = {omr, omr}, c_hi[2] = {r, r};
-      HIPCALL(ctx, vdf_fold_halves(ctx, PRIMARY_FIELD, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, n));
+      HIPCALL(ctx, vdf_fold_halves(ctx, sd.field, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, n));
       out->inner.push_back(ev);
       ry.push_back(r);
     }
   }
   // ---- openings ----------------------------------------------------------------------------------------------
   void* d_eq_ry = d_mvec;                                     // spent: reuse for eq(r_y[1:], .) (NW entries)
-  { std::vector<Fe> rest(ry.begin() + 1, ry.end()); int rc = eq_table_dev(ctx, rest, d_eq_ry); if (rc != VDF_OK) return rc; }
+  { std::vector<Fe> rest(ry.begin() + 1, ry.end()); int rc = eq_table_dev(sd, rest, d_eq_ry); if (rc != VDF_OK) return rc; }
   {
     const vdf_fe* tabs[2] = {(const vdf_fe*)d_w, (const vdf_fe*)d_eq_ry};
-    HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_DOT, tabs, nullptr, L.NW, (vdf_fe*)&out->w_eval));
+    HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_DOT, tabs, nullptr, L.NW, (vdf_fe*)&out->w_eval));
   }
   tr.absorb_fe("weval", &out->w_eval, 1, F);
   // the two openings advance in lockstep (one four-group MSM per round).  W: a = W padded, b = eq(r_y[1:], .);
   // E: a = E padded to M (fresh copy: d_e was folded by the sum-check), b = eq(r_x, .).  Each needs its own coefficient
   // and scalar vectors: the E opening's live in buffers the sum-checks are done with.
   std::vector<Fe> ones_lo(24, one(F));
-  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.l1 - 1, (vdf_fe*)d_s));
+  HIPCALL(ctx, vdf_pair_table(ctx, sd.field, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.l1 - 1, (vdf_fe*)d_s));
   HIPCALL(ctx, vdf_dev_memset(ctx, d_e, 0, L.M * 32));
   HIPCALL(ctx, vdf_dev_memcpy(ctx, d_e, d_E, nc * 32));
   void *d_sE = d_eq, *d_sLE = d_bz, *d_sRE = d_cz;            // M entries each, spent by the outer sum-check (d_az holds eq(r_x, .))
-  HIPCALL(ctx, vdf_pair_table(ctx, PRIMARY_FIELD, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.s, (vdf_fe*)d_sE));
+  HIPCALL(ctx, vdf_pair_table(ctx, sd.field, (const vdf_fe*)ones_lo.data(), (const vdf_fe*)ones_lo.data(), L.s, (vdf_fe*)d_sE));
   IpaJob jobs[2];
   jobs[0].label = "ipaW"; jobs[0].n = L.NW; jobs[0].d_a = d_w; jobs[0].d_b = d_eq_ry; jobs[0].d_s = d_s; jobs[0].d_sL = d_sL;
   jobs[0].d_sR = d_sR; jobs[0].v = out->w_eval; jobs[0].P = cW; jobs[0].out = &out->ipaW;
   jobs[1].label = "ipaE"; jobs[1].n = L.M; jobs[1].d_a = d_e; jobs[1].d_b = d_eq_rx; jobs[1].d_s = d_sE; jobs[1].d_sL = d_sLE;
   jobs[1].d_sR = d_sRE; jobs[1].v = out->claims[3]; jobs[1].P = cE; jobs[1].out = &out->ipaE;
-  return ipa_prove_many(pp, tr, jobs, 2, h_lr);
+  return ipa_prove_many(sd, tr, jobs, 2, h_lr);
 }
 
-int spartan_verify(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Spartan& pf, bool* ok) {
-  vdf_ctx* ctx = pp->ctx;
-  const Field& F = field(PRIMARY_FIELD);
-  const Layout L = layout_of(pp);
+int spartan_verify(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const Spartan& pf, bool* ok) {
+  const Side* pp = &sd;
+  vdf_ctx* ctx = sd.ctx;
+  const Field& F = *sd.F;
+  const Layout L = layout_of(sd);
   *ok = false;
   if ((int)pf.outer.size() != L.s || (int)pf.inner.size() != L.l1) return VDF_OK;
   Transcript tr("compress");
-  instance_bytes(tr, pp, cW, cE, u, X);
+  instance_bytes(tr, sd, cW, cE, u, X);
   uint64_t raw[4];
   std::vector<Fe> tau(L.s), rx, ry;
   for (int j = 0; j < L.s; ++j) tau[j] = tr.challenge("tau", F, raw);
@@ -506,13 +512,13 @@ int spartan_verify(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const 
   { int rc = bufs.zeros(pp->ncols, &d_cols); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   for (void** p : {&d_mvec, &d_eq_ry}) { int rc = bufs.zeros(L.Z, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   { int rc = bufs.zeros(L.NW, &d_s); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
-  { int rc = eq_table_dev(ctx, rx, d_eq_rx); if (rc != VDF_OK) return rc; }
-  { int rc = m_vector_dev(pp, L, d_eq_rx, rho, d_cols, d_mvec); if (rc != VDF_OK) return rc; }
-  { int rc = eq_table_dev(ctx, ry, d_eq_ry); if (rc != VDF_OK) return rc; }
+  { int rc = eq_table_dev(sd, rx, d_eq_rx); if (rc != VDF_OK) return rc; }
+  { int rc = m_vector_dev(sd, L, d_eq_rx, rho, d_cols, d_mvec); if (rc != VDF_OK) return rc; }
+  { int rc = eq_table_dev(sd, ry, d_eq_ry); if (rc != VDF_OK) return rc; }
   Fe m_ry;
   {
     const vdf_fe* tabs[2] = {(const vdf_fe*)d_mvec, (const vdf_fe*)d_eq_ry};
-    HIPCALL(ctx, vdf_reduce(ctx, PRIMARY_FIELD, VDF_REDUCE_DOT, tabs, nullptr, L.Z, (vdf_fe*)&m_ry));
+    HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_DOT, tabs, nullptr, L.Z, (vdf_fe*)&m_ry));
   }
   // z(r_y) = (1 - r_y[0]) W~(rest) + r_y[0] * (u, X)~(rest); index i of the public half has bits MSB-first over rest
   std::vector<Fe> rest(ry.begin() + 1, ry.end());
@@ -529,19 +535,57 @@ int spartan_verify(vdf_pp* pp, const Aff& cW, const Aff& cE, const Fe& u, const 
   IpaCheck checks[2];
   checks[0].label = "ipaW"; checks[0].n = L.NW; checks[0].rb = &rest; checks[0].v = pf.w_eval; checks[0].P = cW; checks[0].proof = &pf.ipaW;
   checks[1].label = "ipaE"; checks[1].n = L.M; checks[1].rb = &rx; checks[1].v = e; checks[1].P = cE; checks[1].proof = &pf.ipaE;
-  return ipa_verify_many(pp, tr, checks, 2, d_s, ok);
+  return ipa_verify_many(sd, tr, checks, 2, d_s, ok);
 }
 
 }  // namespace
 
-struct vdf_snark {          // NovaVDFProof::Compressed, src/nova/proof.rs:54
-  std::vector<StepRecord> steps;
-  Aff comm_W, comm_E;       // the folded instance the argument is about
-  Fe u, X[NUM_IO];
-  Spartan sp;
+struct vdf_snark {          // NovaVDFProof::Compressed, src/nova/proof.rs:54 = nova-snark CompressedSNARK
+  Inst r_U1, r_U2, l_u2;    // running primary, running secondary BEFORE the last fold, the last secondary instance
+  Aff T2;                   // cross-term commitment of that last fold
+  Spartan sp[2];            // sp[0]: r_U1 is satisfiable; sp[1]: fold(r_U2, l_u2) is
+  Fe zi1[3], zi2[1];
   uint64_t t = 0;           // the public parameters it was made under (wire header)
   uint8_t digest[32];
 };
+
+namespace {
+
+// instance fold on the host: U + r u with the cross-term commitment T (two 128-bit scalar multiplications)
+Inst fold_instance(const Side& sd, const Inst& U, const Inst& u, const Aff& T, const uint64_t r[4]) {
+  const Field& F = *sd.F;
+  const Field& Fb = *sd.Fb;
+  const Fe rf = int_to_fe(r, F);
+  Inst o;
+  o.comm_W = pt_to_aff(pt_add(pt_from_aff(U.comm_W, Fb), pt_mul(pt_from_aff(u.comm_W, Fb), r, 128, Fb), Fb), Fb);
+  o.comm_E = pt_to_aff(pt_add(pt_from_aff(U.comm_E, Fb), pt_mul(pt_from_aff(T, Fb), r, 128, Fb), Fb), Fb);
+  o.u = add(U.u, rf, F);
+  for (int k = 0; k < NUM_IO; ++k) o.X[k] = add(U.X[k], mul(rf, u.X[k], F), F);
+  return o;
+}
+
+void fold_challenge(const vdf_pp* pp, const Inst& U2, const Inst& l2, const Aff& T2, uint64_t r[4]) {
+  const Field& F2 = *pp->s[SECONDARY].F;
+  uint64_t ux[2][4];
+  for (int k = 0; k < 2; ++k) fe_to_int(l2.X[k], F2, ux[k]);
+  hash_challenge(pp->s[PRIMARY].field, pp->params[PRIMARY], to_relaxed(U2, F2), l2.comm_W, ux, T2, r);
+}
+
+size_t spartan_flat_size(const Spartan& p) {
+  return 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) + 128 * (p.ipaW.L.size() + p.ipaE.L.size());
+}
+size_t spartan_wire_size(const Layout& L) {
+  return 32 * (3 * (size_t)L.s + 4 + 2 * (size_t)L.l1 + 1 + ipa_final(L.NW) + ipa_final(L.M)) + 64 * (ipa_rounds(L.NW) + ipa_rounds(L.M));
+}
+void spartan_resize(Spartan& p, const Layout& L) {
+  p.outer.resize(L.s); p.inner.resize(L.l1);
+  p.ipaW.L.resize(ipa_rounds(L.NW)); p.ipaW.R.resize(ipa_rounds(L.NW)); p.ipaW.a.resize(ipa_final(L.NW));
+  p.ipaE.L.resize(ipa_rounds(L.M)); p.ipaE.R.resize(ipa_rounds(L.M)); p.ipaE.a.resize(ipa_final(L.M));
+}
+
+// the statement part of a compressed proof on the wire: instances with 32-byte points, then both z_i
+constexpr size_t STATEMENT_WIRE = 5 * 32 * 2 + 3 * 32 + 32 + 96 + 32;
+}  // namespace
 
 extern "C" {
 
@@ -549,21 +593,45 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
   if (!p || !pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
   *out = nullptr;
   if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
-  if (p->steps.empty()) return fail(VDF_ERR_BAD_LENGTH, "nothing to compress");
-  p->join();
+  if (p->i == 0) return fail(VDF_ERR_BAD_LENGTH, "nothing to compress");
+  { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
   vdf_ctx* ctx = pp->ctx;
+  const Side& S1 = pp->s[PRIMARY];
+  const Side& S2 = pp->s[SECONDARY];
   int was_async = 0;
   HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
   HIPCALL(ctx, vdf_ctx_sync(ctx));
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
   std::unique_ptr<vdf_snark> s(new vdf_snark());
-  s->steps = p->steps;
   s->t = pp->t;
   memcpy(s->digest, pp->digest, 32);
-  s->comm_W = p->comm_W; s->comm_E = p->comm_E; s->u = p->u;
-  for (int j = 0; j < NUM_IO; ++j) s->X[j] = p->X[j];
-  int rc = spartan_prove(pp, s->comm_W, s->comm_E, s->u, s->X, p->d_z1, p->d_E, &s->sp);
+  s->r_U1 = p->r[PRIMARY].inst; s->r_U2 = p->r[SECONDARY].inst; s->l_u2 = p->l2;
+  memcpy(s->zi1, p->zi[PRIMARY].data(), 96);
+  s->zi2[0] = p->zi[SECONDARY][0];
+  // the last secondary instance is folded into the running one (NIFS, as a prove_step would): into scratch, the proof is
+  // left as it is
+  vdf_proof* q = const_cast<vdf_proof*>(p);
+  SideState& s2 = q->r[SECONDARY];
+  DevBufs bufs(ctx);
+  void *d_fz, *d_fE;
+  { int rc = bufs.zeros(S2.ncols, &d_fz); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
+  { int rc = bufs.zeros(S2.num_cons, &d_fE); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
+  HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
+                                   (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
+                                   (vdf_fe*)s2.d_abc2[2], (vdf_fe*)s2.d_T));
+  vdf_jac jt;
+  HIPCALL(ctx, vdf_msm(ctx, S2.gens, 0, (const vdf_fe*)s2.d_T, S2.num_cons, 1, &jt));
+  s->T2 = jac_to_aff(jt, *S2.Fb);
+  uint64_t r[4];
+  fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
+  const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
+  const Fe rf = int_to_fe(r, *S2.F);
+  HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_z, (const vdf_fe*)&rf, (const vdf_fe*)p->d_l2z, S2.ncols, (vdf_fe*)d_fz));
+  HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_E, (const vdf_fe*)&rf, (const vdf_fe*)s2.d_T, S2.num_cons, (vdf_fe*)d_fE));
+  int rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]);
+  if (rc != VDF_OK) return rc;
+  rc = spartan_prove(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, d_fz, d_fE, &s->sp[1]);
   if (rc != VDF_OK) return rc;
   *out = s.release();
   return VDF_OK;
@@ -571,141 +639,26 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
 
 void vdf_nova_snark_free(vdf_snark* s) { delete s; }
 
-// flat canonical encoding of the argument (little-endian, non-Montgomery): outer rounds (3 each), 4 claims, inner
-// rounds (2 each), w, then per opening: (L, R) per round as affine (x, y), the final vector (at most 16 elements)
-size_t vdf_nova_snark_size(const vdf_snark* s) {
-  if (!s) return 0;
-  const Spartan& p = s->sp;
-  return 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) +
-         128 * (p.ipaW.L.size() + p.ipaE.L.size());
-}
-
-int vdf_nova_snark_bytes(const vdf_snark* s, uint8_t* out, size_t cap) {
-  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (cap < vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
-  uint8_t* o = out;
-  auto put = [&](const Fe& v, const Field& f) { const Fe c = from_mont(v, f); memcpy(o, c.l, 32); o += 32; };
-  auto put_pt = [&](const Aff& a) { if (a.is_id()) { memset(o, 0, 64); o += 64; } else { put(a.x, Fb); put(a.y, Fb); } };
-  for (const auto& ev : s->sp.outer) for (const Fe& v : ev) put(v, F);
-  for (const Fe& v : s->sp.claims) put(v, F);
-  for (const auto& ev : s->sp.inner) for (const Fe& v : ev) put(v, F);
-  put(s->sp.w_eval, F);
-  for (const Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
-    for (size_t j = 0; j < ip->L.size(); ++j) { put_pt(ip->L[j]); put_pt(ip->R[j]); }
-    for (const Fe& v : ip->a) put(v, F);
-  }
-  return VDF_OK;
-}
-
-// replaces the argument by the given encoding (deserialisation; the tests use it to tamper)
-int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
-  if (!s || !in) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (len != vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
-  const uint8_t* i = in;
-  bool canonical = true;
-  auto get = [&](Fe& v, const Field& f) { Fe c; memcpy(c.l, i, 32); i += 32; if (geq(c.l, f.m)) canonical = false; v = to_mont(c, f); };
-  auto get_pt = [&](Aff& a) { get(a.x, Fb); get(a.y, Fb); };
-  for (auto& ev : s->sp.outer) for (Fe& v : ev) get(v, F);
-  for (Fe& v : s->sp.claims) get(v, F);
-  for (auto& ev : s->sp.inner) for (Fe& v : ev) get(v, F);
-  get(s->sp.w_eval, F);
-  for (Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
-    for (size_t j = 0; j < ip->L.size(); ++j) { get_pt(ip->L[j]); get_pt(ip->R[j]); }
-    for (Fe& v : ip->a) get(v, F);
-  }
-  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
-  return VDF_OK;
-}
-
-// ---- the whole compressed proof as one byte string: chain (wire_host.cpp) | argument with 32-byte points --------
-static size_t argument_wire_size(const Layout& L) {
-  return 32 * (3 * (size_t)L.s + 4 + 2 * (size_t)L.l1 + 1 + ipa_final(L.NW) + ipa_final(L.M)) +
-         64 * (ipa_rounds(L.NW) + ipa_rounds(L.M));
-}
-
-size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
-  if (!s) return 0;
-  const Spartan& p = s->sp;
-  return wire_chain_size(s->steps.size()) + 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) +
-         64 * (p.ipaW.L.size() + p.ipaE.L.size());
-}
-
-int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
-  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (cap < vdf_nova_snark_serialized_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
-  uint8_t* o = wire_put_chain(out, WIRE_MAGIC_SNARK, s->t, s->digest, s->steps);
-  for (const auto& ev : s->sp.outer) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
-  for (const Fe& v : s->sp.claims) o = wire_put_fe(o, v, F);
-  for (const auto& ev : s->sp.inner) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
-  o = wire_put_fe(o, s->sp.w_eval, F);
-  for (const Ipa* ip : {&s->sp.ipaW, &s->sp.ipaE}) {
-    for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
-    for (const Fe& v : ip->a) o = wire_put_fe(o, v, F);
-  }
-  return VDF_OK;
-}
-
-// A verifier that never saw the prover's objects: bytes -> vdf_snark.  The folded instance is recomputed from the
-// chain (a verifier replays the folds anyway), so a decoded proof states nothing it does not derive.
-int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out) {
-  if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  *out = nullptr;
-  const Field& F = field(PRIMARY_FIELD);
-  const Field& Fb = field_fp();
-  std::unique_ptr<vdf_snark> s(new vdf_snark());
-  int rc = wire_get_chain(&in, &len, WIRE_MAGIC_SNARK, pp, &s->steps, &s->comm_W, &s->comm_E, &s->u, s->X);
-  if (rc != VDF_OK) return rc;
-  s->t = pp->t;
-  memcpy(s->digest, pp->digest, 32);
-  const Layout L = layout_of(pp);
-  if (len != argument_wire_size(L)) return fail(VDF_ERR_BAD_LENGTH, "argument section has the wrong length for this shape");
-  Spartan& p = s->sp;
-  p.outer.resize(L.s); p.inner.resize(L.l1);
-  p.ipaW.L.resize(ipa_rounds(L.NW)); p.ipaW.R.resize(ipa_rounds(L.NW)); p.ipaW.a.resize(ipa_final(L.NW));
-  p.ipaE.L.resize(ipa_rounds(L.M)); p.ipaE.R.resize(ipa_rounds(L.M)); p.ipaE.a.resize(ipa_final(L.M));
-  bool canonical = true, on_curve = true;
-  auto get = [&](Fe& v) { canonical &= wire_get_fe(in, F, &v); in += 32; };
-  for (auto& ev : p.outer) for (Fe& v : ev) get(v);
-  for (Fe& v : p.claims) get(v);
-  for (auto& ev : p.inner) for (Fe& v : ev) get(v);
-  get(p.w_eval);
-  for (Ipa* ip : {&p.ipaW, &p.ipaE}) {
-    for (size_t j = 0; j < ip->L.size(); ++j) {
-      on_curve &= pt_decompress(in, Fb, &ip->L[j]);
-      on_curve &= pt_decompress(in + 32, Fb, &ip->R[j]);
-      in += 64;
-    }
-    for (Fe& v : ip->a) get(v);
-  }
-  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the argument is not canonical");
-  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the argument does not decode to a curve point");
-  *out = s.release();
-  return VDF_OK;
-}
-
-// verification of the compressed proof (src/nova/proof.rs:383): the fold replay of vdf_nova_verify without the
-// witness, then the argument that the folded instance is satisfiable
+// verification of the compressed proof (src/nova/proof.rs:383): the two output hashes, the last fold of the instances,
+// then one argument per side
 int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
   if (!s || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
   *ok = 0;
-  const Field& F = field(PRIMARY_FIELD);
-  if (num_steps == 0 || s->steps.size() != num_steps) return VDF_OK;
-  if (memcmp(s->steps[0].X, z0, 96) != 0) return VDF_OK;
-  for (size_t k = 0; k + 1 < num_steps; ++k)
-    if (memcmp(&s->steps[k].X[3], &s->steps[k + 1].X[0], 96) != 0) return VDF_OK;
-  const Fe tfe = from_u64(pp->t, F);
-  for (size_t k = 0; k < num_steps; ++k)
-    if (sub(s->steps[k].X[2], s->steps[k].X[5], F) != tfe) return VDF_OK;
-  Aff cW, cE;
-  Fe u, X[NUM_IO];
-  if (!fold_replay(pp, s->steps, nullptr, &cW, &cE, &u, X)) return VDF_OK;
-  if (memcmp(&cW, &s->comm_W, 64) || memcmp(&cE, &s->comm_E, 64) || u != s->u || memcmp(X, s->X, sizeof(X))) return VDF_OK;
+  if (s->t != pp->t || memcmp(s->digest, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+  if (num_steps == 0) return VDF_OK;
+  const Side& S1 = pp->s[PRIMARY];
+  const Side& S2 = pp->s[SECONDARY];
+  const Field& F1 = *S1.F;
+  const Field& F2 = *S2.F;
+  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + 3), z0s(1, zero()), zi1(s->zi1, s->zi1 + 3), zi2(s->zi2, s->zi2 + 1);
+  uint64_t hv[4];
+  hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv);
+  if (int_to_fe(hv, F2) != s->l_u2.X[0]) return VDF_OK;
+  hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, zi2, to_relaxed(s->r_U1, F1), hv);
+  if (int_to_fe(hv, F2) != s->l_u2.X[1]) return VDF_OK;
+  uint64_t r[4];
+  fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
+  const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
   vdf_ctx* ctx = pp->ctx;
   int was_async = 0;
   HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
@@ -713,10 +666,160 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
   bool good = false;
-  int rc = spartan_verify(pp, s->comm_W, s->comm_E, s->u, s->X, s->sp, &good);
+  int rc = spartan_verify(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, s->sp[0], &good);
   if (rc != VDF_OK) return rc;
   if (!good) return VDF_OK;
-  *ok = memcmp(&s->steps[num_steps - 1].X[3], zi, 96) == 0 ? 1 : 0;
+  rc = spartan_verify(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, s->sp[1], &good);
+  if (rc != VDF_OK) return rc;
+  if (!good) return VDF_OK;
+  *ok = (memcmp(s->zi1, zi, 96) == 0 && s->zi2[0].is_zero()) ? 1 : 0;       // src/nova/proof.rs:386
+  return VDF_OK;
+}
+
+// flat canonical encoding of the two arguments (little-endian, non-Montgomery), primary then secondary; per argument:
+// outer rounds (3 each), 4 claims, inner rounds (2 each), w, then per opening (L, R) per round as affine (x, y) and the
+// final vector (at most 16 elements)
+size_t vdf_nova_snark_size(const vdf_snark* s) { return s ? spartan_flat_size(s->sp[0]) + spartan_flat_size(s->sp[1]) : 0; }
+
+int vdf_nova_snark_bytes(const vdf_snark* s, uint8_t* out, size_t cap) {
+  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (cap < vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
+  uint8_t* o = out;
+  for (int side = 0; side < 2; ++side) {
+    const Field& F = field(side_field(side));
+    const Field& Fb = field(side_field(1 - side));
+    const Spartan& sp = s->sp[side];
+    auto put = [&](const Fe& v, const Field& f) { const Fe c = from_mont(v, f); memcpy(o, c.l, 32); o += 32; };
+    auto put_pt = [&](const Aff& a) { if (a.is_id()) { memset(o, 0, 64); o += 64; } else { put(a.x, Fb); put(a.y, Fb); } };
+    for (const auto& ev : sp.outer) for (const Fe& v : ev) put(v, F);
+    for (const Fe& v : sp.claims) put(v, F);
+    for (const auto& ev : sp.inner) for (const Fe& v : ev) put(v, F);
+    put(sp.w_eval, F);
+    for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+      for (size_t j = 0; j < ip->L.size(); ++j) { put_pt(ip->L[j]); put_pt(ip->R[j]); }
+      for (const Fe& v : ip->a) put(v, F);
+    }
+  }
+  return VDF_OK;
+}
+
+// replaces both arguments by the given encoding (the tests use it to tamper): field elements must be canonical and
+// every point the identity or on its curve
+int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
+  if (!s || !in) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (len != vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
+  const uint8_t* i = in;
+  bool canonical = true, on_curve = true;
+  Spartan tmp[2] = {s->sp[0], s->sp[1]};
+  for (int side = 0; side < 2; ++side) {
+    const Field& F = field(side_field(side));
+    const Field& Fb = field(side_field(1 - side));
+    Spartan& sp = tmp[side];
+    auto get = [&](Fe& v, const Field& f) { Fe c; memcpy(c.l, i, 32); i += 32; if (geq(c.l, f.m)) canonical = false; v = to_mont(c, f); };
+    auto get_pt = [&](Aff& a) {
+      get(a.x, Fb); get(a.y, Fb);
+      if (!a.is_id() && sqr(a.y, Fb) != add(mul(sqr(a.x, Fb), a.x, Fb), from_u64(5, Fb), Fb)) on_curve = false;
+    };
+    for (auto& ev : sp.outer) for (Fe& v : ev) get(v, F);
+    for (Fe& v : sp.claims) get(v, F);
+    for (auto& ev : sp.inner) for (Fe& v : ev) get(v, F);
+    get(sp.w_eval, F);
+    for (Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+      for (size_t j = 0; j < ip->L.size(); ++j) { get_pt(ip->L[j]); get_pt(ip->R[j]); }
+      for (Fe& v : ip->a) get(v, F);
+    }
+  }
+  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
+  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding is not on its curve");
+  s->sp[0] = tmp[0]; s->sp[1] = tmp[1];
+  return VDF_OK;
+}
+
+// ---- the whole compressed proof as one byte string ("VDFSNK03", layout in include/vdf_nova.h) -----------------------
+size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
+  if (!s) return 0;
+  size_t n = 8 + 8 + 32 + STATEMENT_WIRE;
+  for (const Spartan& p : s->sp)
+    n += 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) + 64 * (p.ipaW.L.size() + p.ipaE.L.size());
+  return n;
+}
+
+int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
+  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (cap < vdf_nova_snark_serialized_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
+  Side sd[2];
+  for (int k = 0; k < 2; ++k) { sd[k].F = &field(side_field(k)); sd[k].Fb = &field(side_field(1 - k)); }
+  uint8_t* o = out;
+  memcpy(o, WIRE_MAGIC_SNARK, 8); o += 8;
+  memcpy(o, &s->t, 8); o += 8;
+  memcpy(o, s->digest, 32); o += 32;
+  o = put_inst(o, s->r_U1, sd[0], true);
+  o = put_inst(o, s->r_U2, sd[1], true);
+  o = put_inst(o, s->l_u2, sd[1], false);
+  pt_compress(s->T2, *sd[1].Fb, o); o += 32;
+  for (int k = 0; k < 3; ++k) o = wire_put_fe(o, s->zi1[k], *sd[0].F);
+  o = wire_put_fe(o, s->zi2[0], *sd[1].F);
+  for (int side = 0; side < 2; ++side) {
+    const Field& F = *sd[side].F;
+    const Field& Fb = *sd[side].Fb;
+    const Spartan& sp = s->sp[side];
+    for (const auto& ev : sp.outer) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+    for (const Fe& v : sp.claims) o = wire_put_fe(o, v, F);
+    for (const auto& ev : sp.inner) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+    o = wire_put_fe(o, sp.w_eval, F);
+    for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+      for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
+      for (const Fe& v : ip->a) o = wire_put_fe(o, v, F);
+    }
+  }
+  return VDF_OK;
+}
+
+// A verifier that never saw the prover's objects: bytes -> vdf_snark
+int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out) {
+  if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  *out = nullptr;
+  if (len < 48 + STATEMENT_WIRE) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
+  if (memcmp(in, WIRE_MAGIC_SNARK, 8) != 0) return fail(VDF_ERR_BAD_ARG, "not this kind of encoding (magic)");
+  uint64_t t;
+  memcpy(&t, in + 8, 8);
+  if (t != pp->t || memcmp(in + 16, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "encoding was made under other public parameters");
+  const Layout L[2] = {layout_of(pp->s[0]), layout_of(pp->s[1])};
+  if (len != 48 + STATEMENT_WIRE + spartan_wire_size(L[0]) + spartan_wire_size(L[1]))
+    return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
+  std::unique_ptr<vdf_snark> s(new vdf_snark());
+  s->t = t;
+  memcpy(s->digest, pp->digest, 32);
+  const uint8_t* i = in + 48;
+  bool canonical = true, on_curve = true;
+  i = get_inst(i, &s->r_U1, pp->s[0], true, &canonical, &on_curve);
+  i = get_inst(i, &s->r_U2, pp->s[1], true, &canonical, &on_curve);
+  i = get_inst(i, &s->l_u2, pp->s[1], false, &canonical, &on_curve);
+  on_curve &= pt_decompress(i, *pp->s[1].Fb, &s->T2); i += 32;
+  for (int k = 0; k < 3; ++k, i += 32) canonical &= wire_get_fe(i, *pp->s[0].F, &s->zi1[k]);
+  canonical &= wire_get_fe(i, *pp->s[1].F, &s->zi2[0]); i += 32;
+  for (int side = 0; side < 2; ++side) {
+    const Field& F = *pp->s[side].F;
+    const Field& Fb = *pp->s[side].Fb;
+    Spartan& p = s->sp[side];
+    spartan_resize(p, L[side]);
+    auto get = [&](Fe& v) { canonical &= wire_get_fe(i, F, &v); i += 32; };
+    for (auto& ev : p.outer) for (Fe& v : ev) get(v);
+    for (Fe& v : p.claims) get(v);
+    for (auto& ev : p.inner) for (Fe& v : ev) get(v);
+    get(p.w_eval);
+    for (Ipa* ip : {&p.ipaW, &p.ipaE}) {
+      for (size_t j = 0; j < ip->L.size(); ++j) {
+        on_curve &= pt_decompress(i, Fb, &ip->L[j]);
+        on_curve &= pt_decompress(i + 32, Fb, &ip->R[j]);
+        i += 64;
+      }
+      for (Fe& v : ip->a) get(v);
+    }
+  }
+  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
+  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding does not decode to a curve point");
+  *out = s.release();
   return VDF_OK;
 }
 

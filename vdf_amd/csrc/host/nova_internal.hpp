@@ -138,4 +138,24 @@ inline bool wire_get_fe(const uint8_t* i, const Field& F, Fe* v) {
   *v = to_mont(c, F);
   return true;
 }
+// an instance on the wire: commitment(s) as 32-byte points, then (u and) X; a strict instance has no comm_E and u = 1
+inline uint8_t* put_inst(uint8_t* o, const Inst& in, const Side& sd, bool relaxed) {
+  pt_compress(in.comm_W, *sd.Fb, o); o += 32;
+  if (relaxed) { pt_compress(in.comm_E, *sd.Fb, o); o += 32; o = wire_put_fe(o, in.u, *sd.F); }
+  for (int k = 0; k < NUM_IO; ++k) o = wire_put_fe(o, in.X[k], *sd.F);
+  return o;
+}
+inline const uint8_t* get_inst(const uint8_t* i, Inst* in, const Side& sd, bool relaxed, bool* canonical, bool* on_curve) {
+  *on_curve &= pt_decompress(i, *sd.Fb, &in->comm_W); i += 32;
+  if (relaxed) {
+    *on_curve &= pt_decompress(i, *sd.Fb, &in->comm_E); i += 32;
+    *canonical &= wire_get_fe(i, *sd.F, &in->u); i += 32;
+  } else {
+    memset(&in->comm_E, 0, sizeof(Aff));
+    in->u = one(*sd.F);
+  }
+  for (int k = 0; k < NUM_IO; ++k) { *canonical &= wire_get_fe(i, *sd.F, &in->X[k]); i += 32; }
+  return i;
+}
+constexpr size_t INST_WIRE_RELAXED = 32 * 5, INST_WIRE_STRICT = 32 * 3;
 }  // namespace vdfnova
