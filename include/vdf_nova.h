@@ -145,6 +145,10 @@ int  vdf_nova_aug_synthesize(int side, uint64_t num_iters_per_step, int circuit_
                              const vdf_state* result, const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars,
                              size_t* num_cons, vdf_fe X[2], vdf_fe z_next[3]);
 
+/* of the calling thread's last augmented-circuit synthesis: how many slope inverses the native pre-pass queued (batched
+ * inversion) and how many of them were wrong or unused (0 for well-formed inputs: the queue is only an accelerator) */
+int  vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses);
+
 /* ---- compression (src/nova/proof.rs:360-368, :383) ---------------------------------------------------------
  * NovaVDFProof::compress -> nova-snark CompressedSNARK::prove: the last secondary instance is folded into the running
  * one, then one succinct argument PER SIDE (SS1 / SS2 of :32-33) that the running primary instance and the folded

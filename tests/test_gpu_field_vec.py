@@ -338,3 +338,68 @@ def test_ctx_marks(ctx):
         assert np.array_equal(got1, exp1)
     finally:
         ctx.set_async(was)
+
+
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+def test_spmv_and_fused_cross_term_on_skewed_rows(ctx, cref, field):
+    """Rows of 0 .. 300 entries with arbitrary coefficients, as an augmented circuit has them (bit packings of 255 terms,
+    Poseidon states of ~60): rows beyond VDF_LONG_ROW = 8 entries are summed by a wavefront each (k_spmv_long) ahead of
+    the lane-per-row kernels.  Against the C restatement, for vdf_spmv3 and for vdf_nifs_cross_term."""
+    m = o.modulus(field)
+    rng = np.random.default_rng(77 + field)
+    lens = [0, 1, 2, 7, 8, 9, 10, 33, 63, 64, 65, 127, 128, 129, 255, 300] * 9 + [1] * 500 + [60] * 200
+    rng.shuffle(lens)
+    nc, ncols = len(lens), 700
+    mats = []
+    for k in range(3):
+        rows, cols, vals = [], [], []
+        for r, ln in enumerate(np.roll(lens, 17 * k)):
+            cs = rng.choice(ncols, size=int(ln), replace=False) if ln <= ncols else rng.integers(0, ncols, size=int(ln))
+            for c in cs:
+                rows.append(r); cols.append(int(c))
+                kind = rng.integers(0, 4)
+                vals.append(1 if kind == 0 else (m - 1 if kind == 1 else int(rng.integers(2, 1 << 62)) * int(rng.integers(1, 1 << 62)) % m))
+        mats.append((np.array(rows, dtype=np.uint32), np.array(cols, dtype=np.uint32), mont(vals, m) if vals else np.zeros((0, 4), dtype="<u8")))
+    shape = ctx.shape_create(field, nc, ncols, mats)
+    z = rand_limbs(rng, ncols)
+    outs = [np.zeros((nc, 4), dtype="<u8") for _ in range(3)]
+    ctx.spmv3(shape, z, *outs)
+    exp = []
+    for (rows, cols, vals), got in zip(mats, outs):
+        e = cref.fe_array(nc)
+        cref.lib().ref_spmv(field, cref.p(rows), cref.p(cols), cref.p(vals), len(rows), cref.p(z), nc, cref.p(e))
+        assert np.array_equal(got, e)
+        exp.append(e)
+    abc1 = [rand_limbs(rng, nc) for _ in range(3)]
+    u1 = rand_limbs(rng, 1)
+    expT = cref.fe_array(nc)
+    cref.lib().ref_cross_term(field, *(cref.p(x) for x in abc1 + exp), cref.p(u1), nc, cref.p(expT))
+    d2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    dT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term(shape, _dev(z), *[_dev(x) for x in abc1], u1, *d2, dT)
+    ctx.sync()
+    for got, e in zip(d2, exp):
+        assert np.array_equal(_host(got), e)
+    assert np.array_equal(_host(dT), expT)
+    shape.free()
+
+
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+@pytest.mark.parametrize("t,per", [(1, 3), (5, 4), (1024, 3), (65536, 3), (4097, 4)])
+def test_minroot_step_segment(ctx, cref, field, t, per):
+    """vdf_minroot_step_segment: the step circuit's own variables inside an augmented circuit -- per = 4 is the reference's
+    allocation (src/nova/proof.rs:167-181), per = 3 the bound form without new_x -- against the C restatement's witness."""
+    m = o.modulus(field)
+    st = mont([o.rand_fe(5, 0, m), 0, 1], m)
+    so, tr = cref.fe_array(3), cref.fe_array(2 * (t + 1))
+    cref.lib().ref_minroot_eval(field, 1, cref.p(st), t, cref.p(so), cref.p(tr))
+    W = cref.fe_array(4 * t + 1)
+    cref.lib().ref_step_witness(field, cref.p(so), t, cref.p(W))
+    out = _dev(np.zeros((per * t + 1, 4), dtype="<u8"))
+    i0 = st[2:3].copy()
+    ctx.minroot_step_segment(field, _dev(tr), t, i0, per, out)
+    ctx.sync()
+    got = _host(out)
+    rounds = W[:4 * t].reshape(t, 4, 4)
+    want = rounds if per == 4 else rounds[:, 1:, :]
+    assert np.array_equal(got[:per * t], want.reshape(per * t, 4)) and np.array_equal(got[per * t], W[4 * t])

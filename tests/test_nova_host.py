@@ -115,6 +115,8 @@ def test_augmented_circuit_witness_equals_the_restatement(oracle_run):
         got = unmont(W, f)
         bad = [k for k in range(len(got)) if got[k] != fresh.W[k]]
         assert not bad, (side, inp.i, bad[:5])
+        # all 2 x (128 chords + 127 tangents + 1 final slope) inverses came from the batched pre-pass
+        assert vn.synthesis_stats() == (512, 0)
 
 
 def test_reference_circuit_witness(oracle_run):

@@ -728,6 +728,7 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
       for (int k = 0; k < 3; ++k) { (void)hipFree(s->d_rowptr[k]); (void)hipFree(s->d_col[k]); (void)hipFree(s->d_coef[k]); }
       (void)hipFree(s->d_dict);
       (void)hipFree(s->d_t_colptr); (void)hipFree(s->d_t_row); (void)hipFree(s->d_t_cm); (void)hipFree(s->d_t_heavy);
+      (void)hipFree(s->d_long);
       delete s;
     };
     hipError_t e = hipMalloc(&s->d_dict, dict.size() * 32);
@@ -769,6 +770,16 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_heavy), (heavy.size() + 1) * 4);
       if (e == hipSuccess && !heavy.empty()) e = hipMemcpy(s->d_t_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess) {
+      std::vector<uint32_t> lng;
+      for (int k = 0; k < 3; ++k)
+        for (size_t r = 0; r < num_cons; ++r)
+          if (rowptr[k][r + 1] - rowptr[k][r] > VDF_LONG_ROW) lng.push_back((uint32_t)r | ((uint32_t)k << 30));
+      if (num_cons >= (1u << 30) && !lng.empty()) e = hipErrorInvalidValue;
+      s->n_long = lng.size();
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_long), (lng.size() + 1) * 4);
+      if (e == hipSuccess && !lng.empty()) e = hipMemcpy(s->d_long, lng.data(), lng.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { cleanup(); return vdf::hip_status(e, "vdf_shape_create upload"); }
     *out = s;
     return Status{};
@@ -784,6 +795,7 @@ void vdf_shape_free(vdf_shape* shape) {
     for (int k = 0; k < 3; ++k) { (void)hipFree(shape->d_rowptr[k]); (void)hipFree(shape->d_col[k]); (void)hipFree(shape->d_coef[k]); }
     (void)hipFree(shape->d_dict);
     (void)hipFree(shape->d_t_colptr); (void)hipFree(shape->d_t_row); (void)hipFree(shape->d_t_cm); (void)hipFree(shape->d_t_heavy);
+    (void)hipFree(shape->d_long);
   }
   delete shape;
 }
@@ -797,6 +809,8 @@ int vdf_spmv3(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z, vdf_fe* Az,
     VDF_TRY(st.out(Az, shape->num_cons * 32, &o[0]));
     VDF_TRY(st.out(Bz, shape->num_cons * 32, &o[1]));
     VDF_TRY(st.out(Cz, shape->num_cons * 32, &o[2]));
+    VDF_TRY(vdf::vec_spmv_long(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, dz, shape->d_long,
+                               shape->n_long, o, ctx->stream));
     for (int k = 0; k < 3; ++k)
       VDF_TRY(vdf::vec_spmv(shape->field, shape->d_rowptr[k], shape->d_col[k], shape->d_coef[k], shape->d_dict, dz,
                             shape->num_cons, o[k], ctx->stream));
@@ -894,6 +908,9 @@ int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, 
     const void* vec[8] = {z2, Az1, Bz1, Cz1, Az2, Bz2, Cz2, T};
     for (const void* v : vec)
       if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    void* const outs[3] = {Az2, Bz2, Cz2};
+    VDF_TRY(vdf::vec_spmv_long(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, shape->d_long,
+                               shape->n_long, outs, ctx->stream));
     VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
                                 u1, shape->num_cons, Az2, Bz2, Cz2, T, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));

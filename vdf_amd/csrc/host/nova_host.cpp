@@ -271,6 +271,12 @@ int vdf_nova_aug_synthesize(int side, uint64_t t, int circuit_kind, const vdf_no
   return VDF_OK;
 }
 
+int vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses) {
+  if (!queued || !misses) return fail(VDF_ERR_BAD_ARG, "null argument");
+  last_synthesis_stats(queued, misses);
+  return VDF_OK;
+}
+
 // ---- public parameters -------------------------------------------------------------------------------
 int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);

@@ -103,6 +103,44 @@ Num CS::mul(const Num& a, const Num& b) {
 }
 void CS::enforce_equal(const Num& a, const Num& b) { enforce(sub(a, b), constant(one(F)), zero_num()); }
 
+Fe CS::take_inverse(const Fe& den) {
+  if (inv_pos < inv_queue.size()) {
+    const Fe& c = inv_queue[inv_pos++];
+    if (den.is_zero() ? c.is_zero() : vdfhost::mul(den, c, F) == one(F)) return c;
+    ++inv_misses;
+  }
+  return inverse(den, F);
+}
+Num CS::alloc_inverse_later(const Fe& a) {
+  if (shape || a.is_zero()) return alloc(vdfhost::zero());     // shape mode: values are never read
+  later_.emplace_back(W.size(), a);
+  return alloc(vdfhost::zero());
+}
+void CS::resolve() {
+  if (later_.empty()) return;
+  std::vector<Fe> v(later_.size());
+  for (size_t k = 0; k < v.size(); ++k) v[k] = later_[k].second;
+  batch_inverse(v.data(), v.size(), F);
+  for (size_t k = 0; k < v.size(); ++k) W[later_[k].first] = v[k];
+  later_.clear();
+}
+
+void batch_inverse(Fe* v, size_t n, const Field& F) {
+  std::vector<Fe> pre(n);
+  Fe run = one(F);
+  for (size_t i = 0; i < n; ++i) {
+    pre[i] = run;
+    if (!v[i].is_zero()) run = vdfhost::mul(run, v[i], F);
+  }
+  Fe inv = inverse(run, F);
+  for (size_t i = n; i-- > 0;) {
+    if (v[i].is_zero()) continue;
+    const Fe x = vdfhost::mul(inv, pre[i], F);
+    inv = vdfhost::mul(inv, v[i], F);
+    v[i] = x;
+  }
+}
+
 void CS::finish(Coo out[3]) const {
   const uint32_t nv = (uint32_t)W.size();
   auto col = [&](uint32_t key) { return key < KEY_ONE ? key : nv + (key - KEY_ONE); };
@@ -146,22 +184,23 @@ const RoConstants& ro_constants(int f) {
   return f == VDF_FIELD_FP ? fp : fq;
 }
 
-static inline Fe times_small(const Fe& a, unsigned k, const Field& F) {
-  Fe acc = vdfhost::zero(), base = a;
-  for (unsigned e = k; e; e >>= 1) {
-    if (e & 1) acc = vdfhost::add(acc, base, F);
-    base = vdfhost::add(base, base, F);
-  }
-  return acc;
-}
+static inline Fe dbl(const Fe& a, const Field& F) { return vdfhost::add(a, a, F); }
+// M4 s with 14 additions (the factorisation of the Poseidon2 paper, section 5.1)
 static inline void ext_layer(Fe s[4], const Field& F) {
-  Fe o[4];
-  for (int i = 0; i < 4; ++i) {
-    Fe acc = vdfhost::zero();
-    for (int j = 0; j < 4; ++j) acc = vdfhost::add(acc, times_small(s[j], (unsigned)M4[i][j], F), F);
-    o[i] = acc;
-  }
-  for (int i = 0; i < 4; ++i) s[i] = o[i];
+  const Fe t0 = vdfhost::add(s[0], s[1], F), t1 = vdfhost::add(s[2], s[3], F);
+  const Fe t2 = vdfhost::add(dbl(s[1], F), t1, F), t3 = vdfhost::add(dbl(s[3], F), t0, F);
+  const Fe t4 = vdfhost::add(dbl(dbl(t1, F), F), t3, F), t5 = vdfhost::add(dbl(dbl(t0, F), F), t2, F);
+  s[0] = vdfhost::add(t3, t5, F); s[1] = t5; s[2] = vdfhost::add(t2, t4, F); s[3] = t4;
+}
+static_assert(true, "M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]");
+// ones off the diagonal, (2, 3, 6, 8) on it: s_i <- sum + (mu_i - 1) s_i with (mu - 1) = (1, 2, 5, 7)
+static inline void int_layer(Fe s[4], const Field& F) {
+  const Fe tot = vdfhost::add(vdfhost::add(s[0], s[1], F), vdfhost::add(s[2], s[3], F), F);
+  const Fe s2x4 = dbl(dbl(s[2], F), F), s3x8 = dbl(dbl(dbl(s[3], F), F), F);
+  s[0] = vdfhost::add(tot, s[0], F);
+  s[1] = vdfhost::add(tot, dbl(s[1], F), F);
+  s[2] = vdfhost::add(tot, vdfhost::add(s2x4, s[2], F), F);
+  s[3] = vdfhost::add(tot, vdfhost::sub(s3x8, s[3], F), F);
 }
 static inline Fe pow5(const Fe& x, const Field& F) { const Fe x2 = sqr(x, F); return vdfhost::mul(sqr(x2, F), x, F); }
 
@@ -176,8 +215,7 @@ void ro_permute(Fe s[RO_T], int f) {
       ext_layer(s, F);
     } else {
       s[0] = pow5(vdfhost::add(s[0], rc.in[r - RO_RF / 2], F), F);
-      const Fe tot = vdfhost::add(vdfhost::add(s[0], s[1], F), vdfhost::add(s[2], s[3], F), F);
-      for (int i = 0; i < 4; ++i) s[i] = vdfhost::add(tot, times_small(s[i], rc.mu_minus_1[i], F), F);
+      int_layer(s, F);
     }
   }
 }
@@ -198,7 +236,7 @@ Fe ro_hash(int f, uint64_t tag, const Fe* xs, size_t n) {
 Num is_zero(CS& cs, const Num& a) {
   const Field& F = cs.F;
   Num z = cs.alloc(a.v.is_zero() ? one(F) : vdfhost::zero());
-  Num inv = cs.alloc(inverse(a.v, F));                  // 0 for 0
+  Num inv = cs.alloc_inverse_later(a.v);                // 0 for 0; filled by cs.resolve()
   cs.enforce(a, inv, cs.sub(cs.constant(one(F)), z));
   cs.enforce(a, z, cs.zero_num());
   return z;
@@ -215,6 +253,15 @@ std::vector<Num> alloc_bits(CS& cs, const uint64_t v[4], int n) {
   const Fe o = one(F), z = vdfhost::zero();
   const Num one_n = cs.constant(o);
   std::vector<Num> bits;
+  if (!cs.shape) {
+    bits.resize(n);
+    for (int k = 0; k < n; ++k) {
+      bits[k].v = ((v[k / 64] >> (k % 64)) & 1) ? o : z;
+      cs.W.push_back(bits[k].v);
+    }
+    cs.rows += n;
+    return bits;
+  }
   bits.reserve(n);
   for (int k = 0; k < n; ++k) {
     Num b = cs.alloc(((v[k / 64] >> (k % 64)) & 1) ? o : z);
@@ -296,6 +343,28 @@ static Num sbox(CS& cs, const Num& x) {
   const Num x4 = cs.mul(x2, x2);
   return cs.mul(x4, x);
 }
+// witness mode: the permutation on bare field elements; an S-box leaves x^2, x^4, x^5 in W (three constraints)
+static void poseidon_permute_witness(CS& cs, Fe s[4]) {
+  const Field& F = cs.F;
+  const RoConstants& rc = ro_constants(cs.field_id);
+  auto sbox_w = [&](const Fe& x) {
+    const Fe x2 = sqr(x, F), x4 = sqr(x2, F), x5 = vdfhost::mul(x4, x, F);
+    cs.W.push_back(x2); cs.W.push_back(x4); cs.W.push_back(x5);
+    cs.rows += 3;
+    return x5;
+  };
+  ext_layer(s, F);
+  for (int r = 0; r < RO_RF + RO_RP; ++r) {
+    if (r < RO_RF / 2 || r >= RO_RF / 2 + RO_RP) {
+      const Fe* k = rc.ext[r < RO_RF / 2 ? r : r - RO_RP];
+      for (int i = 0; i < 4; ++i) s[i] = sbox_w(vdfhost::add(s[i], k[i], F));
+      ext_layer(s, F);
+    } else {
+      s[0] = sbox_w(vdfhost::add(s[0], rc.in[r - RO_RF / 2], F));
+      int_layer(s, F);
+    }
+  }
+}
 static void poseidon_permute(CS& cs, std::vector<Num>& s) {
   const RoConstants& rc = ro_constants(cs.field_id);
   ext_layer_num(cs, s);
@@ -312,6 +381,17 @@ static void poseidon_permute(CS& cs, std::vector<Num>& s) {
   }
 }
 Num poseidon_hash(CS& cs, uint64_t tag, const std::vector<Num>& xs) {
+  if (!cs.shape) {
+    const Field& F = cs.F;
+    Fe st[4] = {from_u64(tag + ((uint64_t)xs.size() << 32), F), vdfhost::zero(), vdfhost::zero(), vdfhost::zero()};
+    for (size_t k = 0; k < xs.size(); k += RO_RATE) {
+      for (size_t j = 0; j < RO_RATE && k + j < xs.size(); ++j) st[1 + j] = vdfhost::add(st[1 + j], xs[k + j].v, F);
+      poseidon_permute_witness(cs, st);
+    }
+    Num out;
+    out.v = st[1];
+    return out;
+  }
   std::vector<Num> s(4);
   s[0] = cs.constant_u64(tag + ((uint64_t)xs.size() << 32));
   s[1] = s[2] = s[3] = cs.zero_num();
@@ -334,7 +414,7 @@ static void ec_double_raw(CS& cs, const Num& x, const Num& y, Num* ox, Num* oy) 
   const Field& F = cs.F;
   const Num x2 = cs.mul(x, x);
   const Num two_y = cs.scale_small(y, 2), three_x2 = cs.scale_small(x2, 3);
-  const Num lam = cs.alloc(vdfhost::mul(three_x2.v, inverse(two_y.v, F), F));
+  const Num lam = cs.alloc(vdfhost::mul(three_x2.v, cs.take_inverse(two_y.v), F));
   cs.enforce(lam, two_y, three_x2);
   const Num two_x = cs.scale_small(x, 2);
   const Num dx = cs.alloc(vdfhost::sub(sqr(lam.v, F), two_x.v, F));
@@ -346,7 +426,7 @@ static void ec_double_raw(CS& cs, const Num& x, const Num& y, Num* ox, Num* oy) 
 static void ec_add_raw(CS& cs, const Num& x1, const Num& y1, const Num& x2, const Num& y2, Num* ox, Num* oy) {
   const Field& F = cs.F;
   const Num dxn = cs.sub(x2, x1), dyn = cs.sub(y2, y1);
-  const Num lam = cs.alloc(vdfhost::mul(dyn.v, inverse(dxn.v, F), F));
+  const Num lam = cs.alloc(vdfhost::mul(dyn.v, cs.take_inverse(dxn.v), F));
   cs.enforce(lam, dxn, dyn);
   const Num sx = cs.alloc(vdfhost::sub(vdfhost::sub(sqr(lam.v, F), x1.v, F), x2.v, F));
   cs.enforce(lam, lam, cs.add(cs.add(sx, x1), x2));
@@ -388,7 +468,7 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
   const Num x1sq = cs.mul(x1, x1);
   const Num num = select(cs, same_x, cs.scale_small(x1sq, 3), cs.sub(y2, y1));
   const Num den = select(cs, same_x, cs.scale_small(y1, 2), cs.sub(x2, x1));
-  const Num lam = cs.alloc(vdfhost::mul(num.v, inverse(den.v, F), F));
+  const Num lam = cs.alloc(vdfhost::mul(num.v, cs.take_inverse(den.v), F));
   cs.enforce(lam, den, num);
   const Num x3 = cs.alloc(vdfhost::sub(vdfhost::sub(sqr(lam.v, F), x1.v, F), x2.v, F));
   cs.enforce(lam, lam, cs.add(cs.add(x3, x1), x2));
@@ -400,6 +480,43 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
   const Num ux = select(cs, i2, x1, tx), uy = select(cs, i2, y1, ty);
   *ox = select(cs, i1, x2, ux);
   *oy = select(cs, i1, y2, uy);
+}
+
+// Native pre-pass for  U + [r] P : the true points 2^k P and (r mod 2^(k+1)) P in projective coordinates, one batched
+// normalisation, then every denominator the gadgets will meet -- chord of (r mod 2^k) P and 2^k P, tangent at 2^k P,
+// k < bits, and the slope of the final complete addition -- inverted in a second batch.
+void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out) {
+  std::vector<Pt> pts(2 * (size_t)bits);                 // [k] = 2^k P, [bits + k] = acc after bit k
+  Pt w = pt_from_aff(P, F), acc = pt_identity();
+  for (int k = 0; k < bits; ++k) {
+    pts[k] = w;
+    if ((r[k / 64] >> (k % 64)) & 1) acc = pt_add(acc, w, F);
+    pts[bits + k] = acc;
+    if (k + 1 < bits) w = pt_dbl(w, F);
+  }
+  // affine forms: x = X / zz, y = Y / zzz, 1 / zz = zz^2 / zzz^2
+  std::vector<Fe> iz(pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) iz[i] = pts[i].zzz;
+  batch_inverse(iz.data(), iz.size(), F);
+  std::vector<Aff> a(pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (pts[i].is_id()) { a[i].x = a[i].y = vdfhost::zero(); continue; }
+    const Fe izz = vdfhost::mul(sqr(iz[i], F), sqr(pts[i].zz, F), F);
+    a[i].x = vdfhost::mul(pts[i].x, izz, F);
+    a[i].y = vdfhost::mul(pts[i].y, iz[i], F);
+  }
+  const size_t base = out->size();
+  out->resize(base + 2 * (size_t)bits);                  // bits chords, bits - 1 tangents, 1 final slope
+  Fe* d = out->data() + base;
+  size_t n = 0;
+  for (int k = 0; k < bits; ++k) {
+    const Fe ax = k ? a[bits + k - 1].x : vdfhost::zero();
+    d[n++] = vdfhost::sub(a[k].x, ax, F);
+    if (k + 1 < bits) d[n++] = vdfhost::add(a[k].y, a[k].y, F);
+  }
+  const Aff& rp = a[2 * bits - 1];                       // [r] P (the identity as (0, 0), also when P is the identity)
+  d[n++] = U.x == rp.x ? vdfhost::add(U.y, U.y, F) : vdfhost::sub(rp.x, U.x, F);
+  batch_inverse(d, n, F);
 }
 
 // ---- multi-limb integers for the foreign fold (little-endian 64-bit limbs) ---------------------------------------
@@ -608,6 +725,7 @@ void hash_challenge(int f, const Fe& params, const RelaxedInst& U, const Aff& u_
   low_bits(h, CHAL_BITS, r_out);
 }
 
+static thread_local uint64_t g_last_queue = 0, g_last_misses = 0;
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out, uint64_t* r_out) {
   const Field& F = cs.F;
   const Field& PF = field(side_field(1 - side));
@@ -645,6 +763,14 @@ std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, cons
   check_on_curve(cs, uWx, uWy, uW_inf);
   const Num T_inf = is_zero(cs, Tx);
   check_on_curve(cs, Tx, Ty, T_inf);
+  if (!cs.shape) {
+    uint64_t rv[4];
+    fe_to_int(r.v, F, rv);
+    cs.inv_queue.clear();
+    cs.inv_pos = 0;
+    ec_fold_inverses(F, in.U.comm_W, in.u_W, rv, CHAL_BITS, &cs.inv_queue);
+    ec_fold_inverses(F, in.U.comm_E, in.T, rv, CHAL_BITS, &cs.inv_queue);
+  }
   // comm_W' = U.W + r u.W ; comm_E' = U.E + r T
   Num rWx, rWy, fWx, fWy, rTx, rTy, fEx, fEy;
   ec_scalar_mul(cs, r_bits, uWx, uWy, uW_inf, &rWx, &rWy);
@@ -688,9 +814,13 @@ std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, cons
   const Num hv = pack(cs, h_out.data(), HASH_BITS);
   const Num x1 = cs.alloc_io(hv.v);
   cs.enforce_equal(x1, hv);
+  cs.resolve();
+  g_last_queue = cs.inv_queue.size();
+  g_last_misses = cs.inv_misses + (cs.inv_queue.size() - cs.inv_pos);       // wrong or unused entries
   std::vector<Fe> out;
   for (const Num& n : z_out) out.push_back(n.v);
   return out;
 }
+void last_synthesis_stats(uint64_t* queued, uint64_t* misses) { *queued = g_last_queue; *misses = g_last_misses; }
 
 }  // namespace vdfnova

@@ -56,9 +56,23 @@ class CS {
   // COO triples in the column numbering of z = (W, u, X); call once, after synthesis (shape mode)
   void finish(Coo out[3]) const;
 
+  // ---- inversions.  A witness holds ~530 field inverses (curve slopes, is-zero helpers); at 6 us each they would be
+  // the whole cost of a step.  Two mechanisms keep them to a handful of real inversions per circuit:
+  //  * slopes: a native pre-pass (projective arithmetic, then batched inversion) queues the inverses in the order the
+  //    gadgets will ask for them; take_inverse hands the next one out after checking den * inv = 1, and computes the
+  //    inverse itself if the queue is empty or the check fails -- the queue is an accelerator, never a source of truth;
+  //  * is-zero helpers are used by no later computation: alloc_inverse_later reserves the variable and resolve() fills
+  //    all of them with one batched inversion at the end of the synthesis.
+  std::vector<Fe> inv_queue;
+  size_t inv_pos = 0, inv_misses = 0;
+  Fe take_inverse(const Fe& den);
+  Num alloc_inverse_later(const Fe& a);
+  void resolve();
+
  private:
   struct Row { LC a, b, c; };
   std::vector<Row> cons_;
+  std::vector<std::pair<size_t, Fe>> later_;       // (position in W, value to invert)
 };
 
 // ---- the random oracle: Poseidon2-style permutation, width 4 (oracle/poseidon.py) -----------------------------------
@@ -78,6 +92,10 @@ Num poseidon_hash(CS& cs, uint64_t tag, const std::vector<Num>& xs);
 void check_on_curve(CS& cs, const Num& x, const Num& y, const Num& inf);
 void ec_scalar_mul(CS& cs, const std::vector<Num>& bits, const Num& px, const Num& py, const Num& p_inf, Num* rx, Num* ry);
 void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const Num& y2, Num* ox, Num* oy);
+// n inverses with one inversion (Montgomery's trick); zeros stay zero
+void batch_inverse(Fe* v, size_t n, const Field& F);
+// the slope inverses of  U + [r] P  as ec_scalar_mul followed by ec_add_complete will request them, appended to out
+void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out);
 void fold_foreign(CS& cs, const Num& a_lo, const Num& a_hi, const std::vector<Num>& b_bits, const std::vector<Num>& r_bits,
                   const Field& foreign, Num* r_lo, Num* r_hi);
 
@@ -139,6 +157,9 @@ void hash_challenge(int field_id, const Fe& params, const RelaxedInst& U, const 
 // r (optional): the fold challenge it derived, a 128-bit integer
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew = nullptr,
                                      uint64_t* r = nullptr);
+// of the calling thread's last synthesize_augmented in witness mode: slope inverses queued by the pre-pass, and how many of
+// them were wrong or left over (0 unless the inputs were malformed)
+void last_synthesis_stats(uint64_t* queued, uint64_t* misses);
 inline int side_field(int side) { return side == 0 ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 inline int side_curve(int side) { return side == 0 ? VDF_CURVE_PALLAS : VDF_CURVE_VESTA; }
 

@@ -65,7 +65,14 @@ struct vdf_shape {
   uint32_t* d_t_cm = nullptr;
   uint32_t* d_t_heavy = nullptr;                          // columns with more than 64 entries
   size_t t_nheavy = 0;
+  // rows with more than VDF_LONG_ROW entries, as row | matrix << 30: one wavefront each (vec_spmv_long) instead of one lane
+  uint32_t* d_long = nullptr;
+  size_t n_long = 0;
 };
+// A row of more than this many entries is summed by a whole wavefront ahead of the lane-per-row kernels, which then
+// only read the result: the rows of an augmented circuit that pack 255 bits or carry a Poseidon state of ~60 terms would
+// otherwise serialise a launch behind one lane (1 ms instead of 20 us at t = 2^16).
+#define VDF_LONG_ROW 8
 
 namespace vdf {
 
@@ -152,6 +159,8 @@ Status vec_axpy(int field, const void* a, const void* r, const void* b, size_t n
 Status vec_cross_term(int field, const void* az1, const void* bz1, const void* cz1, const void* az2,
                       const void* bz2, const void* cz2, const void* u1, size_t n, void* T, hipStream_t s);
 Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint64_t t, void* W, hipStream_t s);
+Status vec_spmv_long(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3], const uint32_t* const coef[3],
+                     const void* dict, const void* z, const uint32_t* long_rows, size_t n_long, void* const out[3], hipStream_t s);
 Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const uint32_t* coef, const void* dict,
                 const void* z, size_t rows, void* out, hipStream_t s);
 // fused step kernels; vdf_fe* arguments are HOST pointers whose values travel as kernel arguments

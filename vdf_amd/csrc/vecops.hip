@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void k_spmv(const uint32_t* __restrict__ rowpt
   const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
+  if (hi - lo > VDF_LONG_ROW) return;                  // summed by a wavefront already (k_spmv_long)
   Fe<P> acc = fe_zero<P>();
   for (uint32_t k = lo; k < hi; ++k) {
     const Fe<P> v = fe_load<P>(z + (size_t)col[k] * 32);
@@ -175,6 +176,33 @@ __device__ __forceinline__ Fe<P> spmv_term(const Fe<P>& v, uint32_t ci, const ch
   return fe_mul(v, fe_load<P>(dict + (size_t)ci * 32));
 }
 
+// Rows of more than VDF_LONG_ROW entries, one wavefront each: lanes stride over the entries, then a butterfly sum.
+template <class P>
+__global__ __launch_bounds__(256) void k_spmv_long(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z,
+                                                   const uint32_t* __restrict__ long_rows, size_t n_long, char* __restrict__ o0,
+                                                   char* __restrict__ o1, char* __restrict__ o2) {
+  __builtin_amdgcn_s_setprio(3);
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_long) return;                                          // whole wavefronts leave together
+  const uint32_t lane = threadIdx.x & 63, packed = long_rows[w], k = packed >> 30, r = packed & 0x3FFFFFFFu;
+  const uint32_t* rowptr = k == 0 ? m.rowptr[0] : (k == 1 ? m.rowptr[1] : m.rowptr[2]);
+  const uint32_t* col = k == 0 ? m.col[0] : (k == 1 ? m.col[1] : m.col[2]);
+  const uint32_t* coef = k == 0 ? m.coef[0] : (k == 1 ? m.coef[1] : m.coef[2]);
+  char* out = k == 0 ? o0 : (k == 1 ? o1 : o2);
+  const uint32_t lo = rowptr[r], hi = rowptr[r + 1];
+  Fe<P> acc = fe_zero<P>();
+  for (uint32_t e = lo + lane; e < hi; e += 64)
+    acc = fe_add(acc, spmv_term<P>(fe_load<P>(z + (size_t)col[e] * 32), coef[e], dict));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Fe<P> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(acc.v[i], off, 64);
+    acc = fe_add(acc, o);
+  }
+  if (lane == 0) fe_store<P>(out + (size_t)r * 32, acc);
+}
+
 // multiply_vec(z2) and the cross term in one pass over the rows:
 //   (a2, b2, c2) = (A z2, B z2, C z2)[row];  T[row] = a1*b2 + a2*b1 - u1*c2 - c1      (u2 = 1)
 // The loads are issued in three waves instead of nine dependent steps: all six row pointers, then the first column /
@@ -201,8 +229,10 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
   Fe<P> v[3], acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) v[k] = fe_load<P>(z2 + (size_t)(hi[k] > lo[k] ? c0[k] : 0u) * 32);
+  char* const outs[3] = {az2, bz2, cz2};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
+    if (hi[k] - lo[k] > VDF_LONG_ROW) { acc[k] = fe_load<P>(outs[k] + r * 32); continue; }      // k_spmv_long ran first
     acc[k] = hi[k] > lo[k] ? spmv_term<P>(v[k], k0[k], dict) : fe_zero<P>();
     for (uint32_t e = lo[k] + 1; e < hi[k]; ++e)
       acc[k] = fe_add(acc[k], spmv_term<P>(fe_load<P>(z2 + (size_t)m.col[k][e] * 32), m.coef[k][e], dict));
@@ -286,6 +316,16 @@ Status vec_cross_term(int field, const void* az1, const void* bz1, const void* c
 
 Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint64_t t, void* W, hipStream_t s) {
   FIELD_DISPATCH(field, k_minroot_witness, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), C(i0), t, M(W));
+  return Status{};
+}
+
+Status vec_spmv_long(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3], const uint32_t* const coef[3],
+                     const void* dict, const void* z, const uint32_t* long_rows, size_t n_long, void* const out[3], hipStream_t s) {
+  if (n_long == 0) return Status{};
+  Csr3 m;
+  for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
+  FIELD_DISPATCH(field, k_spmv_long, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, s, m, C(dict), C(z), long_rows, n_long,
+                 M(out[0]), M(out[1]), M(out[2]));
   return Status{};
 }
 

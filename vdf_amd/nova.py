@@ -39,6 +39,7 @@ for _name, _res, _args in [
     ("vdf_nova_ro_hash", _i, [_i, _u64, _vp, _sz, _vp]),
     ("vdf_nova_shape_digest", _i, [_u64, _i, _i, _vp, _vp]),
     ("vdf_nova_aug_synthesize", _i, [_i, _u64, _i, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp, _vp]),
+    ("vdf_nova_synthesis_stats", _i, [C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_compress", _i, [_vp, _vp, C.POINTER(_vp)]),
     ("vdf_nova_verify_compressed", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
     ("vdf_nova_snark_free", None, [_vp]),
@@ -100,6 +101,13 @@ def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
     sizes = np.zeros((2, 3), dtype="<u8")
     _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+def synthesis_stats() -> Tuple[int, int]:
+    """(slope inverses queued by the batched pre-pass, queue misses) of this thread's last augmented-circuit synthesis."""
+    q, m = C.c_uint64(), C.c_uint64()
+    _check(nova_lib.vdf_nova_synthesis_stats(C.byref(q), C.byref(m)))
+    return q.value, m.value
 
 
 class AugInputs(C.Structure):     # vdf_nova_aug_inputs
