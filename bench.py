@@ -56,15 +56,39 @@ def parse():
 def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     """Rank 0, N = 1 only.  The ONLY place bench.py touches oracle/: times the C restatement on the
     host cores and checks the GPU result against it."""
-    from oracle import cref
+    import threading
+    from oracle import cref, pasta as o
     L = cref.lib()
-    # the restatement spreads its 16 windows (c = 16 at 2^20) over a thread pool: at most 16 threads work
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    # The restatement spreads the windows of one MSM (16 at 2^16+ points) over a thread pool; to use every host core the
+    # points are cut into chunks, each chunk an independent MSM with its own pool (ctypes calls release the GIL), and
+    # the chunk results are added: chunks x 16 threads.
+    cores = os.cpu_count() or 1
+    per_chunk = 16
+    chunks = max(1, min(cores // per_chunk, 32))
+    while n % chunks:
+        chunks -= 1
+    threads_used = chunks * min(per_chunk, cores)
     pts = bases.download(0, n)
     sc = scalars_dev.cpu().numpy().view("<u8").copy()
-    out = np.zeros(12, dtype="<u8")
+    outs = [np.zeros(12, dtype="<u8") for _ in range(chunks)]
+    q = n // chunks
+
+    def work(k):
+        L.ref_msm(curve, cref.p(pts[k * q:(k + 1) * q]), cref.p(sc[k * q:(k + 1) * q]), q, 0, min(per_chunk, cores), 0, cref.p(outs[k]))
     t0 = time.perf_counter()
-    L.ref_msm(curve, cref.p(pts), cref.p(sc), n, 0, cores, 0, cref.p(out))
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(chunks)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    bm = o.curve_base_modulus(curve)
+    acc = None
+    for k in range(chunks):
+        aff = np.zeros(8, dtype="<u8")
+        L.ref_jac_to_affine(curve, cref.p(outs[k]), cref.p(aff))
+        raw = aff.tobytes()
+        pt = (o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:], "little"), bm))
+        acc = o.pt_add(acc, None if pt == (0, 0) else pt, bm)
     dt = time.perf_counter() - t0
     # one thread, on the first 2^17 points of the same inputs (SURVEY.md 8d asks for a 1-thread figure beside it)
     n1 = min(n, 1 << 17)
@@ -72,26 +96,102 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     t0 = time.perf_counter()
     L.ref_msm(curve, cref.p(pts), cref.p(sc), n1, 0, 1, 0, cref.p(out1))
     dt1 = time.perf_counter() - t0
-    aff_cpu = np.zeros(8, dtype="<u8")
     aff_gpu = np.zeros(8, dtype="<u8")
-    L.ref_jac_to_affine(curve, cref.p(out), cref.p(aff_cpu))
     g = np.ascontiguousarray(gpu_jac, dtype="<u8")
     L.ref_jac_to_affine(curve, cref.p(g), cref.p(aff_gpu))
+    raw = aff_gpu.tobytes()
+    gpu_pt = (o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:], "little"), bm))
     return {
-        "value": n / dt / 1e9, "unit": "GPoints/s", "cores": cores, "kind": "port",
+        "value": n / dt / 1e9, "unit": "GPoints/s", "cores": cores, "threads_used": threads_used, "kind": "port",
         "sample": f"the full 2^{n.bit_length() - 1}-point MSM of the timed workload (same bases and scalars), "
-                  f"{dt:.2f} s wall on {cores} threads, windows spread over a pthread pool",
-        "parity_bit_exact": bool(np.array_equal(aff_cpu, aff_gpu)),
+                  f"{dt:.2f} s wall: {chunks} point-chunks x {min(per_chunk, cores)} window threads (oracle/pasta_ref.c), chunk results added",
+        "parity_bit_exact": bool((acc or (0, 0)) == gpu_pt),
         "single_thread": {"value": n1 / dt1 / 1e9, "unit": "GPoints/s", "sample": f"first 2^{n1.bit_length() - 1} points, {dt1:.2f} s"},
     }
 
 
+def cpu_prove_baseline_leg(log2t=10, nsteps=3):
+    """BASELINE config 1 (MinRoot Nova prove, 1024 iterations per step, 3 recursive steps, CPU): the restatement
+    oracle/nova.py -- Python big integers for the circuits and the folds, MSMs in oracle/pasta_ref.c -- timed on this
+    box's host cores.  A port, and a slow one (the reference's Rust prover cannot be built here): reported, never the target."""
+    from oracle import nova as nv, pasta as o
+    t = 1 << log2t
+    cores = os.cpu_count() or 1
+    com = nv.CCommit(threads=min(16, cores))
+    pp = nv.public_params(t, com, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
+    states = [o.State(0x1234567890ABCDEF1234567890ABCDEF, 0, 0)]
+    for _ in range(nsteps):
+        states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+    z0 = [states[nsteps].x, states[nsteps].y, states[nsteps].i]
+    com(0, [1] * pp.shapes[0].num_vars); com(1, [1] * pp.shapes[1].num_vars)      # generators made outside the timed region
+    s, per = None, []
+    for k in range(nsteps):
+        a = time.perf_counter()
+        s = nv.prove_step(pp, s, nv.InverseMinRootCircuit(t, states[nsteps - k], states[nsteps - k - 1]), z0)
+        per.append(time.perf_counter() - a)
+    ok = nv.verify(pp, s, nsteps, z0) is not None
+    steady = per[1:] if nsteps > 1 else per
+    return {"value": len(steady) / sum(steady), "unit": "prove_step/s", "cores": cores, "threads_used": min(16, cores), "kind": "port",
+            "sample": f"oracle/nova.py, t = 2^{log2t}, {nsteps} steps (base case {per[0]:.2f} s apart; steady-state steps timed): Python big "
+                      f"integers for synthesis and folds on one core, the four commitments per step on {min(16, cores)} threads in C",
+            "verified": bool(ok), "seconds_per_step": [round(x, 3) for x in per]}
+
+
+def msm_dlog_self_check(ctx, curve, scalars_dev, n):
+    """A GPU-side parity check that needs no oracle: n scalars of the timed workload over [k_i]G generators (k_i from
+    splitmix64, include/vdf_hip.h VDF_GENS_KNOWN_DLOG) must give [sum s_i k_i mod q] G.  The right-hand side is one
+    host scalar multiplication done with Python integers here (y^2 = x^3 + 5, affine)."""
+    import vdf_amd
+    P_ = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+    Q_ = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+    bm, sm = (P_, Q_) if curve == vdf_amd.CURVE_PALLAS else (Q_, P_)
+    M64 = (1 << 64) - 1
+
+    def splitmix(x):
+        z = (x + 0x9E3779B97F4A7C15) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    def add(a, b):
+        if a is None: return b
+        if b is None: return a
+        if a[0] == b[0]:
+            if (a[1] + b[1]) % bm == 0: return None
+            lam = 3 * a[0] * a[0] * pow(2 * a[1], -1, bm) % bm
+        else:
+            lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, bm) % bm
+        x = (lam * lam - a[0] - b[0]) % bm
+        return (x, (lam * (a[0] - x) - a[1]) % bm)
+    seed = 99
+    bases = ctx.bases_generate(curve, seed, n)
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    ctx.msm(bases, scalars_dev[:n], n=n, out=out)
+    ctx.sync()
+    raw = out.cpu().numpy().view("<u8").tobytes()
+    R = 1 << 256
+    X, Y, Z = (int.from_bytes(raw[32 * k:32 * k + 32], "little") * pow(R, -1, bm) % bm for k in range(3))
+    got = None if Z == 0 else (X * pow(Z, -2, bm) % bm, Y * pow(Z, -3, bm) % bm)
+    sc = scalars_dev[:n].cpu().numpy().view("<u8").tobytes()
+    acc = 0
+    for i in range(n):
+        acc += int.from_bytes(sc[32 * i:32 * i + 32], "little") * (splitmix((seed * 0xD1342543DE82EF95 + i) & M64) | 1)
+    k, want, g = acc % sm, None, ((-1) % bm, 2)
+    while k:
+        if k & 1: want = add(want, g)
+        g = add(g, g)
+        k >>= 1
+    bases.free()
+    return {"ok": bool(got == want), "points": n, "what": "sum s_i [k_i] G = [sum s_i k_i] G over known-dlog generators"}
+
+
 def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset=0):
-    """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU (folding-only
-    stage, see include/vdf_nova.h).  Forward evaluation and public parameters are outside the timed region
-    (benches/nova.rs:28-59); step 0 (base case) is reported apart from the steady-state steps."""
+    """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU -- a full IVC step on the
+    Pallas / Vesta cycle (both augmented circuits, in-circuit NIFS verifier, see include/vdf_nova.h).  Forward
+    evaluation and public parameters are outside the timed region (benches/nova.rs:28-59); step 0 (base case) is
+    reported apart from the steady-state steps."""
     from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode
-    from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+    from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params, INST_FRESH_SECONDARY
     t = 1 << log2t
     pp = public_params(ctx, t)
     initial = State.from_ints(FIELD_FQ, 0x1234567890ABCDEF1234567890ABCDEF + (seed_offset << 64), 0, 0)   # y = 0, i = 0: benches/nova.rs:24-26
@@ -100,9 +200,8 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
         PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, nsteps, initial)
     eval_s = time.perf_counter() - t0
     circuits.upload(ctx)                     # the forward trace is an input: resident in HBM before timing starts
-    # Steps are enqueued asynchronously (a step waits only for its two commitments, and the next step's fresh
-    # commitment is already in flight on a second context), so the steady state is timed
-    # as one region closed by a stream synchronisation, not as a sum of per-call times.
+    # A step's MinRoot rounds and their share of the commitment are in flight one step ahead on a second context; the
+    # steady state is timed as one region closed by the commitment the last step leaves pending and a synchronisation.
     was_async = ctx.get_async()
     ctx.set_async(True)
     proof, stages = None, []
@@ -122,6 +221,7 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
     for k in range(first_timed, nsteps):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
         stages.append(proof.last_step_ms())
+    proof.instance(INST_FRESH_SECONDARY)     # the last secondary commitment (it rides in the NEXT step's batch otherwise)
     ctx.sync()
     steady_total = time.perf_counter() - a
     ctx.set_async(was_async)
@@ -129,13 +229,17 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
     nsteady = max(nsteps - first_timed, 1)
     avg = steady_total / nsteady if nsteps > 1 else base_case
     stage_avg = {k: sum(s[k] for s in stages) / len(stages) for k in stages[-1]} if stages else {}
-    sizes = pp.sizes()
+    sizes = {"primary": pp.sizes(0), "secondary": pp.sizes(1)}
     out = {"metric": "Nova prove_step/sec (MinRoot, 2^%d iters/step)" % log2t, "value": 1.0 / avg, "unit": "prove_step/s",
            "ms_per_step": avg * 1e3, "base_case_ms": base_case * 1e3, "first_fold_ms_untimed_warmup": first_fold * 1e3,
            "steady_state_steps": nsteady if nsteps > 1 else 0,
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes,
            "forward_eval_s_per_step_host": eval_s / nsteps,
-           "stage": "folding-only (step circuit + NIFS on the primary curve; no augmented circuit / secondary curve)"}
+           "stage": "Nova IVC step on the Pallas/Vesta cycle: NIFS of the previous secondary instance, synthesis + commitment + NIFS "
+                    "of the primary augmented circuit (MinRoot step circuit inside), synthesis of the secondary augmented circuit "
+                    "(TrivialTestCircuit); constant-size proof, hash-checking verifier",
+           "stage_ms_meaning": "host wall-clock per stage (vdf_nova_last_step_ms): *_synthesis = host field arithmetic of an augmented "
+                               "circuit (hashes, in-circuit curve arithmetic); secondary_nifs / primary_wait = GPU cross term + commitments"}
     if not with_compress:
         proof.free()
         return out
@@ -148,7 +252,8 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
     verify_c_ms = (time.perf_counter() - a) * 1e3
     out["compress"] = {"compress_ms": compress_ms, "verify_compressed_ms": verify_c_ms, "verified": bool(ok_c),
                        "argument_bytes": len(snark.to_bytes()),
-                       "what": "Spartan-style argument with inner-product-argument openings for the folded instance (vdf_nova.h)"}
+                       "wire_bytes": len(snark.serialize()),
+                       "what": "one Spartan-style argument with inner-product-argument openings per side of the cycle (vdf_nova.h)"}
     snark.free()
     proof.free()
     # Aggregate rate of TWO independent chains proven concurrently on this GPU (two host threads, two contexts):
@@ -179,6 +284,7 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
             pr = proofs[i]
             for k in range(2, nsteps):
                 pr = NovaVDFProof.prove_step(p_, pr, cs, k, z_)
+            pr.instance(INST_FRESH_SECONDARY)
             cx.sync()
 
         ths = [threading.Thread(target=run, args=(i,)) for i in range(chains)]
@@ -325,17 +431,32 @@ def main():
         acc_avg_ms = acc_ms / max(calls, 1)
         acc_iso_ms = iso["accumulate"] if iso else acc_avg_ms
         alg_bytes = 96.0 * n
-        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+        # roofline.achieved prices the kernel's own duration: the launch alone on the device (isolated).  With steps in
+        # flight a launch's HIP-event duration also contains the time its workgroups queue behind the other step's; that
+        # figure is kept beside it (overlapped_*), never used for frac.
+        achieved = alg_bytes / (acc_iso_ms * 1e-3) / 1e9
+        achieved_overlapped = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
         window = shs[0].bases.window or args.window or 16
         windows_eff = (255 + window - 1) // window                    # entries per point: scalars are below 2^255, zero digits are rare
         ctx_num_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
+        # measured inputs of the two derived figures come from profiles/ (tracked, with their provenance), not from literals
+        def latest(prefix):
+            import glob
+            c = sorted(glob.glob(os.path.join(ROOT, "profiles", prefix + "_r*.json")))
             try:
-                traffic = json.load(open(tpath)).get("k_accumulate_hbm_bytes_per_launch")
+                return (json.load(open(c[-1])), os.path.basename(c[-1])) if c else (None, None)
             except Exception:
-                traffic = None
+                return None, None
+        tj, tfile = latest("traffic")
+        traffic = tj.get("k_accumulate_hbm_bytes_per_launch") if tj else None
+        vm, vfile = latest("valu_model")
+        valu = None
+        if vm:
+            per_add, cyc, ghz = vm["valu_per_bucket_addition"], vm["cycles_per_valu_wave_instruction_per_simd"], vm["sustained_shader_clock_ghz"]
+            issue = lambda ms: (per_add * n * windows_eff / 64.0) / (ctx_num_simds * ms * 1e-3 * ghz * 1e9 / cyc)
+            valu = {"valu_issue_frac": issue(acc_iso_ms), "of_timed_region_accumulate_only": issue(elapsed / args.steps * 1e3),
+                    "valu_per_bucket_addition": per_add, "cycles_per_valu_wave_instruction_per_simd": cyc,
+                    "sustained_shader_clock_ghz": ghz, "source": "profiles/" + vfile, "provenance": vm.get("provenance")}
         line = {
             "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step); prove_step/s in `prove_step`",
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -346,36 +467,55 @@ def main():
                                    f"fixed-base table c={window} sets={args.sets}; {depth} independent steps in flight on {depth} streams; "
                                    f"N>1: point-chunk shards + all-gather of 96-B partials",
                        "points_per_gpu": n, "window_bits": window, "bucket_sets": args.sets, "steps_in_flight": depth},
+            # the two ways to run the same MSM, side by side: `value` is the pipelined throughput
+            "single_msm": {"latency_ms": iso["pipeline"] if iso else total_ms / max(calls, 1),
+                           "value": n / ((iso["pipeline"] if iso else total_ms / max(calls, 1)) * 1e-3) / 1e9, "unit": "GPoints/s",
+                           "what": "one MSM at a time on an idle device (stream-synchronised between calls)"},
+            "pipelined": {"ms_per_msm": ms_per_step, "value": value, "unit": "GPoints/s", "steps_in_flight": depth},
             "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),
                          "pipeline": total_ms / max(calls, 1)},
             "stage_ms_one_step_at_a_time": iso,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": ("profiles/" + tfile) if tfile else None,
                          "kernel": "k_accumulate", "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": acc_avg_ms,
-                         # the bound that actually holds: integer VALU issue.  2,586 VALU
-                         # instructions per mixed addition (PMC SQ_INSTS_VALU), 4.1 cycles per wave-instruction per
-                         # SIMD and 2.375 GHz sustained (tools/ubench/op_rates.hip, clock_probe.hip), 4 SIMDs per CU
-                         "valu_issue_frac": (2586.0 * n * windows_eff / 64.0) /
-                                            (ctx_num_simds * acc_iso_ms * 1e-3 * 2.375e9 / 4.1),
-                         "isolated_launch_ms": acc_iso_ms,
-                         # the same instructions over the whole timed region (all kernels of all steps in flight)
-                         "valu_issue_frac_of_timed_region_accumulate_only": (2586.0 * n * windows_eff / 64.0) /
-                                            (ctx_num_simds * (elapsed / args.steps) * 2.375e9 / 4.1),
+                         "avg_launch_ms": acc_iso_ms, "launch_timing": "HIP events on the launching stream, one step at a time",
+                         "overlapped_avg_launch_ms": acc_avg_ms, "overlapped_achieved": achieved_overlapped,
+                         "valu": valu,
                          "note": "k_accumulate is integer-VALU-issue bound, neither HBM nor MFMA: frac is the contract's HBM "
-                                 "figure.  avg_launch_ms is the HIP-event duration in the timed region, where a launch also "
-                                 "waits for the other in-flight step's workgroups to retire; isolated_launch_ms (one step at "
-                                 "a time) is the kernel itself and valu_issue_frac is computed from it (DESIGN.md 4.1, 4.2)"},
+                                 "figure from the isolated launch.  overlapped_* is the HIP-event duration inside the timed region, "
+                                 "where a launch also waits for the other in-flight step's workgroups to retire (it can exceed "
+                                 "ms_per_step and is not kernel time).  valu.* is the bound that holds (DESIGN.md 4.1, 4.2)"},
         }
         if replicas is not None:
             line["prove_step_replicas"] = replicas
         if world == 1 and not args.no_prove and not args.rehearse_collective:
             ctx.set_async(False)
             line["prove_step"] = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, args.prove_chains)
+        failures = []
         if world == 1 and not args.no_cpu:
             ctx.set_async(False)
             line["cpu_baseline"] = cpu_baseline_leg(ctx, sh.bases, sc, n, curve, result.cpu().numpy().view("<u8"))
+            if not line["cpu_baseline"]["parity_bit_exact"]:
+                failures.append("MSM result differs from the CPU restatement")
+            if "prove_step" in line:
+                line["prove_step"]["cpu_baseline"] = cpu_prove_baseline_leg()
+        elif world == 1:
+            # without the CPU leg the result is still checked: the same scalars against generators with known discrete
+            # logarithms, sum s_i [k_i] G = [sum s_i k_i] G (host big integers only; no oracle code involved)
+            line["self_check"] = msm_dlog_self_check(ctx, curve, sc, min(n, 1 << 16))
+            if not line["self_check"]["ok"]:
+                failures.append("MSM result violates the discrete-log identity")
+        for key in ("prove_step", "prove_step_replicas"):
+            if key in line and not line[key].get("verified", True):
+                failures.append(key + ": the proof did not verify")
+        if "prove_step" in line and "compress" in line["prove_step"] and not line["prove_step"]["compress"]["verified"]:
+            failures.append("the compressed proof did not verify")
+        if failures:
+            line["value"] = None
+            line["invalid"] = failures
         print(json.dumps(line), flush=True)
+        if failures:
+            raise SystemExit("bench.py: " + "; ".join(failures))
     if world > 1 or args.rehearse_collective:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,18 +148,19 @@ int  vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf
 int  vdf_ctx_set_timing(vdf_ctx* ctx, int enable);
 int  vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls);
 
-/* Drop-in shims with the upstream pasta-msm 0.1.1 shape (upload-on-call, default context
- * on device 0, abort-free: on failure `out` is set to the identity and the error is
- * readable through vdf_last_error(NULL)). */
+/* Drop-in shims with the upstream pasta-msm 0.1.1 shape (upload-on-call, default context on device 0).  The
+ * signature returns nothing and an all-zero `out` is the identity -- a valid-looking commitment -- so a call that
+ * cannot compute (no device, out of memory, a failed launch) prints the reason on stderr and abort()s instead of
+ * returning; a caller that wants a status code uses vdf_bases_upload + vdf_msm. */
 void mult_pippenger_pallas(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
 void mult_pippenger_vesta(vdf_jac* out, const vdf_affine* points, size_t npoints, const vdf_fe* scalars, bool is_mont);
 /* Generator cache of the shims: keep up to `entries` (0..64; 0 = off, the default; the environment variable
  * VDF_SHIM_CACHE sets the initial value) generator arrays resident, recognised by (curve, address, length) and a
- * fingerprint of 64 sampled points; from the second call on a set also gets its fixed-base table.  For callers whose
- * generators are immutable once made -- nova-snark's CommitGens -- the unmodified pasta-msm call then costs a scalar
- * upload and a table MSM instead of a 64-byte-per-point upload and a table-less one.  A caller that rewrites a
- * generator array in place between calls must leave the cache off (a change outside the sampled points would go
- * unnoticed).  The address is used as a key only and never dereferenced outside the call that passes it. */
+ * content hash of ALL their points (one pass over the array per call, on up to 8 host threads: ~0.3 ms at 2^19
+ * points); from the second call on a set also gets its fixed-base table.  For callers whose generators do not change
+ * -- nova-snark's CommitGens -- the unmodified pasta-msm call then costs a hash, a scalar upload and a table MSM instead
+ * of a 64-byte-per-point upload and a table-less MSM.  An array rewritten in place, anywhere, hashes differently and is
+ * uploaded again.  The address is used as a key only and never dereferenced outside the call that passes it. */
 int  vdf_shim_set_cache(int entries);
 
 /* ---- R1CS shape + sparse mat-vec ------------------------------------------------------- */

@@ -112,7 +112,10 @@ size_t vdf_nova_proof_num_steps(const vdf_proof* proof);
 /* Introspection for the parity tests.  Instances: commitments as affine points, u and X[2] in Montgomery form of the
  * instance's own scalar field (Fq on the primary side, Fp on the secondary).  Witness pointers: device memory,
  * z = [W | u | X] (W = the first num_vars elements) and E (NULL for the fresh instance). */
-enum { VDF_INST_RUNNING_PRIMARY = 0, VDF_INST_RUNNING_SECONDARY = 1, VDF_INST_FRESH_SECONDARY = 2 };
+enum { VDF_INST_RUNNING_PRIMARY = 0, VDF_INST_RUNNING_SECONDARY = 1, VDF_INST_FRESH_SECONDARY = 2,
+       /* witness pointer only: z of the fresh primary instance the LAST prove_step folded (its instance: vdf_nova_proof_last_step);
+        * valid until the next step */
+       VDF_INST_FRESH_PRIMARY_LAST = 3 };
 int  vdf_nova_proof_instance(const vdf_proof* proof, int which, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[2]);
 int  vdf_nova_proof_witness_ptrs(const vdf_proof* proof, int which, const void** d_z, const void** d_E);
 int  vdf_nova_proof_zi(const vdf_proof* proof, vdf_fe zi_primary[3], vdf_fe zi_secondary[1]);

@@ -258,7 +258,8 @@ def test_pippenger_shims(cref):
 
 def test_pippenger_shim_generator_cache(cref):
     """vdf_shim_set_cache: the same generator array on later calls is served from HBM (plain, then with its table);
-    results stay those of the uncached shim; a rewritten array (sampled point), another length and eviction are handled."""
+    results stay those of the uncached shim; an array rewritten in place ANYWHERE (the cache hashes every point), another
+    length and eviction are handled."""
     import time
     from vdf_amd._lib import lib
     curve, n = o.CURVE_PALLAS, 1 << 16
@@ -293,6 +294,13 @@ def test_pippenger_shim_generator_cache(cref):
         got, sc, _ = run(pts, n, 9)
         want = o.pt_add(o.msm_by_dlog(sc, curve, 3), o.pt_mul(sc[0], g0, o.P), o.P)      # + one more s_0 * G_0
         assert got == want
+        # ... and rewritten at an arbitrary index (a sampled fingerprint would have missed it): generator 12345 doubled
+        g1 = o.synthetic_bases(curve, 3, 1, start=12345)[0]
+        pts[12345] = affine_array([o.pt_add(g1, g1, o.P)], curve)[0]
+        got, sc, _ = run(pts, n, 19)
+        want = o.pt_add(o.pt_add(o.msm_by_dlog(sc, curve, 3), o.pt_mul(sc[0], g0, o.P), o.P), o.pt_mul(sc[12345], g1, o.P), o.P)
+        assert got == want
+        pts[12345] = pts2[12345]
         # eviction: two other sets push the first one out; it still computes correctly afterwards
         for k, arr in enumerate((pts2, pts2[:30000].copy())):
             got, sc, _ = run(arr, len(arr), 50 + k)

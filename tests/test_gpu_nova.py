@@ -136,7 +136,11 @@ def test_tampered_witness_is_rejected(ctx):
     for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
         dz, dE = C.c_void_p(), C.c_void_p()
         assert nova_lib.vdf_nova_proof_witness_ptrs(proof.handle, which, C.byref(dz), C.byref(dE)) == 0
-        for base, off in ((dz.value, 32 * 40), (dE.value, 32 * 11)):
+        seg_b, seg_n = pp.segment()
+        spots = [(dz.value, 32 * 40), (dE.value, 32 * 11)]
+        if which == INST_RUNNING_PRIMARY:
+            spots.append((dz.value, 32 * (seg_b + 7)))       # a MinRoot round variable (tmp2 of round 2) of the folded witness
+        for base, off in spots:
             if not base:
                 continue
             word = np.zeros(1, dtype="<u8")
@@ -173,3 +177,90 @@ def test_lookahead_is_invisible(ctx):
         for key in ia:
             assert np.array_equal(ia[key], ib[key]), (which, key)
     assert b.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+
+
+def _canon(cref, field, arr):
+    out = np.zeros_like(arr)
+    cref.lib().ref_fe_from_mont(field, cref.p(np.ascontiguousarray(arr)), arr.shape[0], cref.p(out))
+    return out
+
+
+@pytest.mark.parametrize("t,n", [(1024, 3), (1 << 16, 2)])
+def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n):
+    """BASELINE config 1 (t = 1024, 3 steps) and config 3 (t = 2^16) checked against the CPU restatements instead of the
+    product's own verifier: generators with known discrete logarithms (tests only), then for the LAST step --
+      * both R1CS shapes: the parameters digest equals the oracle's (every triple of both matrices triples);
+      * the MinRoot rounds of the fresh witness = the C restatement's ref_step_witness (src/nova/proof.rs:162-189);
+      * commitments of the fresh witness, of the cross term T and of the folded W, E = [sum s_i k_i] G (discrete-log identity);
+      * A z, B z, C z (C restatement ref_spmv over the ORACLE's shape), T (ref_cross_term), W' = W + r W2 and E' = E + r T
+        (ref_axpy) element for element, u' = u + r, X' = X + r X2.
+    Then the product's own verify, and zi."""
+    from vdf_amd.nova import INST_FRESH_PRIMARY_LAST
+    from vdf_amd.nova import nova_lib
+    L, fld, m = cref.lib(), o.FIELD_FQ, o.Q
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=3, kind=CIRCUIT_MINROOT_BOUND, family=GENS_KNOWN_DLOG,
+                                                mode=EvalMode.LTRAddChainSequential)
+    opp = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_KNOWN_DLOG)
+    assert pp.digest() == opp.params
+    sh = opp.shapes[0]
+    nvar, nc = sh.num_vars, sh.num_cons
+    seg_b, seg_n = pp.segment()
+    assert seg_n == 3 * t + 1 and seg_b + seg_n <= nvar
+    proof = None
+    for k in range(n - 1):
+        proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+    z_old, E_old = proof.witness(INST_RUNNING_PRIMARY)
+    inst_old = proof.instance(INST_RUNNING_PRIMARY)
+    proof = NovaVDFProof.prove_step(pp, proof, circuits, n - 1, z0)
+    ls = proof.last_step()
+    z2, _ = proof.witness(INST_FRESH_PRIMARY_LAST)
+    z_new, E_new = proof.witness(INST_RUNNING_PRIMARY)
+    inst_new = proof.instance(INST_RUNNING_PRIMARY)
+    # MinRoot rounds of the fresh witness: the C restatement's 4t + 1 values without new_x
+    res, _inp = circuits.states(n - 1)
+    st = np.frombuffer(res.x + res.y + res.i, dtype="<u8").reshape(3, 4).copy()
+    Wref = cref.fe_array(4 * t + 1)
+    L.ref_step_witness(fld, cref.p(st), t, cref.p(Wref))
+    want_seg = np.concatenate([Wref[:4 * t].reshape(t, 4, 4)[:, 1:, :].reshape(3 * t, 4), Wref[4 * t:]])
+    assert np.array_equal(z2[seg_b:seg_b + seg_n], want_seg)
+    assert unmont(z2[nvar:nvar + 1], m) == [1] and np.array_equal(z2[nvar + 1:], ls["X1"])
+    # commitments by the discrete-log identity
+    dl = lambda vec: o.msm_by_dlog_limbs(_canon(cref, fld, np.ascontiguousarray(vec)), o.CURVE_PALLAS, nv.GENS_SEED) or (0, 0)
+    assert aff_ints(ls["comm_W1"], 0) == dl(z2[:nvar])
+    # the fold through the C restatement over the oracle's shape
+    def coo(mat):
+        rows = np.array([e[0] for e in mat], dtype=np.uint32)
+        cols = np.array([e[1] for e in mat], dtype=np.uint32)
+        vals = limbs([o.to_mont(e[2], m) for e in mat])
+        return rows, cols, vals
+    mats = [coo(x) for x in (sh.A, sh.B, sh.C)]
+
+    def mv(z):
+        out = []
+        for rows, cols, vals in mats:
+            e = cref.fe_array(nc)
+            L.ref_spmv(fld, cref.p(rows), cref.p(cols), cref.p(vals), len(rows), cref.p(np.ascontiguousarray(z)), nc, cref.p(e))
+            out.append(e)
+        return out
+    abc1, abc2 = mv(z_old), mv(z2)
+    T = cref.fe_array(nc)
+    L.ref_cross_term(fld, *(cref.p(x) for x in abc1 + abc2), cref.p(np.ascontiguousarray(inst_old["u"].reshape(1, 4))), nc, cref.p(T))
+    assert aff_ints(ls["comm_T1"], 0) == dl(T)
+    r = limbs([o.to_mont(ls["r1"], m)])
+    W_exp, E_exp = cref.fe_array(nvar + 3), cref.fe_array(nc)
+    L.ref_axpy(fld, cref.p(np.ascontiguousarray(z_old)), cref.p(r), cref.p(np.ascontiguousarray(z2)), nvar + 3, cref.p(W_exp))
+    L.ref_axpy(fld, cref.p(np.ascontiguousarray(E_old)), cref.p(r), cref.p(T), nc, cref.p(E_exp))
+    assert np.array_equal(z_new, W_exp)            # W', and with it u' = u + r and X' = X + r X2 (they ride in z)
+    assert np.array_equal(E_new, E_exp)
+    assert np.array_equal(z_new[nvar], inst_new["u"]) and np.array_equal(z_new[nvar + 1:], inst_new["X"])
+    assert aff_ints(inst_new["comm_W"], 0) == dl(z_new[:nvar]) and aff_ints(inst_new["comm_E"], 0) == dl(E_new)
+    # relaxed satisfiability of the folded instance, by the C restatement
+    a, b, c = mv(z_new)
+    ab, uc = cref.fe_array(nc), cref.fe_array(nc)
+    L.ref_fe_mul(fld, cref.p(a), cref.p(b), nc, cref.p(ab))
+    uvec = np.ascontiguousarray(np.broadcast_to(inst_new["u"].reshape(1, 4), (nc, 4)))
+    L.ref_fe_mul(fld, cref.p(uvec), cref.p(c), nc, cref.p(uc))
+    lhs, zero1 = cref.fe_array(nc), limbs([o.to_mont(m - 1, m)])
+    L.ref_axpy(fld, cref.p(ab), cref.p(zero1), cref.p(uc), nc, cref.p(lhs))          # ab - u c
+    assert np.array_equal(lhs, E_new)
+    assert proof.verify(pp, n, z0, [initial.x, initial.y, initial.i])

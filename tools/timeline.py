@@ -1,12 +1,13 @@
 """Print a kernel timeline from a rocprofv3 rocpd database: the span between two occurrences of an anchor kernel
-(default: the two k_nifs_cross before the last three, i.e. one steady-state prove_step with its overlaps)."""
+(default: k_nifs_cross, which runs twice per prove_step -- secondary side, then primary side -- so the span is one
+steady-state step with its overlaps)."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 anchor = sys.argv[2] if len(sys.argv) > 2 else "k_nifs_cross"
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows = list(db.execute("select name,start,end,stream_id from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if anchor in r[0]]
-i0, i1 = idx[-back], idx[-back + 1]
+i0, i1 = idx[-back], idx[-back + 2]      # two cross terms per step (secondary side, primary side)
 t0 = rows[i0][1]
 for r in rows[i0:i1 + 1]:
     nm = r[0].split('(')[0].replace('void vdf::', '').replace('vdf::', '')

@@ -1,6 +1,9 @@
 // extern "C" boundary of libvdf_hip.so (include/vdf_hip.h).  Plain pointers and sizes only; no
 // exception leaves this file.  There is no CPU back-end: without a GPU vdf_ctx_create fails.
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <map>
 #include <array>
 #include <new>
@@ -200,7 +203,7 @@ vdf_ctx* default_ctx() {
 
 // Generator cache of the shims (vdf_shim_set_cache).  nova-snark commits under the same CommitGens for the life of the
 // process; the upstream signature gives no handle to keep them resident, so the shim recognises a generator array by
-// (curve, address, length) and a fingerprint of 64 sampled points, keeps it in HBM, and from the second call on with
+// (curve, address, length) and a content hash of all its points, keeps it in HBM, and from the second call on with
 // its fixed-base table.  The address is a key only: it is dereferenced in the call that passes it, never later.
 struct ShimEntry { int curve; const void* ptr; size_t n; uint64_t fp; vdf_bases* bases; uint64_t last_use; bool table; };
 std::mutex g_shim_mu;
@@ -208,16 +211,34 @@ std::vector<ShimEntry> g_shim;
 int g_shim_cap = -1;                 // -1: not decided yet (environment), 0: off
 uint64_t g_shim_clock = 0;
 
+// Content hash of the WHOLE array (every coordinate word), so a generator rewritten in place anywhere is a different
+// set: chunks hashed on up to 8 threads (a 2^19-point array is 32 MiB; one pass costs ~0.3 ms that way), combined in
+// chunk order.  64-bit multiply-xorshift per word; a collision needs a deliberate adversary, which a process's own
+// generator arrays are not.
 uint64_t shim_fingerprint(const vdf_affine* points, size_t n) {
-  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
-  const size_t samples = n < 64 ? n : 64;
-  for (size_t k = 0; k < samples; ++k) {
-    const size_t i = samples == n ? k : (k == samples - 1 ? n - 1 : k * (n / samples));
-    uint64_t w[8];
-    std::memcpy(w, &points[i], 64);
-    for (uint64_t v : w) { h ^= v; h *= 0x100000001b3ull; h ^= h >> 29; }
-  }
+  auto hash_range = [points](size_t lo, size_t hi) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)lo;
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(points + lo);
+    for (size_t k = 0, e = (hi - lo) * 8; k < e; ++k) { h = (h ^ w[k]) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    return h;
+  };
+  const size_t nth = n >= (1u << 16) ? 8 : 1, per = (n + nth - 1) / nth;
+  std::vector<uint64_t> part(nth, 0);
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < nth; ++t)
+    th.emplace_back([&, t] { const size_t lo = t * per, hi = lo + per < n ? lo + per : n; if (lo < hi) part[t] = hash_range(lo, hi); });
+  part[0] = hash_range(0, per < n ? per : n);
+  for (auto& t : th) t.join();
+  uint64_t h = 0x100000001b3ull ^ (uint64_t)n;
+  for (uint64_t v : part) { h = (h ^ v) * 0x100000001b3ull; h ^= h >> 31; }
   return h;
+}
+
+// The upstream signature returns nothing, and an all-zero `out` is the identity -- a valid-looking commitment.  A failed
+// shim call therefore must not return: it says why on stderr and aborts (a caller that wants a status uses vdf_msm).
+[[noreturn]] void shim_die(const char* what, const std::string& why) {
+  std::fprintf(stderr, "libvdf_hip: mult_pippenger shim failed (%s): %s\n", what, why.c_str());
+  std::abort();
 }
 
 int shim_cache_capacity() {          // caller holds g_shim_mu
@@ -230,9 +251,10 @@ int shim_cache_capacity() {          // caller holds g_shim_mu
 }
 
 void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf_fe* scalars, bool is_mont) {
-  if (out) std::memset(out, 0, sizeof(*out));
+  if (!out) shim_die("arguments", "null output pointer");
+  std::memset(out, 0, sizeof(*out));
   vdf_ctx* ctx = default_ctx();
-  if (!ctx || !out) return;
+  if (!ctx) shim_die("default context", g_create_err);
   // With the cache on, a call holds the cache lock from lookup to the end of its MSM: an entry must not be evicted (and
   // its generators freed) by another thread while this one computes with it.  Nothing is lost -- the shims share one
   // default context, whose calls are serialised anyway.
@@ -241,11 +263,8 @@ void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf
   if (cap <= 0 || !points || !n) {
     lock.unlock();
     vdf_bases* b = nullptr;
-    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
-    if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
-      g_create_err = ctx->err;
-      std::memset(out, 0, sizeof(*out));
-    }
+    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) shim_die("generator upload", ctx->err);
+    if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) shim_die("MSM", ctx->err);
     vdf_bases_free(b);
     return;
   }
@@ -265,7 +284,7 @@ void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf
       g_shim.erase(g_shim.begin() + lru);
     }
     vdf_bases* b = nullptr;
-    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) { g_create_err = ctx->err; return; }
+    if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) shim_die("generator upload", ctx->err);
     g_shim.push_back(ShimEntry{curve, (const void*)points, n, fp, b, 0, false});
     hit = &g_shim.back();
   } else if (!hit->table) {
@@ -273,10 +292,7 @@ void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf
     hit->table = true;                                                   // failure (memory) leaves the plain path
   }
   hit->last_use = ++g_shim_clock;
-  if (vdf_msm(ctx, hit->bases, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) {
-    g_create_err = ctx->err;
-    std::memset(out, 0, sizeof(*out));
-  }
+  if (vdf_msm(ctx, hit->bases, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) shim_die("MSM", ctx->err);
 }
 
 template <class P>

@@ -735,9 +735,10 @@ int vdf_nova_proof_instance(const vdf_proof* p, int which, vdf_affine* comm_W, v
   return VDF_OK;
 }
 int vdf_nova_proof_witness_ptrs(const vdf_proof* p, int which, const void** d_z, const void** d_E) {
-  if (!p || which < 0 || which > 2) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  if (!p || which < 0 || which > 3) return fail(VDF_ERR_BAD_ARG, "bad argument");
   HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
-  if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }
+  if (which == VDF_INST_FRESH_PRIMARY_LAST) { if (d_z) *d_z = p->d_z2s[p->slot]; if (d_E) *d_E = nullptr; }
+  else if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }
   else { if (d_z) *d_z = p->r[which].d_z; if (d_E) *d_E = p->r[which].d_E; }
   return VDF_OK;
 }

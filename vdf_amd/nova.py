@@ -62,7 +62,7 @@ for _name, _res, _args in [
 
 CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE = 0, 1
 SIDE_PRIMARY, SIDE_SECONDARY = 0, 1
-INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY = 0, 1, 2
+INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY, INST_FRESH_PRIMARY_LAST = 0, 1, 2, 3
 GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT = 0, 1
 
 
@@ -285,7 +285,7 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
     def witness(self, which: int = INST_RUNNING_PRIMARY) -> Tuple[np.ndarray, np.ndarray]:
         """Downloads (z = [W | u | X], E) of one of the three instances for parity checks (E is None for the fresh one)."""
         from ._lib import lib
-        s = self.pp.sizes(0 if which == INST_RUNNING_PRIMARY else 1)
+        s = self.pp.sizes(0 if which in (INST_RUNNING_PRIMARY, INST_FRESH_PRIMARY_LAST) else 1)
         dz, dE = C.c_void_p(), C.c_void_p()
         _check(nova_lib.vdf_nova_proof_witness_ptrs(self.handle, which, C.byref(dz), C.byref(dE)))
         z = np.zeros((s["num_vars"] + 3, 4), dtype="<u8")
