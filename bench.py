@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--depth", type=int, default=2, help="independent MSM steps in flight (contexts / streams)")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="take the N > 1 code path (process group, all-gather on the step's stream) with a world of one")
+    ap.add_argument("--strong-log2n", type=int, default=24,
+                    help="BASELINE config 4: one MSM of 2^k points TOTAL, sharded over the ranks (strong scaling), as a sub-record; "
+                         "runs for N > 1 (and for N = 1 with --rehearse-collective or --strong); 0 = skip")
+    ap.add_argument("--strong", action="store_true", help="run the strong-scaling sub-record on one GPU too")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the prove_step leg (BASELINE config 3)")
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
@@ -135,6 +139,119 @@ def cpu_prove_baseline_leg(log2t=10, nsteps=3):
             "sample": f"oracle/nova.py, t = 2^{log2t}, {nsteps} steps (base case {per[0]:.2f} s apart; steady-state steps timed): Python big "
                       f"integers for synthesis and folds on one core, the four commitments per step on {min(16, cores)} threads in C",
             "verified": bool(ok), "seconds_per_step": [round(x, 3) for x in per]}
+
+
+_P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+_Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+
+
+def _dlogs(seed, start, n):
+    """k_i of the known-dlog generator family (include/vdf_hip.h VDF_GENS_KNOWN_DLOG), i = start .. start + n - 1."""
+    with np.errstate(over="ignore"):
+        z = np.uint64((seed * 0xD1342543DE82EF95 + start) & ((1 << 64) - 1)) + np.arange(n, dtype=np.uint64)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return (z ^ (z >> np.uint64(31))) | np.uint64(1)
+
+
+def _sum_s_k(scalars_u64, k):
+    """sum s_i k_i as a Python integer: 16 x 4 exact uint64 dot products of 16-bit pieces (n <= 2^24)."""
+    n = scalars_u64.shape[0]
+    s16 = scalars_u64.view("<u2").reshape(n, 16).astype(np.uint64)
+    k16 = k.view("<u2").reshape(n, 4).astype(np.uint64)
+    acc = 0
+    for a in range(16):
+        col = np.ascontiguousarray(s16[:, a])
+        for b in range(4):
+            acc += int(np.dot(col, k16[:, b])) << (16 * (a + b))
+    return acc
+
+
+def _scalar_mul_generator(k, bm):
+    """[k] (-1, 2) on y^2 = x^3 + 5 over F_bm, affine, Python integers (None = identity)."""
+    def add(a, b):
+        if a is None: return b
+        if b is None: return a
+        if a[0] == b[0]:
+            if (a[1] + b[1]) % bm == 0: return None
+            lam = 3 * a[0] * a[0] * pow(2 * a[1], -1, bm) % bm
+        else:
+            lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, bm) % bm
+        x = (lam * lam - a[0] - b[0]) % bm
+        return (x, (lam * (a[0] - x) - a[1]) % bm)
+    want, g = None, ((-1) % bm, 2)
+    while k:
+        if k & 1: want = add(want, g)
+        g = add(g, g)
+        k >>= 1
+    return want
+
+
+def _jac_to_affine_ints(raw, bm):
+    R = 1 << 256
+    X, Y, Z = (int.from_bytes(raw[32 * k:32 * k + 32], "little") * pow(R, -1, bm) % bm for k in range(3))
+    return None if Z == 0 else (X * pow(Z, -2, bm) % bm, Y * pow(Z, -3, bm) % bm)
+
+
+def strong_scaling_leg(ctx, curve, log2n, rank, world, steps, dist, always_gather):
+    """BASELINE config 4: ONE MSM of 2^log2n Pallas points sharded by point-chunk over the ranks (rank g owns generators and
+    scalars [start_g, start_g + count_g)), all-gather of the 96-byte partials over RCCL, local point sum -- through the
+    C ABI's vdf_msm_sharded.  Generators with known discrete logarithms, so the result is checked EXACTLY, whatever N is:
+    every rank adds up s_i k_i over its slice on the host, the sums are all-gathered, and rank 0 compares the GPU's point
+    with [sum s_i k_i mod q] G."""
+    import vdf_amd
+    from vdf_amd.dist import ShardedMsm
+    ntot = 1 << log2n
+    sh = ShardedMsm(ctx, curve, seed=11, n_total=ntot, rank=rank, world=world, table=(0, 1), family=vdf_amd.GENS_KNOWN_DLOG)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4321 + rank)
+    sc = torch.randint(-(2**63), 2**63 - 1, (sh.count, 4), dtype=torch.int64, device="cuda", generator=g)
+    sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    partial = torch.zeros(12, dtype=torch.int64, device="cuda")
+    gathered = torch.zeros(world * 12, dtype=torch.int64, device="cuda")
+    result = torch.zeros(12, dtype=torch.int64, device="cuda")
+    collective = world > 1 or always_gather
+
+    def all_gather(dst, src):
+        dist.all_gather_into_tensor(dst, src)
+
+    def fence():
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(2):
+        sh.run(sc, partial, gathered, all_gather, out=result, always_gather=always_gather)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sh.run(sc, partial, gathered, all_gather, out=result, always_gather=always_gather)
+    fence()
+    elapsed = time.perf_counter() - t0
+    # exactness: sum s_i k_i over all ranks
+    mine = _sum_s_k(sc.cpu().numpy().view("<u8"), _dlogs(11, sh.start, sh.count))
+    words = torch.tensor(list(int(mine).to_bytes(48, "little")), dtype=torch.uint8, device="cuda")
+    allw = torch.zeros(world * 48, dtype=torch.uint8, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if collective:
+        dist.all_gather_into_tensor(allw, words)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    else:
+        allw = words
+    sh.bases.free()
+    if rank != 0:
+        return None
+    bm, sm = (_P, _Q) if curve == vdf_amd.CURVE_PALLAS else (_Q, _P)
+    raw = allw.cpu().numpy().tobytes()
+    total = sum(int.from_bytes(raw[48 * r:48 * r + 48], "little") for r in range(world)) % sm
+    ok = _jac_to_affine_ints(result.cpu().numpy().view("<u8").tobytes(), bm) == _scalar_mul_generator(total, bm)
+    dt = float(tmax.item()) / steps
+    return {"metric": "MSM GPoints/s, 2^%d Pallas points in total sharded over the GPUs (BASELINE config 4)" % log2n,
+            "value": ntot / dt / 1e9, "unit": "GPoints/s", "n_gpus": world, "scaling": "strong", "total_points": ntot,
+            "points_per_gpu": ntot // world, "ms_per_msm": dt * 1e3, "steps": steps, "exact": bool(ok),
+            "check": "sum s_i [k_i] G = [sum s_i k_i] G with the per-rank sums all-gathered (known-dlog generators)",
+            "path": "vdf_msm_sharded (C ABI): partial -> all-gather of 96-byte partials (RCCL) -> local point sum"}
 
 
 def msm_dlog_self_check(ctx, curve, scalars_dev, n):
@@ -307,6 +424,11 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: libraries that announce themselves there (RCCL prints a version
+    # banner when the process group starts) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -405,6 +527,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    strong = None
+    if args.strong_log2n and (world > 1 or args.rehearse_collective or args.strong):
+        for c in ctxs:
+            c.set_async(True)
+        strong = strong_scaling_leg(ctx, curve, args.strong_log2n, rank, world, max(3, args.steps // 4), dist,
+                                    args.rehearse_collective)
     # prove_step across GPUs: one chain does not shard (each step needs the previous challenge), so N GPUs prove N
     # independent chains -- replicas, no collective on the data path; only the rates are combined here
     replicas = None
@@ -486,6 +614,8 @@ def main():
                                  "where a launch also waits for the other in-flight step's workgroups to retire (it can exceed "
                                  "ms_per_step and is not kernel time).  valu.* is the bound that holds (DESIGN.md 4.1, 4.2)"},
         }
+        if strong is not None:
+            line["strong_2_%d" % args.strong_log2n] = strong
         if replicas is not None:
             line["prove_step_replicas"] = replicas
         if world == 1 and not args.no_prove and not args.rehearse_collective:
@@ -505,6 +635,8 @@ def main():
             line["self_check"] = msm_dlog_self_check(ctx, curve, sc, min(n, 1 << 16))
             if not line["self_check"]["ok"]:
                 failures.append("MSM result violates the discrete-log identity")
+        if strong is not None and not strong["exact"]:
+            failures.append("the sharded 2^%d MSM violates the discrete-log identity" % args.strong_log2n)
         for key in ("prove_step", "prove_step_replicas"):
             if key in line and not line[key].get("verified", True):
                 failures.append(key + ": the proof did not verify")
@@ -513,7 +645,8 @@ def main():
         if failures:
             line["value"] = None
             line["invalid"] = failures
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
         if failures:
             raise SystemExit("bench.py: " + "; ".join(failures))
     if world > 1 or args.rehearse_collective:

@@ -60,7 +60,8 @@ enum { VDF_FIELD_FP = 0, VDF_FIELD_FQ = 1 };          /* S2 = Fp, S1 = Fq, src/n
 
 /* ---- context ------------------------------------------------------------------------ */
 /* One context drives one GPU.  device_ids/n_devices: n_devices must be 1 (one process per
- * GPU; multi-GPU jobs create one context per rank).  No reference counterpart (the
+ * GPU; multi-GPU jobs create one context per rank, or one per device in a single process, and
+ * combine them with vdf_msm_sharded / vdf_msm_multi).  No reference counterpart (the
  * reference is CPU-only); this is the handle the FFI shim would keep in a OnceCell. */
 int  vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out);
 void vdf_ctx_destroy(vdf_ctx* ctx);
@@ -140,6 +141,26 @@ int  vdf_ctx_set_msm_window(vdf_ctx* ctx, int window_bits);
 /* out = sum of n Jacobian points (the combine step of a point-chunk-sharded MSM: each GPU
  * contributes one 96-byte partial, exchanged with an RCCL all-gather). */
 int  vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_jac* out);
+/* ---- one MSM across the GPUs of a node (no reference counterpart: the reference is one process) ----------
+ * Point-chunk sharding: a rank owns generators [start, start + count) for good (with their fixed-base table) and gets
+ * the matching slice of scalars; it contributes ONE 96-byte partial; elliptic-curve addition is no RCCL reduction
+ * operator, so the exchange is an all-gather of the partials (latency-bound over xGMI) and every rank sums them itself.
+ *
+ * One process per GPU: the host supplies the collective.  `gather` receives device pointers -- `send` (bytes) and `recv`
+ * (world * bytes, rank-major) -- and the hipStream_t the partial was produced on, on which it must order the
+ * collective: RCCL `ncclAllGather(send, recv, bytes, ncclChar, comm, (hipStream_t)stream)`; returns 0 on success.
+ * partial / gathered: device buffers of 1 / `world` points the caller owns (they stay valid through the collective).
+ * flags: VDF_SHARDED_ALWAYS_GATHER takes the collective path for world == 1 too (rehearsal on one GPU). */
+typedef int (*vdf_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream);
+enum { VDF_SHARDED_ALWAYS_GATHER = 1 };
+int  vdf_msm_sharded(vdf_ctx* ctx, const vdf_bases* shard_bases, size_t offset, const vdf_fe* shard_scalars, size_t n, int is_mont,
+                     int rank, int world, vdf_allgather_fn gather, void* user, int flags, vdf_jac* partial, vdf_jac* gathered,
+                     vdf_jac* out);
+/* One process driving k GPUs (k <= 64): ctxs[i] / bases[i] / scalars[i] / n[i] are device i's context, generator shard
+ * and scalar slice (device or host memory); all partials are computed concurrently, land in pinned host memory and are
+ * summed on ctxs[0]'s device.  Blocking. */
+int  vdf_msm_multi(vdf_ctx* const ctxs[], const vdf_bases* const bases[], const size_t offsets[], const vdf_fe* const scalars[],
+                   const size_t n[], int k, int is_mont, vdf_jac* out);
 /* Stage timing of MSM calls (HIP events on the context's stream; for bench.py's roofline leg).
  * enable != 0 records events around the stages of every following vdf_msm.  vdf_msm_timing
  * synchronises and returns, summed over the calls since the last query:

@@ -58,6 +58,20 @@ class OracleBackend:
         out.copy_(torch.from_numpy(res.view(np.int64)))
         return out
 
+    def msm_sharded(self, bases, scalars, n, rank, world, all_gather, partial, gathered, out, is_mont=False,
+                    always_gather=False, offset=0):
+        """The protocol of include/vdf_hip.h vdf_msm_sharded with the C restatement as the device: partial into the
+        caller's buffer, the caller's collective called once on its two buffers, then the sum of the world partials."""
+        assert 0 <= rank < world and partial.numel() == 12 and gathered.numel() == 12 * world
+        self.calls = getattr(self, "calls", 0) + 1
+        self.msm(bases, scalars, n=n, is_mont=is_mont, out=partial)
+        all_gather(gathered, partial)
+        pt = self.point_sum(bases.curve, gathered, world)
+        m = o.curve_base_modulus(bases.curve)
+        enc = [0, 0, 0] if pt is None else [o.to_mont(pt[0], m), o.to_mont(pt[1], m), o.to_mont(1, m)]
+        out.copy_(torch.from_numpy(np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in enc), dtype=np.int64).copy()))
+        return pt
+
     def point_sum(self, curve, points, n, out=None):
         m = o.curve_base_modulus(curve)
         arr = points.numpy().view("<u8").reshape(n, 3, 4)
@@ -98,7 +112,11 @@ def _worker(rank, world, port, n_total, ret):
 
         got = sh.run(sc_t, partial, gathered, all_gather)
         exp = o.msm_by_dlog(all_scalars, curve, 7)
-        ret[rank] = (got == exp, sh.start, sh.count)
+        # the same MSM through the sharded entry point's protocol (what the product's Context.msm_sharded binds)
+        result = torch.zeros(12, dtype=torch.int64)
+        got2 = sh.run(sc_t, partial, gathered, all_gather, out=result)
+        X, Y, Z = (o.from_mont(int.from_bytes(result.numpy().view("<u8")[4 * j:4 * j + 4].tobytes(), "little"), o.P) for j in range(3))
+        ret[rank] = (got == exp and got2 == exp and sh.backend.calls == 1 and (X, Y, Z) == (exp[0], exp[1], 1), sh.start, sh.count)
     finally:
         dist.destroy_process_group()
 

@@ -650,3 +650,60 @@ def test_one_context_from_several_threads(ctx, cref):
         t.join()
     assert not errors, errors
     bases.free()
+
+
+def test_sharded_and_multi_context_msm_through_the_c_abi(ctx):
+    """vdf_msm_sharded with an injected collective (here: two 'ranks' played in turn on one GPU, the gather done by hand)
+    and vdf_msm_multi (one process, a context per device -- two contexts of device 0 here): both equal the plain MSM."""
+    import torch
+    import vdf_amd
+    from vdf_amd.hip import msm_multi
+    from vdf_amd.dist import shard_range
+    curve, n, world = o.CURVE_PALLAS, 50000, 2
+    sc = rand_limbs(np.random.default_rng(12), n)
+    want = o.msm_by_dlog(ints(sc), curve, 5)
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    shards = []
+    for r in range(world):
+        start, count = shard_range(n, r, world)
+        b = ctx.bases_generate(curve, 5, count, start=start)
+        b.precompute(0, 1)
+        shards.append((b, start, count))
+    partials = [torch.zeros(12, dtype=torch.int64, device="cuda") for _ in range(world)]
+    gathered = torch.zeros(world * 12, dtype=torch.int64, device="cuda")
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    # rank 1's partial first (as its own process would), then rank 0 runs the whole sharded call with a gather that
+    # places both partials
+    b1, s1, c1 = shards[1]
+    ctx.msm(b1, d[s1:s1 + c1], n=c1, out=partials[1])
+    calls = []
+
+    def all_gather(dst, src):
+        calls.append(1)
+        dst[:12].copy_(src)
+        dst[12:].copy_(partials[1])
+    b0, s0, c0 = shards[0]
+    ctx.msm_sharded(b0, d[s0:s0 + c0], c0, 0, world, all_gather, partials[0], gathered, out)
+    ctx.sync()
+    assert calls == [1] and jac_to_affine(out.cpu().numpy().view("<u8"), curve) == want
+    # world of one: no collective unless asked for
+    ball = ctx.bases_generate(curve, 5, n)
+    ctx.msm_sharded(ball, d, n, 0, 1, None, partials[0], gathered[:12], out)
+    ctx.sync()
+    assert jac_to_affine(out.cpu().numpy().view("<u8"), curve) == want
+    with pytest.raises(vdf_amd.VdfError):
+        ctx.msm_sharded(b0, d[s0:s0 + c0], c0, 2, world, all_gather, partials[0], gathered, out)       # rank out of range
+
+    def failing(dst, src):
+        raise RuntimeError("link down")
+    with pytest.raises(RuntimeError):
+        ctx.msm_sharded(b0, d[s0:s0 + c0], c0, 0, world, failing, partials[0], gathered, out)
+    # one process, two contexts: scalars in host memory for one, device memory for the other
+    with vdf_amd.Context(0) as c2:
+        b2 = c2.bases_generate(curve, 5, c1, start=s1)
+        got = msm_multi([ctx, c2], [b0, b2], [d[s0:s0 + c0], sc[s1:s1 + c1]], [c0, c1])
+        assert jac_to_affine(got, curve) == want
+        b2.free()
+    for b, _, _ in shards:
+        b.free()
+    ball.free()

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "vdf_ctx_set_msm_window": (_i, [_vp, _i]),
     "vdf_point_sum": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_ctx_set_timing": (_i, [_vp, _i]),
+    "vdf_msm_sharded": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vdf_msm_multi": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _i, _i, _vp]),
     "vdf_msm_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "mult_pippenger_pallas": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
     "mult_pippenger_vesta": (None, [_vp, _vp, _sz, _vp, C.c_bool]),

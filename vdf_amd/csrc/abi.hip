@@ -661,6 +661,60 @@ int vdf_point_sum(vdf_ctx* ctx, int curve, const vdf_jac* points, size_t n, vdf_
   });
 }
 
+// ---- point-chunk-sharded MSM across GPUs -------------------------------------------------------------
+int vdf_msm_sharded(vdf_ctx* ctx, const vdf_bases* shard_bases, size_t offset, const vdf_fe* shard_scalars, size_t n, int is_mont,
+                    int rank, int world, vdf_allgather_fn gather, void* user, int flags, vdf_jac* partial, vdf_jac* gathered,
+                    vdf_jac* out) {
+  if (!ctx) return VDF_ERR_BAD_ARG;
+  if (world < 1 || rank < 0 || rank >= world) { ctx->err = "rank / world out of range"; return VDF_ERR_BAD_ARG; }
+  const bool always = (flags & VDF_SHARDED_ALWAYS_GATHER) != 0;
+  if (world == 1 && !always)                               // one rank: its partial is the result
+    return vdf_msm(ctx, shard_bases, offset, shard_scalars, n, is_mont, out);
+  if (!gather || !partial || !gathered) { ctx->err = "sharded MSM needs a collective and its two buffers"; return VDF_ERR_BAD_ARG; }
+  if (!ptr_is_device(partial) || !ptr_is_device(gathered)) {
+    ctx->err = "the collective's buffers live in device memory";
+    return VDF_ERR_BAD_ARG;
+  }
+  int rc = vdf_msm(ctx, shard_bases, offset, shard_scalars, n, is_mont, partial);
+  if (rc != VDF_OK) return rc;
+  // the host's collective, ordered on this context's stream after the partial; no lock held: it may block on other ranks
+  if (gather(user, partial, gathered, sizeof(vdf_jac), ctx->stream) != 0) {
+    ctx->err = "the all-gather supplied by the host failed";
+    return VDF_ERR_DEVICE;
+  }
+  return vdf_point_sum(ctx, shard_bases->curve, gathered, (size_t)world, out);
+}
+
+// One process driving several GPUs: a context, a generator shard and a scalar slice per device; the partials land in
+// pinned host memory and are summed on the first context's device.
+int vdf_msm_multi(vdf_ctx* const ctxs[], const vdf_bases* const bases[], const size_t offsets[], const vdf_fe* const scalars[],
+                  const size_t n[], int k, int is_mont, vdf_jac* out) {
+  if (!ctxs || !bases || !scalars || !n || !out || k < 1 || k > 64 || !ctxs[0]) return VDF_ERR_BAD_ARG;
+  vdf_ctx* c0 = ctxs[0];
+  vdf_jac* h = nullptr;
+  int rc = vdf_host_alloc(c0, (size_t)k * sizeof(vdf_jac), reinterpret_cast<void**>(&h));
+  if (rc != VDF_OK) return rc;
+  int was_async[64];
+  for (int i = 0; i < k && rc == VDF_OK; ++i) {
+    if (!ctxs[i] || !bases[i] || bases[i]->curve != bases[0]->curve) { c0->err = "bad context / generator shard"; rc = VDF_ERR_BAD_ARG; break; }
+    rc = vdf_ctx_get_async(ctxs[i], &was_async[i]);
+    if (rc == VDF_OK) rc = vdf_ctx_set_async(ctxs[i], 1);
+    // every device works at once: enqueue all partials (results into pinned memory), then wait for each
+    if (rc == VDF_OK) rc = vdf_msm(ctxs[i], bases[i], offsets ? offsets[i] : 0, scalars[i], n[i], is_mont, &h[i]);
+    if (rc != VDF_OK && ctxs[i] != c0) c0->err = ctxs[i]->err;
+  }
+  for (int i = 0; i < k; ++i) {
+    if (!ctxs[i]) continue;
+    const int r2 = vdf_ctx_sync(ctxs[i]);
+    if (rc == VDF_OK && r2 != VDF_OK) { rc = r2; c0->err = ctxs[i]->err; }
+    (void)vdf_ctx_set_async(ctxs[i], was_async[i]);
+  }
+  if (rc == VDF_OK) rc = vdf_point_sum(c0, bases[0]->curve, h, (size_t)k, out);
+  if (rc == VDF_OK) rc = vdf_ctx_sync(c0);
+  (void)vdf_host_free(c0, h);
+  return rc;
+}
+
 int vdf_ctx_set_timing(vdf_ctx* ctx, int enable) {
   return guarded(ctx, [&]() -> Status { ctx->timing = enable != 0; return Status{}; });
 }

@@ -58,6 +58,11 @@ class ShardedMsm:
         if self.world == 1 and not always_gather:
             # one rank: its partial is the result (nothing to gather, nothing to sum)
             return self.local_partial(scalars_local, partial_buf if out is None else out, is_mont=is_mont)
+        if out is not None and hasattr(self.backend, "msm_sharded"):
+            # the product path: one C-ABI call (include/vdf_hip.h vdf_msm_sharded) that runs the partial, calls the
+            # collective handed in here, and sums -- what a non-Python host does with an RCCL communicator
+            return self.backend.msm_sharded(self.bases, scalars_local, self.count, self.rank, self.world, all_gather,
+                                            partial_buf, gathered_buf, out, is_mont=is_mont, always_gather=always_gather)
         self.local_partial(scalars_local, partial_buf, is_mont=is_mont)
         all_gather(gathered_buf, partial_buf)
         return self.combine(gathered_buf, out=out)

@@ -95,6 +95,21 @@ class Bases:
             pass
 
 
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)     # vdf_allgather_fn
+
+
+def msm_multi(ctxs, bases, scalars, n, offsets=None, is_mont: bool = False):
+    """vdf_msm_multi: one process, one Context / generator shard / scalar slice per device; returns uint64[12]."""
+    k = len(ctxs)
+    out = np.zeros(12, dtype="<u8")
+    offs = (C.c_size_t * k)(*(offsets or [0] * k))
+    rc = lib.vdf_msm_multi((C.c_void_p * k)(*[c.handle for c in ctxs]), (C.c_void_p * k)(*[b.handle for b in bases]), offs,
+                           (C.c_void_p * k)(*[_ptr(x) for x in scalars]), (C.c_size_t * k)(*[int(x) for x in n]), k,
+                           int(is_mont), out.ctypes.data)
+    ctxs[0]._check(rc)
+    return out
+
+
 class Shape:
     def __init__(self, ctx: "Context", handle: int, field: int, num_cons: int, num_cols: int):
         self.ctx, self.handle, self.field, self.num_cons, self.num_cols = ctx, handle, field, num_cons, num_cols
@@ -235,6 +250,28 @@ class Context:
         self._check(lib.vdf_msm_job_begin(self.handle, bases.handle, k, (C.c_size_t * k)(*offsets), (C.c_size_t * k)(*n),
                                           int(is_mont), C.byref(h)))
         return MsmJob(self, h.value, k)
+
+    def msm_sharded(self, bases: Bases, scalars, n: int, rank: int, world: int, all_gather, partial, gathered, out,
+                    is_mont: bool = False, always_gather: bool = False, offset: int = 0):
+        """vdf_msm_sharded: this rank's partial, the host's all-gather of the world partials, the local point sum.
+        all_gather(dst, src) is the collective on the caller's buffers `gathered` (world x 12 words) and `partial` (12),
+        both device memory; it is called once, from inside the library, ordered after the partial."""
+        err = []
+
+        def cb(_user, _send, _recv, _bytes, _stream):
+            try:
+                all_gather(gathered, partial)
+                return 0
+            except Exception as e:            # an exception must not unwind through the C frames
+                err.append(e)
+                return 1
+        fn = _ALLGATHER(cb)
+        rc = lib.vdf_msm_sharded(self.handle, bases.handle, offset, _ptr(scalars), n, int(is_mont), rank, world, fn, None,
+                                 1 if always_gather else 0, _ptr(partial), _ptr(gathered), _ptr(out))
+        if err:
+            raise err[0]
+        self._check(rc)
+        return out
 
     def point_sum(self, curve: int, points, n: int, out=None):
         host_out = out is None
