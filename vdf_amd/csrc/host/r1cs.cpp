@@ -2,7 +2,12 @@
 // (see r1cs.hpp).  Host code only: O(10^4) sequential field operations per step, no kernel work.
 #include "r1cs.hpp"
 
+#include <condition_variable>
 #include <mutex>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace vdfnova {
 
@@ -482,6 +487,64 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
   *oy = select(cs, i1, y2, uy);
 }
 
+// Two helper threads for the native pre-passes of a synthesis (one per folded commitment): they run while the calling
+// thread emits the hash gadgets, so the ~0.25 ms of projective arithmetic and batched inversion leave the critical path.
+// Persistent (created on first use, parked on a condition variable), one pair per process; a synthesis that finds them
+// busy (another prover thread) simply does its pre-pass inline.
+namespace {
+class Helpers {
+ public:
+  static Helpers& get() { static Helpers* h = new Helpers(); return *h; }     // never destroyed: its threads outlive main
+  // returns false when the helpers are taken: the caller then runs the work itself
+  bool try_acquire() { bool f = false; return busy_.compare_exchange_strong(f, true); }
+  void release() { busy_.store(false); }
+  void start(int k, std::function<void()> fn) {
+    Slot& s = slots_[k];
+    s.fn = std::move(fn);
+    s.state.store(1, std::memory_order_release);           // 1 = posted
+    if (s.parked.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> l(s.mu); s.cv.notify_one(); }
+  }
+  void wait(int k) {
+    Slot& s = slots_[k];
+    // the job is ~0.1 ms: spin, but hand the core over if it has not even started (an oversubscribed host)
+    for (unsigned n = 0; s.state.load(std::memory_order_acquire) != 0; ++n) {
+      if (n < 20000) __builtin_ia32_pause(); else std::this_thread::yield();
+    }
+  }
+ private:
+  // A helper polls for ~2 ms after its last job before it parks on a condition variable: a prover calls every
+  // ~1.3 ms, and waking a parked thread (futex, idle core) costs about as much as the job itself.
+  struct Slot {
+    std::function<void()> fn;
+    std::atomic<int> state{0};
+    std::atomic<bool> parked{false};
+    std::mutex mu;
+    std::condition_variable cv;
+  };
+  Helpers() { for (int k = 0; k < 2; ++k) std::thread([this, k] { loop(k); }).detach(); }
+  void loop(int k) {
+    Slot& s = slots_[k];
+    for (;;) {
+      auto idle_since = std::chrono::steady_clock::now();
+      while (s.state.load(std::memory_order_acquire) != 1) {
+        __builtin_ia32_pause();
+        if (std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
+          std::unique_lock<std::mutex> l(s.mu);
+          s.parked.store(true, std::memory_order_release);
+          s.cv.wait(l, [&] { return s.state.load(std::memory_order_acquire) == 1; });
+          s.parked.store(false, std::memory_order_release);
+        }
+      }
+      s.fn();
+      s.fn = nullptr;
+      s.state.store(0, std::memory_order_release);
+    }
+  }
+  Slot slots_[2];
+  std::atomic<bool> busy_{false};
+};
+}  // namespace
+
 // Native pre-pass for  U + [r] P : the true points 2^k P and (r mod 2^(k+1)) P in projective coordinates, one batched
 // normalisation, then every denominator the gadgets will meet -- chord of (r mod 2^k) P and 2^k P, tangent at 2^k P,
 // k < bits, and the slope of the final complete addition -- inverted in a second batch.
@@ -731,6 +794,24 @@ std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, cons
   const Field& PF = field(side_field(1 - side));
   const size_t a = step.arity();
   const Num one_n = cs.constant(one(F));
+  // witness mode: the fold challenge is known natively from the inputs alone, so the slope inverses of both in-circuit
+  // folds are computed on the helper threads while this thread emits the hash gadgets (CS::take_inverse checks them)
+  std::vector<Fe> q_w, q_e;
+  bool helped = false;
+  if (!cs.shape) {
+    uint64_t rv[4];
+    hash_challenge(cs.field_id, in.params, in.U, in.u_W, in.u_X, in.T, rv);
+    helped = Helpers::get().try_acquire();
+    if (helped) {
+      const Field* Fp = &F;
+      const AugInputs* ip = &in;
+      std::vector<Fe>* qw = &q_w; std::vector<Fe>* qe = &q_e;
+      const std::array<uint64_t, 4> ra = {rv[0], rv[1], rv[2], rv[3]};
+      Helpers::get().start(0, [=] { ec_fold_inverses(*Fp, ip->U.comm_W, ip->u_W, ra.data(), CHAL_BITS, qw); });
+      Helpers::get().start(1, [=] { ec_fold_inverses(*Fp, ip->U.comm_E, ip->T, ra.data(), CHAL_BITS, qe); });
+    }
+  }
+  struct Joiner { bool on; ~Joiner() { if (on) { Helpers::get().wait(0); Helpers::get().wait(1); Helpers::get().release(); } } } joiner{helped};
   const Num params = cs.alloc(in.params);
   const Num i = cs.alloc(in.i);
   std::vector<Num> z0, zi;
@@ -764,12 +845,20 @@ std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, cons
   const Num T_inf = is_zero(cs, Tx);
   check_on_curve(cs, Tx, Ty, T_inf);
   if (!cs.shape) {
-    uint64_t rv[4];
-    fe_to_int(r.v, F, rv);
     cs.inv_queue.clear();
     cs.inv_pos = 0;
-    ec_fold_inverses(F, in.U.comm_W, in.u_W, rv, CHAL_BITS, &cs.inv_queue);
-    ec_fold_inverses(F, in.U.comm_E, in.T, rv, CHAL_BITS, &cs.inv_queue);
+    if (helped) {
+      Helpers::get().wait(0); Helpers::get().wait(1);
+      Helpers::get().release();
+      joiner.on = false;
+      cs.inv_queue = std::move(q_w);
+      cs.inv_queue.insert(cs.inv_queue.end(), q_e.begin(), q_e.end());
+    } else {
+      uint64_t rv[4];
+      fe_to_int(r.v, F, rv);
+      ec_fold_inverses(F, in.U.comm_W, in.u_W, rv, CHAL_BITS, &cs.inv_queue);
+      ec_fold_inverses(F, in.U.comm_E, in.T, rv, CHAL_BITS, &cs.inv_queue);
+    }
   }
   // comm_W' = U.W + r u.W ; comm_E' = U.E + r T
   Num rWx, rWy, fWx, fWy, rTx, rTy, fEx, fEy;
