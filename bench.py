@@ -57,6 +57,25 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota where one is set (the GPU box shows 256 logical CPUs
+    and grants a share of them), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     """Rank 0, N = 1 only.  The ONLY place bench.py touches oracle/: times the C restatement on the
     host cores and checks the GPU result against it."""
@@ -66,7 +85,7 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     # The restatement spreads the windows of one MSM (16 at 2^16+ points) over a thread pool; to use every host core the
     # points are cut into chunks, each chunk an independent MSM with its own pool (ctypes calls release the GIL), and
     # the chunk results are added: chunks x 16 threads.
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     per_chunk = 16
     chunks = max(1, min(cores // per_chunk, 32))
     while n % chunks:
@@ -107,6 +126,7 @@ def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
     gpu_pt = (o.from_mont(int.from_bytes(raw[:32], "little"), bm), o.from_mont(int.from_bytes(raw[32:], "little"), bm))
     return {
         "value": n / dt / 1e9, "unit": "GPoints/s", "cores": cores, "threads_used": threads_used, "kind": "port",
+        "logical_cpus_visible": os.cpu_count(),
         "sample": f"the full 2^{n.bit_length() - 1}-point MSM of the timed workload (same bases and scalars), "
                   f"{dt:.2f} s wall: {chunks} point-chunks x {min(per_chunk, cores)} window threads (oracle/pasta_ref.c), chunk results added",
         "parity_bit_exact": bool((acc or (0, 0)) == gpu_pt),
@@ -120,7 +140,7 @@ def cpu_prove_baseline_leg(log2t=10, nsteps=3):
     box's host cores.  A port, and a slow one (the reference's Rust prover cannot be built here): reported, never the target."""
     from oracle import nova as nv, pasta as o
     t = 1 << log2t
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     com = nv.CCommit(threads=min(16, cores))
     pp = nv.public_params(t, com, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
     states = [o.State(0x1234567890ABCDEF1234567890ABCDEF, 0, 0)]

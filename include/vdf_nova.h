@@ -61,7 +61,7 @@ typedef struct vdf_snark vdf_snark;       /* NovaVDFProof::Compressed, :54 */
  * circuit exactly as the reference writes it (4 variables per round; new_x allocated at :167-173 and used by no
  * constraint, :219-227 takes y - i + 1 directly), kept for shape / witness parity; a prover may set its new_x freely,
  * so a proof over it does not attest the VDF (tests/test_oracle_nova.py shows the forgery). */
-enum { VDF_CIRCUIT_MINROOT_BOUND = 0, VDF_CIRCUIT_MINROOT_REFERENCE = 1 };
+enum { VDF_CIRCUIT_MINROOT_BOUND = 0, VDF_CIRCUIT_MINROOT_REFERENCE = 1, VDF_CIRCUIT_CUSTOM = 2 /* vdf_step_circuit, below */ };
 enum { VDF_SIDE_PRIMARY = 0, VDF_SIDE_SECONDARY = 1 };
 
 /* public_params(num_iters_per_step), :232-237: both augmented circuits synthesised once for their R1CS shapes,
@@ -129,12 +129,43 @@ int  vdf_nova_proof_last_step(const vdf_proof* proof, vdf_nova_step_info* out);
  * launch, [7] total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
 
+/* ---- the step-circuit seam (src/nova/proof.rs:79-153: `impl StepCircuit for InverseMinRootCircuit` -- arity, synthesize,
+ * output) ---------------------------------------------------------------------------------------------------------
+ * A step circuit written by the host: `synthesize` receives the constraint system and the arity handles of z_in, makes
+ * its variables and constraints through the vdf_cs_* calls below, and stores the handles of z_out.  The same function
+ * runs in two modes, as a bellperson circuit does: when the parameters are made the constraints are recorded (values
+ * are ignored); in every prove_step only the values are computed (vdf_cs_is_witness).  `output` of the trait is the
+ * value of z_out after a witness synthesis.  The library's own circuits (both MinRoot forms, TrivialTestCircuit) sit
+ * behind the same C++ interface (host/r1cs.hpp StepCircuit); a custom circuit's variables are all made on the host. */
+typedef struct vdf_cs vdf_cs;
+typedef uint32_t vdf_num;                 /* a linear combination with its value, owned by the vdf_cs */
+typedef struct {
+  size_t arity;
+  int (*synthesize)(void* self, vdf_cs* cs, const vdf_num* z_in, vdf_num* z_out);       /* 0 = ok */
+  void* self;
+} vdf_step_circuit;
+int     vdf_cs_is_witness(const vdf_cs* cs);                          /* 1: values are live; 0: the shape is being recorded */
+vdf_num vdf_cs_const(vdf_cs* cs, const vdf_fe* k);                    /* the constant k (Montgomery form) */
+vdf_num vdf_cs_add(vdf_cs* cs, vdf_num a, vdf_num b);
+vdf_num vdf_cs_sub(vdf_cs* cs, vdf_num a, vdf_num b);
+vdf_num vdf_cs_scale(vdf_cs* cs, vdf_num a, const vdf_fe* k);
+vdf_num vdf_cs_alloc(vdf_cs* cs, const vdf_fe* value);                /* a new variable (AllocatedNum::alloc) */
+vdf_num vdf_cs_mul(vdf_cs* cs, vdf_num a, vdf_num b);                 /* a new variable a * b and its constraint */
+int     vdf_cs_enforce(vdf_cs* cs, vdf_num a, vdf_num b, vdf_num c);  /* a * b = c */
+int     vdf_cs_value(const vdf_cs* cs, vdf_num a, vdf_fe* out);       /* witness mode */
+/* public_params / prove_step / verify for a custom primary step circuit (the secondary stays TrivialTestCircuit).
+ * z0, zi: `arity` elements.  compress, verify_compressed and the wire formats work on such proofs unchanged. */
+int  vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary, int gens_family, vdf_pp** out);
+int  vdf_nova_prove_step_custom(vdf_pp* pp, vdf_proof** proof, const vdf_step_circuit* primary, const vdf_fe* z0);
+int  vdf_nova_verify_custom(const vdf_proof* proof, vdf_pp* pp, size_t num_steps, const vdf_fe* z0, const vdf_fe* zi, int* ok);
+
 /* ---- host-only entry points (no device): what the CPU tests pin against oracle/nova.py ------------------------- */
 /* the random oracle: lane 1 of the sponge after absorbing xs under `tag` (a full field element, Montgomery in and out) */
 int  vdf_nova_ro_hash(int field, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out);
 /* digest of the parameters public_params would make (both shapes synthesised on the host), and the sizes per side:
  * sizes[side] = {num_cons, num_vars, nnz(A) + nnz(B) + nnz(C)} */
 int  vdf_nova_shape_digest(uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]);
+int  vdf_nova_shape_digest_custom(const vdf_step_circuit* primary, int gens_family, uint8_t out[32], uint64_t sizes[2][3]);
 /* One augmented circuit synthesised on the host with every variable computed there (small t only).  The inputs that
  * belong to the folded side (U_u, U_X, u_X) are in Montgomery form of THAT side's scalar field, everything else in the
  * circuit's own field.  result / input: the MinRoot step's states (side 0; ignored for side 1).  arity = 3 / 1. */

@@ -363,6 +363,25 @@ class InverseMinRootCircuit:
         return [self.input.x, self.input.y, self.input.i]
 
 
+class CubicCircuit:
+    """A second primary step circuit for the seam's tests (nova-snark's own example): arity 1, z -> z^3 + z + 5."""
+
+    def arity(self) -> int:
+        return 1
+
+    def synthesize(self, cs: CS, z: Sequence[Num]) -> List[Num]:
+        x = z[0]
+        x2 = cs.mul(x, x)
+        x3 = cs.mul(x2, x)
+        rhs = cs.add(cs.add(x3, x), cs.const(5))
+        y = cs.alloc(rhs.v)
+        cs.enforce(rhs, cs.const(1), y)
+        return [y]
+
+    def output(self, z: Sequence[int]) -> List[int]:
+        return [(z[0] ** 3 + z[0] + 5) % o.Q]
+
+
 class TrivialTestCircuit:
     """nova-snark's TrivialTestCircuit (src/nova/proof.rs:258-260): arity 1, z_out = z_in, no constraint."""
 
@@ -528,10 +547,11 @@ class PublicParams:
     commit: Callable[[int, Sequence[int]], Aff]               # commit(side, vector) under that side's generators
 
 
-def public_params(t: int, commit, gens_seed: int, gens_family: int, bound: bool = True) -> PublicParams:
-    """src/nova/proof.rs:232-237: both augmented circuits synthesised once for their shapes."""
+def public_params(t: int, commit, gens_seed: int, gens_family: int, bound: bool = True, primary=None) -> PublicParams:
+    """src/nova/proof.rs:232-237: both augmented circuits synthesised once for their shapes.  `primary`: another step
+    circuit than InverseMinRootCircuit on the primary side (anything with arity / synthesize / output; t is then 0)."""
     shapes = []
-    for side, step in ((0, InverseMinRootCircuit(t, None, None, bound)), (1, TrivialTestCircuit())):
+    for side, step in ((0, primary or InverseMinRootCircuit(t, None, None, bound)), (1, TrivialTestCircuit())):
         cs = CS(SIDE_FIELD[side])
         synthesize_augmented(cs, side, dummy_inputs(step.arity()), step)
         shapes.append(cs.shape())
@@ -575,7 +595,7 @@ def synth_fresh(pp: PublicParams, side: int, inp: AugInputs, step) -> Tuple[Fres
     return Fresh(pp.commit(side, cs.W), list(cs.X), list(cs.W)), z_next
 
 
-def prove_step(pp: PublicParams, snark: Optional[RecursiveSNARK], c1: InverseMinRootCircuit, z0_1: Sequence[int],
+def prove_step(pp: PublicParams, snark: Optional[RecursiveSNARK], c1, z0_1: Sequence[int],
                z0_2: Sequence[int] = (0,)) -> RecursiveSNARK:
     """RecursiveSNARK::prove_step (src/nova/proof.rs:342-349)."""
     c2 = TrivialTestCircuit()

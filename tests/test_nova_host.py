@@ -138,3 +138,32 @@ def test_committed_known_answers(golden):
         assert ps.hash_elements(1, [1, 2, 3, 4, 5], field) == want
         assert unmont(vn.ro_hash(field, 1, mont([1, 2, 3, 4, 5], field)), field)[0] == want
     assert vn.shape_digest(1, 0, 1)[0] == int(golden["params_t1"], 16)
+
+
+def test_custom_step_circuit_shape_through_the_seam():
+    """The C ABI's vdf_step_circuit (src/nova/proof.rs:79-153): a host-written circuit's shapes hash to the oracle's
+    `params` for the same circuit; a circuit that fails while its shape is recorded is an error."""
+    Q = o.Q
+    fe = lambda v: limbs([o.to_mont(v % Q, Q)]).tobytes()
+
+    class Cubic(vn.StepCircuit):
+        arity = 1
+
+        def synthesize(self, cs, z):
+            x = z[0]
+            x3 = cs.mul(cs.mul(x, x), x)
+            rhs = cs.add(cs.add(x3, x), cs.const(fe(5)))
+            y = cs.alloc(cs.value(rhs) if cs.is_witness else None)
+            cs.enforce(rhs, cs.const(fe(1)), y)
+            return [y]
+
+    class Broken(vn.StepCircuit):
+        arity = 1
+
+        def synthesize(self, cs, z):
+            raise RuntimeError("no shape")
+    digest, sizes = vn.shape_digest_custom(Cubic())
+    opp = nv.public_params(0, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, primary=nv.CubicCircuit())
+    assert digest == opp.params and sizes[0][:2] == [opp.shapes[0].num_cons, opp.shapes[0].num_vars]
+    with pytest.raises(RuntimeError):
+        vn.shape_digest_custom(Broken())

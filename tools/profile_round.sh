@@ -10,7 +10,7 @@ mkdir -p $OUT
 make -s -C $R/oracle all || exit 1
 cd /tmp && export TMPDIR=/tmp
 for t in op_rates clock_probe; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $R/tools/ubench/$t.hip -o $OUT/$t || exit 1
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I $R/vdf_amd/csrc $R/tools/ubench/$t.hip -o $OUT/$t || exit 1
   timeout -k 10 120 $OUT/$t > $OUT/$t.txt 2>&1 || exit 1
 done
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_under_rocprof.log 2>&1 || exit 1

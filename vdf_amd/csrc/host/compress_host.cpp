@@ -544,7 +544,8 @@ struct vdf_snark {          // NovaVDFProof::Compressed, src/nova/proof.rs:54 = 
   Inst r_U1, r_U2, l_u2;    // running primary, running secondary BEFORE the last fold, the last secondary instance
   Aff T2;                   // cross-term commitment of that last fold
   Spartan sp[2];            // sp[0]: r_U1 is satisfiable; sp[1]: fold(r_U2, l_u2) is
-  Fe zi1[3], zi2[1];
+  std::vector<Fe> zi1;      // z_i of the primary side (arity of its step circuit)
+  Fe zi2[1];
   uint64_t t = 0;           // the public parameters it was made under (wire header)
   uint8_t digest[32];
 };
@@ -584,7 +585,9 @@ void spartan_resize(Spartan& p, const Layout& L) {
 }
 
 // the statement part of a compressed proof on the wire: instances with 32-byte points, then both z_i
-constexpr size_t STATEMENT_WIRE = 5 * 32 * 2 + 3 * 32 + 32 + 96 + 32;
+// without the primary z_i (32 bytes per element of the step circuit's arity)
+constexpr size_t STATEMENT_WIRE_FIXED = 5 * 32 * 2 + 3 * 32 + 32 + 32;
+inline size_t statement_wire(size_t arity) { return STATEMENT_WIRE_FIXED + 32 * arity; }
 }  // namespace
 
 extern "C" {
@@ -607,7 +610,7 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
   s->t = pp->t;
   memcpy(s->digest, pp->digest, 32);
   s->r_U1 = p->r[PRIMARY].inst; s->r_U2 = p->r[SECONDARY].inst; s->l_u2 = p->l2;
-  memcpy(s->zi1, p->zi[PRIMARY].data(), 96);
+  s->zi1 = p->zi[PRIMARY];
   s->zi2[0] = p->zi[SECONDARY][0];
   // the last secondary instance is folded into the running one (NIFS, as a prove_step would): into scratch, the proof is
   // left as it is
@@ -650,7 +653,8 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
   const Side& S2 = pp->s[SECONDARY];
   const Field& F1 = *S1.F;
   const Field& F2 = *S2.F;
-  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + 3), z0s(1, zero()), zi1(s->zi1, s->zi1 + 3), zi2(s->zi2, s->zi2 + 1);
+  if (s->zi1.size() != pp->arity) return VDF_OK;
+  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero()), zi1 = s->zi1, zi2(s->zi2, s->zi2 + 1);
   uint64_t hv[4];
   hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv);
   if (int_to_fe(hv, F2) != s->l_u2.X[0]) return VDF_OK;
@@ -672,7 +676,7 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
   rc = spartan_verify(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, s->sp[1], &good);
   if (rc != VDF_OK) return rc;
   if (!good) return VDF_OK;
-  *ok = (memcmp(s->zi1, zi, 96) == 0 && s->zi2[0].is_zero()) ? 1 : 0;       // src/nova/proof.rs:386
+  *ok = (memcmp(s->zi1.data(), zi, 32 * pp->arity) == 0 && s->zi2[0].is_zero()) ? 1 : 0;       // src/nova/proof.rs:386
   return VDF_OK;
 }
 
@@ -738,7 +742,7 @@ int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
 // ---- the whole compressed proof as one byte string ("VDFSNK03", layout in include/vdf_nova.h) -----------------------
 size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
   if (!s) return 0;
-  size_t n = 8 + 8 + 32 + STATEMENT_WIRE;
+  size_t n = 8 + 8 + 32 + statement_wire(s->zi1.size());
   for (const Spartan& p : s->sp)
     n += 32 * (3 * p.outer.size() + 4 + 2 * p.inner.size() + 1 + p.ipaW.a.size() + p.ipaE.a.size()) + 64 * (p.ipaW.L.size() + p.ipaE.L.size());
   return n;
@@ -757,7 +761,7 @@ int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
   o = put_inst(o, s->r_U2, sd[1], true);
   o = put_inst(o, s->l_u2, sd[1], false);
   pt_compress(s->T2, *sd[1].Fb, o); o += 32;
-  for (int k = 0; k < 3; ++k) o = wire_put_fe(o, s->zi1[k], *sd[0].F);
+  for (const Fe& v : s->zi1) o = wire_put_fe(o, v, *sd[0].F);
   o = wire_put_fe(o, s->zi2[0], *sd[1].F);
   for (int side = 0; side < 2; ++side) {
     const Field& F = *sd[side].F;
@@ -779,13 +783,13 @@ int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
 int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out) {
   if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
   *out = nullptr;
-  if (len < 48 + STATEMENT_WIRE) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
+  if (len < 48 + statement_wire(pp->arity)) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
   if (memcmp(in, WIRE_MAGIC_SNARK, 8) != 0) return fail(VDF_ERR_BAD_ARG, "not this kind of encoding (magic)");
   uint64_t t;
   memcpy(&t, in + 8, 8);
   if (t != pp->t || memcmp(in + 16, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "encoding was made under other public parameters");
   const Layout L[2] = {layout_of(pp->s[0]), layout_of(pp->s[1])};
-  if (len != 48 + STATEMENT_WIRE + spartan_wire_size(L[0]) + spartan_wire_size(L[1]))
+  if (len != 48 + statement_wire(pp->arity) + spartan_wire_size(L[0]) + spartan_wire_size(L[1]))
     return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
   std::unique_ptr<vdf_snark> s(new vdf_snark());
   s->t = t;
@@ -796,7 +800,8 @@ int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_sn
   i = get_inst(i, &s->r_U2, pp->s[1], true, &canonical, &on_curve);
   i = get_inst(i, &s->l_u2, pp->s[1], false, &canonical, &on_curve);
   on_curve &= pt_decompress(i, *pp->s[1].Fb, &s->T2); i += 32;
-  for (int k = 0; k < 3; ++k, i += 32) canonical &= wire_get_fe(i, *pp->s[0].F, &s->zi1[k]);
+  s->zi1.resize(pp->arity);
+  for (size_t k = 0; k < pp->arity; ++k, i += 32) canonical &= wire_get_fe(i, *pp->s[0].F, &s->zi1[k]);
   canonical &= wire_get_fe(i, *pp->s[1].F, &s->zi2[0]); i += 32;
   for (int side = 0; side < 2; ++side) {
     const Field& F = *pp->s[side].F;

@@ -33,6 +33,76 @@ std::unique_ptr<StepCircuit> make_primary_circuit(const vdf_pp* pp, const Circui
 }
 }  // namespace vdfnova
 
+// ---- the step-circuit seam in the C ABI (include/vdf_nova.h) --------------------------------------------------------
+struct vdf_cs { CS* cs; std::vector<Num> pool; bool bad = false; };
+namespace {
+const Num* cs_get(const vdf_cs* c, vdf_num h) { return h < c->pool.size() ? &c->pool[h] : nullptr; }
+vdf_num cs_put(vdf_cs* c, Num n) { c->pool.push_back(std::move(n)); return (vdf_num)(c->pool.size() - 1); }
+struct CustomStepCircuit : StepCircuit {
+  vdf_step_circuit c;
+  mutable int rc = 0;
+  size_t arity() const override { return c.arity; }
+  std::vector<Num> synthesize(CS& cs, const std::vector<Num>& z) const override {
+    vdf_cs h{&cs, z, false};
+    std::vector<vdf_num> zin(c.arity), zout(c.arity, 0);
+    for (size_t k = 0; k < c.arity; ++k) zin[k] = (vdf_num)k;
+    rc = c.synthesize(c.self, &h, zin.data(), zout.data());
+    std::vector<Num> out(c.arity);
+    for (size_t k = 0; k < c.arity; ++k) {
+      const Num* n = cs_get(&h, zout[k]);
+      if (!n || h.bad) { rc = rc ? rc : VDF_ERR_BAD_ARG; out[k] = cs.zero_num(); } else out[k] = *n;
+    }
+    return out;
+  }
+  void output(const Fe*, Fe*) const override {}        // z_{i+1} is the value of z_out after a witness synthesis
+};
+}  // namespace
+namespace vdfnova {
+std::unique_ptr<StepCircuit> make_custom_circuit(const vdf_step_circuit* c) {
+  std::unique_ptr<CustomStepCircuit> m(new CustomStepCircuit());
+  m->c = *c;
+  return std::unique_ptr<StepCircuit>(m.release());
+}
+}  // namespace vdfnova
+
+extern "C" {
+int vdf_cs_is_witness(const vdf_cs* c) { return c && !c->cs->shape ? 1 : 0; }
+vdf_num vdf_cs_const(vdf_cs* c, const vdf_fe* k) { Fe v; memcpy(&v, k, 32); return cs_put(c, c->cs->constant(v)); }
+#define CS_BIN(name, op)                                                                      \
+  vdf_num name(vdf_cs* c, vdf_num a, vdf_num b) {                                             \
+    const Num *x = cs_get(c, a), *y = cs_get(c, b);                                           \
+    if (!x || !y) { c->bad = true; return 0; }                                                \
+    return cs_put(c, c->cs->op(*x, *y));                                                      \
+  }
+CS_BIN(vdf_cs_add, add)
+CS_BIN(vdf_cs_sub, sub)
+CS_BIN(vdf_cs_mul, mul)
+#undef CS_BIN
+vdf_num vdf_cs_scale(vdf_cs* c, vdf_num a, const vdf_fe* k) {
+  const Num* x = cs_get(c, a);
+  if (!x) { c->bad = true; return 0; }
+  Fe v; memcpy(&v, k, 32);
+  return cs_put(c, c->cs->scale(*x, v));
+}
+vdf_num vdf_cs_alloc(vdf_cs* c, const vdf_fe* value) {
+  Fe v = zero();
+  if (value && !c->cs->shape) memcpy(&v, value, 32);
+  return cs_put(c, c->cs->alloc(v));
+}
+int vdf_cs_enforce(vdf_cs* c, vdf_num a, vdf_num b, vdf_num cc) {
+  const Num *x = cs_get(c, a), *y = cs_get(c, b), *z = cs_get(c, cc);
+  if (!x || !y || !z) { c->bad = true; return VDF_ERR_BAD_ARG; }
+  c->cs->enforce(*x, *y, *z);
+  return VDF_OK;
+}
+int vdf_cs_value(const vdf_cs* c, vdf_num a, vdf_fe* out) {
+  const Num* x = cs_get(c, a);
+  if (!x || !out) return VDF_ERR_BAD_ARG;
+  memcpy(out, &x->v, 32);
+  return VDF_OK;
+}
+}  // extern "C"
+
 namespace {
 
 AugInputs blank_inputs(size_t arity) {
@@ -50,23 +120,26 @@ AugInputs blank_inputs(size_t arity) {
 struct HostShape { Coo m[3]; size_t num_cons = 0, num_vars = 0, step_begin = 0, step_end = 0; };
 
 // both augmented circuits in shape mode (PublicParams::setup, src/nova/proof.rs:236)
-void build_shapes(uint64_t t, int circuit_kind, HostShape out[2]) {
+int build_shapes(uint64_t t, int circuit_kind, HostShape out[2], const vdf_step_circuit* custom = nullptr) {
   vdf_pp tmp;
   tmp.t = t;
   tmp.circuit_kind = circuit_kind;
   for (int side = 0; side < 2; ++side) {
     CS cs(side_field(side), true);
     std::unique_ptr<StepCircuit> step;
-    if (side == PRIMARY) step = make_primary_circuit(&tmp, nullptr, false);
+    if (side == PRIMARY) step = custom ? make_custom_circuit(custom) : make_primary_circuit(&tmp, nullptr, false);
     else step.reset(new TrivialTestCircuit());
     // the step circuit's variables are one contiguous run: find it by synthesising the wrapper once around an empty step
     synthesize_augmented(cs, side, blank_inputs(step->arity()), *step);
+    if (side == PRIMARY && custom && static_cast<const CustomStepCircuit*>(step.get())->rc != 0)
+      return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed while its shape was recorded");
     cs.finish(out[side].m);
     out[side].num_cons = cs.rows;
     out[side].num_vars = cs.W.size();
     out[side].step_begin = cs.step_begin;
     out[side].step_end = cs.step_end;
   }
+  return VDF_OK;
 }
 
 // oracle/nova.py digest_shapes
@@ -225,6 +298,19 @@ int vdf_nova_shape_digest(uint64_t t, int circuit_kind, int gens_family, uint8_t
   return VDF_OK;
 }
 
+int vdf_nova_shape_digest_custom(const vdf_step_circuit* primary, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
+  if (!primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64 || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  HostShape sh[2];
+  { int rc = build_shapes(0, VDF_CIRCUIT_CUSTOM, sh, primary); if (rc != VDF_OK) return rc; }
+  digest_shapes(0, gens_family, sh, out);
+  if (sizes)
+    for (int s = 0; s < 2; ++s) {
+      sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
+      sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
+    }
+  return VDF_OK;
+}
+
 static AugInputs aug_from_abi(int side, const vdf_nova_aug_inputs* a) {
   const Field& own = field(side_field(1 - side));                       // the folded side's scalar field
   const size_t arity = side == PRIMARY ? 3 : 1;
@@ -282,10 +368,22 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);
 }
 
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out);
+
 int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
   if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
   if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
     return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
+  return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, out);
+}
+
+int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary, int gens_family, vdf_pp** out) {
+  if (!ctx || !out || !primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64)
+    return fail(VDF_ERR_BAD_ARG, "bad argument");
+  return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, out);
+}
+
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out) {
   if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG) return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
   std::unique_ptr<vdf_pp, void (*)(vdf_pp*)> pp(new vdf_pp(), vdf_nova_pp_free);
@@ -293,11 +391,13 @@ int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int ge
   pp->t = t;
   pp->circuit_kind = circuit_kind;
   pp->gens_family = gens_family;
+  pp->arity = custom ? custom->arity : 3;
   HostShape sh[2];
-  build_shapes(t, circuit_kind, sh);
+  { int rc = build_shapes(t, circuit_kind, sh, custom); if (rc != VDF_OK) return rc; }
   digest_shapes(t, gens_family, sh, pp->digest);
-  pp->seg_begin = sh[PRIMARY].step_begin;
-  pp->seg_len = sh[PRIMARY].step_end - sh[PRIMARY].step_begin;
+  // only the MinRoot rounds are made on the device; a custom circuit's variables all come from the host
+  pp->seg_begin = custom ? 0 : sh[PRIMARY].step_begin;
+  pp->seg_len = custom ? 0 : sh[PRIMARY].step_end - sh[PRIMARY].step_begin;
   for (int s = 0; s < 2; ++s) {
     Side& sd = pp->s[s];
     sd.side = s; sd.field = side_field(s); sd.curve = side_curve(s);
@@ -419,13 +519,24 @@ void vdf_nova_circuits_free(vdf_circuits* c) {
 }
 
 // ---- prove_step ----------------------------------------------------------------------------------------
-static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3],
-                           vdf_proof** fresh);
+static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_step_circuit* custom,
+                           const vdf_fe* z0, vdf_proof** fresh);
 
 int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]) {
+  if (pp && pp->circuit_kind == VDF_CIRCUIT_CUSTOM) return fail(VDF_ERR_BAD_ARG, "these parameters are for a custom step circuit: vdf_nova_prove_step_custom");
   vdf_proof* fresh = nullptr;                     // a proof object this call created (the `None` case)
-  const int rc = prove_step_impl(pp, proof, circuits, k, z0, &fresh);
+  const int rc = prove_step_impl(pp, proof, circuits, k, nullptr, z0, &fresh);
   if (rc != VDF_OK && fresh) vdf_nova_proof_free(fresh);      // never leak a half-built proof
+  return rc;
+}
+
+int vdf_nova_prove_step_custom(vdf_pp* pp, vdf_proof** proof, const vdf_step_circuit* primary, const vdf_fe* z0) {
+  if (!pp || !primary || !primary->synthesize) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (pp->circuit_kind != VDF_CIRCUIT_CUSTOM || primary->arity != pp->arity)
+    return fail(VDF_ERR_BAD_ARG, "the circuit does not belong to these parameters");
+  vdf_proof* fresh = nullptr;
+  const int rc = prove_step_impl(pp, proof, nullptr, 0, primary, z0, &fresh);
+  if (rc != VDF_OK && fresh) vdf_nova_proof_free(fresh);
   return rc;
 }
 
@@ -447,12 +558,14 @@ static int upload_fresh(vdf_ctx* ctx, const Side& sd, const CS& cs, Fe* stage, v
   return VDF_OK;
 }
 
-static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3],
-                           vdf_proof** fresh) {
-  if (!pp || !proof || !circuits || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
-  const Circuit& c = circuits->v[k];
-  if (c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
+static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_step_circuit* custom,
+                           const vdf_fe* z0, vdf_proof** fresh) {
+  if (!pp || !proof || (!circuits && !custom) || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
+  static const Circuit no_circuit{};
+  if (!custom && k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
+  const Circuit& c = custom ? no_circuit : circuits->v[k];
+  if (!custom && c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
+  const size_t arity = pp->arity;
   vdf_ctx* ctx = pp->ctx;
   const Side& S1 = pp->s[PRIMARY];
   const Side& S2 = pp->s[SECONDARY];
@@ -464,17 +577,17 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p = new vdf_proof();
     *fresh = p;
     p->pp = pp;
-    p->z0[PRIMARY].assign((const Fe*)z0, (const Fe*)z0 + 3);
+    p->z0[PRIMARY].assign((const Fe*)z0, (const Fe*)z0 + arity);
     p->z0[SECONDARY].assign(1, zero());                              // z0_secondary = [0], :310, :389-391
     p->zi[PRIMARY] = p->z0[PRIMARY];
     p->zi[SECONDARY] = p->z0[SECONDARY];
     int rc = alloc_proof_buffers(p);
     if (rc != VDF_OK) return rc;
-  } else if (memcmp(p->z0[PRIMARY].data(), z0, 96) != 0) {
+  } else if (memcmp(p->z0[PRIMARY].data(), z0, 32 * arity) != 0) {
     return fail(VDF_ERR_BAD_ARG, "z0 differs from the one this proof was started with");
   }
   // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
-  if (memcmp(p->zi[PRIMARY].data(), &c.result, 96) != 0)
+  if (!custom && memcmp(p->zi[PRIMARY].data(), &c.result, 96) != 0)
     return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
   const double t0 = now_ms();
   int was_async = 0;
@@ -510,9 +623,14 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->ahead.push_back(a);
     return VDF_OK;
   };
-  const bool hit = !p->ahead.empty() && p->ahead_circuits == circuits && p->ahead_k == k &&
+  const bool hit = !custom && !p->ahead.empty() && p->ahead_circuits == circuits && p->ahead_k == k &&
                    memcmp(&p->ahead[0].result, &c.result, sizeof(St)) == 0 && memcmp(&p->ahead[0].input, &c.input, sizeof(St)) == 0;
-  if (!hit) {
+  if (custom) {
+    // every variable comes from the host: no rounds to make ahead of time, the ring just rotates
+    vdf_proof::Ahead a;
+    a.slot = first ? 0 : (p->slot + 1) % R;
+    p->ahead.assign(1, a);
+  } else if (!hit) {
     if (!p->ahead.empty()) for (vdf_ctx* q : p->ctx2) HIPCALL(q, vdf_ctx_sync(q));       // lookaheads nobody came for
     p->ahead.clear();
     p->ahead_circuits = circuits;
@@ -526,6 +644,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   void* d_z2 = p->d_z2s[slot];
   auto look_ahead = [&]() -> int {
     p->ahead.erase(p->ahead.begin());
+    if (custom) return VDF_OK;
     p->ahead_k = k + 1;
     while (p->ahead.size() < (size_t)D) {
       const size_t j = p->ahead_k + p->ahead.size();
@@ -570,7 +689,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     in.z0 = p->z0[PRIMARY];
     in.zi = p->zi[PRIMARY];
     if (first) {
-      const AugInputs b = blank_inputs(3);
+      const AugInputs b = blank_inputs(arity);
       in.U = b.U; in.u_W = b.u_W; memcpy(in.u_X, b.u_X, sizeof(in.u_X)); in.T = b.T;
     } else {
       in.U = to_relaxed(p->r[SECONDARY].inst, F2);
@@ -579,10 +698,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       in.T = comm_T2;
     }
     CS cs(S1.field, false);
-    const std::unique_ptr<StepCircuit> c1 = make_primary_circuit(pp, &c, true);
+    const std::unique_ptr<StepCircuit> c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
     Fe unew[9];
     const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2);
-    if (cs.dev_begin != seg_b || cs.dev_len != seg_n) return fail(VDF_ERR_DEVICE, "device segment moved");
+    if (custom && static_cast<const CustomStepCircuit*>(c1.get())->rc != 0) return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed");
+    if (cs.dev_len != seg_n || (seg_n && cs.dev_begin != seg_b)) return fail(VDF_ERR_DEVICE, "device segment moved");
     t2 = now_ms();
     if (!first) {
       // fold the secondary witness on the device (z, E, A z, B z, C z += r2 * fresh), the instance from the circuit
@@ -606,23 +726,28 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // ---- (c) NIFS on the primary side ----------------------------------------------------------------------------
   {
     SideState& s1 = p->r[PRIMARY];
-    const size_t off[3] = {0, seg_e, 0}, len[3] = {seg_b, S1.num_vars - seg_e, S1.num_cons};
+    // host-made variables before and after the device's run (one group when there is no such run), then T
+    size_t off[3] = {0, seg_e, 0}, len[3] = {seg_b, S1.num_vars - seg_e, S1.num_cons};
     const vdf_fe* sc[3] = {(const vdf_fe*)d_z2, (const vdf_fe*)((const char*)d_z2 + seg_e * 32), (const vdf_fe*)s1.d_T};
+    int ng = 3;
+    if (seg_n == 0) { len[0] = S1.num_vars; off[1] = 0; len[1] = S1.num_cons; sc[1] = (const vdf_fe*)s1.d_T; ng = 2; }
     if (first) {
-      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, 2, off, sc, len, 1, hb));
+      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng - 1, off, sc, len, 1, hb));
     } else {
       HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
                                        (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
                                        (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
-      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, 3, off, sc, len, 1, hb));
+      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
     }
     t3 = now_ms();
-    HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     const Field& Fb = *S1.Fb;
-    l1.comm_W = pt_to_aff(pt_add(pt_add(pt_from_aff(jac_aff(p->h_pts[slot], Fb), Fb), pt_from_aff(jac_aff(hb[0], Fb), Fb), Fb),
-                                 pt_from_aff(jac_aff(hb[1], Fb), Fb), Fb), Fb);
-    if (!first) comm_T1 = jac_aff(hb[2], Fb);
+    if (seg_n)
+      l1.comm_W = pt_to_aff(pt_add(pt_add(pt_from_aff(jac_aff(p->h_pts[slot], Fb), Fb), pt_from_aff(jac_aff(hb[0], Fb), Fb), Fb),
+                                   pt_from_aff(jac_aff(hb[1], Fb), Fb), Fb), Fb);
+    else l1.comm_W = jac_aff(hb[0], Fb);
+    if (!first) comm_T1 = jac_aff(hb[ng - 1], Fb);
     if (first) {
       // running primary := the fresh instance, relaxed; its A z, B z, C z once, folded from then on
       HIPCALL(ctx, vdf_dev_memcpy(ctx, s1.d_z, d_z2, S1.ncols * 32));
@@ -748,7 +873,7 @@ int vdf_nova_proof_witness_ptrs(const vdf_proof* p, int which, const void** d_z,
 }
 int vdf_nova_proof_zi(const vdf_proof* p, vdf_fe zi_primary[3], vdf_fe zi_secondary[1]) {
   if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
-  if (zi_primary) memcpy(zi_primary, p->zi[PRIMARY].data(), 96);
+  if (zi_primary) memcpy(zi_primary, p->zi[PRIMARY].data(), 32 * p->pp->arity);
   if (zi_secondary) memcpy(zi_secondary, p->zi[SECONDARY].data(), 32);
   return VDF_OK;
 }
@@ -767,6 +892,10 @@ int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
 // RecursiveSNARK::verify(pp, num_steps, z0_primary, z0_secondary) -> (zi_primary, zi_secondary), then the comparison of
 // src/nova/proof.rs:386 with z0_secondary = [0] (:389-391)
 int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
+  return vdf_nova_verify_custom(p, pp, num_steps, z0, zi, ok);
+}
+
+int vdf_nova_verify_custom(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe* z0, const vdf_fe* zi, int* ok) {
   if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
   *ok = 0;
   if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
@@ -777,7 +906,7 @@ int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_
   const Field& F1 = *S1.F;
   const Field& F2 = *S2.F;
   // (1) the two output hashes the last secondary instance carries
-  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + 3), z0s(1, zero());
+  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero());
   uint64_t hv[4];
   hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv);
   if (int_to_fe(hv, F2) != p->l2.X[0]) return VDF_OK;
@@ -800,7 +929,7 @@ int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_
     if (!good) return VDF_OK;
   }
   // Ok(zi_primary == zi && zi_secondary == [0]), src/nova/proof.rs:386
-  *ok = (memcmp(p->zi[PRIMARY].data(), zi, 96) == 0 && p->zi[SECONDARY][0].is_zero()) ? 1 : 0;
+  *ok = (memcmp(p->zi[PRIMARY].data(), zi, 32 * pp->arity) == 0 && p->zi[SECONDARY][0].is_zero()) ? 1 : 0;
   return VDF_OK;
 }
 

@@ -75,6 +75,7 @@ struct vdf_pp {
   Fe params[2];                            // the digest as an element of each side's field
   // variables of the primary witness that the GPU fills from the forward trace (the MinRoot rounds): [seg_begin, seg_begin + seg_len)
   size_t seg_begin = 0, seg_len = 0;
+  size_t arity = 3;                        // of the primary step circuit (z0, zi)
 };
 
 struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-66, + the forward trace
@@ -126,6 +127,7 @@ namespace vdfnova {
 int alloc_proof_buffers(vdf_proof* p);
 int finalize_l2(const vdf_proof* p);      // commits to the last secondary witness if that is still pending
 std::unique_ptr<StepCircuit> make_primary_circuit(const vdf_pp* pp, const Circuit* c, bool device_rounds);
+std::unique_ptr<StepCircuit> make_custom_circuit(const vdf_step_circuit* c);
 
 // ---- wire formats (wire_host.cpp; layout in include/vdf_nova.h) --------------------------------------------
 constexpr char WIRE_MAGIC_SNARK[9] = "VDFSNK03";      // compressed proof

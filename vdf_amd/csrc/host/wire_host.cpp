@@ -28,12 +28,12 @@ int vdf_nova_point_decompress(int curve, const uint8_t in[32], vdf_affine* out) 
 // "VDFRSK02": magic[8] | t u64 | i u64 | digest[32] | z_0 [96] | z_i primary [96] | z_i secondary [32]
 //   | running primary instance [160] | running secondary instance [160] | fresh secondary instance [96]
 //   | W1 | E1 | W2 | E2 | w2   (num_vars / num_cons elements of the side, 32 bytes each, canonical)
-static size_t header_size() { return 8 + 8 + 8 + 32 + 96 + 96 + 32 + 2 * INST_WIRE_RELAXED + INST_WIRE_STRICT; }
+static size_t header_size(const vdf_pp* pp) { return 8 + 8 + 8 + 32 + 64 * pp->arity + 32 + 2 * INST_WIRE_RELAXED + INST_WIRE_STRICT; }
 
 size_t vdf_nova_proof_serialized_size(const vdf_proof* p) {
   if (!p || p->i == 0) return 0;
   const vdf_pp* pp = p->pp;
-  return header_size() + 32 * (pp->s[0].num_vars + pp->s[0].num_cons + 2 * pp->s[1].num_vars + pp->s[1].num_cons);
+  return header_size(pp) + 32 * (pp->s[0].num_vars + pp->s[0].num_cons + 2 * pp->s[1].num_vars + pp->s[1].num_cons);
 }
 
 int vdf_nova_proof_serialize(const vdf_proof* p, uint8_t* out, size_t cap) {
@@ -49,8 +49,8 @@ int vdf_nova_proof_serialize(const vdf_proof* p, uint8_t* out, size_t cap) {
   memcpy(o, &pp->t, 8); o += 8;
   memcpy(o, &steps, 8); o += 8;
   memcpy(o, pp->digest, 32); o += 32;
-  for (int k = 0; k < 3; ++k) o = wire_put_fe(o, p->z0[PRIMARY][k], *pp->s[0].F);
-  for (int k = 0; k < 3; ++k) o = wire_put_fe(o, p->zi[PRIMARY][k], *pp->s[0].F);
+  for (size_t k = 0; k < pp->arity; ++k) o = wire_put_fe(o, p->z0[PRIMARY][k], *pp->s[0].F);
+  for (size_t k = 0; k < pp->arity; ++k) o = wire_put_fe(o, p->zi[PRIMARY][k], *pp->s[0].F);
   o = wire_put_fe(o, p->zi[SECONDARY][0], *pp->s[1].F);
   o = put_inst(o, p->r[0].inst, pp->s[0], true);
   o = put_inst(o, p->r[1].inst, pp->s[1], true);
@@ -76,7 +76,7 @@ int vdf_nova_proof_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_pr
   if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
   *out = nullptr;
   vdf_ctx* ctx = pp->ctx;
-  if (len < header_size()) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
+  if (len < header_size(pp)) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
   if (memcmp(in, WIRE_MAGIC_PROOF, 8) != 0) return fail(VDF_ERR_BAD_ARG, "not this kind of encoding (magic)");
   uint64_t t, steps;
   memcpy(&t, in + 8, 8);
@@ -84,7 +84,7 @@ int vdf_nova_proof_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_pr
   if (t != pp->t || memcmp(in + 24, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "encoding was made under other public parameters");
   const Side& S1 = pp->s[0];
   const Side& S2 = pp->s[1];
-  if (steps == 0 || len != header_size() + 32 * (S1.num_vars + S1.num_cons + 2 * S2.num_vars + S2.num_cons))
+  if (steps == 0 || len != header_size(pp) + 32 * (S1.num_vars + S1.num_cons + 2 * S2.num_vars + S2.num_cons))
     return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
   struct Guard { vdf_proof* p; ~Guard() { if (p) vdf_nova_proof_free(p); } } g{new vdf_proof()};
   vdf_proof* p = g.p;
@@ -92,10 +92,10 @@ int vdf_nova_proof_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_pr
   p->i = steps;
   const uint8_t* i = in + 56;
   bool canonical = true, on_curve = true;
-  p->z0[PRIMARY].resize(3); p->zi[PRIMARY].resize(3);
+  p->z0[PRIMARY].resize(pp->arity); p->zi[PRIMARY].resize(pp->arity);
   p->z0[SECONDARY].assign(1, zero()); p->zi[SECONDARY].resize(1);
-  for (int k = 0; k < 3; ++k, i += 32) canonical &= wire_get_fe(i, *S1.F, &p->z0[PRIMARY][k]);
-  for (int k = 0; k < 3; ++k, i += 32) canonical &= wire_get_fe(i, *S1.F, &p->zi[PRIMARY][k]);
+  for (size_t k = 0; k < pp->arity; ++k, i += 32) canonical &= wire_get_fe(i, *S1.F, &p->z0[PRIMARY][k]);
+  for (size_t k = 0; k < pp->arity; ++k, i += 32) canonical &= wire_get_fe(i, *S1.F, &p->zi[PRIMARY][k]);
   canonical &= wire_get_fe(i, *S2.F, &p->zi[SECONDARY][0]); i += 32;
   Inst r1, r2, l2;
   i = get_inst(i, &r1, S1, true, &canonical, &on_curve);

@@ -38,7 +38,20 @@ for _name, _res, _args in [
     ("vdf_nova_last_step_ms", _i, [_vp, C.POINTER(C.c_double * 8)]),
     ("vdf_nova_ro_hash", _i, [_i, _u64, _vp, _sz, _vp]),
     ("vdf_nova_shape_digest", _i, [_u64, _i, _i, _vp, _vp]),
+    ("vdf_nova_shape_digest_custom", _i, [_vp, _i, _vp, _vp]),
     ("vdf_nova_aug_synthesize", _i, [_i, _u64, _i, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp, _vp]),
+    ("vdf_nova_public_params_custom", _i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    ("vdf_nova_prove_step_custom", _i, [_vp, C.POINTER(_vp), _vp, _vp]),
+    ("vdf_nova_verify_custom", _i, [_vp, _vp, _sz, _vp, _vp, C.POINTER(_i)]),
+    ("vdf_cs_is_witness", _i, [_vp]),
+    ("vdf_cs_const", C.c_uint32, [_vp, _vp]),
+    ("vdf_cs_add", C.c_uint32, [_vp, C.c_uint32, C.c_uint32]),
+    ("vdf_cs_sub", C.c_uint32, [_vp, C.c_uint32, C.c_uint32]),
+    ("vdf_cs_scale", C.c_uint32, [_vp, C.c_uint32, _vp]),
+    ("vdf_cs_alloc", C.c_uint32, [_vp, _vp]),
+    ("vdf_cs_mul", C.c_uint32, [_vp, C.c_uint32, C.c_uint32]),
+    ("vdf_cs_enforce", _i, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("vdf_cs_value", _i, [_vp, C.c_uint32, _vp]),
     ("vdf_nova_synthesis_stats", _i, [C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_compress", _i, [_vp, _vp, C.POINTER(_vp)]),
     ("vdf_nova_verify_compressed", _i, [_vp, _vp, _sz, C.POINTER(_Fe * 3), C.POINTER(_Fe * 3), C.POINTER(_i)]),
@@ -101,6 +114,106 @@ def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
     sizes = np.zeros((2, 3), dtype="<u8")
     _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+# ---- the step-circuit seam (include/vdf_nova.h vdf_step_circuit; src/nova/proof.rs:79-153) ---------------------------
+_SYNTH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+
+class _StepCircuitC(C.Structure):
+    _fields_ = [("arity", C.c_size_t), ("synthesize", _SYNTH), ("self", C.c_void_p)]
+
+
+class ConstraintSystem:
+    """The vdf_cs a step circuit's synthesize receives: numbers are opaque handles; field elements cross as 32-byte
+    Montgomery limbs (Fq: the primary circuit's field)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @property
+    def is_witness(self) -> bool:
+        return bool(nova_lib.vdf_cs_is_witness(self.h))
+
+    def const(self, k: bytes) -> int:
+        return nova_lib.vdf_cs_const(self.h, C.byref(_Fe.from_buffer_copy(k)))
+
+    def add(self, a: int, b: int) -> int:
+        return nova_lib.vdf_cs_add(self.h, a, b)
+
+    def sub(self, a: int, b: int) -> int:
+        return nova_lib.vdf_cs_sub(self.h, a, b)
+
+    def scale(self, a: int, k: bytes) -> int:
+        return nova_lib.vdf_cs_scale(self.h, a, C.byref(_Fe.from_buffer_copy(k)))
+
+    def alloc(self, value: bytes = None) -> int:
+        return nova_lib.vdf_cs_alloc(self.h, C.byref(_Fe.from_buffer_copy(value)) if value is not None else None)
+
+    def mul(self, a: int, b: int) -> int:
+        return nova_lib.vdf_cs_mul(self.h, a, b)
+
+    def enforce(self, a: int, b: int, c: int) -> None:
+        _check(nova_lib.vdf_cs_enforce(self.h, a, b, c))
+
+    def value(self, a: int) -> bytes:
+        out = _Fe()
+        _check(nova_lib.vdf_cs_value(self.h, a, C.byref(out)))
+        return bytes(out)
+
+
+class StepCircuit:
+    """trait StepCircuit (src/nova/proof.rs:79-153) for a circuit written by the host: subclass with `arity` and
+    `synthesize(cs, z_in) -> z_out` (lists of handles).  The instance is handed to the library as a vdf_step_circuit."""
+    arity = 1
+
+    def synthesize(self, cs: ConstraintSystem, z_in):
+        raise NotImplementedError
+
+    def _c(self):
+        def cb(_self, cs, zin, zout):
+            try:
+                out = self.synthesize(ConstraintSystem(cs), [zin[k] for k in range(self.arity)])
+                for k in range(self.arity):
+                    zout[k] = out[k]
+                return 0
+            except Exception as e:            # must not unwind through the C frames
+                self._error = e
+                return 1
+        self._cb = _SYNTH(cb)                 # kept alive with the circuit
+        self._struct = _StepCircuitC(self.arity, self._cb, None)
+        return self._struct
+
+
+def shape_digest_custom(circuit: StepCircuit, gens_family: int = 1):
+    """Host only: (digest, sizes) of the parameters public_params_custom would make for this circuit."""
+    d = (C.c_uint8 * 32)()
+    sizes = np.zeros((2, 3), dtype="<u8")
+    rc = nova_lib.vdf_nova_shape_digest_custom(C.byref(circuit._c()), gens_family, d, sizes.ctypes.data)
+    _reraise(circuit)
+    _check(rc)
+    return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+def _reraise(circuit) -> None:
+    e = getattr(circuit, "_error", None)
+    if e is not None:
+        circuit._error = None
+        raise e
+
+
+def public_params_custom(ctx: Context, circuit: StepCircuit, gens_family: int = GENS_TRY_AND_INCREMENT) -> "NovaVDFPublicParams":
+    h = C.c_void_p()
+    rc = nova_lib.vdf_nova_public_params_custom(ctx.handle, C.byref(circuit._c()), gens_family, C.byref(h))
+    _reraise(circuit)
+    _check(rc)
+    pp = NovaVDFPublicParams(ctx, h.value, 0)
+    pp.arity = circuit.arity
+    return pp
+
+
+def _zn(vals: Sequence[bytes]):
+    return (_Fe * len(vals))(*[_Fe.from_buffer_copy(v) for v in vals])
 
 
 def synthesis_stats() -> Tuple[int, int]:
@@ -249,8 +362,18 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
 
     def verify(self, pp: NovaVDFPublicParams, num_steps: int, z0: Sequence[bytes], zi: Sequence[bytes]) -> bool:   # :370-387
         ok = C.c_int(0)
-        _check(nova_lib.vdf_nova_verify(self.handle, pp.handle, num_steps, C.byref(_z(z0)), C.byref(_z(zi)), C.byref(ok)))
+        _check(nova_lib.vdf_nova_verify_custom(self.handle, pp.handle, num_steps, _zn(z0), _zn(zi), C.byref(ok)))
         return bool(ok.value)
+
+    @staticmethod
+    def prove_step_custom(pp: NovaVDFPublicParams, proof: "NovaVDFProof | None", circuit: "StepCircuit",
+                          z0: Sequence[bytes]) -> "NovaVDFProof":
+        """prove_step for a host-written primary step circuit (public_params_custom)."""
+        h = C.c_void_p(proof.handle if proof is not None else None)
+        rc = nova_lib.vdf_nova_prove_step_custom(pp.handle, C.byref(h), C.byref(circuit._c()), _zn(z0))
+        _reraise(circuit)
+        _check(rc)
+        return NovaVDFProof(h.value, pp) if proof is None else proof
 
     def compress(self, pp: NovaVDFPublicParams) -> "CompressedNovaVDFProof":            # :360-368
         h = C.c_void_p()
@@ -297,7 +420,7 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
         return z, E
 
     def zi(self) -> Tuple[np.ndarray, np.ndarray]:
-        a, b = np.zeros((3, 4), dtype="<u8"), np.zeros((1, 4), dtype="<u8")
+        a, b = np.zeros((getattr(self.pp, "arity", 3), 4), dtype="<u8"), np.zeros((1, 4), dtype="<u8")
         _check(nova_lib.vdf_nova_proof_zi(self.handle, a.ctypes.data, b.ctypes.data))
         return a, b
 
@@ -333,7 +456,8 @@ class CompressedNovaVDFProof:     # NovaVDFProof::Compressed, src/nova/proof.rs:
 
     def verify(self, pp: NovaVDFPublicParams, num_steps: int, z0: Sequence[bytes], zi: Sequence[bytes]) -> bool:   # :370-387
         ok = C.c_int(0)
-        _check(nova_lib.vdf_nova_verify_compressed(self.handle, pp.handle, num_steps, C.byref(_z(z0)), C.byref(_z(zi)), C.byref(ok)))
+        _check(nova_lib.vdf_nova_verify_compressed(self.handle, pp.handle, num_steps, C.cast(_zn(z0), C.POINTER(_Fe * 3)),
+                                                   C.cast(_zn(zi), C.POINTER(_Fe * 3)), C.byref(ok)))
         return bool(ok.value)
 
     def to_bytes(self) -> bytes:
