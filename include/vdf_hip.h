@@ -94,8 +94,15 @@ int  vdf_bases_generate_range(vdf_ctx* ctx, int curve, uint64_t seed, size_t sta
  * from a hash: per index a xoshiro256** stream seeded by splitmix64(seed, index) yields candidates
  * x = 256 bits mod p; the first x with x^3 + 5 a square is taken, y = the even root (SURVEY.md 8d, config 2;
  * restated in oracle/pasta.py tai_base).  Setup-time only. */
-enum { VDF_GENS_KNOWN_DLOG = 0, VDF_GENS_TRY_AND_INCREMENT = 1 };
+enum { VDF_GENS_KNOWN_DLOG = 0, VDF_GENS_TRY_AND_INCREMENT = 1, VDF_GENS_LABEL_SHAKE = 2 /* vdf_bases_generate_label; a family id for the proof layer */ };
 int  vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed, size_t start, size_t n, vdf_bases** out);
+/* Generators derived from a LABEL, as nova-snark derives its CommitGens (label -> SHAKE256 -> curve points;
+ * PublicParams::setup, src/nova/proof.rs:236).  nova-snark's own encoding is not in /root/reference, so
+ * this one is the build's own (restated in oracle/pasta.py label_base): for index i and counter c = 0, 1, ... one SHAKE256
+ * block "vdf-gens-v1" | curve u8 | len u8 | label | i LE64 | c LE32 yields 64 bytes = x mod p; the first x != 0 with
+ * x^3 + 5 a square is taken, y = the even root.  Unknown discrete logarithms; reproducible from the string alone; index-
+ * addressed like the other families (a rank generates its own range).  label_len <= 64. */
+int  vdf_bases_generate_label(vdf_ctx* ctx, int curve, const uint8_t* label, size_t label_len, size_t start, size_t n, vdf_bases** out);
 /* Build the fixed-base table  2^(window_bits*sets*j) * P_i, j = 0..tables-1, so that an MSM
  * needs only `sets` bucket sets (sets == 0: library default; sets == windows: no table).  window_bits == 0: the
  * recommended window for this many generators (16 below 2^19 generators, 17 from there on).  A table serves MSMs over

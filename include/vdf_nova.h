@@ -70,7 +70,9 @@ enum { VDF_SIDE_PRIMARY = 0, VDF_SIDE_SECONDARY = 1 };
  * all of it that every hash of the protocol absorbs.  One-time; outside every timed region (benches/nova.rs:51-58). */
 int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** out);
 /* The same with the step circuit and the generator family chosen.  gens_family = VDF_GENS_KNOWN_DLOG is for tests only
- * (commitments checkable by the discrete-log identity at full size; such commitments are not binding). */
+ * (commitments checkable by the discrete-log identity at full size; such commitments are not binding);
+ * VDF_GENS_LABEL_SHAKE derives the generators from the label "vdf-nova-ivc-v1 gens" through SHAKE256, the way nova-snark
+ * derives its CommitGens (vdf_bases_generate_label): parameters reproducible from a string. */
 int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, vdf_pp** out);
 void vdf_nova_pp_free(vdf_pp* pp);
 int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,

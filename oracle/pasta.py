@@ -251,6 +251,23 @@ def tai_base(curve: int, seed: int, i: int) -> Point:
         return (x, y)
 
 
+def label_base(curve: int, label: bytes, i: int) -> Point:
+    """Generator family 2 (include/vdf_hip.h vdf_bases_generate_label): derived from a label through SHAKE256, the way
+    nova-snark derives CommitGens (its own encoding is absent from /root/reference: this one is the build's own)."""
+    import hashlib
+    assert len(label) <= 64
+    m = curve_base_modulus(curve)
+    ctr = 0
+    while True:
+        msg = b"vdf-gens-v1" + bytes([curve, len(label)]) + label + int(i).to_bytes(8, "little") + ctr.to_bytes(4, "little")
+        x = int.from_bytes(hashlib.shake_256(msg).digest(64), "little") % m
+        ctr += 1
+        y = sqrt_mod(x * x * x + 5, m) if x else None
+        if y is None:
+            continue
+        return (x, m - y if y & 1 else y)
+
+
 def tai_bases(curve: int, seed: int, n: int, start: int = 0) -> List[Point]:
     return [tai_base(curve, seed, start + i) for i in range(n)]
 

@@ -707,3 +707,21 @@ def test_sharded_and_multi_context_msm_through_the_c_abi(ctx):
     for b, _, _ in shards:
         b.free()
     ball.free()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_label_derived_bases_match_oracle(ctx, curve):
+    """Generator family 2: label -> SHAKE256 -> curve points (nova-snark derives CommitGens this way),
+    against oracle/pasta.py label_base: the first points, a range far out, another label, the empty label."""
+    m = o.curve_base_modulus(curve)
+    for label, start, n in ((b"vdf-nova-ivc-v1 gens", 0, 300), (b"vdf-nova-ivc-v1 gens", (1 << 40) + 17, 70), (b"x", 5, 40), (b"", 0, 9),
+                            (bytes(range(64)), 3, 33)):
+        b = ctx.bases_generate_label(curve, label, n, start=start)
+        pts = b.download()
+        got = [tuple(unmont(pts[k].reshape(2, 4), m)) for k in range(n)]
+        assert got == [o.label_base(curve, label, start + k) for k in range(n)]
+        for x, y in got:
+            assert (y * y - x * x * x - 5) % m == 0 and y % 2 == 0 and x != 0
+        b.free()
+    with pytest.raises(Exception):
+        ctx.bases_generate_label(curve, b"a" * 65, 4)

@@ -264,3 +264,19 @@ def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n):
     L.ref_axpy(fld, cref.p(ab), cref.p(zero1), cref.p(uc), nc, cref.p(lhs))          # ab - u c
     assert np.array_equal(lhs, E_new)
     assert proof.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+
+
+def test_parameters_from_a_label(ctx):
+    """gens_family = VDF_GENS_LABEL_SHAKE: Pedersen generators derived from a label through SHAKE256 (as nova-snark's
+    CommitGens are; the points themselves are checked against the oracle in tests/test_gpu_msm.py).  Same shapes, another
+    digest; a proof under them verifies, compresses and verifies compressed."""
+    from vdf_amd.nova import GENS_LABEL_SHAKE
+    t, n = 9, 3
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=8, family=GENS_LABEL_SHAKE)
+    pp_tai = public_params(ctx, t)
+    assert pp.digest() != pp_tai.digest() and pp.sizes(0) == pp_tai.sizes(0) and pp.sizes(1) == pp_tai.sizes(1)
+    zi = [initial.x, initial.y, initial.i]
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.verify(pp, n, z0, zi)
+    snark = proof.compress(pp)
+    assert snark.verify(pp, n, z0, zi)

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "vdf_bases_generate": (_i, [_vp, _i, _u64, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate_range": (_i, [_vp, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
     "vdf_bases_generate_family": (_i, [_vp, _i, _i, _u64, _sz, _sz, C.POINTER(_vp)]),
+    "vdf_bases_generate_label": (_i, [_vp, _i, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "vdf_bases_precompute": (_i, [_vp, _vp, _i, _i]),
     "vdf_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "vdf_bases_window": (_i, [_vp]),

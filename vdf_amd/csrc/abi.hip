@@ -492,6 +492,27 @@ int vdf_bases_generate_family(vdf_ctx* ctx, int curve, int family, uint64_t seed
   });
 }
 
+int vdf_bases_generate_label(vdf_ctx* ctx, int curve, const uint8_t* label, size_t label_len, size_t start, size_t n, vdf_bases** out) {
+  return guarded(ctx, [&]() -> Status {
+    if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
+    *out = nullptr;
+    if (curve != VDF_CURVE_PALLAS && curve != VDF_CURVE_VESTA) return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+    if (n >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "too many bases"};
+    if (label_len > 64 || (label_len && !label)) return Status{VDF_ERR_BAD_LENGTH, "label of at most 64 bytes"};
+    vdf_bases* b = new vdf_bases();
+    b->ctx = ctx; b->curve = curve; b->n = n;
+    if (n) {
+      hipError_t e = hipMalloc(&b->d_pts, n * sizeof(vdf_affine));
+      if (e != hipSuccess) { delete b; return vdf::hip_status(e, "hipMalloc(bases)"); }
+      Status s = vdf::bases_generate_label(curve, label, label_len, start, n, b->d_pts, ctx->stream);
+      if (s.ok()) s = vdf::hip_status(hipStreamSynchronize(ctx->stream), "bases_generate_label");
+      if (!s.ok()) { (void)hipFree(b->d_pts); delete b; return s; }
+    }
+    *out = b;
+    return Status{};
+  });
+}
+
 int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets) {
   return guarded(ctx, [&]() -> Status {
     if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};

@@ -384,8 +384,16 @@ int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary,
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out) {
-  if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG) return fail(VDF_ERR_BAD_ARG, "unknown generator family");
+  if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG && gens_family != VDF_GENS_LABEL_SHAKE)
+    return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
+  // family 2: CommitGens from a label, as nova-snark makes them (PublicParams::setup, src/nova/proof.rs:236)
+  static const char GENS_LABEL[] = "vdf-nova-ivc-v1 gens";
+  auto make_gens = [&](int curve, size_t start, size_t n, vdf_bases** b) {
+    return gens_family == VDF_GENS_LABEL_SHAKE
+               ? vdf_bases_generate_label(ctx, curve, (const uint8_t*)GENS_LABEL, sizeof(GENS_LABEL) - 1, start, n, b)
+               : vdf_bases_generate_family(ctx, curve, gens_family, GENS_SEED, start, n, b);
+  };
   std::unique_ptr<vdf_pp, void (*)(vdf_pp*)> pp(new vdf_pp(), vdf_nova_pp_free);
   pp->ctx = ctx;
   pp->t = t;
@@ -417,14 +425,14 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     size_t need = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons, g = 1;
     while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
     sd.num_gens = g;
-    HIPCALL(ctx, vdf_bases_generate_family(ctx, sd.curve, gens_family, GENS_SEED, 0, g, &sd.gens));
+    HIPCALL(ctx, make_gens(sd.curve, 0, g, &sd.gens));
     // window of the fixed-base table by the size of the MSMs taken over it: 2^17 terms and more -> 16 bits, the
     // ~10^4-term witnesses of an augmented circuit -> 15 (measured: 10, 11, 13 and 15 within 4 %, 15 best)
     int small_c = 15;
     if (const char* ov = std::getenv("VDF_NOVA_SMALL_WINDOW")) { const int v = atoi(ov); if (v >= 6 && v <= 16) small_c = v; }   // tuning
     HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? 16 : small_c, 1));
     vdf_bases* ub = nullptr;
-    HIPCALL(ctx, vdf_bases_generate_family(ctx, sd.curve, gens_family, GENS_SEED, g, 1, &ub));
+    HIPCALL(ctx, make_gens(sd.curve, g, 1, &ub));
     const int rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&sd.gen_u);
     vdf_bases_free(ub);
     if (rc != VDF_OK) return fail(rc, std::string("generator download: ") + vdf_last_error(ctx));
@@ -900,6 +908,7 @@ int vdf_nova_verify_custom(const vdf_proof* p, vdf_pp* pp, size_t num_steps, con
   *ok = 0;
   if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
   if (num_steps == 0 || p->i != num_steps) return VDF_OK;                  // NovaError::ProofVerifyError
+  if (memcmp(p->z0[PRIMARY].data(), z0, 32 * pp->arity) != 0) return VDF_OK;   // not the chain this proof was started for
   { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
   const Side& S1 = pp->s[PRIMARY];
   const Side& S2 = pp->s[SECONDARY];

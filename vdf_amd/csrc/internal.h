@@ -149,6 +149,7 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
 size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
+Status bases_generate_label(int curve, const uint8_t* label, size_t len, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_validate(int curve, const void* d_pts, size_t n, uint32_t* d_flags, hipStream_t stream);   // d_flags: 2 words
 Status bases_precompute(int curve, const void* d_pts, size_t n, int c, int sets, int tables, void* d_table,

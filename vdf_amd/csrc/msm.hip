@@ -34,6 +34,7 @@
 // (2^(c*sets*j) * P_i) and feeds bucket set s, so the Horner tail is (sets-1)*c doublings; sets = 1
 // removes it entirely.  The table trades HBM capacity (288 GB) for the serial tail.
 #include <cstdlib>
+#include <cstring>
 #include "internal.h"
 #include "ec.cuh"
 #include "ecq.cuh"
@@ -988,6 +989,103 @@ __global__ __launch_bounds__(256) void k_bases_generate_tai(uint64_t seed, uint6
   }
 }
 
+// ---- generator family 2: derived from a label, the way nova-snark derives its CommitGens (label -> SHAKE256 stream ->
+// curve points).  Its own constants are not in /root/reference, so the encoding is this build's:
+//   block = "vdf-gens-v1" | curve u8 | len u8 | label[len <= 64] | index LE64 | counter LE32       (one SHAKE256 block)
+//   x = first 64 output bytes as a little-endian integer mod m;  accepted if x^3 + 5 is a square;  y = the even root;
+//   counter = 0, 1, ... until accepted.  Restated in oracle/pasta.py label_base.
+__device__ __forceinline__ void keccak_f1600(uint64_t s[25]) {
+  const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  for (int round = 0; round < 24; ++round) {
+    uint64_t C[5], D[5], B[25];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) C[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) D[x] = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
+#pragma unroll
+    for (int i = 0; i < 25; ++i) s[i] ^= D[i % 5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+      for (int y = 0; y < 5; ++y) {
+        const int i = x + 5 * y;
+        B[y + 5 * ((2 * x + 3 * y) % 5)] = ROT[i] ? rotl64(s[i], ROT[i]) : s[i];
+      }
+#pragma unroll
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+      for (int x = 0; x < 5; ++x) s[x + 5 * y] = B[x + 5 * y] ^ ((~B[(x + 1) % 5 + 5 * y]) & B[(x + 2) % 5 + 5 * y]);
+    s[0] ^= RC[round];
+  }
+}
+
+struct GenLabel { uint8_t bytes[64]; uint32_t len; };
+
+template <class P>
+__global__ __launch_bounds__(256) void k_bases_generate_label(GenLabel label, uint32_t curve, uint64_t start, uint32_t n,
+                                                              char* __restrict__ pts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Fe<P> five, r2;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { five.v[l] = P::FIVE[l]; r2.v[l] = P::R2[l]; }
+  uint8_t msg[136];
+  const char head[12] = "vdf-gens-v1";
+  for (uint32_t ctr = 0;; ++ctr) {
+    for (int k = 0; k < 136; ++k) msg[k] = 0;
+    int pos = 0;
+    for (int k = 0; k < 11; ++k) msg[pos++] = (uint8_t)head[k];
+    msg[pos++] = (uint8_t)curve;
+    msg[pos++] = (uint8_t)label.len;
+    for (uint32_t k = 0; k < label.len; ++k) msg[pos++] = label.bytes[k];
+    const uint64_t idx = start + i;
+    for (int k = 0; k < 8; ++k) msg[pos++] = (uint8_t)(idx >> (8 * k));
+    for (int k = 0; k < 4; ++k) msg[pos++] = (uint8_t)(ctr >> (8 * k));
+    msg[pos] ^= 0x1F;                                   // SHAKE domain bits + first padding bit
+    msg[135] ^= 0x80;
+    uint64_t st[25];
+    for (int w = 0; w < 25; ++w) st[w] = 0;
+    for (int w = 0; w < 17; ++w) {
+      uint64_t v = 0;
+      for (int k = 0; k < 8; ++k) v |= (uint64_t)msg[8 * w + k] << (8 * k);
+      st[w] = v;
+    }
+    keccak_f1600(st);
+    // 64 output bytes = lo | hi (256 bits each); x = lo + hi * 2^256 mod m
+    Fe<P> lo, hi;
+    for (int k = 0; k < 4; ++k) {
+      lo.v[2 * k] = (uint32_t)st[k]; lo.v[2 * k + 1] = (uint32_t)(st[k] >> 32);
+      hi.v[2 * k] = (uint32_t)st[4 + k]; hi.v[2 * k + 1] = (uint32_t)(st[4 + k] >> 32);
+    }
+    for (int half = 0; half < 2; ++half) {
+      Fe<P>& x = half ? hi : lo;
+      for (int k = 0; k < 3; ++k) {                     // 2^256 < 4m: at most three subtractions of m
+        if (fe_is_canonical(x)) break;
+        uint32_t borrow = 0;
+        for (int l = 0; l < 8; ++l) {
+          const uint64_t d = (uint64_t)x.v[l] - P::MOD[l] - borrow;
+          x.v[l] = (uint32_t)d;
+          borrow = (uint32_t)(d >> 63);
+        }
+      }
+    }
+    const Fe<P> xm = fe_add(fe_to_mont(lo), fe_mul(fe_to_mont(hi), r2));      // Montgomery form of lo + hi * R
+    const Fe<P> rhs = fe_add(fe_mul(fe_sqr(xm), xm), five);
+    Fe<P> y;
+    if (fe_is_zero(xm) || !fe_sqrt(rhs, y)) continue;
+    if (fe_from_mont(y).v[0] & 1u) y = fe_neg(y);
+    Affine<P> a; a.x = xm; a.y = y;
+    affine_store<P>(pts + (size_t)i * 64, a);
+    return;
+  }
+}
+
 // flags[0] |= 1: a coordinate is not a canonical residue; |= 2: a canonical point that is neither the identity
 // (0, 0) nor on y^2 = x^3 + 5.  flags[1] = smallest offending index.
 template <class P>
@@ -1194,6 +1292,26 @@ Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t
                        reinterpret_cast<char*>(d_pts));
   else if (curve == VDF_CURVE_VESTA)
     hipLaunchKernelGGL((k_bases_generate<FqParams>), grid, dim3(256), 0, stream, seed, (uint64_t)start, (uint32_t)n,
+                       reinterpret_cast<char*>(d_pts));
+  else
+    return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
+Status bases_generate_label(int curve, const uint8_t* label, size_t len, size_t start, size_t n, void* d_pts, hipStream_t stream) {
+  if (n == 0) return Status{};
+  if (len > 64 || (len && !label)) return Status{VDF_ERR_BAD_LENGTH, "label of at most 64 bytes"};
+  GenLabel gl;
+  std::memset(&gl, 0, sizeof(gl));
+  if (len) std::memcpy(gl.bytes, label, len);
+  gl.len = (uint32_t)len;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (curve == VDF_CURVE_PALLAS)
+    hipLaunchKernelGGL((k_bases_generate_label<FpParams>), grid, dim3(256), 0, stream, gl, (uint32_t)curve, (uint64_t)start, (uint32_t)n,
+                       reinterpret_cast<char*>(d_pts));
+  else if (curve == VDF_CURVE_VESTA)
+    hipLaunchKernelGGL((k_bases_generate_label<FqParams>), grid, dim3(256), 0, stream, gl, (uint32_t)curve, (uint64_t)start, (uint32_t)n,
                        reinterpret_cast<char*>(d_pts));
   else
     return Status{VDF_ERR_BAD_ARG, "unknown curve"};

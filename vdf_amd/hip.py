@@ -220,6 +220,13 @@ class Context:
         self._check(lib.vdf_bases_generate_family(self.handle, curve, family, seed, start, n, C.byref(h)))
         return Bases(self, h.value, curve)
 
+    def bases_generate_label(self, curve: int, label: bytes, n: int, start: int = 0) -> Bases:
+        """Generators derived from a label (SHAKE256 -> curve points): include/vdf_hip.h vdf_bases_generate_label."""
+        h = C.c_void_p()
+        buf = (C.c_uint8 * max(len(label), 1)).from_buffer_copy(label or b"\0")
+        self._check(lib.vdf_bases_generate_label(self.handle, curve, buf, len(label), start, n, C.byref(h)))
+        return Bases(self, h.value, curve)
+
     # ---- msm ---------------------------------------------------------------------------
     def msm(self, bases: Bases, scalars, n: Optional[int] = None, offset: int = 0, is_mont: bool = False, out=None):
         """Returns the Jacobian result as uint64[12] (numpy) unless `out` (device tensor) is given."""

@@ -76,7 +76,7 @@ for _name, _res, _args in [
 CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE = 0, 1
 SIDE_PRIMARY, SIDE_SECONDARY = 0, 1
 INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY, INST_FRESH_PRIMARY_LAST = 0, 1, 2, 3
-GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT = 0, 1
+GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT, GENS_LABEL_SHAKE = 0, 1, 2
 
 
 def _check(rc: int) -> None:
