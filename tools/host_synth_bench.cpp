@@ -1,4 +1,6 @@
+#include <algorithm>
 #include <chrono>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include "vdf_nova.h"
@@ -11,9 +13,13 @@ int main() {
   for (int side = 0; side < 2; ++side) {
     if (side == 1) vdf_minroot_element(VDF_FIELD_FP, 1, &in.i);
     vdf_nova_aug_synthesize(side, 5, 0, &in, &res, &inp, W, 1<<14, &nv, &nc, X, zn);
-    auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < 200; ++k) vdf_nova_aug_synthesize(side, 5, 0, &in, &res, &inp, W, 1<<14, &nv, &nc, X, zn);
-    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 200;
-    printf("side %d: %.3f ms (nv %zu nc %zu)\n", side, ms, nv, nc);
+    std::vector<double> ms;
+    for (int k = 0; k < 400; ++k) {
+      auto t0 = std::chrono::steady_clock::now();
+      vdf_nova_aug_synthesize(side, 5, 0, &in, &res, &inp, W, 1<<14, &nv, &nc, X, zn);
+      ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("side %d: min %.3f  median %.3f  p90 %.3f  max %.3f ms (nv %zu nc %zu)\n", side, ms[0], ms[200], ms[360], ms[399], nv, nc);
   }
 }

@@ -3,6 +3,7 @@
 #include "r1cs.hpp"
 
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <array>
 #include <atomic>
@@ -487,8 +488,8 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
   *oy = select(cs, i1, y2, uy);
 }
 
-// Two helper threads for the native pre-passes of a synthesis (one per folded commitment): they run while the calling
-// thread emits the hash gadgets, so the ~0.25 ms of projective arithmetic and batched inversion leave the critical path.
+// Three helper threads for the independent blocks of a synthesis (the state hash, and one in-circuit fold per folded
+// commitment): they run while the calling thread computes the challenge hash and the non-native folds.
 // Persistent (created on first use, parked on a condition variable), one pair per process; a synthesis that finds them
 // busy (another prover thread) simply does its pre-pass inline.
 namespace {
@@ -521,7 +522,7 @@ class Helpers {
     std::mutex mu;
     std::condition_variable cv;
   };
-  Helpers() { for (int k = 0; k < 2; ++k) std::thread([this, k] { loop(k); }).detach(); }
+  Helpers() { for (int k = 0; k < NSLOT; ++k) std::thread([this, k] { loop(k); }).detach(); }
   void loop(int k) {
     Slot& s = slots_[k];
     for (;;) {
@@ -540,7 +541,8 @@ class Helpers {
       s.state.store(0, std::memory_order_release);
     }
   }
-  Slot slots_[2];
+  static constexpr int NSLOT = 3;
+  Slot slots_[NSLOT];
   std::atomic<bool> busy_{false};
 };
 }  // namespace
@@ -789,29 +791,167 @@ void hash_challenge(int f, const Fe& params, const RelaxedInst& U, const Aff& u_
 }
 
 static thread_local uint64_t g_last_queue = 0, g_last_misses = 0;
+
+// Witness mode, block-parallel.  The augmented circuit's variables come in contiguous runs that depend on each other only
+// through a few values: [inputs] [state hash] [challenge hash] [curve checks] [fold of comm_W] [fold of comm_E]
+// [non-native folds] [selection, step circuit, output hash].  Each independent run is synthesised into a CS of its own by
+// THE SAME gadget code (so its variables come out in the order the shape has them) and spliced into place:
+//   helper 0: state hash;            this thread: challenge hash -> r;
+//   helpers 1, 2: the two in-circuit folds (native pre-pass + gadgets);     this thread meanwhile: the non-native folds.
+// tests/test_nova_host.py compares every variable with the oracle; VDF_NOVA_SEQ_SYNTH=1 selects the sequential path.
+namespace {
+struct Blk { std::vector<Fe> W; size_t rows = 0; };
+inline Num val(const Fe& v) { Num n; n.v = v; return n; }
+inline void splice(CS& cs, Blk& b) { cs.W.insert(cs.W.end(), b.W.begin(), b.W.end()); cs.rows += b.rows; }
+inline void take(Blk& b, CS& t) { t.resolve(); b.W = std::move(t.W); b.rows = t.rows; }
+}  // namespace
+
+static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out,
+                                                   uint64_t* r_out) {
+  const Field& F = cs.F;
+  const Field& PF = field(side_field(1 - side));
+  const int fid = cs.field_id;
+  const size_t a = step.arity();
+  const Fe ONE = one(F), ZERO = vdfhost::zero();
+  Fe ue[9];
+  relaxed_elements(in.U, F, ue);
+  const Fe uX[2] = {int_to_fe(in.u_X[0], F), int_to_fe(in.u_X[1], F)};
+  const Fe i_new_v = vdfhost::add(in.i, ONE, F);
+  // ---- block 1 (helper 0): the hash this step must have been handed
+  Blk b1, b2, b3, b4, b5;
+  Fe h_in;
+  auto run_b1 = [&] {
+    CS t(fid, false);
+    std::vector<Num> xs = {val(in.params), val(in.i)};
+    for (size_t k = 0; k < a; ++k) xs.push_back(val(in.z0[k]));
+    for (size_t k = 0; k < a; ++k) xs.push_back(val(in.zi[k]));
+    for (int k = 0; k < 9; ++k) xs.push_back(val(ue[k]));
+    const std::vector<Num> bits = strict_bits(t, poseidon_hash(t, TAG_STATE, xs));
+    h_in = pack(t, bits.data(), HASH_BITS).v;
+    take(b1, t);
+  };
+  // ---- blocks 3, 4 (helpers 1, 2): U + [r] P through the gadgets, slopes from the native pre-pass
+  uint64_t rv[4] = {0, 0, 0, 0};
+  struct FoldOut { Fe x, y; size_t queued = 0, misses = 0; } fo_w, fo_e;
+  auto run_fold = [&](const Aff& Upt, const Aff& P, Blk* b, FoldOut* o) {
+    CS t(fid, false);
+    ec_fold_inverses(F, Upt, P, rv, CHAL_BITS, &t.inv_queue);
+    std::vector<Num> bits(CHAL_BITS);
+    for (int k = 0; k < CHAL_BITS; ++k) bits[k].v = ((rv[k / 64] >> (k % 64)) & 1) ? ONE : ZERO;
+    Num rx, ry, fx, fy;
+    ec_scalar_mul(t, bits, val(P.x), val(P.y), val(P.x.is_zero() ? ONE : ZERO), &rx, &ry);
+    ec_add_complete(t, val(Upt.x), val(Upt.y), rx, ry, &fx, &fy);
+    o->x = fx.v; o->y = fy.v;
+    o->queued = t.inv_queue.size();
+    o->misses = t.inv_misses + (t.inv_queue.size() - t.inv_pos);
+    take(*b, t);
+  };
+  Helpers& H = Helpers::get();
+  const bool helped = H.try_acquire();
+  bool pending[3] = {false, false, false};
+  struct Joiner { Helpers& h; bool on; bool* p; ~Joiner() { if (on) { for (int k = 0; k < 3; ++k) if (p[k]) h.wait(k); h.release(); } } } joiner{H, helped, pending};
+  if (helped) { H.start(0, run_b1); pending[0] = true; } else run_b1();
+  // ---- block 2 (this thread): the fold challenge
+  std::vector<Num> r_bits;
+  {
+    CS t(fid, false);
+    std::vector<Num> xs = {val(in.params)};
+    for (int k = 0; k < 9; ++k) xs.push_back(val(ue[k]));
+    for (const Fe& v : {in.u_W.x, in.u_W.y, uX[0], uX[1], in.T.x, in.T.y}) xs.push_back(val(v));
+    r_bits = strict_bits(t, poseidon_hash(t, TAG_CHAL, xs));
+    r_bits.resize(CHAL_BITS);
+    fe_to_int(pack(t, r_bits.data(), CHAL_BITS).v, F, rv);
+    take(b2, t);
+  }
+  if (helped) {
+    H.start(1, [&] { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); }); pending[1] = true;
+    H.start(2, [&] { run_fold(in.U.comm_E, in.T, &b4, &fo_e); }); pending[2] = true;
+  }
+  // ---- block 5 (this thread, while the folds run): X' = X + r x in the other field
+  Fe f_lo[2], f_hi[2], x_lo[2], x_hi[2];
+  {
+    CS t(fid, false);
+    std::vector<Num> xb[2];
+    for (int k = 0; k < 2; ++k) xb[k] = alloc_bits(t, in.u_X[k], HASH_BITS);
+    t.rows += 2;                                      // the two packings equal u.X[k]
+    for (int k = 0; k < 2; ++k) {
+      Num lo, hi;
+      fold_foreign(t, val(ue[5 + 2 * k]), val(ue[6 + 2 * k]), xb[k], r_bits, PF, &lo, &hi);
+      f_lo[k] = lo.v; f_hi[k] = hi.v;
+      x_lo[k] = pack(t, xb[k].data(), LIMB_BITS).v;
+      x_hi[k] = pack(t, xb[k].data() + LIMB_BITS, HASH_BITS - LIMB_BITS).v;
+    }
+    take(b5, t);
+  }
+  if (!helped) { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); run_fold(in.U.comm_E, in.T, &b4, &fo_e); }
+  // ---- assembly, in the shape's order
+  const Num params = cs.alloc(in.params);
+  const Num i = cs.alloc(in.i);
+  std::vector<Num> z0, zi;
+  for (size_t k = 0; k < a; ++k) z0.push_back(cs.alloc(in.z0[k]));
+  for (size_t k = 0; k < a; ++k) zi.push_back(cs.alloc(in.zi[k]));
+  std::vector<Num> U;
+  for (int k = 0; k < 9; ++k) U.push_back(cs.alloc(ue[k]));
+  const Num uWx = cs.alloc(in.u_W.x), uWy = cs.alloc(in.u_W.y);
+  cs.alloc(uX[0]); cs.alloc(uX[1]);
+  const Num Tx = cs.alloc(in.T.x), Ty = cs.alloc(in.T.y);
+  const Num is_base = is_zero(cs, i);
+  if (pending[0]) { H.wait(0); pending[0] = false; }
+  splice(cs, b1);
+  cs.rows += 1;                                       // (1 - is_base) (u.X[0] - h_in) = 0
+  splice(cs, b2);
+  const Num uW_inf = is_zero(cs, uWx);
+  check_on_curve(cs, uWx, uWy, uW_inf);
+  const Num T_inf = is_zero(cs, Tx);
+  check_on_curve(cs, Tx, Ty, T_inf);
+  if (pending[1]) { H.wait(1); pending[1] = false; }
+  if (pending[2]) { H.wait(2); pending[2] = false; }
+  if (helped) { H.release(); joiner.on = false; }
+  splice(cs, b3);
+  splice(cs, b4);
+  splice(cs, b5);
+  uint64_t ui[4];
+  fe_to_int(ue[4], F, ui);
+  const Fe fu = vdfhost::add(ue[4], int_to_fe(rv, F), F);
+  const Fe fold[9] = {fo_w.x, fo_w.y, fo_e.x, fo_e.y, fu, f_lo[0], f_hi[0], f_lo[1], f_hi[1]};
+  Fe base[9];
+  if (side == 0) for (int k = 0; k < 9; ++k) base[k] = ZERO;
+  else { base[0] = in.u_W.x; base[1] = in.u_W.y; base[2] = ZERO; base[3] = ZERO; base[4] = ONE;
+         base[5] = x_lo[0]; base[6] = x_hi[0]; base[7] = x_lo[1]; base[8] = x_hi[1]; }
+  std::vector<Num> Unew;
+  for (int k = 0; k < 9; ++k) Unew.push_back(select(cs, is_base, val(base[k]), val(fold[k])));
+  std::vector<Num> z_in;
+  for (size_t k = 0; k < a; ++k) z_in.push_back(select(cs, is_base, z0[k], zi[k]));
+  cs.step_begin = cs.num_vars();
+  const std::vector<Num> z_out = step.synthesize(cs, z_in);
+  cs.step_end = cs.num_vars();
+  if (unew_out) for (int k = 0; k < 9; ++k) unew_out[k] = Unew[k].v;
+  if (r_out) memcpy(r_out, rv, 32);
+  std::vector<Num> hout = {params, val(i_new_v)};
+  hout.insert(hout.end(), z0.begin(), z0.end());
+  hout.insert(hout.end(), z_out.begin(), z_out.end());
+  hout.insert(hout.end(), Unew.begin(), Unew.end());
+  const std::vector<Num> h_out = strict_bits(cs, poseidon_hash(cs, TAG_STATE, hout));
+  cs.alloc_io(uX[1]);
+  cs.rows += 1;
+  cs.alloc_io(pack(cs, h_out.data(), HASH_BITS).v);
+  cs.rows += 1;
+  cs.resolve();
+  (void)h_in; (void)ui; (void)Ty; (void)uWy; (void)T_inf;
+  g_last_queue = fo_w.queued + fo_e.queued;
+  g_last_misses = fo_w.misses + fo_e.misses;
+  std::vector<Fe> out;
+  for (const Num& n : z_out) out.push_back(n.v);
+  return out;
+}
+
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out, uint64_t* r_out) {
+  static const bool sequential = [] { const char* e = std::getenv("VDF_NOVA_SEQ_SYNTH"); return e && e[0] == '1'; }();
+  if (!cs.shape && !sequential) return synthesize_augmented_blocks(cs, side, in, step, unew_out, r_out);
   const Field& F = cs.F;
   const Field& PF = field(side_field(1 - side));
   const size_t a = step.arity();
   const Num one_n = cs.constant(one(F));
-  // witness mode: the fold challenge is known natively from the inputs alone, so the slope inverses of both in-circuit
-  // folds are computed on the helper threads while this thread emits the hash gadgets (CS::take_inverse checks them)
-  std::vector<Fe> q_w, q_e;
-  bool helped = false;
-  if (!cs.shape) {
-    uint64_t rv[4];
-    hash_challenge(cs.field_id, in.params, in.U, in.u_W, in.u_X, in.T, rv);
-    helped = Helpers::get().try_acquire();
-    if (helped) {
-      const Field* Fp = &F;
-      const AugInputs* ip = &in;
-      std::vector<Fe>* qw = &q_w; std::vector<Fe>* qe = &q_e;
-      const std::array<uint64_t, 4> ra = {rv[0], rv[1], rv[2], rv[3]};
-      Helpers::get().start(0, [=] { ec_fold_inverses(*Fp, ip->U.comm_W, ip->u_W, ra.data(), CHAL_BITS, qw); });
-      Helpers::get().start(1, [=] { ec_fold_inverses(*Fp, ip->U.comm_E, ip->T, ra.data(), CHAL_BITS, qe); });
-    }
-  }
-  struct Joiner { bool on; ~Joiner() { if (on) { Helpers::get().wait(0); Helpers::get().wait(1); Helpers::get().release(); } } } joiner{helped};
   const Num params = cs.alloc(in.params);
   const Num i = cs.alloc(in.i);
   std::vector<Num> z0, zi;
@@ -845,20 +985,12 @@ std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, cons
   const Num T_inf = is_zero(cs, Tx);
   check_on_curve(cs, Tx, Ty, T_inf);
   if (!cs.shape) {
+    uint64_t rv[4];
+    fe_to_int(r.v, F, rv);
     cs.inv_queue.clear();
     cs.inv_pos = 0;
-    if (helped) {
-      Helpers::get().wait(0); Helpers::get().wait(1);
-      Helpers::get().release();
-      joiner.on = false;
-      cs.inv_queue = std::move(q_w);
-      cs.inv_queue.insert(cs.inv_queue.end(), q_e.begin(), q_e.end());
-    } else {
-      uint64_t rv[4];
-      fe_to_int(r.v, F, rv);
-      ec_fold_inverses(F, in.U.comm_W, in.u_W, rv, CHAL_BITS, &cs.inv_queue);
-      ec_fold_inverses(F, in.U.comm_E, in.T, rv, CHAL_BITS, &cs.inv_queue);
-    }
+    ec_fold_inverses(F, in.U.comm_W, in.u_W, rv, CHAL_BITS, &cs.inv_queue);
+    ec_fold_inverses(F, in.U.comm_E, in.T, rv, CHAL_BITS, &cs.inv_queue);
   }
   // comm_W' = U.W + r u.W ; comm_E' = U.E + r T
   Num rWx, rWy, fWx, fWy, rTx, rTy, fEx, fEy;
