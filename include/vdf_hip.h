@@ -251,6 +251,17 @@ int  vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, u
  * (num_cons each) and T.  u1: host memory.  (nova-snark NIFS::prove -> commit_T, K4 + K5.) */
 int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
                          const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T);
+/* The same over part of the rows: VDF_ROWS_INSIDE = the rows [row_begin, row_begin + row_count) only, VDF_ROWS_OUTSIDE =
+ * every row but those.  The vectors are full-length either way (num_cons); only the selected rows are read and written.
+ * A prover that knows part of the fresh witness early (the step circuit's own variables, made ahead of the step) runs
+ * the rows that read nothing else on another context before the rest of the witness exists; the range must not hold a
+ * row of more than 8 entries (those are summed by a wavefront in the OUTSIDE / ALL call). */
+#define VDF_ROWS_ALL 0
+#define VDF_ROWS_INSIDE 1
+#define VDF_ROWS_OUTSIDE 2
+int  vdf_nifs_cross_term_rows(vdf_ctx* ctx, const vdf_shape* shape, size_t row_begin, size_t row_count, int part, const vdf_fe* z2,
+                              const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2,
+                              vdf_fe* Cz2, vdf_fe* T);
 /* acc[i] <- acc[i] + r * add[i], i < k <= 8, n[i] elements each: k vdf_axpy calls with a common r (host
  * memory).  The fold of a relaxed witness is k = 2 (W, E); a prover that keeps A z, B z, C z of the running
  * instance folds them too (they are linear in z), k = 5, instead of recomputing three sparse products. */

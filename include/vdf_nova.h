@@ -80,6 +80,9 @@ int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t*
 /* the 250-bit digest of the parameters (little-endian), and the run of primary variables the GPU fills (MinRoot rounds) */
 int  vdf_nova_pp_digest(const vdf_pp* pp, uint8_t out[32]);
 int  vdf_nova_pp_segment(const vdf_pp* pp, uint64_t* begin, uint64_t* len);
+/* the run of primary constraints whose share of a step's cross term T and of comm_T prove_step makes ahead of the rest of
+ * the step (they read only that segment, the step's input and the constant); len = 0: none, T is committed in one piece */
+int  vdf_nova_pp_early_rows(const vdf_pp* pp, uint64_t* begin, uint64_t* len);
 
 /* InverseMinRootCircuit::eval_and_make_circuits, :262-299: num_steps forward evaluations of
  * num_iters_per_step rounds each from initial_state (host, sequential), one circuit per step

@@ -254,6 +254,24 @@ def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
     for got, e in zip(d2, abc2):
         assert np.array_equal(_host(got), e)
     assert np.array_equal(_host(dT), expT)
+    # the same in two calls over complementary row ranges (vdf_nifs_cross_term_rows): the rows of a range first, from a
+    # z2 whose other columns are still garbage where those rows do not read them -- here simply: inside, then outside
+    for rb, rn in ((0, nc), (nc, 0), (1, nc // 2), (nc // 3, nc - nc // 3)):
+        e2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+        eT = _dev(np.zeros((nc, 4), dtype="<u8"))
+        ctx.nifs_cross_term_rows(shape, rb, rn, 1, _dev(z2), *d1, u1, *e2, eT)
+        ctx.sync()
+        part = _host(eT).copy()
+        assert np.array_equal(part[rb:rb + rn], expT[rb:rb + rn]) and not part[:rb].any() and not part[rb + rn:].any()
+        ctx.nifs_cross_term_rows(shape, rb, rn, 2, _dev(z2), *d1, u1, *e2, eT)
+        ctx.sync()
+        assert np.array_equal(_host(eT), expT)
+        for got, e in zip(e2, abc2):
+            assert np.array_equal(_host(got), e)
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_rows(shape, 1, nc, 1, _dev(z2), *d1, u1, *d2, dT)      # range beyond the shape
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_rows(shape, 0, 1, 3, _dev(z2), *d1, u1, *d2, dT)       # unknown selection
     # scalars of fused calls must be host memory; vectors device memory
     with pytest.raises(Exception):
         ctx.nifs_cross_term(shape, z2, *d1, u1, *d2, dT)
@@ -381,6 +399,17 @@ def test_spmv_and_fused_cross_term_on_skewed_rows(ctx, cref, field):
     for got, e in zip(d2, exp):
         assert np.array_equal(_host(got), e)
     assert np.array_equal(_host(dT), expT)
+    # a row range must not hold a long row (they are the OUTSIDE call's work); a range of short rows is fine
+    long_rows = [r for r in range(nc) if any(np.roll(lens, 17 * k)[r] > 8 for k in range(3))]
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_rows(shape, long_rows[0], 1, 1, _dev(z), *[_dev(x) for x in abc1], u1, *d2, dT)
+    short = next(r for r in range(nc) if r not in set(long_rows))
+    e2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    eT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term_rows(shape, short, 1, 1, _dev(z), *[_dev(x) for x in abc1], u1, *e2, eT)
+    ctx.nifs_cross_term_rows(shape, short, 1, 2, _dev(z), *[_dev(x) for x in abc1], u1, *e2, eT)
+    ctx.sync()
+    assert np.array_equal(_host(eT), expT)
     shape.free()
 
 

@@ -179,6 +179,29 @@ def test_lookahead_is_invisible(ctx):
     assert b.verify(pp, n, z0, [initial.x, initial.y, initial.i])
 
 
+def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
+    """prove_step commits the MinRoot rounds' share of T ahead of the rest of a step (vdf_nova_pp_early_rows): the same
+    proof as with T in one piece, and the early run covers the rounds' constraints (3 per round, all but the first
+    round's, which read more of the witness)."""
+    t, n = 64, 4
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=12)
+    rb, rn = pp.early_rows()
+    assert 3 * t - 8 <= rn <= 3 * t + 2 and rb > 0
+    a = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    monkeypatch.setenv("VDF_NOVA_T_AHEAD", "0")
+    pp1 = public_params(ctx, t, CIRCUIT_MINROOT_BOUND, GENS_TRY_AND_INCREMENT)
+    monkeypatch.delenv("VDF_NOVA_T_AHEAD")
+    assert pp1.early_rows() == (0, 0) and pp1.digest() == pp.digest()
+    b = NovaVDFProof.prove_recursively(pp1, circuits, t, z0)
+    for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+        ia, ib = a.instance(which), b.instance(which)
+        for key in ia:
+            assert np.array_equal(ia[key], ib[key]), (which, key)
+        for va, vb in zip(a.witness(which), b.witness(which)):
+            assert (va is None and vb is None) or np.array_equal(va, vb)
+    assert a.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+
+
 def _canon(cref, field, arr):
     out = np.zeros_like(arr)
     cref.lib().ref_fe_from_mont(field, cref.p(np.ascontiguousarray(arr)), arr.shape[0], cref.p(out))

@@ -9,7 +9,7 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 t = 1 << lg
 ctx = vdf_amd.Context(0)
-t0 = time.time(); pp = public_params(ctx, t); print("public_params %.2f s" % (time.time() - t0), pp.sizes(0), pp.sizes(1))
+t0 = time.time(); pp = public_params(ctx, t); print("public_params %.2f s" % (time.time() - t0), pp.sizes(0), pp.sizes(1), "early rows", pp.early_rows())
 initial = State.from_ints(FIELD_FQ, o.rand_fe(1, 0, o.Q), 0, 0)
 t0 = time.time(); z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, n, initial)
 print("forward evaluation of %d x 2^%d rounds: %.2f s (host, sequential)" % (n, lg, time.time() - t0))

@@ -1,5 +1,6 @@
 // extern "C" boundary of libvdf_hip.so (include/vdf_hip.h).  Plain pointers and sizes only; no
 // exception leaves this file.  There is no CPU back-end: without a GPU vdf_ctx_create fails.
+#include <algorithm>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -868,6 +869,8 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
           if (rowptr[k][r + 1] - rowptr[k][r] > VDF_LONG_ROW) lng.push_back((uint32_t)r | ((uint32_t)k << 30));
       if (num_cons >= (1u << 30) && !lng.empty()) e = hipErrorInvalidValue;
       s->n_long = lng.size();
+      for (uint32_t v : lng) s->h_long_rows.push_back(v & 0x3FFFFFFFu);
+      std::sort(s->h_long_rows.begin(), s->h_long_rows.end());
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_long), (lng.size() + 1) * 4);
       if (e == hipSuccess && !lng.empty()) e = hipMemcpy(s->d_long, lng.data(), lng.size() * 4, hipMemcpyHostToDevice);
     }
@@ -991,22 +994,46 @@ int vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, ui
   });
 }
 
-int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
-                        const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T) {
-  return guarded(ctx, [&]() -> Status {
-    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
-    if (!u1 || ptr_is_device(u1)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
-    const void* vec[8] = {z2, Az1, Bz1, Cz1, Az2, Bz2, Cz2, T};
-    for (const void* v : vec)
-      if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+static Status nifs_cross_impl(vdf_ctx* ctx, const vdf_shape* shape, size_t row_begin, size_t row_count, int part, const vdf_fe* z2,
+                              const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2,
+                              vdf_fe* Cz2, vdf_fe* T) {
+  // the shape is read-only device data: any context of its device may run over it (the early rows run on a second one)
+  if (!shape || !shape->ctx || shape->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+  if (!u1 || ptr_is_device(u1)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+  const void* vec[8] = {z2, Az1, Bz1, Cz1, Az2, Bz2, Cz2, T};
+  for (const void* v : vec)
+    if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+  if (part != VDF_ROWS_ALL && part != VDF_ROWS_INSIDE && part != VDF_ROWS_OUTSIDE) return Status{VDF_ERR_BAD_ARG, "unknown row selection"};
+  if (part != VDF_ROWS_ALL) {
+    if (row_begin > shape->num_cons || row_count > shape->num_cons - row_begin) return Status{VDF_ERR_BAD_LENGTH, "row range outside the shape"};
+    // the range is meant for the uniform rows of a step circuit: a row summed by a wavefront (k_spmv_long) has no place in it
+    const auto it = std::lower_bound(shape->h_long_rows.begin(), shape->h_long_rows.end(), (uint32_t)row_begin);
+    if (row_count && it != shape->h_long_rows.end() && *it < row_begin + row_count)
+      return Status{VDF_ERR_BAD_ARG, "the row range holds a row of more than VDF_LONG_ROW entries"};
+  }
+  size_t rows = shape->num_cons, skip_begin = shape->num_cons, skip_len = 0;
+  if (part == VDF_ROWS_INSIDE) { rows = row_count; skip_begin = 0; skip_len = row_begin; }
+  if (part == VDF_ROWS_OUTSIDE) { rows = shape->num_cons - row_count; skip_begin = row_begin; skip_len = row_count; }
+  if (part != VDF_ROWS_INSIDE) {
     void* const outs[3] = {Az2, Bz2, Cz2};
     VDF_TRY(vdf::vec_spmv_long(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, shape->d_long,
                                shape->n_long, outs, ctx->stream));
-    VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
-                                u1, shape->num_cons, Az2, Bz2, Cz2, T, ctx->stream));
-    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
-    return Status{};
-  });
+  }
+  VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
+                              u1, rows, skip_begin, skip_len, Az2, Bz2, Cz2, T, ctx->stream));
+  if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+  return Status{};
+}
+
+int vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,
+                        const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status { return nifs_cross_impl(ctx, shape, 0, 0, VDF_ROWS_ALL, z2, Az1, Bz1, Cz1, u1, Az2, Bz2, Cz2, T); });
+}
+
+int vdf_nifs_cross_term_rows(vdf_ctx* ctx, const vdf_shape* shape, size_t row_begin, size_t row_count, int part, const vdf_fe* z2,
+                             const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2,
+                             vdf_fe* Cz2, vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status { return nifs_cross_impl(ctx, shape, row_begin, row_count, part, z2, Az1, Bz1, Cz1, u1, Az2, Bz2, Cz2, T); });
 }
 
 int vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* const acc[], const vdf_fe* const add[],

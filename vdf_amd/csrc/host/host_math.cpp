@@ -69,6 +69,25 @@ Aff pt_to_aff(const Pt& a, const Field& F) {
   r.y = mul(a.y, izzz, F);
   return r;
 }
+void pt_to_aff2(const Pt& pa, const Pt& pb, const Field& F, Aff* a, Aff* b) {
+  if (pa.is_id() || pb.is_id()) { *a = pt_to_aff(pa, F); *b = pt_to_aff(pb, F); return; }
+  const Fe inv_ab = inverse(mul(pa.zzz, pb.zzz, F), F);
+  auto fin = [&](const Pt& q, const Fe& izzz, Aff* o) {
+    o->x = mul(q.x, mul(sqr(izzz, F), sqr(q.zz, F), F), F);       // 1 / zz = zz^2 / zzz^2
+    o->y = mul(q.y, izzz, F);
+  };
+  fin(pa, mul(inv_ab, pb.zzz, F), a);
+  fin(pb, mul(inv_ab, pa.zzz, F), b);
+}
+Pt pt_from_jac(const vdf_jac& j, const Field& F) {
+  Pt p;
+  Fe Z;
+  memcpy(p.x.l, j.x.l, 32); memcpy(p.y.l, j.y.l, 32); memcpy(Z.l, j.z.l, 32);
+  if (Z.is_zero()) return pt_identity();
+  p.zz = sqr(Z, F);
+  p.zzz = mul(p.zz, Z, F);
+  return p;
+}
 Aff jac_to_aff(const vdf_jac& j, const Field& F) {
   Fe X, Y, Z;
   memcpy(X.l, j.x.l, 32); memcpy(Y.l, j.y.l, 32); memcpy(Z.l, j.z.l, 32);

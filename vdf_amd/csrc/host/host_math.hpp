@@ -192,6 +192,8 @@ Pt pt_dbl(const Pt& a, const Field& F);
 Pt pt_add(const Pt& a, const Pt& b, const Field& F);
 Pt pt_mul(const Pt& a, const uint64_t k[4], int bits, const Field& F);
 Aff pt_to_aff(const Pt& a, const Field& F);
+void pt_to_aff2(const Pt& pa, const Pt& pb, const Field& F, Aff* a, Aff* b);     // one inversion for both
+Pt pt_from_jac(const vdf_jac& j, const Field& F);                                // (X, Y, Z) -> (X, Y, Z^2, Z^3): no inversion
 Aff jac_to_aff(const vdf_jac& j, const Field& F);
 void jac_to_aff2(const vdf_jac& ja, const vdf_jac& jb, const Field& F, Aff* a, Aff* b);
 

@@ -216,14 +216,21 @@ int alloc_proof_buffers(vdf_proof* p) {
     HIPCALL(ctx, vdf_host_alloc(ctx, (sd.ncols - (s == PRIMARY ? pp->seg_len : 0)) * 32, (void**)&p->h_stage[s]));
   }
   HIPCALL(ctx, vdf_dev_alloc(ctx, pp->s[SECONDARY].ncols * 32, &p->d_l2z));
-  for (int k = 0; k < vdf_proof::RING; ++k) HIPCALL(ctx, vdf_dev_alloc(ctx, pp->s[PRIMARY].ncols * 32, &p->d_z2s[k]));
+  for (int k = 0; k < vdf_proof::RING; ++k) {
+    HIPCALL(ctx, vdf_dev_alloc(ctx, pp->s[PRIMARY].ncols * 32, &p->d_z2s[k]));
+    // a fresh instance has u = 1: in place from the start, because the early rows of a cross term read it before the
+    // host's share of that witness is uploaded
+    const Fe u_one = one(*pp->s[PRIMARY].F);
+    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[k] + pp->s[PRIMARY].num_vars * 32, &u_one, 32));
+  }
   for (int k = 0; k < vdf_proof::DEPTH; ++k) {
     const int dev = vdf_ctx_device(ctx);
     if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
   }
-  HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 4) * sizeof(vdf_jac), (void**)&p->h_pts));
+  HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 5) * sizeof(vdf_jac), (void**)&p->h_pts));
+  HIPCALL(ctx, vdf_host_alloc(ctx, pp->arity * 32, (void**)&p->h_zin));
   memset(&p->last, 0, sizeof(p->last));
   return VDF_OK;
 }
@@ -406,6 +413,27 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
   // only the MinRoot rounds are made on the device; a custom circuit's variables all come from the host
   pp->seg_begin = custom ? 0 : sh[PRIMARY].step_begin;
   pp->seg_len = custom ? 0 : sh[PRIMARY].step_end - sh[PRIMARY].step_begin;
+  if (pp->seg_len) {
+    // the longest run of primary constraints that read nothing of a witness but the segment, the step circuit's input z_in
+    // (the `arity` variables allocated right before it, synthesize_augmented; known when a step begins) and the constant,
+    // none of them a row the device sums by a wavefront (vdf_nifs_cross_term_rows)
+    const HostShape& h = sh[PRIMARY];
+    const size_t sb = pp->seg_begin - pp->arity, se = pp->seg_begin + pp->seg_len;
+    std::vector<uint8_t> early(h.num_cons, 1);
+    for (int k = 0; k < 3; ++k) {
+      std::vector<uint32_t> per_row(h.num_cons, 0);
+      for (size_t e = 0; e < h.m[k].rows.size(); ++e) {
+        const uint32_t r = h.m[k].rows[e], c = h.m[k].cols[e];
+        if (!((c >= sb && c < se) || c == h.num_vars) || ++per_row[r] > 8) early[r] = 0;
+      }
+    }
+    size_t best_b = 0, best_n = 0, run_b = 0;
+    for (size_t r = 0; r <= h.num_cons; ++r)
+      if (r == h.num_cons || !early[r]) { if (r - run_b > best_n) { best_b = run_b; best_n = r - run_b; } run_b = r + 1; }
+    const char* ov = std::getenv("VDF_NOVA_T_AHEAD");                 // tuning: 0 = one cross term, one commitment of T per step
+    if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0')) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
+    pp->ahead_mode = (ov && ov[0] == '2') ? 2 : 1;
+  }
   for (int s = 0; s < 2; ++s) {
     Side& sd = pp->s[s];
     sd.side = s; sd.field = side_field(s); sd.curve = side_curve(s);
@@ -474,6 +502,12 @@ int vdf_nova_pp_segment(const vdf_pp* pp, uint64_t* begin, uint64_t* len) {
   if (!pp) return fail(VDF_ERR_BAD_ARG, "null argument");
   if (begin) *begin = pp->seg_begin;
   if (len) *len = pp->seg_len;
+  return VDF_OK;
+}
+int vdf_nova_pp_early_rows(const vdf_pp* pp, uint64_t* begin, uint64_t* len) {
+  if (!pp) return fail(VDF_ERR_BAD_ARG, "null argument");
+  if (begin) *begin = pp->ahead_row;
+  if (len) *len = pp->ahead_rows;
   return VDF_OK;
 }
 
@@ -603,7 +637,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
-  enum { MARK_Z = 0, MARK_W = 1 };                // marks on a lookahead context: segment written / its commitment landed
+  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2 };    // marks on a lookahead context: segment written / its commitment landed / early rows of T committed
   bool touched[D] = {};
   const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
   const int per = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
@@ -664,6 +698,24 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     return VDF_OK;
   };
   vdf_jac* hb = &p->h_pts[R];                     // four result slots of the batched commitments
+  // The constraints of the MinRoot rounds read nothing of this step's witness but the rounds themselves, which are on
+  // the device already, and the running instance they are crossed with is final since the last step: their rows of T,
+  // and that part of comm_T, start NOW on the lookahead context, beside the secondary side's NIFS and the host's
+  // synthesis of the primary circuit, and leave ~10^4 rows instead of 2 x 10^5 on the critical path.
+  const bool t_ahead = !first && !custom && pp->ahead_rows != 0;
+  const size_t ta_b = pp->ahead_row, ta_n = pp->ahead_rows, ta_e = ta_b + ta_n;
+  auto early_rows = [&]() -> int {
+    SideState& s1 = p->r[PRIMARY];
+    // z_in = z_i past the base step (the circuit's selection); the same values arrive again with the host's variables
+    memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);            // pinned: the copy reads it when it runs
+    HIPCALL(cq, vdf_dev_memcpy(cq, (char*)d_z2 + (seg_b - arity) * 32, p->h_zin, arity * 32));
+    HIPCALL(cq, vdf_nifs_cross_term_rows(cq, S1.shape, ta_b, ta_n, VDF_ROWS_INSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
+                                         (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
+                                         (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+    HIPCALL(cq, vdf_msm(cq, S1.gens, ta_b, (const vdf_fe*)((const char*)s1.d_T + ta_b * 32), ta_n, 1, &hb[4]));
+    HIPCALL(cq, vdf_ctx_mark(cq, MARK_T));
+    return VDF_OK;
+  };
   double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
   Aff comm_T2, comm_T1;
   memset(&comm_T2, 0, sizeof(Aff)); memset(&comm_T1, 0, sizeof(Aff));
@@ -682,6 +734,13 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const size_t off[2] = {0, 0}, len[2] = {S2.num_vars, S2.num_cons};
       const vdf_fe* sc[2] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T};
       HIPCALL(ctx, vdf_msm_batch(ctx, S2.gens, 2, off, sc, len, 1, hb));
+    }
+    // launched while the host waits for this side's commitments, run when those are done: side by side the two
+    // bucket accumulations would share the SIMDs and this side, which the host is waiting for, would take twice as long
+    if (t_ahead) {
+      if (pp->ahead_mode != 2) HIPCALL(cq, vdf_ctx_wait(cq, ctx));
+      int rc = early_rows();
+      if (rc != VDF_OK) return rc;
     }
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     if (!p->l2_committed) { p->l2.comm_W = jac_aff(hb[0], *S2.Fb); p->l2_committed = true; }
@@ -734,28 +793,41 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // ---- (c) NIFS on the primary side ----------------------------------------------------------------------------
   {
     SideState& s1 = p->r[PRIMARY];
-    // host-made variables before and after the device's run (one group when there is no such run), then T
-    size_t off[3] = {0, seg_e, 0}, len[3] = {seg_b, S1.num_vars - seg_e, S1.num_cons};
-    const vdf_fe* sc[3] = {(const vdf_fe*)d_z2, (const vdf_fe*)((const char*)d_z2 + seg_e * 32), (const vdf_fe*)s1.d_T};
-    int ng = 3;
-    if (seg_n == 0) { len[0] = S1.num_vars; off[1] = 0; len[1] = S1.num_cons; sc[1] = (const vdf_fe*)s1.d_T; ng = 2; }
-    if (first) {
-      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng - 1, off, sc, len, 1, hb));
-    } else {
-      HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
-                                       (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
-                                       (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
-      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
+    // host-made variables before and after the device's run (one group when there is no such run), then T -- all of it,
+    // or the rows before and after the ones committed early
+    size_t off[4], len[4];
+    const vdf_fe* sc[4];
+    int ng = 0, first_T = 0;
+    auto group = [&](const void* base, size_t begin, size_t n) {
+      if (n == 0) return;
+      off[ng] = begin; len[ng] = n; sc[ng] = (const vdf_fe*)((const char*)base + begin * 32); ++ng;
+    };
+    if (seg_n) { group(d_z2, 0, seg_b); group(d_z2, seg_e, S1.num_vars - seg_e); }
+    else group(d_z2, 0, S1.num_vars);
+    first_T = ng;
+    if (!first) {
+      if (t_ahead) {
+        group(s1.d_T, 0, ta_b); group(s1.d_T, ta_e, S1.num_cons - ta_e);
+        HIPCALL(ctx, vdf_nifs_cross_term_rows(ctx, S1.shape, ta_b, ta_n, VDF_ROWS_OUTSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
+                                              (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
+                                              (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+      } else {
+        group(s1.d_T, 0, S1.num_cons);
+        HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
+                                         (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
+                                         (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+      }
     }
+    HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
     t3 = now_ms();
-    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, t_ahead ? MARK_T : MARK_W));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     const Field& Fb = *S1.Fb;
-    if (seg_n)
-      l1.comm_W = pt_to_aff(pt_add(pt_add(pt_from_aff(jac_aff(p->h_pts[slot], Fb), Fb), pt_from_aff(jac_aff(hb[0], Fb), Fb), Fb),
-                                   pt_from_aff(jac_aff(hb[1], Fb), Fb), Fb), Fb);
-    else l1.comm_W = jac_aff(hb[0], Fb);
-    if (!first) comm_T1 = jac_aff(hb[ng - 1], Fb);
+    // partial commitments leave the device as Jacobian points: summed as they are, one inversion for W and T together
+    auto sum = [&](Pt acc, int from, int to) { for (int g = from; g < to; ++g) acc = pt_add(acc, pt_from_jac(hb[g], Fb), Fb); return acc; };
+    const Pt w_sum = seg_n ? sum(pt_from_jac(p->h_pts[slot], Fb), 0, first_T) : pt_from_jac(hb[0], Fb);
+    if (first) l1.comm_W = pt_to_aff(w_sum, Fb);
+    else pt_to_aff2(w_sum, t_ahead ? sum(pt_from_jac(hb[4], Fb), first_T, ng) : pt_from_jac(hb[first_T], Fb), Fb, &l1.comm_W, &comm_T1);
     if (first) {
       // running primary := the fresh instance, relaxed; its A z, B z, C z once, folded from then on
       HIPCALL(ctx, vdf_dev_memcpy(ctx, s1.d_z, d_z2, S1.ncols * 32));
@@ -855,6 +927,7 @@ void vdf_nova_proof_free(vdf_proof* p) {
     for (void* b : p->d_traces) if (b) vdf_dev_free(ctx, b);
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_destroy(q);
     if (p->h_pts) vdf_host_free(ctx, p->h_pts);
+    if (p->h_zin) vdf_host_free(ctx, p->h_zin);
     for (Fe* h : p->h_stage) if (h) vdf_host_free(ctx, h);
   }
   delete p;

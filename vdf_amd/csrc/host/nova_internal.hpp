@@ -75,6 +75,10 @@ struct vdf_pp {
   Fe params[2];                            // the digest as an element of each side's field
   // variables of the primary witness that the GPU fills from the forward trace (the MinRoot rounds): [seg_begin, seg_begin + seg_len)
   size_t seg_begin = 0, seg_len = 0;
+  // constraints of the primary shape that read nothing of a fresh witness but that segment (and the constant): their
+  // share of a step's cross term and of its commitment is made ahead of the rest, [ahead_row, ahead_row + ahead_rows)
+  size_t ahead_row = 0, ahead_rows = 0;
+  int ahead_mode = 1;            // when they run: 1 = once the secondary side's NIFS has left the device, 2 = beside it (tuning)
   size_t arity = 3;                        // of the primary step circuit (z0, zi)
 };
 
@@ -116,7 +120,8 @@ struct vdf_proof {
   const vdf_circuits* ahead_circuits = nullptr;
   size_t ahead_k = 0;
   std::vector<Ahead> ahead;
-  vdf_jac* h_pts = nullptr;      // pinned result slots: [0, RING) segment commitments per ring slot, then 4 for the batches
+  Fe* h_zin = nullptr;           // pinned: the step circuit's input for the early rows of T
+  vdf_jac* h_pts = nullptr;      // pinned result slots: [0, RING) segment commitments per ring slot, 4 for the batches, 1 for the early rows of T
   Fe* h_stage[2] = {};           // pinned staging of a host-synthesised witness, one per side
   // the last step's by-products, for the parity tests
   vdf_nova_step_info last;

@@ -68,6 +68,7 @@ struct vdf_shape {
   // rows with more than VDF_LONG_ROW entries, as row | matrix << 30: one wavefront each (vec_spmv_long) instead of one lane
   uint32_t* d_long = nullptr;
   size_t n_long = 0;
+  std::vector<uint32_t> h_long_rows;                      // ... their row numbers, ascending (vdf_nifs_cross_term_rows)
 };
 // A row of more than this many entries is summed by a whole wavefront ahead of the lane-per-row kernels, which then
 // only read the result: the rows of an augmented circuit that pack 255 bits or carry a Poseidon state of ~60 terms would
@@ -170,8 +171,8 @@ Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in
                   const vdf_fe X[6], void* z, void* packed, hipStream_t s);
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
-                      const void* cz1, const vdf_fe* u1, size_t rows, void* az2, void* bz2, void* cz2, void* T,
-                      hipStream_t s);
+                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
+                      void* bz2, void* cz2, void* T, hipStream_t s);
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);

@@ -51,10 +51,20 @@ __device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setpr
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
 static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many: two waves per SIMD already issue at ~99 % of three,
                                             // and a third fewer slices means a third fewer slice heads for k_fixup to add
-static constexpr int HEAVY_SPAN = 24;       // slices per bucket above which a wavefront takes over
-static constexpr uint32_t GIANT_SPAN = 1024; // ... and above which GIANT_PARTS wavefronts share the bucket
-static constexpr uint32_t GIANT_PARTS = 256;
-static constexpr uint32_t MAX_GIANTS = 192;  // more giant buckets than this cannot exist (slots / GIANT_SPAN)
+// The fix-up is a chain of dependent additions per bucket, so its duration is the LONGEST chain of the launch (a quad
+// addition is ~3 us): a bucket spanning more than heavy_span slices goes to a wavefront (chain span/16 + 5), one
+// spanning more than GIANT_SPAN to several wavefronts, GIANT_CHUNK heads each.  heavy_span adapts to the launch
+// (k_fixup): twice the average span + 4, never below HEAVY_MIN -- a 0/1-heavy witness of a few thousand scalars puts
+// hundreds of slice heads into ONE bucket while the average bucket spans one or two slices.
+static constexpr uint32_t HEAVY_MIN = 6;
+static constexpr uint32_t GIANT_SPAN = 64;
+static constexpr uint32_t GIANT_CHUNK = 32;  // heads per wavefront of a shared bucket (two per quad), while the parts last
+static constexpr uint32_t GIANT_PARTS = 256; // wavefronts per shared bucket at most
+static constexpr uint32_t MAX_GIANTS = 192;  // shared buckets per launch; the surplus is reduced by one wavefront each
+__device__ __forceinline__ uint32_t giant_parts(uint32_t span) {
+  const uint32_t p = (span + GIANT_CHUNK - 1) / GIANT_CHUNK;
+  return p > GIANT_PARTS ? GIANT_PARTS : p;
+}
 
 // Slice length of k_accumulate, computed on the device from the ACTUAL entry count (zero digits are skipped, so
 // scalars with few non-zero windows produce far fewer entries than n * windows): one round over `slots` threads,
@@ -598,24 +608,36 @@ __host__ __device__ __forceinline__ HeavyLayout heavy_layout(uint32_t* heavy, ui
   return q;
 }
 
-// One quad per bucket: add the heads of the slices the bucket spans (table mode: ~8 per bucket).
+struct FixupTune { uint32_t heavy_min, giant_span; };
+static FixupTune fixup_tune() {                                     // tuning overrides
+  FixupTune t{HEAVY_MIN, GIANT_SPAN};
+  if (const char* e = std::getenv("VDF_MSM_HEAVY_MIN")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) t.heavy_min = (uint32_t)v; }
+  if (const char* e = std::getenv("VDF_MSM_GIANT_SPAN")) { const long v = std::atol(e); if (v >= 16 && v <= (1 << 20)) t.giant_span = (uint32_t)v; }
+  return t;
+}
+
+// One quad per bucket: add the heads of the slices the bucket spans.
 template <class P>
 __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
                                                uint32_t Lfixed, char* __restrict__ bucket_acc,
-                                               const char* __restrict__ heads, uint32_t* __restrict__ heavy) {
+                                               const char* __restrict__ heads, uint32_t* __restrict__ heavy,
+                                               uint32_t heavy_min, uint32_t giant_span) {
   raise_wave_priority();
   const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 2;
   if (g >= nkeys) return;                                          // quad-uniform from here on
-  const uint32_t L = slice_len(bstart[nkeys], slots, Lfixed);
+  const uint32_t ne = bstart[nkeys];
+  const uint32_t L = slice_len(ne, slots, Lfixed);
   const uint32_t s = bstart[g], e = bstart[g + 1];
   if (e <= s) return;
   const uint32_t tf = s / L, tl = (e - 1) / L;
   if (tl == tf) return;
-  if (tl - tf > (uint32_t)HEAVY_SPAN) {
+  uint32_t heavy_span = 2u * ((ne / nkeys + L - 1) / L) + 4u;
+  if (heavy_span < heavy_min) heavy_span = heavy_min;
+  if (tl - tf > heavy_span) {
     if ((threadIdx.x & 3u) == 0) {
       const HeavyLayout q = heavy_layout(heavy, nkeys);
       bool queued = false;
-      if (tl - tf > GIANT_SPAN) {                                  // its own queue: the position is the giant's number
+      if (tl - tf > giant_span) {                                  // its own queue: the position is the giant's number
         const uint32_t idx = atomicAdd(q.giant_count, 1u);
         if (idx < MAX_GIANTS) { q.giants[idx] = g; queued = true; }
       }
@@ -659,7 +681,9 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
       const uint32_t g = q.giants[my];
       const uint32_t s = bstart[g], e = bstart[g + 1];
       const uint32_t tf = s / L, tl = (e - 1) / L, span = tl - tf;  // heads tf+1 .. tl
-      const uint32_t chunk = (span + GIANT_PARTS - 1) / GIANT_PARTS;
+      const uint32_t parts = giant_parts(span);
+      if (part >= parts) continue;
+      const uint32_t chunk = (span + parts - 1) / parts;
       const uint32_t t0 = tf + 1 + part * chunk;
       const uint32_t t1 = (t0 + chunk - 1 < tl) ? t0 + chunk - 1 : tl;
       QPoint<P> acc = qpoint_identity<P>();
@@ -671,10 +695,10 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
       uint32_t arrived = 0;
       if (threadIdx.x == 0) arrived = atomicAdd(&q.done[my], 1u);
       arrived = (uint32_t)__builtin_amdgcn_readfirstlane(arrived);
-      if (arrived != GIANT_PARTS - 1) continue;
+      if (arrived != parts - 1) continue;
       __threadfence();
       QPoint<P> tot = qpoint_identity<P>();
-      for (uint32_t p = quad; p < GIANT_PARTS; p += 16) tot = qpoint_add<P>(tot, qpoint_load<P>(giant + ((size_t)my * GIANT_PARTS + p) * 128));
+      for (uint32_t p = quad; p < parts; p += 16) tot = qpoint_add<P>(tot, qpoint_load<P>(giant + ((size_t)my * GIANT_PARTS + p) * 128));
       tot = qpoint_wave_sum(tot);
       if (quad == 0) {
         QPoint<P> base = qpoint_load_lazy<P>(bucket_acc + (size_t)g * 128);
@@ -1187,6 +1211,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
+  static const FixupTune tune = fixup_tune();
   // pass B
   hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
                      reinterpret_cast<uint32_t*>(base + w.tstart));
@@ -1195,7 +1220,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
                      reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.slots, p.Lfixed, p.nthreads);
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
-                     heavy);
+                     heavy, tune.heavy_min, tune.giant_span);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(16 * GIANT_PARTS), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
                      base + w.giant);
   if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st));

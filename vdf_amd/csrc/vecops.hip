@@ -212,11 +212,13 @@ template <class P>
 __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
                                                     const char* __restrict__ az1, const char* __restrict__ bz1,
                                                     const char* __restrict__ cz1, FeVal u1, size_t rows,
+                                                    size_t skip_begin, size_t skip_len,
                                                     char* __restrict__ az2, char* __restrict__ bz2,
                                                     char* __restrict__ cz2, char* __restrict__ T) {
   __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
-  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
+  if (r >= skip_begin) r += skip_len;  // `rows` rows of the matrix, leaving out [skip_begin, skip_begin + skip_len)
   uint32_t lo[3], hi[3], c0[3], k0[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
@@ -356,13 +358,13 @@ Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_f
 
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
-                      const void* cz1, const vdf_fe* u1, size_t rows, void* az2, void* bz2, void* cz2, void* T,
-                      hipStream_t s) {
+                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
+                      void* bz2, void* cz2, void* T, hipStream_t s) {
   if (rows == 0) return Status{};
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
   FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
-                 to_val(u1), rows, M(az2), M(bz2), M(cz2), M(T));
+                 to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
   return Status{};
 }
 

@@ -339,6 +339,11 @@ class Context:
         self._check(lib.vdf_nifs_cross_term(self.handle, shape.handle, _ptr(z2), _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(u1),
                                             _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
 
+    def nifs_cross_term_rows(self, shape: Shape, row_begin: int, row_count: int, part: int, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
+        """part: 1 = only the rows [row_begin, row_begin + row_count), 2 = every row but those (vdf_hip.h VDF_ROWS_*)."""
+        self._check(lib.vdf_nifs_cross_term_rows(self.handle, shape.handle, row_begin, row_count, part, _ptr(z2), _ptr(az1), _ptr(bz1),
+                                                 _ptr(cz1), _ptr(u1), _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
+
     def fold_many(self, field, r, acc, add, n) -> None:
         k = len(acc)
         a = (C.c_void_p * k)(*[_ptr(x) for x in acc])

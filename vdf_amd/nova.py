@@ -21,6 +21,7 @@ for _name, _res, _args in [
     ("vdf_nova_pp_sizes", _i, [_vp, _i] + [C.POINTER(_u64)] * 5),
     ("vdf_nova_pp_digest", _i, [_vp, _vp]),
     ("vdf_nova_pp_segment", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    ("vdf_nova_pp_early_rows", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_eval_and_make_circuits", _i, [_i, _u64, _sz, C.POINTER(_State), C.POINTER(_Fe * 3), C.POINTER(_vp)]),
     ("vdf_nova_circuits_len", _sz, [_vp]),
     ("vdf_nova_circuits_upload", _i, [_vp, _vp]),
@@ -266,6 +267,12 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         """(first variable, count) of the primary witness's run that the GPU fills: the MinRoot rounds."""
         b, n = C.c_uint64(), C.c_uint64()
         _check(nova_lib.vdf_nova_pp_segment(self.handle, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def early_rows(self) -> Tuple[int, int]:
+        """(first constraint, count) of the primary rows whose share of T and comm_T a step makes ahead of the rest."""
+        b, n = C.c_uint64(), C.c_uint64()
+        _check(nova_lib.vdf_nova_pp_early_rows(self.handle, C.byref(b), C.byref(n)))
         return b.value, n.value
 
     def free(self) -> None:
