@@ -109,6 +109,16 @@ int  vdf_bases_generate_label(vdf_ctx* ctx, int curve, const uint8_t* label, siz
  * any sub-range of its generators; for MSMs much shorter than the table choose the window by their length. */
 int  vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets);
 int  vdf_bases_window(const vdf_bases* bases);            /* window of the current table, 0 without one */
+/* Digit table for the SMALL commitments a prover waits on (the ~10^4-term witnesses and cross-term rows of
+ * RecursiveSNARK::prove_step, src/nova/proof.rs:342-349): every multiple d * 2^(window_bits * j) * P_i, d = 1 .. 2^(window_bits-1),
+ * of the generators in up to 4 disjoint index ranges.  vdf_msm / vdf_msm_batch calls whose vectors all lie inside those
+ * ranges (at most 2^17 scalars per call) then skip the bucket method: signed digits select table entries and the MSM is
+ * a plain sum of gathered points -- two launches, ~20 dependent additions instead of a sort and ~80.  Same group element;
+ * its Jacobian representative differs from the bucket method's.  HBM: count * W * 2^(window_bits-1) * 64 bytes, W =
+ * ceil(256 / window_bits) (+1 when the top digit could overflow): 852 KB per generator at window_bits = 10 (0 = that).
+ * ranges = 0 drops the table.  VDF_MSM_DIRECT=0 in the environment disables the path (tuning). */
+int  vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int ranges, const size_t begin[], const size_t count[]);
+int  vdf_bases_digit_window(const vdf_bases* bases);      /* window of the digit table, 0 without one */
 int  vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out);
 size_t vdf_bases_len(const vdf_bases* bases);
 const void* vdf_bases_device_ptr(const vdf_bases* bases);

@@ -725,3 +725,82 @@ def test_label_derived_bases_match_oracle(ctx, curve):
         b.free()
     with pytest.raises(Exception):
         ctx.bases_generate_label(curve, b"a" * 65, 4)
+
+
+# ---- direct-sum MSM over a digit table (msm_direct.hip): the small commitments on a prover's critical path ------------
+def _digit_edge_scalars(sm, c, n, rng):
+    """Scalars whose signed digits sit at the edges of [-2^(c-1), 2^(c-1)): all-ones, runs of 2^(c-1) and 2^(c-1) - 1
+    in every window, carries running to the top, the largest scalars of the field."""
+    half = 1 << (c - 1)
+    vals = [0, 1, 2, half - 1, half, half + 1, (1 << c) - 1, 1 << c, sm - 1, sm - 2, sm >> 1, (sm >> 1) + 1]
+    vals += [sum(half << (c * j) for j in range(0, 254 // c)) % sm, sum((half - 1) << (c * j) for j in range(0, 254 // c)) % sm,
+             ((1 << 254) - 1) % sm, (1 << 253), (1 << 254) % sm]
+    vals += [int(x) for x in rng.integers(0, 2, size=max(0, n - len(vals)))]           # a witness's bits
+    return limbs(vals[:n])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("c", [8, 9, 10, 11])
+def test_digit_table_msm_equals_the_bucket_method(ctx, cref, curve, c):
+    nb = 700
+    sm = o.curve_scalar_modulus(curve)
+    bases = ctx.bases_generate(curve, 5, nb)
+    pts = bases.download()
+    bases.precompute(15, 1)
+    ranges = [(0, 300), (450, 250)]
+    bases.precompute_digits(ranges, c)
+    assert bases.digit_window == c
+    rng = np.random.default_rng(c)
+    cases = {"random": rand_limbs(rng, 300), "edges": _digit_edge_scalars(sm, c, 300, rng)}
+    cases.update({k: v for k, v in _distributions(300, sm, rng).items()})
+    for name, sc in cases.items():
+        for is_mont in (False, True):
+            s_in = mont(ints(sc), sm) if is_mont else sc
+            got = jac_to_affine(ctx.msm(bases, s_in, is_mont=is_mont), curve)
+            assert got == cpu_msm(cref, curve, pts[:300].copy(), sc), (name, is_mont)
+    # sub-ranges, the second range, a batch across both; a vector that leaves the ranges takes the bucket method
+    sc = [rand_limbs(rng, n) for n in (250, 120, 1, 300)]
+    offs = [450, 37, 699, 0]
+    got = ctx.msm_batch(bases, sc, offsets=offs)
+    for g in range(4):
+        assert jac_to_affine(got[g], curve) == cpu_msm(cref, curve, pts[offs[g]:offs[g] + len(sc[g])].copy(), sc[g]), g
+    wide = rand_limbs(rng, 500)
+    assert jac_to_affine(ctx.msm(bases, wide, offset=100), curve) == cpu_msm(cref, curve, pts[100:600].copy(), wide)
+    mixed = ctx.msm_batch(bases, [sc[0], wide], offsets=[450, 100])
+    assert jac_to_affine(mixed[0], curve) == cpu_msm(cref, curve, pts[450:700].copy(), sc[0])
+    assert jac_to_affine(mixed[1], curve) == cpu_msm(cref, curve, pts[100:600].copy(), wide)
+    # empty vectors and an all-zero vector give the identity
+    z = ctx.msm_batch(bases, [np.zeros((0, 4), dtype="<u8"), np.zeros((9, 4), dtype="<u8")], offsets=[0, 460])
+    assert jac_to_affine(z[0], curve) is None and jac_to_affine(z[1], curve) is None
+    with pytest.raises(Exception):
+        bases.precompute_digits([(0, 300), (299, 10)], c)              # overlapping ranges
+    with pytest.raises(Exception):
+        bases.precompute_digits([(0, nb + 1)], c)                      # beyond the generators
+    with pytest.raises(Exception):
+        bases.precompute_digits([(0, 10)], 13)                         # window out of range
+    bases.precompute_digits([])
+    assert bases.digit_window == 0
+    bases.free()
+
+
+def test_digit_table_msm_at_witness_size_dlog_identity(ctx):
+    """The shape a Nova step waits for: two ~10^4-term vectors in one call (a witness full of bits and small values, and a
+    random cross term), device-resident, through the digit table; the discrete-log identity of the synthetic generators
+    needs no CPU MSM."""
+    import torch
+    curve, n = o.CURVE_VESTA, 10049
+    sm = o.curve_scalar_modulus(curve)
+    bases = ctx.bases_generate(curve, 0x4E6F7661, n)
+    bases.precompute_digits([(0, n)])
+    rng = np.random.default_rng(3)
+    w = rand_limbs(rng, n)
+    bits = rng.random(n) < 0.5
+    w[bits] = 0
+    w[bits, 0] = rng.integers(0, 2, size=int(bits.sum()), dtype=np.uint64)
+    t = rand_limbs(rng, n)
+    dw, dt = (torch.from_numpy(x.view(np.int64)).cuda() for x in (w, t))
+    got = ctx.msm_batch(bases, [dw, dt])
+    ctx.sync()
+    for vec, res in ((w, got[0]), (t, got[1])):
+        assert jac_to_affine(res, curve) == o.msm_by_dlog_limbs(vec, curve, 0x4E6F7661)
+    bases.free()

@@ -42,6 +42,8 @@ PROTOTYPES = {
     "vdf_bases_precompute": (_i, [_vp, _vp, _i, _i]),
     "vdf_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "vdf_bases_window": (_i, [_vp]),
+    "vdf_bases_precompute_digits": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "vdf_bases_digit_window": (_i, [_vp]),
     "vdf_bases_len": (_sz, [_vp]),
     "vdf_bases_device_ptr": (_vp, [_vp]),
     "vdf_bases_free": (None, [_vp]),

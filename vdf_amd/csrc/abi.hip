@@ -136,6 +136,13 @@ Status ensure_ws(vdf_ctx* ctx, size_t bytes) {
   return Status{};
 }
 
+// the direct sum is for commitments a host waits on; beyond this many scalars per call the bucket method's throughput wins
+constexpr size_t DIRECT_MAX_SCALARS = (size_t)1 << 17;
+bool direct_enabled() {
+  static const bool on = [] { const char* e = std::getenv("VDF_MSM_DIRECT"); return !(e && e[0] == '0'); }();   // tuning: 0 = bucket method only
+  return on;
+}
+
 size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 
 Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* offset, const vdf_fe* const* scalars,
@@ -161,6 +168,39 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
   }
   const void* d_scalars[vdf::MSM_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
   for (int g = 0; g < groups; ++g) VDF_TRY(st.in(scalars[g], n[g] * sizeof(vdf_fe), &d_scalars[g]));
+  // small commitments over generators that have a digit table: a plain sum of gathered multiples (msm_direct.hip)
+  if (bases->d_digits && ctx->msm_window == 0 && ntot <= DIRECT_MAX_SCALARS && direct_enabled()) {
+    size_t slot0[vdf::MSM_MAX_GROUPS] = {0, 0, 0, 0};
+    bool inside = true;
+    for (int g = 0; g < groups && inside; ++g) {
+      int r = 0;
+      while (r < bases->dg_ranges && !(offset[g] >= bases->dg_begin[r] && offset[g] + n[g] <= bases->dg_begin[r] + bases->dg_count[r])) ++r;
+      if (r == bases->dg_ranges) inside = n[g] == 0;
+      else slot0[g] = bases->dg_slot0[r] + (offset[g] - bases->dg_begin[r]);
+    }
+    if (inside) {
+      VDF_TRY(ensure_ws(ctx, vdf::direct_ws_bytes(groups, n, bases->dg_c, ctx->num_cus)));
+      hipEvent_t* dev = nullptr;
+      vdf_ctx::TimedCall dtc;
+      if (ctx->timing) {
+        for (int i = 0; i < 4; ++i) {
+          if (!ctx->ev_pool.empty()) { dtc.ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+          else VDF_TRY_HIP(hipEventCreate(&dtc.ev[i]));
+        }
+        dev = dtc.ev;
+        VDF_TRY_HIP(hipEventRecord(dev[0], ctx->stream));
+        VDF_TRY_HIP(hipEventRecord(dev[1], ctx->stream));
+      }
+      VDF_TRY(vdf::msm_direct_run(bases->curve, groups, n, slot0, d_scalars, is_mont != 0, bases->dg_c, ctx->num_cus, bases->d_digits, ctx->ws, d_out,
+                                  ctx->stream));
+      if (dev) {
+        VDF_TRY_HIP(hipEventRecord(dev[2], ctx->stream));
+        VDF_TRY_HIP(hipEventRecord(dev[3], ctx->stream));
+        ctx->timed.push_back(dtc);
+      }
+      return st.finish();
+    }
+  }
   vdf::MsmPlan plan;
   const char* pts;
   if (bases->d_table && (ctx->msm_window == 0 || ctx->msm_window == bases->tbl_c)) {
@@ -536,6 +576,45 @@ int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int se
   });
 }
 
+int vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int ranges, const size_t begin[], const size_t count[]) {
+  return guarded(ctx, [&]() -> Status {
+    if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
+    if (bases->d_digits) { (void)hipFree(bases->d_digits); bases->d_digits = nullptr; }
+    bases->dg_c = bases->dg_ranges = 0;
+    if (ranges == 0) return Status{};
+    if (ranges < 0 || ranges > 4 || !begin || !count) return Status{VDF_ERR_BAD_ARG, "1..4 generator ranges"};
+    if (window_bits == 0) window_bits = 10;
+    if (window_bits < 4 || window_bits > 12) return Status{VDF_ERR_BAD_ARG, "digit window must be 0 (recommended) or 4..12"};
+    size_t slots = 0;
+    for (int r = 0; r < ranges; ++r) {
+      if (begin[r] > bases->n || count[r] > bases->n - begin[r]) return Status{VDF_ERR_BAD_LENGTH, "range exceeds the generator table"};
+      for (int q = 0; q < r; ++q)
+        if (begin[r] < begin[q] + count[q] && begin[q] < begin[r] + count[r]) return Status{VDF_ERR_BAD_ARG, "generator ranges overlap"};
+      slots += count[r];
+    }
+    if (slots == 0) return Status{};
+    const int W = vdf::direct_windows(window_bits);
+    if (slots * W >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "too many generators for a digit table"};
+    const size_t bytes = ((slots * W) << (window_bits - 1)) * sizeof(vdf_affine);
+    size_t free_b = 0, total_b = 0;
+    VDF_TRY_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + ((size_t)1 << 30) > free_b) return Status{VDF_ERR_OOM, "the digit table does not fit the free device memory"};
+    VDF_TRY_HIP(hipMalloc(&bases->d_digits, bytes));
+    size_t slot0 = 0;
+    Status s{};
+    for (int r = 0; r < ranges && s.ok(); ++r) {
+      s = vdf::digits_build(bases->curve, bases->d_pts, begin[r], count[r], slot0, window_bits, bases->d_digits, ctx->stream);
+      bases->dg_begin[r] = begin[r]; bases->dg_count[r] = count[r]; bases->dg_slot0[r] = slot0;
+      slot0 += count[r];
+    }
+    if (!s.ok()) { (void)hipFree(bases->d_digits); bases->d_digits = nullptr; return s; }
+    bases->dg_c = window_bits; bases->dg_ranges = ranges;
+    return Status{};
+  });
+}
+
+int vdf_bases_digit_window(const vdf_bases* bases) { return bases && bases->d_digits ? bases->dg_c : 0; }
+
 int vdf_bases_window(const vdf_bases* bases) { return bases && bases->d_table ? bases->tbl_c : 0; }
 
 int vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out) {
@@ -560,6 +639,7 @@ void vdf_bases_free(vdf_bases* bases) {
     (void)hipStreamSynchronize(bases->ctx->stream);
     if (bases->d_pts) (void)hipFree(bases->d_pts);
     if (bases->d_table) (void)hipFree(bases->d_table);
+    if (bases->d_digits) (void)hipFree(bases->d_digits);
   }
   delete bases;
 }

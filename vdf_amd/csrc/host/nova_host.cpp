@@ -459,6 +459,26 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     int small_c = 15;
     if (const char* ov = std::getenv("VDF_NOVA_SMALL_WINDOW")) { const int v = atoi(ov); if (v >= 6 && v <= 16) small_c = v; }   // tuning
     HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? 16 : small_c, 1));
+    // The commitments a step WAITS for are small: the secondary circuit's witness and cross term (~10^4 terms each), and
+    // on the primary side what the host made of the witness and the rows of T that depend on it.  Their generators get
+    // a digit table (vdf_bases_precompute_digits: a plain sum of gathered multiples, no buckets); the rounds' 2 x 10^5
+    // terms, committed ahead of the step, stay with the bucket method.
+    {
+      int digit_c = 10;
+      if (const char* ov = std::getenv("VDF_NOVA_DIGIT_WINDOW")) digit_c = atoi(ov);                 // tuning; 0 = no digit tables
+      size_t db[2] = {0, 0}, dn[2] = {0, 0};
+      int nr = 0;
+      const size_t top = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons;
+      if (s == SECONDARY || pp->seg_len == 0) { dn[0] = top; nr = 1; }
+      else if (pp->ahead_rows) {
+        const size_t se = pp->seg_begin + pp->seg_len, ae = pp->ahead_row + pp->ahead_rows;
+        dn[0] = pp->seg_begin > pp->ahead_row ? pp->seg_begin : pp->ahead_row;
+        db[1] = se < ae ? se : ae;
+        dn[1] = top - db[1];
+        nr = db[1] > dn[0] ? 2 : 0;
+      }
+      if (digit_c && nr && dn[0] + dn[1] <= (1u << 16)) HIPCALL(ctx, vdf_bases_precompute_digits(ctx, sd.gens, digit_c, nr, db, dn));
+    }
     vdf_bases* ub = nullptr;
     HIPCALL(ctx, make_gens(sd.curve, g, 1, &ub));
     const int rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&sd.gen_u);

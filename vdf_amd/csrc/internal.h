@@ -47,6 +47,11 @@ struct vdf_bases {
   // fixed-base table: tables x n affine points; table j holds 2^(c*sets*j) * P_i
   int tbl_c = 0, tbl_sets = 0, tbl_tables = 0;
   void* d_table = nullptr;
+  // digit table (vdf_bases_precompute_digits, msm_direct.hip): every multiple d * 2^(c j) of the generators in up to 4
+  // index ranges; range r holds slots [dg_slot0[r], dg_slot0[r] + dg_count[r])
+  int dg_c = 0, dg_ranges = 0;
+  size_t dg_begin[4] = {0, 0, 0, 0}, dg_count[4] = {0, 0, 0, 0}, dg_slot0[4] = {0, 0, 0, 0};
+  void* d_digits = nullptr;
 };
 
 struct vdf_shape {
@@ -150,6 +155,13 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
 size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
+// msm_direct.hip: the digit table of generators [first, first + nslots) into slots [slot0, ...) of d_digits, and the
+// direct sum over it (groups x 96 B Jacobian to d_out; ws: direct_ws_bytes)
+int direct_windows(int c);
+Status digits_build(int curve, const void* d_pts, size_t first, size_t nslots, size_t slot0, int c, void* d_digits, hipStream_t stream);
+size_t direct_ws_bytes(int groups, const size_t* n, int c, int num_cus);
+Status msm_direct_run(int curve, int groups, const size_t* n, const size_t* slot0, const void* const* d_scalars, bool is_mont,
+                      int c, int num_cus, const void* d_digits, void* ws, void* d_out, hipStream_t stream);
 Status bases_generate_label(int curve, const uint8_t* label, size_t len, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_validate(int curve, const void* d_pts, size_t n, uint32_t* d_flags, hipStream_t stream);   // d_flags: 2 words

@@ -75,6 +75,18 @@ class Bases:
         """Window of the fixed-base table (0 without one)."""
         return lib.vdf_bases_window(self.handle)
 
+    def precompute_digits(self, ranges, window_bits: int = 0) -> None:
+        """Digit table over the generator ranges [(begin, count), ...] (at most 4): MSMs inside them of up to 2^17 scalars
+        become a plain sum of gathered multiples (vdf_hip.h vdf_bases_precompute_digits).  [] drops the table."""
+        k = len(ranges)
+        b = (C.c_size_t * max(k, 1))(*[int(r[0]) for r in ranges])
+        n = (C.c_size_t * max(k, 1))(*[int(r[1]) for r in ranges])
+        self.ctx._check(lib.vdf_bases_precompute_digits(self.ctx.handle, self.handle, window_bits, k, b, n))
+
+    @property
+    def digit_window(self) -> int:
+        return lib.vdf_bases_digit_window(self.handle)
+
     def download(self, offset: int = 0, n: Optional[int] = None) -> np.ndarray:
         n = len(self) - offset if n is None else n
         out = np.zeros((n, 8), dtype="<u8")
