@@ -1,0 +1,6 @@
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/synth; mkdir -p $OUT
+cd $R && g++ -O3 -std=c++17 -I vdf_amd/csrc/host -I include -I vdf_amd/csrc tools/scratch/mulbench.cpp vdf_amd/csrc/host/host_math.cpp -o /tmp/mulbench && /tmp/mulbench
+VDF_NOVA_SYNTH_TRACE=1 python tools/gpu_prove_time.py 16 12 > $OUT/prove_trace.log 2>&1 || { tail -n 20 $OUT/prove_trace.log; exit 1; }
+grep "synth side" $OUT/prove_trace.log | tail -n 6; tail -n 2 $OUT/prove_trace.log
+cat /sys/devices/system/cpu/cpu0/topology/thread_siblings_list /sys/devices/system/cpu/cpu1/topology/thread_siblings_list
+cat /proc/self/status | grep Cpus_allowed_list

@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <x86intrin.h>
 #include <vector>
 #include "../../../include/vdf_hip.h"
 
@@ -45,25 +46,39 @@ struct Fe {
 };
 static_assert(sizeof(Fe) == sizeof(vdf_fe), "layout");
 
+// Branch-free: whether a sum wraps past m is a coin flip for random operands, and the linear layers of the hash are
+// hundreds of additions per permutation -- a mispredicted branch each would cost more than the multiplications.
 inline Fe add(const Fe& a, const Fe& b, const Field& F) {
+  unsigned long long r0, r1, r2, r3, t0, t1, t2, t3;
+  unsigned char c = _addcarry_u64(0, a.l[0], b.l[0], &r0);
+  c = _addcarry_u64(c, a.l[1], b.l[1], &r1);
+  c = _addcarry_u64(c, a.l[2], b.l[2], &r2);
+  c = _addcarry_u64(c, a.l[3], b.l[3], &r3);                     // operands below 2^255: no carry out
+  unsigned char br = _subborrow_u64(0, r0, F.m[0], &t0);
+  br = _subborrow_u64(br, r1, F.m[1], &t1);
+  br = _subborrow_u64(br, r2, F.m[2], &t2);
+  br = _subborrow_u64(br, r3, F.m[3], &t3);
+  const uint64_t keep = 0 - (uint64_t)(br & (unsigned char)(c ^ 1));    // all ones: the sum was below m already
   Fe r;
-  u128 c = 0;
-  for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-  if (geq(r.l, F.m)) sub4(r.l, F.m);
+  r.l[0] = (r0 & keep) | (t0 & ~keep); r.l[1] = (r1 & keep) | (t1 & ~keep);
+  r.l[2] = (r2 & keep) | (t2 & ~keep); r.l[3] = (r3 & keep) | (t3 & ~keep);
   return r;
 }
 inline Fe sub(const Fe& a, const Fe& b, const Field& F) {
-  Fe r = a;
-  u128 br = 0;
-  for (int i = 0; i < 4; ++i) {
-    u128 d = (u128)r.l[i] - b.l[i] - (uint64_t)br;
-    r.l[i] = (uint64_t)d;
-    br = (d >> 64) & 1;
-  }
-  if (br) {
-    u128 c = 0;
-    for (int i = 0; i < 4; ++i) { c += (u128)r.l[i] + F.m[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-  }
+  unsigned long long r0, r1, r2, r3;
+  unsigned char br = _subborrow_u64(0, a.l[0], b.l[0], &r0);
+  br = _subborrow_u64(br, a.l[1], b.l[1], &r1);
+  br = _subborrow_u64(br, a.l[2], b.l[2], &r2);
+  br = _subborrow_u64(br, a.l[3], b.l[3], &r3);
+  const uint64_t fix = 0 - (uint64_t)br;                          // all ones: add m back
+  Fe r;
+  unsigned long long o0, o1, o2, o3;
+  unsigned char c = _addcarry_u64(0, r0, F.m[0] & fix, &o0);
+  c = _addcarry_u64(c, r1, F.m[1] & fix, &o1);
+  c = _addcarry_u64(c, r2, F.m[2] & fix, &o2);
+  c = _addcarry_u64(c, r3, F.m[3] & fix, &o3);
+  (void)c;
+  r.l[0] = o0; r.l[1] = o1; r.l[2] = o2; r.l[3] = o3;
   return r;
 }
 inline Fe neg(const Fe& a, const Field& F) {

@@ -587,7 +587,9 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
 int vdf_nova_prove_step(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_fe z0[3]) {
   if (pp && pp->circuit_kind == VDF_CIRCUIT_CUSTOM) return fail(VDF_ERR_BAD_ARG, "these parameters are for a custom step circuit: vdf_nova_prove_step_custom");
   vdf_proof* fresh = nullptr;                     // a proof object this call created (the `None` case)
-  const int rc = prove_step_impl(pp, proof, circuits, k, nullptr, z0, &fresh);
+  int rc;
+  try { rc = prove_step_impl(pp, proof, circuits, k, nullptr, z0, &fresh); }
+  catch (const std::exception& ex) { rc = fail(VDF_ERR_DEVICE, ex.what()); }
   if (rc != VDF_OK && fresh) vdf_nova_proof_free(fresh);      // never leak a half-built proof
   return rc;
 }
@@ -597,7 +599,9 @@ int vdf_nova_prove_step_custom(vdf_pp* pp, vdf_proof** proof, const vdf_step_cir
   if (pp->circuit_kind != VDF_CIRCUIT_CUSTOM || primary->arity != pp->arity)
     return fail(VDF_ERR_BAD_ARG, "the circuit does not belong to these parameters");
   vdf_proof* fresh = nullptr;
-  const int rc = prove_step_impl(pp, proof, nullptr, 0, primary, z0, &fresh);
+  int rc;
+  try { rc = prove_step_impl(pp, proof, nullptr, 0, primary, z0, &fresh); }
+  catch (const std::exception& ex) { rc = fail(VDF_ERR_DEVICE, ex.what()); }
   if (rc != VDF_OK && fresh) vdf_nova_proof_free(fresh);
   return rc;
 }
@@ -742,6 +746,25 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   uint64_t r2[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
   const Fe i_fe1 = from_u64((uint64_t)p->i, F1), i_fe2 = from_u64((uint64_t)p->i, F2);
 
+  // the primary circuit's inputs but for the two commitments of (a); its step circuit
+  AugInputs in1;
+  in1.params = pp->params[PRIMARY];
+  in1.i = i_fe1;
+  in1.z0 = p->z0[PRIMARY];
+  in1.zi = p->zi[PRIMARY];
+  if (first) {
+    const AugInputs b = blank_inputs(arity);
+    in1.U = b.U; in1.u_W = b.u_W; memcpy(in1.u_X, b.u_X, sizeof(in1.u_X)); in1.T = b.T;
+  } else {
+    in1.U = to_relaxed(p->r[SECONDARY].inst, F2);
+    memset(&in1.u_W, 0, sizeof(Aff)); memset(&in1.T, 0, sizeof(Aff));
+    for (int j = 0; j < 2; ++j) fe_to_int(p->l2.X[j], F2, in1.u_X[j]);
+  }
+  const std::unique_ptr<StepCircuit> c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
+  AugInputs in2;
+  const TrivialTestCircuit c2;
+  AugEarlyPtr early1(nullptr, aug_early_free), early2(nullptr, aug_early_free);
+  auto make_early1 = [&] { return synthesize_augmented_early(PRIMARY, in1, *c1); };
   // ---- (a) NIFS on the secondary side: cross term of (running, l2), commitments of l2's witness and of T ----------
   if (!first) {
     SideState& s2 = p->r[SECONDARY];
@@ -762,6 +785,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       int rc = early_rows();
       if (rc != VDF_OK) return rc;
     }
+    early1 = make_early1();                         // the host's share of the wait: what the circuit can do without T
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     if (!p->l2_committed) { p->l2.comm_W = jac_aff(hb[0], *S2.Fb); p->l2_committed = true; }
     comm_T2 = jac_aff(hb[1], *S2.Fb);
@@ -770,24 +794,12 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // ---- (b) the primary augmented circuit -----------------------------------------------------------------------
   Inst l1;
   {
-    AugInputs in;
-    in.params = pp->params[PRIMARY];
-    in.i = i_fe1;
-    in.z0 = p->z0[PRIMARY];
-    in.zi = p->zi[PRIMARY];
-    if (first) {
-      const AugInputs b = blank_inputs(arity);
-      in.U = b.U; in.u_W = b.u_W; memcpy(in.u_X, b.u_X, sizeof(in.u_X)); in.T = b.T;
-    } else {
-      in.U = to_relaxed(p->r[SECONDARY].inst, F2);
-      in.u_W = p->l2.comm_W;
-      for (int j = 0; j < 2; ++j) fe_to_int(p->l2.X[j], F2, in.u_X[j]);
-      in.T = comm_T2;
-    }
+    AugInputs& in = in1;
+    if (!first) { in.u_W = p->l2.comm_W; in.T = comm_T2; }
     CS cs(S1.field, false);
-    const std::unique_ptr<StepCircuit> c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
     Fe unew[9];
-    const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2);
+    const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2, early1.get());
+    early1.reset();
     if (custom && static_cast<const CustomStepCircuit*>(c1.get())->rc != 0) return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed");
     if (cs.dev_len != seg_n || (seg_n && cs.dev_begin != seg_b)) return fail(VDF_ERR_DEVICE, "device segment moved");
     t2 = now_ms();
@@ -840,6 +852,16 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     }
     HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
     t3 = now_ms();
+    // the host's share of this wait: the secondary circuit's inputs but for comm_W and comm_T, and what it can do with them
+    in2.params = pp->params[SECONDARY];
+    in2.i = i_fe2;
+    in2.z0 = p->z0[SECONDARY];
+    in2.zi = p->zi[SECONDARY];
+    if (first) { const AugInputs b = blank_inputs(1); in2.U = b.U; }
+    else in2.U = to_relaxed(p->r[PRIMARY].inst, F1);
+    memset(&in2.u_W, 0, sizeof(Aff)); memset(&in2.T, 0, sizeof(Aff));
+    for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in2.u_X[j]);
+    early2 = synthesize_augmented_early(SECONDARY, in2, c2);
     if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, t_ahead ? MARK_T : MARK_W));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     const Field& Fb = *S1.Fb;
@@ -863,20 +885,13 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   }
   // ---- (d) the secondary augmented circuit -----------------------------------------------------------------------
   {
-    AugInputs in;
-    in.params = pp->params[SECONDARY];
-    in.i = i_fe2;
-    in.z0 = p->z0[SECONDARY];
-    in.zi = p->zi[SECONDARY];
-    if (first) { const AugInputs b = blank_inputs(1); in.U = b.U; }
-    else in.U = to_relaxed(p->r[PRIMARY].inst, F1);
+    AugInputs& in = in2;
     in.u_W = l1.comm_W;
-    for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in.u_X[j]);
     in.T = comm_T1;
     CS cs(S2.field, false);
-    const TrivialTestCircuit c2;
     Fe unew[9];
-    const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1);
+    const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
+    early2.reset();
     t5 = now_ms();
     if (!first) {
       SideState& s1 = p->r[PRIMARY];

@@ -24,9 +24,17 @@ struct Num { Fe v; LC lc; };
 
 struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
 
+// Witness vectors are ~0.5 MB: taken from a small pool and given back (a fresh allocation of that size is an mmap and a
+// page fault per 4 KB touched, every step -- a third of a synthesis).
+std::vector<Fe> witness_buffer_take();
+void witness_buffer_give(std::vector<Fe>&& v);
+
 class CS {
  public:
   CS(int field_id, bool shape_mode);
+  ~CS();
+  CS(const CS&) = delete;
+  CS& operator=(const CS&) = delete;
   const int field_id;
   const Field& F;
   const bool shape;                      // true: record constraints; false: witness only
@@ -106,6 +114,8 @@ struct StepCircuit {
   // allocates the circuit's variables and constraints over z_in, returns z_out (values valid in witness mode)
   virtual std::vector<Num> synthesize(CS& cs, const std::vector<Num>& z) const = 0;
   virtual void output(const Fe* z, Fe* out) const = 0;
+  // true: output() tells z_out without a synthesis (the augmented circuit then starts hashing it before the folds are done)
+  virtual bool output_known() const { return false; }
 };
 
 struct MinRootState { Fe x, y, i; };
@@ -120,6 +130,7 @@ struct InverseMinRootCircuit : StepCircuit {
   size_t arity() const override { return 3; }
   std::vector<Num> synthesize(CS& cs, const std::vector<Num>& z) const override;
   void output(const Fe* z, Fe* out) const override;
+  bool output_known() const override { return !blank; }
   size_t vars_per_round() const { return bound ? 3 : 4; }
 };
 // nova-snark's TrivialTestCircuit (src/nova/proof.rs:258-260): arity 1, z_out = z_in
@@ -127,6 +138,7 @@ struct TrivialTestCircuit : StepCircuit {
   size_t arity() const override { return 1; }
   std::vector<Num> synthesize(CS&, const std::vector<Num>& z) const override { return z; }
   void output(const Fe* z, Fe* out) const override { out[0] = z[0]; }
+  bool output_known() const override { return true; }
 };
 
 // ---- instances and the augmented circuit ---------------------------------------------------------------------------
@@ -155,8 +167,17 @@ void hash_challenge(int field_id, const Fe& params, const RelaxedInst& U, const 
 // side 0 = primary (circuit over Fq, folds Vesta instances), side 1 = secondary; returns z_{i+1}
 // unew (optional): the nine elements of the running instance the circuit hands on (the folded one, or the base case's);
 // r (optional): the fold challenge it derived, a 128-bit integer
+// Witness mode, in two halves.  Everything that does not depend on the two commitments a step is waiting for (u.comm_W
+// and T) -- the state hash, the challenge hash up to the running instance, the bits of u.X, the output hash up to z_out
+// -- can be made while the device still computes them: synthesize_augmented_early takes the inputs with u_W and T unset
+// and returns what it prepared; synthesize_augmented(..., early) then only finishes.  Without `early` the same work
+// happens inside the call.  The result is the same witness either way.
+struct AugEarly;
+void aug_early_free(AugEarly* e);
+typedef std::unique_ptr<AugEarly, void (*)(AugEarly*)> AugEarlyPtr;
+AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const StepCircuit& step);
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew = nullptr,
-                                     uint64_t* r = nullptr);
+                                     uint64_t* r = nullptr, AugEarly* early = nullptr);
 // of the calling thread's last synthesize_augmented in witness mode: slope inverses queued by the pre-pass, and how many of
 // them were wrong or left over (0 unless the inputs were malformed)
 void last_synthesis_stats(uint64_t* queued, uint64_t* misses);
