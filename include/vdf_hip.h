@@ -285,6 +285,9 @@ int  vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other);
  * prover that looks one step ahead waits for this step's commitment without waiting for the next step's. */
 int  vdf_ctx_mark(vdf_ctx* ctx, int slot);
 int  vdf_ctx_sync_mark(vdf_ctx* ctx, int slot);
+/* ... and vdf_ctx_wait_mark makes work enqueued on `ctx` from now on start only after `other`'s mark `slot` has been
+ * reached -- not after whatever `other` was given since (vdf_ctx_wait would wait for that too). */
+int  vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot);
 
 /* ---- compression SNARK building blocks ------------------------------------------------------ */
 /* The passes behind `NovaVDFProof::compress` and the verification of a compressed proof

@@ -354,6 +354,26 @@ def test_ctx_marks(ctx):
         ctx.set_async(False)
         ctx.fe_mul(o.FIELD_FQ, a, b, n, exp1)
         assert np.array_equal(got1, exp1)
+        # a second context waits for a mark of the first, not for the long work behind it
+        import vdf_amd
+        other = vdf_amd.Context(0)
+        other.set_async(True)
+        ctx.set_async(True)
+        d3, d4 = _dev(np.zeros_like(a)), _dev(np.zeros_like(a))
+        ctx.fe_mul(o.FIELD_FQ, da, db, n, d3)
+        ctx.mark(1)
+        ctx.fe_mul_chain(o.FIELD_FQ, da, n, 2000, d2)
+        other.wait_mark(ctx, 1)
+        other.fe_mul(o.FIELD_FQ, d3, db, n, d4)        # reads what was written before the mark
+        other.sync()
+        ctx.sync()
+        ctx.set_async(False)
+        exp4 = np.zeros_like(a)
+        ctx.fe_mul(o.FIELD_FQ, exp1, b, n, exp4)
+        assert np.array_equal(_host(d4), exp4)
+        with pytest.raises(Exception):
+            other.wait_mark(ctx, 3)                    # never set
+        other.close() if hasattr(other, "close") else None
     finally:
         ctx.set_async(was)
 

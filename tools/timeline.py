@@ -7,7 +7,8 @@ anchor = sys.argv[2] if len(sys.argv) > 2 else "k_nifs_cross"
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows = list(db.execute("select name,start,end,stream_id from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if anchor in r[0]]
-i0, i1 = idx[-back], idx[-back + 2]      # two cross terms per step (secondary side, primary side)
+span = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+i0, i1 = idx[-back], idx[-back + span]    # cross terms per step: secondary side, primary side (+ the early rows of T when they run apart)
 t0 = rows[i0][1]
 for r in rows[i0:i1 + 1]:
     nm = r[0].split('(')[0].replace('void vdf::', '').replace('vdf::', '')

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "vdf_shim_set_cache": (_i, [_i]),
     "vdf_ctx_mark": (_i, [_vp, _i]),
     "vdf_ctx_sync_mark": (_i, [_vp, _i]),
+    "vdf_ctx_wait_mark": (_i, [_vp, _vp, _i]),
     "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),

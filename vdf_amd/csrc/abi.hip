@@ -1155,6 +1155,18 @@ int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
   });
 }
 
+int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
+  if (!other) return VDF_ERR_BAD_ARG;
+  return guarded(ctx, [&]() -> Status {
+    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
+    if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
+    if (other == ctx) return Status{};
+    VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, other->marks[slot], 0));
+    return Status{};
+  });
+}
+
 int vdf_ctx_sync_mark(vdf_ctx* ctx, int slot) {
   return guarded(ctx, [&]() -> Status {
     if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};

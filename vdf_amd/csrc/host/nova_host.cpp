@@ -229,6 +229,11 @@ int alloc_proof_buffers(vdf_proof* p) {
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
   }
+  {
+    const int dev = vdf_ctx_device(ctx);
+    if (vdf_ctx_create(&dev, 1, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
+    HIPCALL(p->ctx3, vdf_ctx_set_async(p->ctx3, 1));
+  }
   HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 5) * sizeof(vdf_jac), (void**)&p->h_pts));
   HIPCALL(ctx, vdf_host_alloc(ctx, pp->arity * 32, (void**)&p->h_zin));
   memset(&p->last, 0, sizeof(p->last));
@@ -432,7 +437,7 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
       if (r == h.num_cons || !early[r]) { if (r - run_b > best_n) { best_b = run_b; best_n = r - run_b; } run_b = r + 1; }
     const char* ov = std::getenv("VDF_NOVA_T_AHEAD");                 // tuning: 0 = one cross term, one commitment of T per step
     if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0')) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
-    pp->ahead_mode = (ov && ov[0] == '2') ? 2 : 1;
+    pp->ahead_mode = (ov && ov[0] == '1') ? 1 : 2;
   }
   for (int s = 0; s < 2; ++s) {
     Side& sd = pp->s[s];
@@ -728,16 +733,18 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // synthesis of the primary circuit, and leave ~10^4 rows instead of 2 x 10^5 on the critical path.
   const bool t_ahead = !first && !custom && pp->ahead_rows != 0;
   const size_t ta_b = pp->ahead_row, ta_n = pp->ahead_rows, ta_e = ta_b + ta_n;
+  vdf_ctx* ct = p->ctx3;
   auto early_rows = [&]() -> int {
     SideState& s1 = p->r[PRIMARY];
+    HIPCALL(ct, vdf_ctx_wait_mark(ct, cq, MARK_Z));                 // the rounds are in place (written a step ago, normally)
     // z_in = z_i past the base step (the circuit's selection); the same values arrive again with the host's variables
     memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);            // pinned: the copy reads it when it runs
-    HIPCALL(cq, vdf_dev_memcpy(cq, (char*)d_z2 + (seg_b - arity) * 32, p->h_zin, arity * 32));
-    HIPCALL(cq, vdf_nifs_cross_term_rows(cq, S1.shape, ta_b, ta_n, VDF_ROWS_INSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
+    HIPCALL(ct, vdf_dev_memcpy(ct, (char*)d_z2 + (seg_b - arity) * 32, p->h_zin, arity * 32));
+    HIPCALL(ct, vdf_nifs_cross_term_rows(ct, S1.shape, ta_b, ta_n, VDF_ROWS_INSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
                                          (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
                                          (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
-    HIPCALL(cq, vdf_msm(cq, S1.gens, ta_b, (const vdf_fe*)((const char*)s1.d_T + ta_b * 32), ta_n, 1, &hb[4]));
-    HIPCALL(cq, vdf_ctx_mark(cq, MARK_T));
+    HIPCALL(ct, vdf_msm(ct, S1.gens, ta_b, (const vdf_fe*)((const char*)s1.d_T + ta_b * 32), ta_n, 1, &hb[4]));
+    HIPCALL(ct, vdf_ctx_mark(ct, MARK_T));
     return VDF_OK;
   };
   double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
@@ -778,10 +785,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const vdf_fe* sc[2] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T};
       HIPCALL(ctx, vdf_msm_batch(ctx, S2.gens, 2, off, sc, len, 1, hb));
     }
-    // launched while the host waits for this side's commitments, run when those are done: side by side the two
-    // bucket accumulations would share the SIMDs and this side, which the host is waiting for, would take twice as long
+    // launched while the host waits for this side's commitments, on a queue of their own: their 0.6 ms must be over when
+    // the primary side's own commitments are (0.65 ms into the step), and this side's direct sum, one prioritised
+    // wavefront per SIMD for 0.1 ms, loses little to a bucket accumulation beside it
     if (t_ahead) {
-      if (pp->ahead_mode != 2) HIPCALL(cq, vdf_ctx_wait(cq, ctx));
+      if (pp->ahead_mode == 1) HIPCALL(ct, vdf_ctx_wait(ct, ctx));
       int rc = early_rows();
       if (rc != VDF_OK) return rc;
     }
@@ -862,7 +870,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     memset(&in2.u_W, 0, sizeof(Aff)); memset(&in2.T, 0, sizeof(Aff));
     for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in2.u_X[j]);
     early2 = synthesize_augmented_early(SECONDARY, in2, c2);
-    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, t_ahead ? MARK_T : MARK_W));
+    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+    if (t_ahead) HIPCALL(ct, vdf_ctx_sync_mark(ct, MARK_T));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     const Field& Fb = *S1.Fb;
     // partial commitments leave the device as Jacobian points: summed as they are, one inversion for W and T together
@@ -952,6 +961,7 @@ void vdf_nova_proof_free(vdf_proof* p) {
   vdf_ctx* ctx = p->pp ? p->pp->ctx : nullptr;
   if (ctx) {
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_sync(q);                   // lookaheads may still be in flight
+    if (p->ctx3) vdf_ctx_sync(p->ctx3);
     vdf_ctx_sync(ctx);
     for (SideState& st : p->r) {
       void* bufs[] = {st.d_z, st.d_E, st.d_T, st.d_abc[0], st.d_abc[1], st.d_abc[2], st.d_abc2[0], st.d_abc2[1], st.d_abc2[2]};
@@ -961,6 +971,7 @@ void vdf_nova_proof_free(vdf_proof* p) {
     for (void* b : p->d_z2s) if (b) vdf_dev_free(ctx, b);
     for (void* b : p->d_traces) if (b) vdf_dev_free(ctx, b);
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_destroy(q);
+    if (p->ctx3) vdf_ctx_destroy(p->ctx3);
     if (p->h_pts) vdf_host_free(ctx, p->h_pts);
     if (p->h_zin) vdf_host_free(ctx, p->h_zin);
     for (Fe* h : p->h_stage) if (h) vdf_host_free(ctx, h);

@@ -78,7 +78,7 @@ struct vdf_pp {
   // constraints of the primary shape that read nothing of a fresh witness but that segment (and the constant): their
   // share of a step's cross term and of its commitment is made ahead of the rest, [ahead_row, ahead_row + ahead_rows)
   size_t ahead_row = 0, ahead_rows = 0;
-  int ahead_mode = 1;            // when they run: 1 = once the secondary side's NIFS has left the device, 2 = beside it (tuning)
+  int ahead_mode = 2;            // when they run: 2 = from the start of the step, beside the secondary side's NIFS; 1 = after it (tuning)
   size_t arity = 3;                        // of the primary step circuit (z0, zi)
 };
 
@@ -113,6 +113,8 @@ struct vdf_proof {
   // fresh primary z: ring of slots, the MinRoot segment of a later step is filled (and committed) ahead of time on ctx2
   static constexpr int DEPTH = 1, RING = DEPTH + 2;
   vdf_ctx* ctx2[DEPTH] = {};
+  vdf_ctx* ctx3 = nullptr;       // the early rows of a step's cross term and their commitment: a queue of their own, so that
+                                 // they start with the step and not behind the previous lookahead's commitment
   void* d_z2s[RING] = {};
   void* d_traces[DEPTH] = {};
   int slot = 0;

@@ -336,6 +336,21 @@ Num pack(const CS& cs, const Num* bits, size_t n) {
   return out;
 }
 
+// 1 / k in the field for k = 0 .. 128 (0 for 0), made once per field with one batched inversion
+static const Fe& small_inverse(int field_id, uint64_t k) {
+  static const std::vector<Fe>* tables[2] = {nullptr, nullptr};
+  static std::once_flag once[2];
+  const int slot = field_id == VDF_FIELD_FP ? 0 : 1;
+  std::call_once(once[slot], [&] {
+    const Field& F = field(field_id);
+    std::vector<Fe>* t = new std::vector<Fe>(129);
+    for (uint64_t v = 0; v <= 128; ++v) (*t)[v] = from_u64(v, F);
+    batch_inverse(t->data(), t->size(), F);
+    tables[slot] = t;
+  });
+  return (*tables[slot])[k];
+}
+
 std::vector<Num> strict_bits(CS& cs, const Num& a) {
   const Field& F = cs.F;
   uint64_t av[4];
@@ -349,7 +364,16 @@ std::vector<Num> strict_bits(CS& cs, const Num& a) {
     mid.v = from_u64(cnt, F);
     if (cs.shape) for (int k = 126; k < 254; ++k) mid.lc.push_back(Term{bits[k].lc[0].key, one(F)});
   }
-  const Num mz = is_zero(cs, mid);
+  Num mz;
+  if (cs.shape) mz = is_zero(cs, mid);
+  else {
+    // is_zero's two variables; the inverse of a count of at most 128 comes from a table, not from a field inversion
+    uint64_t cnt = 0;
+    for (int k = 126; k < 254; ++k) cnt += bits[k].v.is_zero() ? 0 : 1;
+    mz = cs.alloc(cnt ? vdfhost::zero() : one(F));
+    cs.alloc(small_inverse(cs.field_id, cnt));
+    cs.rows += 2;
+  }
   const Num low = pack(cs, bits.data(), 126);
   // c = m - 2^254; v = low + (2^126 - c) < 2^127, bit 126 clear iff low < c
   uint64_t k126[4] = {0, 1ull << 62, 0, 0}, c[4] = {F.m[0], F.m[1], F.m[2], F.m[3] - (1ull << 62)};
@@ -921,6 +945,8 @@ struct AugEarly {
 void aug_early_free(AugEarly* e) { delete e; }
 
 AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const StepCircuit& step) {
+  static const bool trace = [] { const char* e = std::getenv("VDF_NOVA_SYNTH_TRACE"); return e && e[0] == '1'; }();
+  const auto T0 = std::chrono::steady_clock::now();
   AugEarlyPtr e(new AugEarly(), aug_early_free);
   const int fid = side_field(side);
   const Field& F = field(fid);
@@ -969,6 +995,8 @@ AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const Step
     for (size_t k = 0; k < a; ++k) e->out_sp.absorb(*e->outh, e->z_out[k]);
     e->have_out = true;
   }
+  if (trace) fprintf(stderr, "synth side %d: early half %.0f us on the calling thread\n", side,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count());
   return e;
 }
 

@@ -184,10 +184,12 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
     const uint32_t mask = (1u << c) - 1u, mid = 1u << (c - 1);
     const char* Dg = D + ((((size_t)a.slot0[g]) * W) << (c - 1)) * 64;
     const uint32_t* sc = a.scalars[g];
+    // Three entries in flight: the scalar of entry i + 2 is being read while the table point of entry i + 1 (whose address
+    // needed ITS scalar) is being gathered and entry i is added -- two dependent memory round trips behind one addition.
+    auto scalar_of = [&](uint32_t e) -> Fe<SP> { return fe_load<SP>(sc + (size_t)(e % n) * 8); };
     // entry -> signed digit and the address of its table point (nullptr: digit 0)
-    auto locate = [&](uint32_t e, bool& neg) -> const char* {
+    auto locate = [&](uint32_t e, Fe<SP> k, bool& neg) -> const char* {
       const uint32_t j = e / n, s = e - j * n;
-      Fe<SP> k = fe_load<SP>(sc + (size_t)s * 8);
       if (is_mont) k = fe_from_mont(k);
       uint64_t carry = 0;
 #pragma unroll
@@ -206,21 +208,29 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
       const uint32_t mag = (uint32_t)(neg ? -d : d);
       return Dg + (((((size_t)s * W) + j) << (c - 1)) + (mag - 1)) * 64;
     };
+    const uint32_t count = x < E ? (E - x + L - 1) / L : 0u;       // entries of this lane (at most per_lane)
     uint32_t e = x;
     bool neg = false, negn = false;
-    const char* ptr = e < E ? locate(e, neg) : nullptr;
+    Fe<SP> k1 = fe_zero<SP>();
+    const char* ptr = nullptr;
     Affine<P> pt;
-    if (ptr) pt = affine_load<P>(ptr);
-    for (uint32_t i = 0; i < a.per_lane && e < E; ++i) {
-      const uint32_t en = e + L;
-      const char* ptrn = (i + 1 < a.per_lane && en < E) ? locate(en, negn) : nullptr;
+    if (count) {
+      const Fe<SP> k0 = scalar_of(e);
+      if (count > 1) k1 = scalar_of(e + L);
+      ptr = locate(e, k0, neg);
+      if (ptr) pt = affine_load<P>(ptr);
+    }
+    for (uint32_t i = 0; i < count; ++i) {
+      Fe<SP> k2 = fe_zero<SP>();
+      if (i + 2 < count) k2 = scalar_of(e + 2 * L);
+      const char* ptrn = (i + 1 < count) ? locate(e + L, k1, negn) : nullptr;
       Affine<P> ptn;
-      if (ptrn) ptn = affine_load<P>(ptrn);                        // the next gather is in flight during this addition
+      if (ptrn) ptn = affine_load<P>(ptrn);
       if (ptr) {
         if (neg) pt.y = fe_neg(pt.y);
         dmadd<P>(acc, have, pt);
       }
-      e = en; ptr = ptrn; neg = negn; pt = ptn;
+      e += L; ptr = ptrn; neg = negn; pt = ptn; k1 = k2;
     }
   }
   xyzz_store<P>(pts + (size_t)threadIdx.x * 128, have ? acc : xyzz_identity<P>());

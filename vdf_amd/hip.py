@@ -216,6 +216,11 @@ class Context:
         """Waits for everything enqueued before mark `slot`; later work keeps running."""
         self._check(lib.vdf_ctx_sync_mark(self.handle, slot))
 
+    def wait_mark(self, other: "Context", slot: int = 0) -> None:
+        """Work enqueued on this context from now on starts after `other` has reached its mark `slot` (not after what
+        `other` was given since)."""
+        self._check(lib.vdf_ctx_wait_mark(self.handle, other.handle, slot))
+
     def set_msm_window(self, c: int) -> None:
         self._check(lib.vdf_ctx_set_msm_window(self.handle, c))
 
