@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A prove_step keeps three queues busy at once (the step's chain, the next step's rounds, the early rows of T) beside the
+# two of the MSM leg and torch's own: with the runtime's default of 4 hardware queues they share, and the chain's
+# kernels then wait behind another queue's 0.25 ms bucket accumulation (measured: 1.5 ms per step instead of 1.05).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -358,6 +362,8 @@ def prove_step_leg(ctx, log2t, nsteps, chains=2, with_compress=True, seed_offset
     for k in range(first_timed, nsteps):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
         stages.append(proof.last_step_ms())
+        if os.environ.get("VDF_BENCH_TRACE"):
+            print("step %d" % k, {a_: round(b_, 3) for a_, b_ in stages[-1].items()}, file=sys.stderr)
     proof.instance(INST_FRESH_SECONDARY)     # the last secondary commitment (it rides in the NEXT step's batch otherwise)
     ctx.sync()
     steady_total = time.perf_counter() - a

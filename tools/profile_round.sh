@@ -25,7 +25,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format c
 cd $R
 python tools/parse_pmc.py $OUT/fetch $OUT/write $OUT/traffic_$TAG.json k_accumulate 15728640 > $OUT/traffic.log 2>&1
 python tools/make_valu_model.py $OUT/op_rates.txt $OUT/clock_probe.txt $OUT/valu 15728640 $OUT/valu_model_$TAG.json > $OUT/valu_model.log 2>&1
-python tools/timeline.py $(ls $OUT/prove/*.db | head -1) k_nifs_cross 6 > $OUT/prove_step_timeline.txt 2>&1
+python tools/timeline.py $(ls $OUT/prove/*.db | head -1) k_nifs_cross 7 3 > $OUT/prove_step_timeline.txt 2>&1
 python tools/pmc_sum.py $OUT/prove_valu > $OUT/prove_step_valu_per_kernel.txt 2>&1
 timeout -k 10 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err || exit 1
 tail -c 800 $OUT/bench_line.json

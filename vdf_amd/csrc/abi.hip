@@ -358,6 +358,9 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
     g_create_err = "vdf_ctx_create: exactly one device per context (one process per GPU); there is no CPU back-end";
     return n_devices == 0 ? VDF_ERR_NO_DEVICE : VDF_ERR_BAD_ARG;
   }
+  // a prover keeps several queues busy at once (vdf_nova.h): the runtime's default of 4 hardware queues makes streams share
+  // one, and kernels then wait behind another stream's; honoured only when this is the process's first HIP call
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
