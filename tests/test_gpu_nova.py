@@ -202,6 +202,46 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
     assert a.verify(pp, n, z0, [initial.x, initial.y, initial.i])
 
 
+def test_two_chains_proven_concurrently(ctx):
+    """Two host threads, two contexts, two chains at once (the bench's aggregate leg): the helper threads of the witness
+    synthesis are taken by one prover at a time and the other synthesises inline -- both must give the proofs they give
+    when run alone."""
+    import threading
+    import vdf_amd
+    t, n = 64, 5
+    ctxs = [ctx, vdf_amd.Context(0)]
+    work = [make(c, t, n, seed=21 + k) for k, c in enumerate(ctxs)]
+    alone = [NovaVDFProof.prove_recursively(w[0], w[2], t, w[1]) for w in work]
+    both, errs = [None, None], []
+
+    def run(k):
+        try:
+            pp, z0, circuits, _, _ = work[k]
+            pr = None
+            for j in range(n):
+                pr = NovaVDFProof.prove_step(pp, pr, circuits, j, z0)
+            both[k] = pr
+        except Exception as e:                                  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for k in range(2):
+        pp, z0, _, initial, _ = work[k]
+        assert both[k].verify(pp, n, z0, [initial.x, initial.y, initial.i])
+        for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+            ia, ib = alone[k].instance(which), both[k].instance(which)
+            for key in ia:
+                assert np.array_equal(ia[key], ib[key]), (k, which, key)
+    for k in range(2):
+        alone[k].free(); both[k].free(); work[k][0].free()
+    ctxs[1].close()
+
+
 def _canon(cref, field, arr):
     out = np.zeros_like(arr)
     cref.lib().ref_fe_from_mont(field, cref.p(np.ascontiguousarray(arr)), arr.shape[0], cref.p(out))

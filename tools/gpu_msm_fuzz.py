@@ -64,6 +64,21 @@ for it in range(iters):
         off = int(rng.integers(0, ntot - ln + 1))
         offs.append(off); lens.append(ln); scs.append(scalars(ln, int(rng.integers(0, 6)), sm))
     single = k == 1 and rng.random() < 0.5
+    # digit table (msm_direct.hip) over 1-3 random ranges of a small generator set, random window: vectors inside the ranges
+    # take the direct sum, the others (and mixed batches) the bucket method
+    digits = None
+    if not BIG and ntot <= 3000 and rng.random() < 0.5:
+        cuts = sorted(set(int(x) for x in rng.integers(0, ntot + 1, size=int(rng.integers(2, 7)))))
+        rngs = [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(0, len(cuts) - 1, 2)][:3]
+        rngs = [r for r in rngs if r[1] > 0]
+        if rngs:
+            digits = (int(rng.integers(4, 12)), rngs)
+            if rng.random() < 0.7:                       # mostly: put every vector inside a range
+                offs, lens, scs = [], [], []
+                for g in range(k):
+                    b, cnt = rngs[int(rng.integers(0, len(rngs)))]
+                    ln = int(rng.integers(1, cnt + 1)); off = b + int(rng.integers(0, cnt - ln + 1))
+                    offs.append(off); lens.append(ln); scs.append(scalars(ln, int(rng.integers(0, 6)), sm))
     if only >= 0 and it != only:
         continue
     if only >= 0 or os.environ.get("FUZZ_VERBOSE"):
@@ -74,7 +89,9 @@ for it in range(iters):
         bases.precompute(c, sets)
         ctx.set_msm_window(0)
     else:
-        ctx.set_msm_window(win)
+        ctx.set_msm_window(0 if digits else win)
+    if digits:
+        bases.precompute_digits(digits[1], digits[0])
     if single:
         got = [jac_to_affine(ctx.msm(bases, scs[0], n=lens[0], offset=offs[0]), curve)]
     else:
@@ -83,7 +100,7 @@ for it in range(iters):
     exp = [cpu_msm(curve, pts[offs[g]:offs[g] + lens[g]], scs[g]) for g in range(k)]
     if got != exp:
         bad += 1
-        print("MISMATCH", dict(it=it, curve=curve, ntot=ntot, c=c, table=table, k=k, offs=offs, lens=lens), flush=True)
+        print("MISMATCH", dict(it=it, curve=curve, ntot=ntot, c=c, table=table, k=k, offs=offs, lens=lens, digits=digits), flush=True)
     bases.free()
     if it % 50 == 49:
         print(f"{it + 1} configurations, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
