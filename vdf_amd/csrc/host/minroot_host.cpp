@@ -144,7 +144,11 @@ int vdf_minroot_inverse_round(int f, const vdf_state* s, vdf_state* out) {
 }
 // The sequential loop itself, compiled twice: baseline x86-64 and a BMI2/ADX (Broadwell and later, Zen) clone chosen
 // by the dynamic loader, with the field arithmetic flattened into it.  ~285 dependent multiplications per round.
+#if defined(__SANITIZE_THREAD__)
+__attribute__((flatten, noinline))               // an ifunc resolver runs before ThreadSanitizer's runtime is up
+#else
 __attribute__((target_clones("default", "arch=broadwell"), flatten, noinline))
+#endif
 void eval_rounds(int f, int mode, St* acc, uint64_t t, vdf_fe* trace_xy) {
   for (uint64_t k = 0; k < t; ++k) {                               // simple_eval, :352-359
     *acc = round_fwd(f, mode, *acc);
