@@ -593,51 +593,53 @@ inline size_t statement_wire(size_t arity) { return STATEMENT_WIRE_FIXED + 32 * 
 extern "C" {
 
 int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
-  if (!p || !pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  *out = nullptr;
-  if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
-  if (p->i == 0) return fail(VDF_ERR_BAD_LENGTH, "nothing to compress");
-  { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
-  vdf_ctx* ctx = pp->ctx;
-  const Side& S1 = pp->s[PRIMARY];
-  const Side& S2 = pp->s[SECONDARY];
-  int was_async = 0;
-  HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
-  HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
-  struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
-  std::unique_ptr<vdf_snark> s(new vdf_snark());
-  s->t = pp->t;
-  memcpy(s->digest, pp->digest, 32);
-  s->r_U1 = p->r[PRIMARY].inst; s->r_U2 = p->r[SECONDARY].inst; s->l_u2 = p->l2;
-  s->zi1 = p->zi[PRIMARY];
-  s->zi2[0] = p->zi[SECONDARY][0];
-  // the last secondary instance is folded into the running one (NIFS, as a prove_step would): into scratch, the proof is
-  // left as it is
-  vdf_proof* q = const_cast<vdf_proof*>(p);
-  SideState& s2 = q->r[SECONDARY];
-  DevBufs bufs(ctx);
-  void *d_fz, *d_fE;
-  { int rc = bufs.zeros(S2.ncols, &d_fz); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
-  { int rc = bufs.zeros(S2.num_cons, &d_fE); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
-  HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
-                                   (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
-                                   (vdf_fe*)s2.d_abc2[2], (vdf_fe*)s2.d_T));
-  vdf_jac jt;
-  HIPCALL(ctx, vdf_msm(ctx, S2.gens, 0, (const vdf_fe*)s2.d_T, S2.num_cons, 1, &jt));
-  s->T2 = jac_to_aff(jt, *S2.Fb);
-  uint64_t r[4];
-  fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
-  const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
-  const Fe rf = int_to_fe(r, *S2.F);
-  HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_z, (const vdf_fe*)&rf, (const vdf_fe*)p->d_l2z, S2.ncols, (vdf_fe*)d_fz));
-  HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_E, (const vdf_fe*)&rf, (const vdf_fe*)s2.d_T, S2.num_cons, (vdf_fe*)d_fE));
-  int rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]);
-  if (rc != VDF_OK) return rc;
-  rc = spartan_prove(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, d_fz, d_fE, &s->sp[1]);
-  if (rc != VDF_OK) return rc;
-  *out = s.release();
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!p || !pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+    if (p->i == 0) return fail(VDF_ERR_BAD_LENGTH, "nothing to compress");
+    { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
+    vdf_ctx* ctx = pp->ctx;
+    const Side& S1 = pp->s[PRIMARY];
+    const Side& S2 = pp->s[SECONDARY];
+    int was_async = 0;
+    HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
+    struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
+    std::unique_ptr<vdf_snark> s(new vdf_snark());
+    s->t = pp->t;
+    memcpy(s->digest, pp->digest, 32);
+    s->r_U1 = p->r[PRIMARY].inst; s->r_U2 = p->r[SECONDARY].inst; s->l_u2 = p->l2;
+    s->zi1 = p->zi[PRIMARY];
+    s->zi2[0] = p->zi[SECONDARY][0];
+    // the last secondary instance is folded into the running one (NIFS, as a prove_step would): into scratch, the proof is
+    // left as it is
+    vdf_proof* q = const_cast<vdf_proof*>(p);
+    SideState& s2 = q->r[SECONDARY];
+    DevBufs bufs(ctx);
+    void *d_fz, *d_fE;
+    { int rc = bufs.zeros(S2.ncols, &d_fz); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
+    { int rc = bufs.zeros(S2.num_cons, &d_fE); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
+    HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
+                                     (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
+                                     (vdf_fe*)s2.d_abc2[2], (vdf_fe*)s2.d_T));
+    vdf_jac jt;
+    HIPCALL(ctx, vdf_msm(ctx, S2.gens, 0, (const vdf_fe*)s2.d_T, S2.num_cons, 1, &jt));
+    s->T2 = jac_to_aff(jt, *S2.Fb);
+    uint64_t r[4];
+    fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
+    const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
+    const Fe rf = int_to_fe(r, *S2.F);
+    HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_z, (const vdf_fe*)&rf, (const vdf_fe*)p->d_l2z, S2.ncols, (vdf_fe*)d_fz));
+    HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_E, (const vdf_fe*)&rf, (const vdf_fe*)s2.d_T, S2.num_cons, (vdf_fe*)d_fE));
+    int rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]);
+    if (rc != VDF_OK) return rc;
+    rc = spartan_prove(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, d_fz, d_fE, &s->sp[1]);
+    if (rc != VDF_OK) return rc;
+    *out = s.release();
+    return VDF_OK;
+  });
 }
 
 void vdf_nova_snark_free(vdf_snark* s) { delete s; }
@@ -645,39 +647,41 @@ void vdf_nova_snark_free(vdf_snark* s) { delete s; }
 // verification of the compressed proof (src/nova/proof.rs:383): the two output hashes, the last fold of the instances,
 // then one argument per side
 int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
-  if (!s || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
-  *ok = 0;
-  if (s->t != pp->t || memcmp(s->digest, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
-  if (num_steps == 0) return VDF_OK;
-  const Side& S1 = pp->s[PRIMARY];
-  const Side& S2 = pp->s[SECONDARY];
-  const Field& F1 = *S1.F;
-  const Field& F2 = *S2.F;
-  if (s->zi1.size() != pp->arity) return VDF_OK;
-  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero()), zi1 = s->zi1, zi2(s->zi2, s->zi2 + 1);
-  uint64_t hv[4];
-  hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv);
-  if (int_to_fe(hv, F2) != s->l_u2.X[0]) return VDF_OK;
-  hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, zi2, to_relaxed(s->r_U1, F1), hv);
-  if (int_to_fe(hv, F2) != s->l_u2.X[1]) return VDF_OK;
-  uint64_t r[4];
-  fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
-  const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
-  vdf_ctx* ctx = pp->ctx;
-  int was_async = 0;
-  HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
-  HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
-  struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
-  bool good = false;
-  int rc = spartan_verify(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, s->sp[0], &good);
-  if (rc != VDF_OK) return rc;
-  if (!good) return VDF_OK;
-  rc = spartan_verify(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, s->sp[1], &good);
-  if (rc != VDF_OK) return rc;
-  if (!good) return VDF_OK;
-  *ok = (memcmp(s->zi1.data(), zi, 32 * pp->arity) == 0 && s->zi2[0].is_zero()) ? 1 : 0;       // src/nova/proof.rs:386
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!s || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
+    *ok = 0;
+    if (s->t != pp->t || memcmp(s->digest, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+    if (num_steps == 0) return VDF_OK;
+    const Side& S1 = pp->s[PRIMARY];
+    const Side& S2 = pp->s[SECONDARY];
+    const Field& F1 = *S1.F;
+    const Field& F2 = *S2.F;
+    if (s->zi1.size() != pp->arity) return VDF_OK;
+    const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero()), zi1 = s->zi1, zi2(s->zi2, s->zi2 + 1);
+    uint64_t hv[4];
+    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv);
+    if (int_to_fe(hv, F2) != s->l_u2.X[0]) return VDF_OK;
+    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, zi2, to_relaxed(s->r_U1, F1), hv);
+    if (int_to_fe(hv, F2) != s->l_u2.X[1]) return VDF_OK;
+    uint64_t r[4];
+    fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);
+    const Inst f2 = fold_instance(S2, s->r_U2, s->l_u2, s->T2, r);
+    vdf_ctx* ctx = pp->ctx;
+    int was_async = 0;
+    HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
+    struct Restore { vdf_ctx* c; int a; ~Restore() { vdf_ctx_sync(c); vdf_ctx_set_async(c, a); } } restore{ctx, was_async};
+    bool good = false;
+    int rc = spartan_verify(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, s->sp[0], &good);
+    if (rc != VDF_OK) return rc;
+    if (!good) return VDF_OK;
+    rc = spartan_verify(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, s->sp[1], &good);
+    if (rc != VDF_OK) return rc;
+    if (!good) return VDF_OK;
+    *ok = (memcmp(s->zi1.data(), zi, 32 * pp->arity) == 0 && s->zi2[0].is_zero()) ? 1 : 0;       // src/nova/proof.rs:386
+    return VDF_OK;
+  });
 }
 
 // flat canonical encoding of the two arguments (little-endian, non-Montgomery), primary then secondary; per argument:
@@ -686,57 +690,61 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
 size_t vdf_nova_snark_size(const vdf_snark* s) { return s ? spartan_flat_size(s->sp[0]) + spartan_flat_size(s->sp[1]) : 0; }
 
 int vdf_nova_snark_bytes(const vdf_snark* s, uint8_t* out, size_t cap) {
-  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (cap < vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
-  uint8_t* o = out;
-  for (int side = 0; side < 2; ++side) {
-    const Field& F = field(side_field(side));
-    const Field& Fb = field(side_field(1 - side));
-    const Spartan& sp = s->sp[side];
-    auto put = [&](const Fe& v, const Field& f) { const Fe c = from_mont(v, f); memcpy(o, c.l, 32); o += 32; };
-    auto put_pt = [&](const Aff& a) { if (a.is_id()) { memset(o, 0, 64); o += 64; } else { put(a.x, Fb); put(a.y, Fb); } };
-    for (const auto& ev : sp.outer) for (const Fe& v : ev) put(v, F);
-    for (const Fe& v : sp.claims) put(v, F);
-    for (const auto& ev : sp.inner) for (const Fe& v : ev) put(v, F);
-    put(sp.w_eval, F);
-    for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
-      for (size_t j = 0; j < ip->L.size(); ++j) { put_pt(ip->L[j]); put_pt(ip->R[j]); }
-      for (const Fe& v : ip->a) put(v, F);
+  return nova_guard([&]() -> int {
+    if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+    if (cap < vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
+    uint8_t* o = out;
+    for (int side = 0; side < 2; ++side) {
+      const Field& F = field(side_field(side));
+      const Field& Fb = field(side_field(1 - side));
+      const Spartan& sp = s->sp[side];
+      auto put = [&](const Fe& v, const Field& f) { const Fe c = from_mont(v, f); memcpy(o, c.l, 32); o += 32; };
+      auto put_pt = [&](const Aff& a) { if (a.is_id()) { memset(o, 0, 64); o += 64; } else { put(a.x, Fb); put(a.y, Fb); } };
+      for (const auto& ev : sp.outer) for (const Fe& v : ev) put(v, F);
+      for (const Fe& v : sp.claims) put(v, F);
+      for (const auto& ev : sp.inner) for (const Fe& v : ev) put(v, F);
+      put(sp.w_eval, F);
+      for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+        for (size_t j = 0; j < ip->L.size(); ++j) { put_pt(ip->L[j]); put_pt(ip->R[j]); }
+        for (const Fe& v : ip->a) put(v, F);
+      }
     }
-  }
-  return VDF_OK;
+    return VDF_OK;
+  });
 }
 
 // replaces both arguments by the given encoding (the tests use it to tamper): field elements must be canonical and
 // every point the identity or on its curve
 int vdf_nova_snark_set_bytes(vdf_snark* s, const uint8_t* in, size_t len) {
-  if (!s || !in) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (len != vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
-  const uint8_t* i = in;
-  bool canonical = true, on_curve = true;
-  Spartan tmp[2] = {s->sp[0], s->sp[1]};
-  for (int side = 0; side < 2; ++side) {
-    const Field& F = field(side_field(side));
-    const Field& Fb = field(side_field(1 - side));
-    Spartan& sp = tmp[side];
-    auto get = [&](Fe& v, const Field& f) { Fe c; memcpy(c.l, i, 32); i += 32; if (geq(c.l, f.m)) canonical = false; v = to_mont(c, f); };
-    auto get_pt = [&](Aff& a) {
-      get(a.x, Fb); get(a.y, Fb);
-      if (!a.is_id() && sqr(a.y, Fb) != add(mul(sqr(a.x, Fb), a.x, Fb), from_u64(5, Fb), Fb)) on_curve = false;
-    };
-    for (auto& ev : sp.outer) for (Fe& v : ev) get(v, F);
-    for (Fe& v : sp.claims) get(v, F);
-    for (auto& ev : sp.inner) for (Fe& v : ev) get(v, F);
-    get(sp.w_eval, F);
-    for (Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
-      for (size_t j = 0; j < ip->L.size(); ++j) { get_pt(ip->L[j]); get_pt(ip->R[j]); }
-      for (Fe& v : ip->a) get(v, F);
+  return nova_guard([&]() -> int {
+    if (!s || !in) return fail(VDF_ERR_BAD_ARG, "null argument");
+    if (len != vdf_nova_snark_size(s)) return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
+    const uint8_t* i = in;
+    bool canonical = true, on_curve = true;
+    Spartan tmp[2] = {s->sp[0], s->sp[1]};
+    for (int side = 0; side < 2; ++side) {
+      const Field& F = field(side_field(side));
+      const Field& Fb = field(side_field(1 - side));
+      Spartan& sp = tmp[side];
+      auto get = [&](Fe& v, const Field& f) { Fe c; memcpy(c.l, i, 32); i += 32; if (geq(c.l, f.m)) canonical = false; v = to_mont(c, f); };
+      auto get_pt = [&](Aff& a) {
+        get(a.x, Fb); get(a.y, Fb);
+        if (!a.is_id() && sqr(a.y, Fb) != add(mul(sqr(a.x, Fb), a.x, Fb), from_u64(5, Fb), Fb)) on_curve = false;
+      };
+      for (auto& ev : sp.outer) for (Fe& v : ev) get(v, F);
+      for (Fe& v : sp.claims) get(v, F);
+      for (auto& ev : sp.inner) for (Fe& v : ev) get(v, F);
+      get(sp.w_eval, F);
+      for (Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+        for (size_t j = 0; j < ip->L.size(); ++j) { get_pt(ip->L[j]); get_pt(ip->R[j]); }
+        for (Fe& v : ip->a) get(v, F);
+      }
     }
-  }
-  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
-  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding is not on its curve");
-  s->sp[0] = tmp[0]; s->sp[1] = tmp[1];
-  return VDF_OK;
+    if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
+    if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding is not on its curve");
+    s->sp[0] = tmp[0]; s->sp[1] = tmp[1];
+    return VDF_OK;
+  });
 }
 
 // ---- the whole compressed proof as one byte string ("VDFSNK03", layout in include/vdf_nova.h) -----------------------
@@ -749,83 +757,87 @@ size_t vdf_nova_snark_serialized_size(const vdf_snark* s) {
 }
 
 int vdf_nova_snark_serialize(const vdf_snark* s, uint8_t* out, size_t cap) {
-  if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (cap < vdf_nova_snark_serialized_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
-  Side sd[2];
-  for (int k = 0; k < 2; ++k) { sd[k].F = &field(side_field(k)); sd[k].Fb = &field(side_field(1 - k)); }
-  uint8_t* o = out;
-  memcpy(o, WIRE_MAGIC_SNARK, 8); o += 8;
-  memcpy(o, &s->t, 8); o += 8;
-  memcpy(o, s->digest, 32); o += 32;
-  o = put_inst(o, s->r_U1, sd[0], true);
-  o = put_inst(o, s->r_U2, sd[1], true);
-  o = put_inst(o, s->l_u2, sd[1], false);
-  pt_compress(s->T2, *sd[1].Fb, o); o += 32;
-  for (const Fe& v : s->zi1) o = wire_put_fe(o, v, *sd[0].F);
-  o = wire_put_fe(o, s->zi2[0], *sd[1].F);
-  for (int side = 0; side < 2; ++side) {
-    const Field& F = *sd[side].F;
-    const Field& Fb = *sd[side].Fb;
-    const Spartan& sp = s->sp[side];
-    for (const auto& ev : sp.outer) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
-    for (const Fe& v : sp.claims) o = wire_put_fe(o, v, F);
-    for (const auto& ev : sp.inner) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
-    o = wire_put_fe(o, sp.w_eval, F);
-    for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
-      for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
-      for (const Fe& v : ip->a) o = wire_put_fe(o, v, F);
+  return nova_guard([&]() -> int {
+    if (!s || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+    if (cap < vdf_nova_snark_serialized_size(s)) return fail(VDF_ERR_BAD_LENGTH, "buffer too small");
+    Side sd[2];
+    for (int k = 0; k < 2; ++k) { sd[k].F = &field(side_field(k)); sd[k].Fb = &field(side_field(1 - k)); }
+    uint8_t* o = out;
+    memcpy(o, WIRE_MAGIC_SNARK, 8); o += 8;
+    memcpy(o, &s->t, 8); o += 8;
+    memcpy(o, s->digest, 32); o += 32;
+    o = put_inst(o, s->r_U1, sd[0], true);
+    o = put_inst(o, s->r_U2, sd[1], true);
+    o = put_inst(o, s->l_u2, sd[1], false);
+    pt_compress(s->T2, *sd[1].Fb, o); o += 32;
+    for (const Fe& v : s->zi1) o = wire_put_fe(o, v, *sd[0].F);
+    o = wire_put_fe(o, s->zi2[0], *sd[1].F);
+    for (int side = 0; side < 2; ++side) {
+      const Field& F = *sd[side].F;
+      const Field& Fb = *sd[side].Fb;
+      const Spartan& sp = s->sp[side];
+      for (const auto& ev : sp.outer) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+      for (const Fe& v : sp.claims) o = wire_put_fe(o, v, F);
+      for (const auto& ev : sp.inner) for (const Fe& v : ev) o = wire_put_fe(o, v, F);
+      o = wire_put_fe(o, sp.w_eval, F);
+      for (const Ipa* ip : {&sp.ipaW, &sp.ipaE}) {
+        for (size_t j = 0; j < ip->L.size(); ++j) { pt_compress(ip->L[j], Fb, o); pt_compress(ip->R[j], Fb, o + 32); o += 64; }
+        for (const Fe& v : ip->a) o = wire_put_fe(o, v, F);
+      }
     }
-  }
-  return VDF_OK;
+    return VDF_OK;
+  });
 }
 
 // A verifier that never saw the prover's objects: bytes -> vdf_snark
 int vdf_nova_snark_deserialize(vdf_pp* pp, const uint8_t* in, size_t len, vdf_snark** out) {
-  if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
-  *out = nullptr;
-  if (len < 48 + statement_wire(pp->arity)) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
-  if (memcmp(in, WIRE_MAGIC_SNARK, 8) != 0) return fail(VDF_ERR_BAD_ARG, "not this kind of encoding (magic)");
-  uint64_t t;
-  memcpy(&t, in + 8, 8);
-  if (t != pp->t || memcmp(in + 16, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "encoding was made under other public parameters");
-  const Layout L[2] = {layout_of(pp->s[0]), layout_of(pp->s[1])};
-  if (len != 48 + statement_wire(pp->arity) + spartan_wire_size(L[0]) + spartan_wire_size(L[1]))
-    return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
-  std::unique_ptr<vdf_snark> s(new vdf_snark());
-  s->t = t;
-  memcpy(s->digest, pp->digest, 32);
-  const uint8_t* i = in + 48;
-  bool canonical = true, on_curve = true;
-  i = get_inst(i, &s->r_U1, pp->s[0], true, &canonical, &on_curve);
-  i = get_inst(i, &s->r_U2, pp->s[1], true, &canonical, &on_curve);
-  i = get_inst(i, &s->l_u2, pp->s[1], false, &canonical, &on_curve);
-  on_curve &= pt_decompress(i, *pp->s[1].Fb, &s->T2); i += 32;
-  s->zi1.resize(pp->arity);
-  for (size_t k = 0; k < pp->arity; ++k, i += 32) canonical &= wire_get_fe(i, *pp->s[0].F, &s->zi1[k]);
-  canonical &= wire_get_fe(i, *pp->s[1].F, &s->zi2[0]); i += 32;
-  for (int side = 0; side < 2; ++side) {
-    const Field& F = *pp->s[side].F;
-    const Field& Fb = *pp->s[side].Fb;
-    Spartan& p = s->sp[side];
-    spartan_resize(p, L[side]);
-    auto get = [&](Fe& v) { canonical &= wire_get_fe(i, F, &v); i += 32; };
-    for (auto& ev : p.outer) for (Fe& v : ev) get(v);
-    for (Fe& v : p.claims) get(v);
-    for (auto& ev : p.inner) for (Fe& v : ev) get(v);
-    get(p.w_eval);
-    for (Ipa* ip : {&p.ipaW, &p.ipaE}) {
-      for (size_t j = 0; j < ip->L.size(); ++j) {
-        on_curve &= pt_decompress(i, Fb, &ip->L[j]);
-        on_curve &= pt_decompress(i + 32, Fb, &ip->R[j]);
-        i += 64;
+  return nova_guard([&]() -> int {
+    if (!pp || !in || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (len < 48 + statement_wire(pp->arity)) return fail(VDF_ERR_BAD_LENGTH, "encoding is shorter than its header");
+    if (memcmp(in, WIRE_MAGIC_SNARK, 8) != 0) return fail(VDF_ERR_BAD_ARG, "not this kind of encoding (magic)");
+    uint64_t t;
+    memcpy(&t, in + 8, 8);
+    if (t != pp->t || memcmp(in + 16, pp->digest, 32) != 0) return fail(VDF_ERR_BAD_ARG, "encoding was made under other public parameters");
+    const Layout L[2] = {layout_of(pp->s[0]), layout_of(pp->s[1])};
+    if (len != 48 + statement_wire(pp->arity) + spartan_wire_size(L[0]) + spartan_wire_size(L[1]))
+      return fail(VDF_ERR_BAD_LENGTH, "encoding has the wrong length for this shape");
+    std::unique_ptr<vdf_snark> s(new vdf_snark());
+    s->t = t;
+    memcpy(s->digest, pp->digest, 32);
+    const uint8_t* i = in + 48;
+    bool canonical = true, on_curve = true;
+    i = get_inst(i, &s->r_U1, pp->s[0], true, &canonical, &on_curve);
+    i = get_inst(i, &s->r_U2, pp->s[1], true, &canonical, &on_curve);
+    i = get_inst(i, &s->l_u2, pp->s[1], false, &canonical, &on_curve);
+    on_curve &= pt_decompress(i, *pp->s[1].Fb, &s->T2); i += 32;
+    s->zi1.resize(pp->arity);
+    for (size_t k = 0; k < pp->arity; ++k, i += 32) canonical &= wire_get_fe(i, *pp->s[0].F, &s->zi1[k]);
+    canonical &= wire_get_fe(i, *pp->s[1].F, &s->zi2[0]); i += 32;
+    for (int side = 0; side < 2; ++side) {
+      const Field& F = *pp->s[side].F;
+      const Field& Fb = *pp->s[side].Fb;
+      Spartan& p = s->sp[side];
+      spartan_resize(p, L[side]);
+      auto get = [&](Fe& v) { canonical &= wire_get_fe(i, F, &v); i += 32; };
+      for (auto& ev : p.outer) for (Fe& v : ev) get(v);
+      for (Fe& v : p.claims) get(v);
+      for (auto& ev : p.inner) for (Fe& v : ev) get(v);
+      get(p.w_eval);
+      for (Ipa* ip : {&p.ipaW, &p.ipaE}) {
+        for (size_t j = 0; j < ip->L.size(); ++j) {
+          on_curve &= pt_decompress(i, Fb, &ip->L[j]);
+          on_curve &= pt_decompress(i + 32, Fb, &ip->R[j]);
+          i += 64;
+        }
+        for (Fe& v : ip->a) get(v);
       }
-      for (Fe& v : ip->a) get(v);
     }
-  }
-  if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
-  if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding does not decode to a curve point");
-  *out = s.release();
-  return VDF_OK;
+    if (!canonical) return fail(VDF_ERR_NONCANONICAL, "a field element of the encoding is not canonical");
+    if (!on_curve) return fail(VDF_ERR_NONCANONICAL, "a point of the encoding does not decode to a curve point");
+    *out = s.release();
+    return VDF_OK;
+  });
 }
 
 }  // extern "C"

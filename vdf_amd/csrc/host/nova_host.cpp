@@ -291,36 +291,42 @@ const char* vdf_nova_last_error(void) { return vdfnova::g_err.c_str(); }
 
 // ---- host-only entry points ------------------------------------------------------------------------------------
 int vdf_nova_ro_hash(int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) {
-  if (!valid_field(f) || (!xs && n) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  const Fe r = ro_hash(f, tag, (const Fe*)xs, n);
-  memcpy(out, &r, 32);
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!valid_field(f) || (!xs && n) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    const Fe r = ro_hash(f, tag, (const Fe*)xs, n);
+    memcpy(out, &r, 32);
+    return VDF_OK;
+  });
 }
 
 int vdf_nova_shape_digest(uint64_t t, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
-  if (t == 0 || t > (1ull << 24) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  HostShape sh[2];
-  build_shapes(t, circuit_kind, sh);
-  digest_shapes(t, gens_family, sh, out);
-  if (sizes)
-    for (int s = 0; s < 2; ++s) {
-      sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
-      sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
-    }
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (t == 0 || t > (1ull << 24) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    HostShape sh[2];
+    build_shapes(t, circuit_kind, sh);
+    digest_shapes(t, gens_family, sh, out);
+    if (sizes)
+      for (int s = 0; s < 2; ++s) {
+        sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
+        sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
+      }
+    return VDF_OK;
+  });
 }
 
 int vdf_nova_shape_digest_custom(const vdf_step_circuit* primary, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
-  if (!primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64 || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  HostShape sh[2];
-  { int rc = build_shapes(0, VDF_CIRCUIT_CUSTOM, sh, primary); if (rc != VDF_OK) return rc; }
-  digest_shapes(0, gens_family, sh, out);
-  if (sizes)
-    for (int s = 0; s < 2; ++s) {
-      sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
-      sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
-    }
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64 || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    HostShape sh[2];
+    { int rc = build_shapes(0, VDF_CIRCUIT_CUSTOM, sh, primary); if (rc != VDF_OK) return rc; }
+    digest_shapes(0, gens_family, sh, out);
+    if (sizes)
+      for (int s = 0; s < 2; ++s) {
+        sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
+        sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
+      }
+    return VDF_OK;
+  });
 }
 
 static AugInputs aug_from_abi(int side, const vdf_nova_aug_inputs* a) {
@@ -345,28 +351,30 @@ static AugInputs aug_from_abi(int side, const vdf_nova_aug_inputs* a) {
 int vdf_nova_aug_synthesize(int side, uint64_t t, int circuit_kind, const vdf_nova_aug_inputs* a, const vdf_state* result,
                             const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars, size_t* num_cons, vdf_fe X[2],
                             vdf_fe z_next[3]) {
-  if ((side != PRIMARY && side != SECONDARY) || !a || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  vdf_pp tmp;
-  tmp.t = t;
-  tmp.circuit_kind = circuit_kind;
-  std::unique_ptr<StepCircuit> step;
-  Circuit c;
-  if (side == PRIMARY) {
-    if (!result || !input) return fail(VDF_ERR_BAD_ARG, "the primary circuit needs the step's states");
-    c.result = load_state(result); c.input = load_state(input); c.t = t;
-    step = make_primary_circuit(&tmp, &c, false);
-  } else step.reset(new TrivialTestCircuit());
-  CS cs(side_field(side), false);
-  const std::vector<Fe> zn = synthesize_augmented(cs, side, aug_from_abi(side, a), *step);
-  if (num_vars) *num_vars = cs.W.size();
-  if (num_cons) *num_cons = cs.rows;
-  if (W) {
-    if (w_cap < cs.W.size()) return fail(VDF_ERR_BAD_LENGTH, "W buffer too small");
-    memcpy(W, cs.W.data(), cs.W.size() * 32);
-  }
-  if (X) memcpy(X, cs.X.data(), 64);
-  if (z_next) memcpy(z_next, zn.data(), zn.size() * 32);
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if ((side != PRIMARY && side != SECONDARY) || !a || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    vdf_pp tmp;
+    tmp.t = t;
+    tmp.circuit_kind = circuit_kind;
+    std::unique_ptr<StepCircuit> step;
+    Circuit c;
+    if (side == PRIMARY) {
+      if (!result || !input) return fail(VDF_ERR_BAD_ARG, "the primary circuit needs the step's states");
+      c.result = load_state(result); c.input = load_state(input); c.t = t;
+      step = make_primary_circuit(&tmp, &c, false);
+    } else step.reset(new TrivialTestCircuit());
+    CS cs(side_field(side), false);
+    const std::vector<Fe> zn = synthesize_augmented(cs, side, aug_from_abi(side, a), *step);
+    if (num_vars) *num_vars = cs.W.size();
+    if (num_cons) *num_cons = cs.rows;
+    if (W) {
+      if (w_cap < cs.W.size()) return fail(VDF_ERR_BAD_LENGTH, "W buffer too small");
+      memcpy(W, cs.W.data(), cs.W.size() * 32);
+    }
+    if (X) memcpy(X, cs.X.data(), 64);
+    if (z_next) memcpy(z_next, zn.data(), zn.size() * 32);
+    return VDF_OK;
+  });
 }
 
 int vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses) {
@@ -377,22 +385,28 @@ int vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses) {
 
 // ---- public parameters -------------------------------------------------------------------------------
 int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
-  return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);
+  return nova_guard([&]() -> int {
+    return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);
+  });
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out);
 
 int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
-  if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
-    return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
-  return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, out);
+  return nova_guard([&]() -> int {
+    if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
+      return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
+    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, out);
+  });
 }
 
 int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary, int gens_family, vdf_pp** out) {
-  if (!ctx || !out || !primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64)
-    return fail(VDF_ERR_BAD_ARG, "bad argument");
-  return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, out);
+  return nova_guard([&]() -> int {
+    if (!ctx || !out || !primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64)
+      return fail(VDF_ERR_BAD_ARG, "bad argument");
+    return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, out);
+  });
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out) {
@@ -539,38 +553,42 @@ int vdf_nova_pp_early_rows(const vdf_pp* pp, uint64_t* begin, uint64_t* len) {
 // ---- circuits ----------------------------------------------------------------------------------------
 int vdf_nova_eval_and_make_circuits(int mode, uint64_t t, size_t num_steps, const vdf_state* initial_state,
                                     vdf_fe z0_primary[3], vdf_circuits** out) {
-  if (!valid_mode(mode) || !initial_state || !z0_primary || !out || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  if (num_steps == 0) return fail(VDF_ERR_BAD_ARG, "num_steps must be > 0 (assert!, src/nova/proof.rs:268)");
-  vdf_circuits* cs = new vdf_circuits();
-  St state = load_state(initial_state);
-  for (size_t s = 0; s < num_steps; ++s) {                          // :274-279
-    Circuit c;
-    c.t = t;
-    c.input = state;                                                 // previous_state, :285-291
-    c.trace_xy.resize(2 * (t + 1));
-    vdf_state res;
-    vdf_state in;
-    store_state(&in, state);
-    vdf_minroot_eval(VDF_FIELD_FQ, mode, &in, t, &res, (vdf_fe*)c.trace_xy.data());
-    c.result = load_state(&res);
-    state = c.result;
-    cs->v.push_back(std::move(c));
-  }
-  memcpy(z0_primary, &state, 96);                                    // z0 = final state, :278-281
-  std::vector<Circuit> rev(cs->v.rbegin(), cs->v.rend());            // circuits.reverse(), :294
-  cs->v.swap(rev);
-  *out = cs;
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!valid_mode(mode) || !initial_state || !z0_primary || !out || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (num_steps == 0) return fail(VDF_ERR_BAD_ARG, "num_steps must be > 0 (assert!, src/nova/proof.rs:268)");
+    vdf_circuits* cs = new vdf_circuits();
+    St state = load_state(initial_state);
+    for (size_t s = 0; s < num_steps; ++s) {                          // :274-279
+      Circuit c;
+      c.t = t;
+      c.input = state;                                                 // previous_state, :285-291
+      c.trace_xy.resize(2 * (t + 1));
+      vdf_state res;
+      vdf_state in;
+      store_state(&in, state);
+      vdf_minroot_eval(VDF_FIELD_FQ, mode, &in, t, &res, (vdf_fe*)c.trace_xy.data());
+      c.result = load_state(&res);
+      state = c.result;
+      cs->v.push_back(std::move(c));
+    }
+    memcpy(z0_primary, &state, 96);                                    // z0 = final state, :278-281
+    std::vector<Circuit> rev(cs->v.rbegin(), cs->v.rend());            // circuits.reverse(), :294
+    cs->v.swap(rev);
+    *out = cs;
+    return VDF_OK;
+  });
 }
 int vdf_nova_circuits_upload(vdf_ctx* ctx, vdf_circuits* c) {
-  if (!ctx || !c) return fail(VDF_ERR_BAD_ARG, "null argument");
-  c->ctx = ctx;
-  for (auto& k : c->v) {
-    if (k.d_trace) continue;
-    HIPCALL(ctx, vdf_dev_alloc(ctx, k.trace_xy.size() * 32, &k.d_trace));
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, k.d_trace, k.trace_xy.data(), k.trace_xy.size() * 32));
-  }
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!ctx || !c) return fail(VDF_ERR_BAD_ARG, "null argument");
+    c->ctx = ctx;
+    for (auto& k : c->v) {
+      if (k.d_trace) continue;
+      HIPCALL(ctx, vdf_dev_alloc(ctx, k.trace_xy.size() * 32, &k.d_trace));
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, k.d_trace, k.trace_xy.data(), k.trace_xy.size() * 32));
+    }
+    return VDF_OK;
+  });
 }
 size_t vdf_nova_circuits_len(const vdf_circuits* c) { return c ? c->v.size() : 0; }
 int vdf_nova_circuit_states(const vdf_circuits* c, size_t k, vdf_state* result, vdf_state* input) {
@@ -942,18 +960,20 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
 
 int vdf_nova_prove_recursively(vdf_pp* pp, const vdf_circuits* circuits, uint64_t num_iters_per_step, const vdf_fe z0[3],
                                vdf_proof** out) {
-  if (!pp || !circuits || !out || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
-  if (num_iters_per_step != pp->t) return fail(VDF_ERR_BAD_LENGTH, "num_iters_per_step differs from the public parameters");
-  if (circuits->v.empty()) return fail(VDF_ERR_BAD_LENGTH, "no circuits (recursive_snark.unwrap(), src/nova/proof.rs:357)");
-  vdf_proof* p = nullptr;
-  for (size_t k = 0; k < circuits->v.size(); ++k) {                   // :318-355
-    int rc = vdf_nova_prove_step(pp, &p, circuits, k, z0);
+  return nova_guard([&]() -> int {
+    if (!pp || !circuits || !out || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
+    if (num_iters_per_step != pp->t) return fail(VDF_ERR_BAD_LENGTH, "num_iters_per_step differs from the public parameters");
+    if (circuits->v.empty()) return fail(VDF_ERR_BAD_LENGTH, "no circuits (recursive_snark.unwrap(), src/nova/proof.rs:357)");
+    vdf_proof* p = nullptr;
+    for (size_t k = 0; k < circuits->v.size(); ++k) {                   // :318-355
+      int rc = vdf_nova_prove_step(pp, &p, circuits, k, z0);
+      if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
+    }
+    int rc = finalize_l2(p);
     if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
-  }
-  int rc = finalize_l2(p);
-  if (rc != VDF_OK) { vdf_nova_proof_free(p); *out = nullptr; return rc; }
-  *out = p;
-  return VDF_OK;
+    *out = p;
+    return VDF_OK;
+  });
 }
 
 void vdf_nova_proof_free(vdf_proof* p) {
@@ -981,22 +1001,26 @@ void vdf_nova_proof_free(vdf_proof* p) {
 size_t vdf_nova_proof_num_steps(const vdf_proof* p) { return p ? p->i : 0; }
 
 int vdf_nova_proof_instance(const vdf_proof* p, int which, vdf_affine* comm_W, vdf_affine* comm_E, vdf_fe* u, vdf_fe X[2]) {
-  if (!p || which < 0 || which > 2) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  if (which == VDF_INST_FRESH_SECONDARY) { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
-  const Inst& in = which == VDF_INST_FRESH_SECONDARY ? p->l2 : p->r[which].inst;
-  if (comm_W) memcpy(comm_W, &in.comm_W, 64);
-  if (comm_E) memcpy(comm_E, &in.comm_E, 64);
-  if (u) memcpy(u, &in.u, 32);
-  if (X) memcpy(X, in.X, 32 * NUM_IO);
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!p || which < 0 || which > 2) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (which == VDF_INST_FRESH_SECONDARY) { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
+    const Inst& in = which == VDF_INST_FRESH_SECONDARY ? p->l2 : p->r[which].inst;
+    if (comm_W) memcpy(comm_W, &in.comm_W, 64);
+    if (comm_E) memcpy(comm_E, &in.comm_E, 64);
+    if (u) memcpy(u, &in.u, 32);
+    if (X) memcpy(X, in.X, 32 * NUM_IO);
+    return VDF_OK;
+  });
 }
 int vdf_nova_proof_witness_ptrs(const vdf_proof* p, int which, const void** d_z, const void** d_E) {
-  if (!p || which < 0 || which > 3) return fail(VDF_ERR_BAD_ARG, "bad argument");
-  HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
-  if (which == VDF_INST_FRESH_PRIMARY_LAST) { if (d_z) *d_z = p->d_z2s[p->slot]; if (d_E) *d_E = nullptr; }
-  else if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }
-  else { if (d_z) *d_z = p->r[which].d_z; if (d_E) *d_E = p->r[which].d_E; }
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!p || which < 0 || which > 3) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
+    if (which == VDF_INST_FRESH_PRIMARY_LAST) { if (d_z) *d_z = p->d_z2s[p->slot]; if (d_E) *d_E = nullptr; }
+    else if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }
+    else { if (d_z) *d_z = p->r[which].d_z; if (d_E) *d_E = p->r[which].d_E; }
+    return VDF_OK;
+  });
 }
 int vdf_nova_proof_zi(const vdf_proof* p, vdf_fe zi_primary[3], vdf_fe zi_secondary[1]) {
   if (!p) return fail(VDF_ERR_BAD_ARG, "null proof");
@@ -1019,46 +1043,50 @@ int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
 // RecursiveSNARK::verify(pp, num_steps, z0_primary, z0_secondary) -> (zi_primary, zi_secondary), then the comparison of
 // src/nova/proof.rs:386 with z0_secondary = [0] (:389-391)
 int vdf_nova_verify(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe z0[3], const vdf_fe zi[3], int* ok) {
-  return vdf_nova_verify_custom(p, pp, num_steps, z0, zi, ok);
+  return nova_guard([&]() -> int {
+    return vdf_nova_verify_custom(p, pp, num_steps, z0, zi, ok);
+  });
 }
 
 int vdf_nova_verify_custom(const vdf_proof* p, vdf_pp* pp, size_t num_steps, const vdf_fe* z0, const vdf_fe* zi, int* ok) {
-  if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
-  *ok = 0;
-  if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
-  if (num_steps == 0 || p->i != num_steps) return VDF_OK;                  // NovaError::ProofVerifyError
-  if (memcmp(p->z0[PRIMARY].data(), z0, 32 * pp->arity) != 0) return VDF_OK;   // not the chain this proof was started for
-  { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
-  const Side& S1 = pp->s[PRIMARY];
-  const Side& S2 = pp->s[SECONDARY];
-  const Field& F1 = *S1.F;
-  const Field& F2 = *S2.F;
-  // (1) the two output hashes the last secondary instance carries
-  const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero());
-  uint64_t hv[4];
-  hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv);
-  if (int_to_fe(hv, F2) != p->l2.X[0]) return VDF_OK;
-  hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, p->zi[SECONDARY], to_relaxed(p->r[PRIMARY].inst, F1), hv);
-  if (int_to_fe(hv, F2) != p->l2.X[1]) return VDF_OK;
-  // (2) three satisfiability claims
-  vdf_ctx* ctx = pp->ctx;
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
-  vdf_proof* q = const_cast<vdf_proof*>(p);                                  // scratch buffers only
-  bool good = false;
-  for (int s = 0; s < 2; ++s) {
-    int rc = check_sat(pp->s[s], p->r[s].inst, p->r[s].d_z, p->r[s].d_E, q->r[s].d_abc2, q->r[s].d_T, &good);
-    if (rc != VDF_OK) return rc;
-    if (!good) return VDF_OK;
-  }
-  if (p->l2.u != one(F2)) return VDF_OK;
-  {
-    int rc = check_sat(S2, p->l2, p->d_l2z, nullptr, q->r[SECONDARY].d_abc2, q->r[SECONDARY].d_T, &good);
-    if (rc != VDF_OK) return rc;
-    if (!good) return VDF_OK;
-  }
-  // Ok(zi_primary == zi && zi_secondary == [0]), src/nova/proof.rs:386
-  *ok = (memcmp(p->zi[PRIMARY].data(), zi, 32 * pp->arity) == 0 && p->zi[SECONDARY][0].is_zero()) ? 1 : 0;
-  return VDF_OK;
+  return nova_guard([&]() -> int {
+    if (!p || !pp || !z0 || !zi || !ok) return fail(VDF_ERR_BAD_ARG, "null argument");
+    *ok = 0;
+    if (p->pp != pp) return fail(VDF_ERR_BAD_ARG, "proof was made under other public parameters");
+    if (num_steps == 0 || p->i != num_steps) return VDF_OK;                  // NovaError::ProofVerifyError
+    if (memcmp(p->z0[PRIMARY].data(), z0, 32 * pp->arity) != 0) return VDF_OK;   // not the chain this proof was started for
+    { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }
+    const Side& S1 = pp->s[PRIMARY];
+    const Side& S2 = pp->s[SECONDARY];
+    const Field& F1 = *S1.F;
+    const Field& F2 = *S2.F;
+    // (1) the two output hashes the last secondary instance carries
+    const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero());
+    uint64_t hv[4];
+    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv);
+    if (int_to_fe(hv, F2) != p->l2.X[0]) return VDF_OK;
+    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, p->zi[SECONDARY], to_relaxed(p->r[PRIMARY].inst, F1), hv);
+    if (int_to_fe(hv, F2) != p->l2.X[1]) return VDF_OK;
+    // (2) three satisfiability claims
+    vdf_ctx* ctx = pp->ctx;
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    vdf_proof* q = const_cast<vdf_proof*>(p);                                  // scratch buffers only
+    bool good = false;
+    for (int s = 0; s < 2; ++s) {
+      int rc = check_sat(pp->s[s], p->r[s].inst, p->r[s].d_z, p->r[s].d_E, q->r[s].d_abc2, q->r[s].d_T, &good);
+      if (rc != VDF_OK) return rc;
+      if (!good) return VDF_OK;
+    }
+    if (p->l2.u != one(F2)) return VDF_OK;
+    {
+      int rc = check_sat(S2, p->l2, p->d_l2z, nullptr, q->r[SECONDARY].d_abc2, q->r[SECONDARY].d_T, &good);
+      if (rc != VDF_OK) return rc;
+      if (!good) return VDF_OK;
+    }
+    // Ok(zi_primary == zi && zi_secondary == [0]), src/nova/proof.rs:386
+    *ok = (memcmp(p->zi[PRIMARY].data(), zi, 32 * pp->arity) == 0 && p->zi[SECONDARY][0].is_zero()) ? 1 : 0;
+    return VDF_OK;
+  });
 }
 
 }  // extern "C"

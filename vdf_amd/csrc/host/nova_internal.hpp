@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <initializer_list>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "../../../include/vdf_nova.h"
@@ -17,6 +19,14 @@ namespace vdfnova {
 using namespace vdfhost;
 
 int fail(int code, const std::string& msg);          // records the message for vdf_nova_last_error, returns code
+// no C++ exception crosses the C ABI: an entry point that allocates or synthesises runs its body through this
+template <class F>
+inline int nova_guard(F&& body) {
+  try { return body(); }
+  catch (const std::bad_alloc&) { return fail(VDF_ERR_OOM, "host allocation failed"); }
+  catch (const std::exception& ex) { return fail(VDF_ERR_DEVICE, ex.what()); }
+  catch (...) { return fail(VDF_ERR_DEVICE, "unknown failure"); }
+}
 #define HIPCALL(ctx, expr)                                                          \
   do {                                                                              \
     int rc__ = (expr);                                                              \
