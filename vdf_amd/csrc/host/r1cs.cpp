@@ -607,14 +607,29 @@ class Helpers {
 //   tangent at w_k:             1 / (2 y_w)     = zzz_w / (2 Y_w)
 //   final complete addition:    1 / (x_rP - x_U) = zz / (X - x_U zz)                        (equal x: 1 / (2 y_U), on its own)
 // in the order the gadgets meet them: chord_0, tangent_0, chord_1, ..., chord_(bits-1), final.
-void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out) {
+// The doublings w_k need only P, not r: ec_fold_doublings makes them apart, so that they can run while r is still being
+// hashed (synthesize_augmented's late half).
+void ec_fold_doublings(const Field& F, const Aff& P, int bits, std::vector<Pt>* w) {
+  w->resize((size_t)bits);
+  Pt cur = pt_from_aff(P, F);
+  for (int k = 0; k < bits; ++k) {
+    (*w)[k] = cur;
+    if (k + 1 < bits) cur = pt_dbl(cur, F);
+  }
+}
+void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out,
+                      const std::vector<Pt>* doublings) {
+  std::vector<Pt> own;
+  if (!doublings) { ec_fold_doublings(F, P, bits, &own); doublings = &own; }
+  const std::vector<Pt>& ws = *doublings;
   const size_t base = out->size(), n = 2 * (size_t)bits;
   out->resize(base + n);
   Fe* d = out->data() + base;
   std::vector<Fe> scale(n);                                 // what each inverted denominator is multiplied by
-  Pt w = pt_from_aff(P, F), acc = pt_identity();
+  Pt acc = pt_identity();
   size_t q = 0;
   for (int k = 0; k < bits; ++k) {
+    const Pt& w = ws[k];
     if (acc.is_id()) { d[q] = w.x; scale[q] = w.zz; }
     else {
       d[q] = vdfhost::sub(vdfhost::mul(w.x, acc.zz, F), vdfhost::mul(acc.x, w.zz, F), F);
@@ -626,7 +641,6 @@ void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t
       d[q] = vdfhost::add(w.y, w.y, F);
       scale[q] = w.zzz;
       ++q;
-      w = pt_dbl(w, F);
     }
   }
   // acc = [r] P now (the identity also when P is)
@@ -1021,24 +1035,16 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   const Fe* uX = e.uX;
   const Fe i_new_v = vdfhost::add(in.i, ONE, F);
   tr[0] = us();
-  // ---- block 2, second half (this thread): the fold challenge
   Blk b2, b3, b4, b5, b6;
   uint64_t rv[4] = {0, 0, 0, 0};
-  std::vector<Num> r_bits;
-  {
-    CS& t = *e.chal;
-    for (const Fe& v : {in.u_W.x, in.u_W.y, uX[0], uX[1], in.T.x, in.T.y}) e.chal_sp.absorb(t, v);
-    r_bits = strict_bits(t, val(e.chal_sp.finish(t)));
-    r_bits.resize(CHAL_BITS);
-    fe_to_int(pack(t, r_bits.data(), CHAL_BITS).v, F, rv);
-    take(b2, t);
-  }
-  tr[1] = us();
-  // ---- blocks 3, 4 (helpers 1, 2): U + [r] P, slopes from the native pre-pass
+  std::atomic<bool> r_ready{false};
   struct alignas(64) FoldOut { Fe x, y; size_t queued = 0, misses = 0; double done = 0; } fo_w, fo_e;
   auto run_fold = [&](const Aff& Upt, const Aff& P, Blk* b, FoldOut* o) {
     CS t(fid, false);
-    ec_fold_inverses(F, Upt, P, rv, CHAL_BITS, &t.inv_queue);
+    std::vector<Pt> doublings;
+    ec_fold_doublings(F, P, CHAL_BITS, &doublings);
+    for (unsigned n = 0; !r_ready.load(std::memory_order_acquire); ++n) { if (n < 200000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+    ec_fold_inverses(F, Upt, P, rv, CHAL_BITS, &t.inv_queue, &doublings);
     Num rx, ry, fx, fy;
     ec_scalar_mul_witness(t, rv, CHAL_BITS, P, &rx.v, &ry.v);
     ec_add_complete(t, val(Upt.x), val(Upt.y), rx, ry, &fx, &fy);
@@ -1050,11 +1056,26 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   };
   Helpers& H = Helpers::get();
   bool pending[3] = {e.pending0, false, false};
-  struct Joiner { Helpers& h; bool* p; ~Joiner() { for (int k = 1; k < 3; ++k) if (p[k]) h.wait(k); } } joiner{H, pending};   // slot 0: ~AugEarly
+  // an exception below must not leave a fold spinning for r: the joiner releases them first
+  struct Joiner { Helpers& h; bool* p; std::atomic<bool>* go; ~Joiner() { go->store(true, std::memory_order_release); for (int k = 1; k < 3; ++k) if (p[k]) h.wait(k); } } joiner{H, pending, &r_ready};   // slot 0: ~AugEarly
+  // ---- blocks 3, 4 (helpers 1, 2): U + [r] P, slopes from the native pre-pass.  Started before r is known: the doublings
+  // 2^k P need only P and run beside the challenge hash; each fold then waits for r_ready.
   if (e.helped) {
     H.start(1, [&] { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); }); pending[1] = true;
     H.start(2, [&] { run_fold(in.U.comm_E, in.T, &b4, &fo_e); }); pending[2] = true;
   }
+  // ---- block 2, second half (this thread): the fold challenge
+  std::vector<Num> r_bits;
+  {
+    CS& t = *e.chal;
+    for (const Fe& v : {in.u_W.x, in.u_W.y, uX[0], uX[1], in.T.x, in.T.y}) e.chal_sp.absorb(t, v);
+    r_bits = strict_bits(t, val(e.chal_sp.finish(t)));
+    r_bits.resize(CHAL_BITS);
+    fe_to_int(pack(t, r_bits.data(), CHAL_BITS).v, F, rv);
+    r_ready.store(true, std::memory_order_release);
+    take(b2, t);
+  }
+  tr[1] = us();
   // ---- block 5, second half (this thread, while the folds run): X' = X + r x in the other field
   Fe f_lo[2], f_hi[2], x_lo[2], x_hi[2];
   {
