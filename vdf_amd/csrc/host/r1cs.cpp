@@ -162,7 +162,8 @@ void CS::resolve() {
 }
 
 void batch_inverse(Fe* v, size_t n, const Field& F) {
-  std::vector<Fe> pre(n);
+  static thread_local std::vector<Fe> pre;
+  pre.resize(n);
   Fe run = one(F);
   for (size_t i = 0; i < n; ++i) {
     pre[i] = run;
@@ -607,71 +608,96 @@ class Helpers {
 //   tangent at w_k:             1 / (2 y_w)     = zzz_w / (2 Y_w)
 //   final complete addition:    1 / (x_rP - x_U) = zz / (X - x_U zz)                        (equal x: 1 / (2 y_U), on its own)
 // in the order the gadgets meet them: chord_0, tangent_0, chord_1, ..., chord_(bits-1), final.
-// The doublings w_k need only P, not r: ec_fold_doublings makes them apart, so that they can run while r is still being
-// hashed (synthesize_augmented's late half).
-void ec_fold_doublings(const Field& F, const Aff& P, int bits, std::vector<Pt>* w) {
-  w->resize((size_t)bits);
+// Everything on the doubling side needs only P, not r -- the points w_k, the tangents' inverses (a batch of their own), the
+// affine doublings and the tangent's witness values: ec_fold_prepare makes them apart, while r is still being hashed
+// (synthesize_augmented's late half); after r only the accumulator's chain, the chords' batch and their witness remain.
+void ec_fold_prepare(const Field& F, const Aff& P, int bits, FoldPre* pre) {
+  const size_t nb = (size_t)bits;
+  pre->w.resize(nb);
+  pre->tan_inv.resize(nb ? nb - 1 : 0);
+  pre->wx.resize(nb); pre->wy.resize(nb);
+  pre->x2.resize(nb ? nb - 1 : 0); pre->lam.resize(nb ? nb - 1 : 0);
   Pt cur = pt_from_aff(P, F);
   for (int k = 0; k < bits; ++k) {
-    (*w)[k] = cur;
-    if (k + 1 < bits) cur = pt_dbl(cur, F);
+    pre->w[k] = cur;
+    if (k + 1 < bits) { pre->tan_inv[k] = vdfhost::add(cur.y, cur.y, F); cur = pt_dbl(cur, F); }
+  }
+  // 1 / (2 y_k) = zzz_k / (2 Y_k): one batched inversion for all tangents
+  batch_inverse(pre->tan_inv.data(), pre->tan_inv.size(), F);
+  for (size_t k = 0; k + 1 < nb; ++k) pre->tan_inv[k] = vdfhost::mul(pre->tan_inv[k], pre->w[k].zzz, F);
+  // the affine doublings and the tangent's witness values, as ec_double_raw computes them; each inverse is checked the
+  // way CS::take_inverse checks a queued one (a wrong one is replaced by a real inversion and counted)
+  Fe wx = P.x, wy = P.y;
+  pre->misses = 0;
+  for (size_t k = 0; k < nb; ++k) {
+    pre->wx[k] = wx; pre->wy[k] = wy;
+    if (k + 1 == nb) break;
+    const Fe two_y = vdfhost::add(wy, wy, F);
+    Fe inv = pre->tan_inv[k];
+    if (!(two_y.is_zero() ? inv.is_zero() : vdfhost::mul(two_y, inv, F) == one(F))) { inv = inverse(two_y, F); pre->tan_inv[k] = inv; ++pre->misses; }
+    const Fe x2 = sqr(wx, F);
+    const Fe lam = vdfhost::mul(vdfhost::add(vdfhost::add(x2, x2, F), x2, F), inv, F);
+    const Fe dx = vdfhost::sub(sqr(lam, F), vdfhost::add(wx, wx, F), F);
+    const Fe dy = vdfhost::sub(vdfhost::mul(lam, vdfhost::sub(wx, dx, F), F), wy, F);
+    pre->x2[k] = x2; pre->lam[k] = lam;
+    wx = dx; wy = dy;
   }
 }
 void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out,
-                      const std::vector<Pt>* doublings) {
-  std::vector<Pt> own;
-  if (!doublings) { ec_fold_doublings(F, P, bits, &own); doublings = &own; }
-  const std::vector<Pt>& ws = *doublings;
-  const size_t base = out->size(), n = 2 * (size_t)bits;
+                      const FoldPre* prepared) {
+  FoldPre own;
+  if (!prepared) { ec_fold_prepare(F, P, bits, &own); prepared = &own; }
+  const FoldPre& pre = *prepared;
+  const size_t nb = (size_t)bits, base = out->size(), n = 2 * nb;
   out->resize(base + n);
-  Fe* d = out->data() + base;
-  std::vector<Fe> scale(n);                                 // what each inverted denominator is multiplied by
+  Fe* q = out->data() + base;                               // chord_0, tangent_0, chord_1, ..., chord_(bits-1), final
+  static thread_local std::vector<Fe> d, scale;             // the chords and the final slope: inverted together here
+  d.resize(nb + 1); scale.resize(nb + 1);
   Pt acc = pt_identity();
-  size_t q = 0;
-  for (int k = 0; k < bits; ++k) {
-    const Pt& w = ws[k];
-    if (acc.is_id()) { d[q] = w.x; scale[q] = w.zz; }
+  for (size_t k = 0; k < nb; ++k) {
+    const Pt& w = pre.w[k];
+    if (acc.is_id()) { d[k] = w.x; scale[k] = w.zz; }
     else {
-      d[q] = vdfhost::sub(vdfhost::mul(w.x, acc.zz, F), vdfhost::mul(acc.x, w.zz, F), F);
-      scale[q] = vdfhost::mul(w.zz, acc.zz, F);
+      d[k] = vdfhost::sub(vdfhost::mul(w.x, acc.zz, F), vdfhost::mul(acc.x, w.zz, F), F);
+      scale[k] = vdfhost::mul(w.zz, acc.zz, F);
     }
-    ++q;
     if ((r[k / 64] >> (k % 64)) & 1) acc = pt_add(acc, w, F);
-    if (k + 1 < bits) {
-      d[q] = vdfhost::add(w.y, w.y, F);
-      scale[q] = w.zzz;
-      ++q;
-    }
   }
   // acc = [r] P now (the identity also when P is)
   bool same_x = false;
-  if (acc.is_id()) { d[q] = vdfhost::sub(vdfhost::zero(), U.x, F); scale[q] = one(F); }       // x_rP = 0
+  if (acc.is_id()) { d[nb] = vdfhost::sub(vdfhost::zero(), U.x, F); scale[nb] = one(F); }     // x_rP = 0
   else {
-    d[q] = vdfhost::sub(acc.x, vdfhost::mul(U.x, acc.zz, F), F);
-    scale[q] = acc.zz;
-    same_x = d[q].is_zero();
+    d[nb] = vdfhost::sub(acc.x, vdfhost::mul(U.x, acc.zz, F), F);
+    scale[nb] = acc.zz;
+    same_x = d[nb].is_zero();
   }
   if (U.x.is_zero() && acc.is_id()) same_x = true;
-  if (same_x) { d[q] = vdfhost::add(U.y, U.y, F); scale[q] = one(F); }
-  ++q;
-  batch_inverse(d, n, F);
-  for (size_t i = 0; i < n; ++i) d[i] = vdfhost::mul(d[i], scale[i], F);
+  if (same_x) { d[nb] = vdfhost::add(U.y, U.y, F); scale[nb] = one(F); }
+  batch_inverse(d.data(), nb + 1, F);
+  for (size_t k = 0; k < nb; ++k) {
+    q[2 * k] = vdfhost::mul(d[k], scale[k], F);
+    if (k + 1 < nb) q[2 * k + 1] = pre.tan_inv[k];
+  }
+  q[n - 1] = vdfhost::mul(d[nb], scale[nb], F);
 }
 
 // Witness of ec_scalar_mul (above) written directly: the same variables in the same order -- per bit the chord's slope and
 // sum (3), the two selections by "accumulator still empty" (2), the two by the bit (2), the emptiness flag (1), then the
 // tangent's x^2, slope and double (4, not after the last bit); finally keep * acc (2) -- computed with nine field
-// multiplications per bit instead of through ~40 Num operations.  Slopes take their inverses from cs.inv_queue
-// (ec_fold_inverses), checked as take_inverse checks them.  tests/test_nova_host.py compares the result with the oracle's
+// multiplications per bit instead of through ~40 Num operations (the tangent's four come ready from ec_fold_prepare).
+// Slopes take their inverses from cs.inv_queue (ec_fold_inverses), checked as take_inverse checks them.  tests/test_nova_host.py compares the result with the oracle's
 // gadget-by-gadget synthesis.
-static void ec_scalar_mul_witness(CS& cs, const uint64_t r[4], int bits, const Aff& P, Fe* rx, Fe* ry) {
+static void ec_scalar_mul_witness(CS& cs, const uint64_t r[4], int bits, const Aff& P, const FoldPre& pre, Fe* rx, Fe* ry) {
   const Field& F = cs.F;
   const Fe ONE = one(F), ZERO = vdfhost::zero();
-  Fe ax = ZERO, ay = ZERO, wx = P.x, wy = P.y;
+  Fe ax = ZERO, ay = ZERO;
   bool acc_inf = true;
   std::vector<Fe>& W = cs.W;
+  cs.inv_misses += pre.misses;
   for (int k = 0; k < bits; ++k) {
     const bool bit = (r[k / 64] >> (k % 64)) & 1;
+    const Fe& wx = pre.wx[k];
+    const Fe& wy = pre.wy[k];
     const Fe dxn = vdfhost::sub(wx, ax, F), dyn = vdfhost::sub(wy, ay, F);
     const Fe lam = vdfhost::mul(dyn, cs.take_inverse(dxn), F);
     const Fe sx = vdfhost::sub(vdfhost::sub(sqr(lam, F), ax, F), wx, F);
@@ -680,14 +706,9 @@ static void ec_scalar_mul_witness(CS& cs, const uint64_t r[4], int bits, const A
     if (bit) { ax = cx; ay = cy; acc_inf = false; }
     W.push_back(lam); W.push_back(sx); W.push_back(sy); W.push_back(cx); W.push_back(cy); W.push_back(ax); W.push_back(ay);
     W.push_back(acc_inf ? ONE : ZERO);
-    if (k + 1 < bits) {
-      const Fe x2 = sqr(wx, F);
-      const Fe two_y = vdfhost::add(wy, wy, F), three_x2 = vdfhost::add(vdfhost::add(x2, x2, F), x2, F);
-      const Fe lam_d = vdfhost::mul(three_x2, cs.take_inverse(two_y), F);
-      const Fe dx = vdfhost::sub(sqr(lam_d, F), vdfhost::add(wx, wx, F), F);
-      const Fe dy = vdfhost::sub(vdfhost::mul(lam_d, vdfhost::sub(wx, dx, F), F), wy, F);
-      W.push_back(x2); W.push_back(lam_d); W.push_back(dx); W.push_back(dy);
-      wx = dx; wy = dy;
+    if (k + 1 < bits) {                                   // the tangent: prepared, its inverse checked there
+      ++cs.inv_pos;
+      W.push_back(pre.x2[k]); W.push_back(pre.lam[k]); W.push_back(pre.wx[k + 1]); W.push_back(pre.wy[k + 1]);
     }
   }
   cs.rows += (size_t)bits * 8 + (size_t)(bits - 1) * 4 + 2;
@@ -1038,15 +1059,19 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   Blk b2, b3, b4, b5, b6;
   uint64_t rv[4] = {0, 0, 0, 0};
   std::atomic<bool> r_ready{false};
-  struct alignas(64) FoldOut { Fe x, y; size_t queued = 0, misses = 0; double done = 0; } fo_w, fo_e;
+  struct alignas(64) FoldOut { Fe x, y; size_t queued = 0, misses = 0; double done = 0, tr[4] = {0, 0, 0, 0}; } fo_w, fo_e;
   auto run_fold = [&](const Aff& Upt, const Aff& P, Blk* b, FoldOut* o) {
     CS t(fid, false);
-    std::vector<Pt> doublings;
-    ec_fold_doublings(F, P, CHAL_BITS, &doublings);
+    static thread_local FoldPre pre;                  // a helper thread keeps its scratch: no allocation, no page fault per step
+    ec_fold_prepare(F, P, CHAL_BITS, &pre);
+    o->tr[0] = us();
     for (unsigned n = 0; !r_ready.load(std::memory_order_acquire); ++n) { if (n < 200000) __builtin_ia32_pause(); else std::this_thread::yield(); }
-    ec_fold_inverses(F, Upt, P, rv, CHAL_BITS, &t.inv_queue, &doublings);
+    o->tr[1] = us();
+    ec_fold_inverses(F, Upt, P, rv, CHAL_BITS, &t.inv_queue, &pre);
+    o->tr[2] = us();
     Num rx, ry, fx, fy;
-    ec_scalar_mul_witness(t, rv, CHAL_BITS, P, &rx.v, &ry.v);
+    ec_scalar_mul_witness(t, rv, CHAL_BITS, P, pre, &rx.v, &ry.v);
+    o->tr[3] = us();
     ec_add_complete(t, val(Upt.x), val(Upt.y), rx, ry, &fx, &fy);
     o->x = fx.v; o->y = fy.v;
     o->queued = t.inv_queue.size();
@@ -1058,8 +1083,8 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   bool pending[3] = {e.pending0, false, false};
   // an exception below must not leave a fold spinning for r: the joiner releases them first
   struct Joiner { Helpers& h; bool* p; std::atomic<bool>* go; ~Joiner() { go->store(true, std::memory_order_release); for (int k = 1; k < 3; ++k) if (p[k]) h.wait(k); } } joiner{H, pending, &r_ready};   // slot 0: ~AugEarly
-  // ---- blocks 3, 4 (helpers 1, 2): U + [r] P, slopes from the native pre-pass.  Started before r is known: the doublings
-  // 2^k P need only P and run beside the challenge hash; each fold then waits for r_ready.
+  // ---- blocks 3, 4 (helpers 1, 2): U + [r] P, slopes from the native pre-pass.  Started before r is known: the doubling
+  // side (ec_fold_prepare) needs only P and runs beside the challenge hash; each fold then waits for r_ready.
   if (e.helped) {
     H.start(1, [&] { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); }); pending[1] = true;
     H.start(2, [&] { run_fold(in.U.comm_E, in.T, &b4, &fo_e); }); pending[2] = true;
@@ -1160,8 +1185,8 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   cs.alloc_io(h_out_v);
   cs.rows += 1;
   cs.resolve();
-  if (trace) fprintf(stderr, "synth side %d: late start %.0f  challenge %.0f  foreign %.0f  fold_w %.0f fold_e %.0f  joined %.0f  step done %.0f  end %.0f us\n",
-                     side, tr[0], tr[1], tr[2], fo_w.done, fo_e.done, tr[3], tr[4], us());
+  if (trace) fprintf(stderr, "synth side %d: late start %.0f  challenge %.0f  foreign %.0f  fold_w %.0f [prepared %.0f r %.0f inverses %.0f witness %.0f] fold_e %.0f  joined %.0f  step done %.0f  end %.0f us\n",
+                     side, tr[0], tr[1], tr[2], fo_w.done, fo_w.tr[0], fo_w.tr[1], fo_w.tr[2], fo_w.tr[3], fo_e.done, tr[3], tr[4], us());
   (void)params; (void)Ty; (void)uWy; (void)T_inf;
   g_last_queue = fo_w.queued + fo_e.queued;
   g_last_misses = fo_w.misses + fo_e.misses;

@@ -103,10 +103,16 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
 // n inverses with one inversion (Montgomery's trick); zeros stay zero
 void batch_inverse(Fe* v, size_t n, const Field& F);
 // the slope inverses of  U + [r] P  as ec_scalar_mul followed by ec_add_complete will request them, appended to out
-// (doublings: the points 2^k P, k < bits, from ec_fold_doublings -- they need no r and may be made ahead; null: made here)
-void ec_fold_doublings(const Field& F, const Aff& P, int bits, std::vector<Pt>* w);
+// (prepared: the doubling side, which needs no r and may be made ahead of it -- the points 2^k P, the tangents' inverses,
+// the affine doublings and the tangent's witness values; null: made here)
+struct FoldPre {
+  std::vector<Pt> w;
+  std::vector<Fe> tan_inv, wx, wy, x2, lam;
+  size_t misses = 0;
+};
+void ec_fold_prepare(const Field& F, const Aff& P, int bits, FoldPre* pre);
 void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t r[4], int bits, std::vector<Fe>* out,
-                      const std::vector<Pt>* doublings = nullptr);
+                      const FoldPre* prepared = nullptr);
 void fold_foreign(CS& cs, const Num& a_lo, const Num& a_hi, const std::vector<Num>& b_bits, const std::vector<Num>& r_bits,
                   const Field& foreign, Num* r_lo, Num* r_hi);
 
