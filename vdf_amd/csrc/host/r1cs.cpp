@@ -653,15 +653,31 @@ void ec_fold_inverses(const Field& F, const Aff& U, const Aff& P, const uint64_t
   Fe* q = out->data() + base;                               // chord_0, tangent_0, chord_1, ..., chord_(bits-1), final
   static thread_local std::vector<Fe> d, scale;             // the chords and the final slope: inverted together here
   d.resize(nb + 1); scale.resize(nb + 1);
+  // the accumulator's chain as MIXED additions with the affine doublings of `pre`; the chord's denominator
+  // x_w - x_a = (x_w zz_a - X_a) / zz_a is the first product of that addition
   Pt acc = pt_identity();
+  const bool p_id = P.x.is_zero() && P.y.is_zero();
   for (size_t k = 0; k < nb; ++k) {
-    const Pt& w = pre.w[k];
-    if (acc.is_id()) { d[k] = w.x; scale[k] = w.zz; }
-    else {
-      d[k] = vdfhost::sub(vdfhost::mul(w.x, acc.zz, F), vdfhost::mul(acc.x, w.zz, F), F);
-      scale[k] = vdfhost::mul(w.zz, acc.zz, F);
+    const Fe& wx = pre.wx[k];
+    const Fe& wy = pre.wy[k];
+    const bool bit = (r[k / 64] >> (k % 64)) & 1;
+    if (p_id) { d[k] = vdfhost::zero(); scale[k] = one(F); continue; }
+    if (acc.is_id()) {
+      d[k] = wx; scale[k] = one(F);
+      if (bit) { acc.x = wx; acc.y = wy; acc.zz = one(F); acc.zzz = one(F); }
+      continue;
     }
-    if ((r[k / 64] >> (k % 64)) & 1) acc = pt_add(acc, w, F);
+    const Fe pp1 = vdfhost::sub(vdfhost::mul(wx, acc.zz, F), acc.x, F);
+    d[k] = pp1; scale[k] = acc.zz;
+    if (!bit) continue;
+    if (pp1.is_zero()) { acc = pt_add(acc, pt_from_aff(Aff{wx, wy}, F), F); continue; }    // never for a point of prime order
+    const Fe rr = vdfhost::sub(vdfhost::mul(wy, acc.zzz, F), acc.y, F);
+    const Fe pp = sqr(pp1, F), ppp = vdfhost::mul(pp1, pp, F), qq = vdfhost::mul(acc.x, pp, F);
+    const Fe x3 = vdfhost::sub(vdfhost::sub(vdfhost::sub(sqr(rr, F), ppp, F), qq, F), qq, F);
+    acc.y = vdfhost::sub(vdfhost::mul(rr, vdfhost::sub(qq, x3, F), F), vdfhost::mul(acc.y, ppp, F), F);
+    acc.x = x3;
+    acc.zz = vdfhost::mul(acc.zz, pp, F);
+    acc.zzz = vdfhost::mul(acc.zzz, ppp, F);
   }
   // acc = [r] P now (the identity also when P is)
   bool same_x = false;
@@ -692,8 +708,10 @@ static void ec_scalar_mul_witness(CS& cs, const uint64_t r[4], int bits, const A
   const Fe ONE = one(F), ZERO = vdfhost::zero();
   Fe ax = ZERO, ay = ZERO;
   bool acc_inf = true;
-  std::vector<Fe>& W = cs.W;
   cs.inv_misses += pre.misses;
+  const size_t count = (size_t)bits * 8 + (size_t)(bits - 1) * 4 + 2, at = cs.W.size();
+  cs.W.resize(at + count);
+  Fe* out = cs.W.data() + at;
   for (int k = 0; k < bits; ++k) {
     const bool bit = (r[k / 64] >> (k % 64)) & 1;
     const Fe& wx = pre.wx[k];
@@ -704,18 +722,19 @@ static void ec_scalar_mul_witness(CS& cs, const uint64_t r[4], int bits, const A
     const Fe sy = vdfhost::sub(vdfhost::mul(lam, vdfhost::sub(ax, sx, F), F), ay, F);
     const Fe cx = acc_inf ? wx : sx, cy = acc_inf ? wy : sy;
     if (bit) { ax = cx; ay = cy; acc_inf = false; }
-    W.push_back(lam); W.push_back(sx); W.push_back(sy); W.push_back(cx); W.push_back(cy); W.push_back(ax); W.push_back(ay);
-    W.push_back(acc_inf ? ONE : ZERO);
+    out[0] = lam; out[1] = sx; out[2] = sy; out[3] = cx; out[4] = cy; out[5] = ax; out[6] = ay; out[7] = acc_inf ? ONE : ZERO;
+    out += 8;
     if (k + 1 < bits) {                                   // the tangent: prepared, its inverse checked there
       ++cs.inv_pos;
-      W.push_back(pre.x2[k]); W.push_back(pre.lam[k]); W.push_back(pre.wx[k + 1]); W.push_back(pre.wy[k + 1]);
+      out[0] = pre.x2[k]; out[1] = pre.lam[k]; out[2] = pre.wx[k + 1]; out[3] = pre.wy[k + 1];
+      out += 4;
     }
   }
-  cs.rows += (size_t)bits * 8 + (size_t)(bits - 1) * 4 + 2;
+  cs.rows += count;
   const bool p_inf = P.x.is_zero();
   *rx = p_inf ? ZERO : ax;
   *ry = p_inf ? ZERO : ay;
-  W.push_back(*rx); W.push_back(*ry);
+  out[0] = *rx; out[1] = *ry;
 }
 
 // ---- multi-limb integers for the foreign fold (little-endian 64-bit limbs) ---------------------------------------
