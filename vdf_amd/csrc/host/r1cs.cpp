@@ -550,9 +550,24 @@ void ec_add_complete(CS& cs, const Num& x1, const Num& y1, const Num& x2, const 
 namespace {
 class Helpers {
  public:
-  static Helpers& get() { static Helpers* h = new Helpers(); return *h; }     // never destroyed: its threads outlive main
-  // returns false when the helpers are taken: the caller then runs the work itself
-  bool try_acquire() { bool f = false; return busy_.compare_exchange_strong(f, true); }
+  // A process has up to SETS sets of helpers, made when first wanted and never destroyed (their threads outlive main):
+  // one per prover running at a time -- two chains proven by two host threads each get their own.  nullptr: all taken,
+  // the caller then runs the work itself.
+  static Helpers* acquire() {
+    static std::atomic<Helpers*> sets[SETS] = {};
+    for (int k = 0; k < SETS; ++k) {
+      Helpers* h = sets[k].load(std::memory_order_acquire);
+      if (!h) {
+        Helpers* made = new Helpers();
+        made->busy_.store(true);
+        if (sets[k].compare_exchange_strong(h, made)) return made;
+        made->retire();                                   // lost the race for this slot: h is the winner's set
+      }
+      bool f = false;
+      if (h->busy_.compare_exchange_strong(f, true)) return h;
+    }
+    return nullptr;
+  }
   void release() { busy_.store(false); }
   void start(int k, std::function<void()> fn) {
     Slot& s = slots_[k];
@@ -577,17 +592,20 @@ class Helpers {
     std::mutex mu;
     std::condition_variable cv;
   };
+  static constexpr int SETS = 2;
   Helpers() { for (int k = 0; k < NSLOT; ++k) std::thread([this, k] { loop(k); }).detach(); }
+  void retire() { quit_.store(true); for (int k = 0; k < NSLOT; ++k) { Slot& s = slots_[k]; std::lock_guard<std::mutex> l(s.mu); s.cv.notify_one(); } }   // leaked, threads exit
   void loop(int k) {
     Slot& s = slots_[k];
     for (;;) {
       auto idle_since = std::chrono::steady_clock::now();
       while (s.state.load(std::memory_order_acquire) != 1) {
+        if (quit_.load(std::memory_order_relaxed)) return;
         __builtin_ia32_pause();
         if (std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
           std::unique_lock<std::mutex> l(s.mu);
           s.parked.store(true, std::memory_order_release);
-          s.cv.wait(l, [&] { return s.state.load(std::memory_order_acquire) == 1; });
+          s.cv.wait(l, [&] { return s.state.load(std::memory_order_acquire) == 1 || quit_.load(); });
           s.parked.store(false, std::memory_order_release);
         }
       }
@@ -598,7 +616,7 @@ class Helpers {
   }
   static constexpr int NSLOT = 3;
   Slot slots_[NSLOT];
-  std::atomic<bool> busy_{false};
+  std::atomic<bool> busy_{false}, quit_{false};
 };
 }  // namespace
 
@@ -991,9 +1009,10 @@ struct AugEarly {
   std::vector<Num> xb[2];
   bool have_out = false;
   std::vector<Fe> z_out;
+  Helpers* helpers = nullptr;            // the set this synthesis holds (null: none was free, everything runs inline)
   bool helped = false, pending0 = false;
   ~AugEarly() {
-    if (helped) { if (pending0) Helpers::get().wait(0); Helpers::get().release(); }
+    if (helped) { if (pending0) helpers->wait(0); helpers->release(); }
   }
 };
 void aug_early_free(AugEarly* e) { delete e; }
@@ -1022,9 +1041,9 @@ AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const Step
     strict_bits(t, val(sp.finish(t)));
     take(p->b1, t);
   };
-  Helpers& H = Helpers::get();
-  e->helped = H.try_acquire();
-  if (e->helped) { H.start(0, run_b1); e->pending0 = true; } else run_b1();
+  e->helpers = Helpers::acquire();
+  e->helped = e->helpers != nullptr;
+  if (e->helped) { e->helpers->start(0, run_b1); e->pending0 = true; } else run_b1();
   // ---- block 2, first half: the challenge hash over what is known (params and the running instance)
   e->chal.reset(new CS(fid, false));
   e->chal_sp.init(TAG_CHAL, 16, F);
@@ -1098,15 +1117,15 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
     take(*b, t);
     o->done = us();
   };
-  Helpers& H = Helpers::get();
+  Helpers* Hp = e.helpers;
   bool pending[3] = {e.pending0, false, false};
   // an exception below must not leave a fold spinning for r: the joiner releases them first
-  struct Joiner { Helpers& h; bool* p; std::atomic<bool>* go; ~Joiner() { go->store(true, std::memory_order_release); for (int k = 1; k < 3; ++k) if (p[k]) h.wait(k); } } joiner{H, pending, &r_ready};   // slot 0: ~AugEarly
+  struct Joiner { Helpers* h; bool* p; std::atomic<bool>* go; ~Joiner() { go->store(true, std::memory_order_release); for (int k = 1; k < 3; ++k) if (p[k]) h->wait(k); } } joiner{Hp, pending, &r_ready};   // slot 0: ~AugEarly
   // ---- blocks 3, 4 (helpers 1, 2): U + [r] P, slopes from the native pre-pass.  Started before r is known: the doubling
   // side (ec_fold_prepare) needs only P and runs beside the challenge hash; each fold then waits for r_ready.
   if (e.helped) {
-    H.start(1, [&] { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); }); pending[1] = true;
-    H.start(2, [&] { run_fold(in.U.comm_E, in.T, &b4, &fo_e); }); pending[2] = true;
+    Hp->start(1, [&] { run_fold(in.U.comm_W, in.u_W, &b3, &fo_w); }); pending[1] = true;
+    Hp->start(2, [&] { run_fold(in.U.comm_E, in.T, &b4, &fo_e); }); pending[2] = true;
   }
   // ---- block 2, second half (this thread): the fold challenge
   std::vector<Num> r_bits;
@@ -1146,7 +1165,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   cs.alloc(uX[0]); cs.alloc(uX[1]);
   const Num Tx = cs.alloc(in.T.x), Ty = cs.alloc(in.T.y);
   const Num is_base = is_zero(cs, i);
-  if (e.pending0) { H.wait(0); e.pending0 = false; pending[0] = false; }
+  if (e.pending0) { Hp->wait(0); e.pending0 = false; pending[0] = false; }
   splice(cs, e.b1);
   cs.rows += 1;                                       // (1 - is_base) (u.X[0] - h_in) = 0
   splice(cs, b2);
@@ -1154,9 +1173,9 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   check_on_curve(cs, uWx, uWy, uW_inf);
   const Num T_inf = is_zero(cs, Tx);
   check_on_curve(cs, Tx, Ty, T_inf);
-  if (pending[1]) { H.wait(1); pending[1] = false; }
-  if (pending[2]) { H.wait(2); pending[2] = false; }
-  if (e.helped) { H.release(); e.helped = false; }
+  if (pending[1]) { Hp->wait(1); pending[1] = false; }
+  if (pending[2]) { Hp->wait(2); pending[2] = false; }
+  if (e.helped) { Hp->release(); e.helped = false; }
   tr[3] = us();
   splice(cs, b3);
   splice(cs, b4);
