@@ -243,9 +243,16 @@ int alloc_proof_buffers(vdf_proof* p) {
 // commitment of the last secondary witness (its MSM normally rides in the next step's batch)
 int finalize_l2(const vdf_proof* cp) {
   vdf_proof* p = const_cast<vdf_proof*>(cp);
-  if (p->l2_committed) return VDF_OK;
   const Side& sd = p->pp->s[SECONDARY];
   vdf_ctx* ctx = sd.ctx;
+  if (p->nifs2 == vdf_proof::NIFS2_INFLIGHT) {        // the step launched it on its way out: collect
+    vdf_jac* hb = &p->h_pts[vdf_proof::RING];
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    if (!p->l2_committed) { p->l2.comm_W = jac_to_aff(hb[0], *sd.Fb); p->l2_committed = true; }
+    p->nifs2_T = jac_to_aff(hb[1], *sd.Fb);
+    p->nifs2 = vdf_proof::NIFS2_DONE;
+  }
+  if (p->l2_committed) return VDF_OK;
   vdf_jac* slot = &p->h_pts[vdf_proof::RING];
   HIPCALL(ctx, vdf_msm(ctx, sd.gens, 0, (const vdf_fe*)p->d_l2z, sd.num_vars, 1, slot));
   HIPCALL(ctx, vdf_ctx_sync(ctx));
@@ -752,7 +759,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   const bool t_ahead = !first && !custom && pp->ahead_rows != 0;
   const size_t ta_b = pp->ahead_row, ta_n = pp->ahead_rows, ta_e = ta_b + ta_n;
   vdf_ctx* ct = p->ctx3;
-  auto early_rows = [&]() -> int {
+  auto early_rows = [&](void* d_z2, vdf_ctx* cq) -> int {            // for the step whose fresh witness lives in d_z2
     SideState& s1 = p->r[PRIMARY];
     HIPCALL(ct, vdf_ctx_wait_mark(ct, cq, MARK_Z));                 // the rounds are in place (written a step ago, normally)
     // z_in = z_i past the base step (the circuit's selection); the same values arrive again with the host's variables
@@ -791,7 +798,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   AugEarlyPtr early1(nullptr, aug_early_free), early2(nullptr, aug_early_free);
   auto make_early1 = [&] { return synthesize_augmented_early(PRIMARY, in1, *c1); };
   // ---- (a) NIFS on the secondary side: cross term of (running, l2), commitments of l2's witness and of T ----------
-  if (!first) {
+  auto launch_nifs2 = [&]() -> int {               // cross term of (running secondary, l2), commit(w2) unless known, commit(T2)
     SideState& s2 = p->r[SECONDARY];
     HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
                                      (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
@@ -803,18 +810,30 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const vdf_fe* sc[2] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T};
       HIPCALL(ctx, vdf_msm_batch(ctx, S2.gens, 2, off, sc, len, 1, hb));
     }
+    return VDF_OK;
+  };
+  if (!first) {
+    if (p->nifs2 == vdf_proof::NIFS2_NONE) {       // normally in flight since the previous step's last lines
+      int rc = launch_nifs2();
+      if (rc != VDF_OK) return rc;
+      p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
+    }
     // launched while the host waits for this side's commitments, on a queue of their own: their 0.6 ms must be over when
     // the primary side's own commitments are (0.65 ms into the step), and this side's direct sum, one prioritised
     // wavefront per SIMD for 0.1 ms, loses little to a bucket accumulation beside it
-    if (t_ahead) {
+    const bool rows_inflight = t_ahead && hit && p->tahead_valid && p->tahead_slot == slot && p->tahead_k == k &&
+                               p->tahead_circuits == circuits;       // launched by the previous step on its way out
+    if (t_ahead && !rows_inflight) {
       if (pp->ahead_mode == 1) HIPCALL(ct, vdf_ctx_wait(ct, ctx));
-      int rc = early_rows();
+      else if (p->tahead_valid) HIPCALL(ct, vdf_ctx_sync(ct));       // rows made for a step that did not come: let them finish
+      int rc = early_rows(d_z2, cq);
       if (rc != VDF_OK) return rc;
     }
+    p->tahead_valid = false;
     early1 = make_early1();                         // the host's share of the wait: what the circuit can do without T
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
-    if (!p->l2_committed) { p->l2.comm_W = jac_aff(hb[0], *S2.Fb); p->l2_committed = true; }
-    comm_T2 = jac_aff(hb[1], *S2.Fb);
+    { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }      // waits, collects comm_W2 and comm_T2
+    comm_T2 = p->nifs2_T;
+    p->nifs2 = vdf_proof::NIFS2_NONE;               // consumed: the fold below uses the scratch vectors up
   }
   t1 = now_ms();
   // ---- (b) the primary augmented circuit -----------------------------------------------------------------------
@@ -940,9 +959,27 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->zi[SECONDARY] = z_next;
   }
   t6 = now_ms();
-  // the staging buffers are rewritten by the next call: their copies must have left; and nothing in flight may read the
-  // circuits' memory once this call returns
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
+  // the staging buffers are rewritten by the next call: their copies must have left (mark 3), and nothing in flight may
+  // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
+  // needs nothing of the next step: the NIFS of the secondary instance just made (VDF_NOVA_NIFS_AHEAD=0: left to the next call)
+  HIPCALL(ctx, vdf_ctx_mark(ctx, 3));
+  {
+    static const bool ahead = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
+    // the early rows of the next step's cross term: its rounds are in their ring slot (the lookahead above), its input is
+    // this step's output, the running instance is final once the fold just enqueued is done
+    if (ahead && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
+      HIPCALL(ct, vdf_ctx_wait(ct, ctx));                             // ... and the fold read T and A z, B z, C z of this step
+      int rc = early_rows(p->d_z2s[p->ahead[0].slot], p->ctx2[(k + 1) % D]);
+      if (rc != VDF_OK) return rc;
+      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
+    }
+    if (ahead) {
+      int rc = launch_nifs2();
+      if (rc != VDF_OK) return rc;
+      p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
+    }
+  }
+  HIPCALL(ctx, vdf_ctx_sync_mark(ctx, 3));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   p->i += 1;
   p->last.comm_W1 = *(const vdf_affine*)&l1.comm_W;
@@ -1071,6 +1108,9 @@ int vdf_nova_verify_custom(const vdf_proof* p, vdf_pp* pp, size_t num_steps, con
     vdf_ctx* ctx = pp->ctx;
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     vdf_proof* q = const_cast<vdf_proof*>(p);                                  // scratch buffers only
+    q->nifs2 = vdf_proof::NIFS2_NONE;          // ... which hold the next step's cross terms: that step makes them again
+    if (q->ctx3) HIPCALL(q->ctx3, vdf_ctx_sync(q->ctx3));
+    q->tahead_valid = false;
     bool good = false;
     for (int s = 0; s < 2; ++s) {
       int rc = check_sat(pp->s[s], p->r[s].inst, p->r[s].d_z, p->r[s].d_E, q->r[s].d_abc2, q->r[s].d_T, &good);

@@ -120,6 +120,19 @@ struct vdf_proof {
   vdfnova::Inst l2;
   void* d_l2z = nullptr;
   bool l2_committed = false;
+  // The NIFS of the last secondary instance (cross term, commit(w2), commit(T2)) needs nothing of the next step: prove_step
+  // launches it on its way out, the next prove_step only waits for it.  NONE: not launched / results used or overwritten;
+  // INFLIGHT: on the queue, results going to h_pts[RING], h_pts[RING + 1]; DONE: collected (comm_T2 in nifs2_T, A z, B z,
+  // C z and T of the fresh instance still in the secondary side's scratch vectors)
+  enum { NIFS2_NONE = 0, NIFS2_INFLIGHT = 1, NIFS2_DONE = 2 };
+  int nifs2 = NIFS2_NONE;
+  Aff nifs2_T;
+  // ... and so do the early rows of the NEXT step's cross term, when that step's rounds are already in their ring slot
+  // (the lookahead): launched on the way out of a step too; valid for the step that finds this slot and circuit
+  bool tahead_valid = false;
+  int tahead_slot = -1;
+  size_t tahead_k = 0;
+  const vdf_circuits* tahead_circuits = nullptr;
   // fresh primary z: ring of slots, the MinRoot segment of a later step is filled (and committed) ahead of time on ctx2
   static constexpr int DEPTH = 1, RING = DEPTH + 2;
   vdf_ctx* ctx2[DEPTH] = {};
