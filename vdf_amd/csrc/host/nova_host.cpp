@@ -484,7 +484,9 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     // ~10^4-term witnesses of an augmented circuit -> 15 (measured: 10, 11, 13 and 15 within 4 %, 15 best)
     int small_c = 15;
     if (const char* ov = std::getenv("VDF_NOVA_SMALL_WINDOW")) { const int v = atoi(ov); if (v >= 6 && v <= 16) small_c = v; }   // tuning
-    HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? 16 : small_c, 1));
+    int big_c = 16;
+    if (const char* ov = std::getenv("VDF_NOVA_BIG_WINDOW")) { const int v = atoi(ov); if (v >= 12 && v <= 20) big_c = v; }       // tuning
+    HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? big_c : small_c, 1));
     // The commitments a step WAITS for are small: the secondary circuit's witness and cross term (~10^4 terms each), and
     // on the primary side what the host made of the witness and the rows of T that depend on it.  Their generators get
     // a digit table (vdf_bases_precompute_digits: a plain sum of gathered multiples, no buckets); the rounds' 2 x 10^5
