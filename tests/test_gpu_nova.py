@@ -184,6 +184,7 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
     proof as with T in one piece, and the early run covers the rounds' constraints (3 per round, all but the first
     round's, which read more of the witness)."""
     t, n = 64, 4
+    monkeypatch.delenv("VDF_NOVA_T_AHEAD", raising=False)       # the default is what is under test
     pp, z0, circuits, initial, _ = make(ctx, t, n, seed=12)
     rb, rn = pp.early_rows()
     assert 3 * t - 8 <= rn <= 3 * t + 2 and rb > 0
