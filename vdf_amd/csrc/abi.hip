@@ -935,7 +935,15 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
           tcm[p] = ci | ((uint32_t)k << 30);
         }
       for (size_t c = 0; c < num_cols; ++c) if (tcol[c + 1] - tcol[c] > 64) heavy.push_back((uint32_t)c);
+      // longest first: the few columns of thousands of entries (the constant's, the step counter's) are shared by
+      // several workgroups each, the many of a few hundred (bits used all over an augmented circuit) get one
+      std::sort(heavy.begin(), heavy.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t la = tcol[a + 1] - tcol[a], lb = tcol[b + 1] - tcol[b];
+        return la != lb ? la > lb : a < b;
+      });
       s->t_nheavy = heavy.size();
+      s->t_nbig = 0;
+      while (s->t_nbig < heavy.size() && tcol[heavy[s->t_nbig] + 1] - tcol[heavy[s->t_nbig]] > 4096) ++s->t_nbig;
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_colptr), (num_cols + 1) * 4);
       if (e == hipSuccess) e = hipMemcpy(s->d_t_colptr, tcol.data(), (num_cols + 1) * 4, hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_t_row), (nnz3 + 1) * 4);
@@ -1254,7 +1262,7 @@ int vdf_spmv3_t(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* eq, const vd
     if (!all_device({eq, out})) return Status{VDF_ERR_BAD_ARG, kDevVec};
     if (!ctx->reduce_scratch) VDF_TRY_HIP(hipMalloc(&ctx->reduce_scratch, vdf::snark_reduce_scratch_bytes()));
     VDF_TRY(vdf::snark_spmvt(shape->field, shape->d_t_colptr, shape->d_t_row, shape->d_t_cm, shape->d_t_heavy, shape->t_nheavy,
-                             shape->d_dict, eq, rho, shape->num_cols, out, ctx->reduce_scratch, ctx->stream));
+                             shape->t_nbig, shape->d_dict, eq, rho, shape->num_cols, out, ctx->reduce_scratch, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });

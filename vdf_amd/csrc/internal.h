@@ -69,7 +69,7 @@ struct vdf_shape {
   uint32_t* d_t_row = nullptr;                            // nnz[0] + nnz[1] + nnz[2]
   uint32_t* d_t_cm = nullptr;
   uint32_t* d_t_heavy = nullptr;                          // columns with more than 64 entries
-  size_t t_nheavy = 0;
+  size_t t_nheavy = 0, t_nbig = 0;                        // ... sorted longest first; the first t_nbig have more than 4096
   // rows with more than VDF_LONG_ROW entries, as row | matrix << 30: one wavefront each (vec_spmv_long) instead of one lane
   uint32_t* d_long = nullptr;
   size_t n_long = 0;
@@ -202,7 +202,7 @@ size_t snark_reduce_scratch_bytes();
 Status snark_reduce(int field, int kind, const void* const tables[], const vdf_fe* u, size_t n, void* scratch, void* out,
                     hipStream_t s);
 Status snark_spmvt(int field, const uint32_t* colptr, const uint32_t* rows, const uint32_t* cm, const uint32_t* heavy,
-                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, void* scratch,
+                   size_t nheavy, size_t nbig, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, void* scratch,
                    hipStream_t s);
 Status snark_ipa_scalars(int field, const void* a, const void* sv, size_t n, size_t nj, void* sL, void* sR, hipStream_t s);
 Status snark_scale_pattern(int field, void* sv, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi, hipStream_t s);

@@ -328,22 +328,30 @@ __global__ __launch_bounds__(64) void k_spmvt_heavy_sum(const uint32_t* __restri
 
 // scratch: snark_reduce_scratch_bytes() bytes (the context's reduction scratch), or nullptr
 Status snark_spmvt(int field, const uint32_t* colptr, const uint32_t* rows, const uint32_t* cm, const uint32_t* heavy,
-                   size_t nheavy, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out, void* scratch,
-                   hipStream_t s) {
+                   size_t nheavy, size_t nbig, const void* dict, const void* eq, const vdf_fe* rho, size_t ncols, void* out,
+                   void* scratch, hipStream_t s) {
   if (ncols == 0) return Status{};
   const FeArg r = to_arg(rho);
   SNARK_DISPATCH(field, k_spmvt, grid_for(ncols), dim3(256), 0, s, colptr, rows, cm, reinterpret_cast<const char*>(dict),
                  reinterpret_cast<const char*>(eq), r, ncols, reinterpret_cast<char*>(out));
   if (!nheavy) return Status{};
-  if (scratch && nheavy * SPMVT_PARTS * 32 <= snark_reduce_scratch_bytes()) {
-    SNARK_DISPATCH(field, k_spmvt_heavy_part, dim3((unsigned)(nheavy * SPMVT_PARTS)), dim3(256), 0, s, heavy, colptr, rows, cm,
-                   reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(scratch));
-    SNARK_DISPATCH(field, k_spmvt_heavy_sum, dim3((unsigned)nheavy), dim3(64), 0, s, heavy, reinterpret_cast<const char*>(scratch),
-                   reinterpret_cast<char*>(out));
-  } else {
-    SNARK_DISPATCH(field, k_spmvt_heavy, dim3((unsigned)nheavy), dim3(256), 0, s, heavy, colptr, rows, cm,
-                   reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(out));
+  // the list is sorted longest first: the first `nbig` columns (thousands of entries) are shared by SPMVT_PARTS workgroups
+  // each, as far as the scratch reaches; the others get one workgroup each
+  size_t shared = 0;
+  if (scratch) {
+    shared = nbig < nheavy ? nbig : nheavy;
+    const size_t room = snark_reduce_scratch_bytes() / (SPMVT_PARTS * 32);
+    if (shared > room) shared = room;
   }
+  if (shared) {
+    SNARK_DISPATCH(field, k_spmvt_heavy_part, dim3((unsigned)(shared * SPMVT_PARTS)), dim3(256), 0, s, heavy, colptr, rows, cm,
+                   reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(scratch));
+    SNARK_DISPATCH(field, k_spmvt_heavy_sum, dim3((unsigned)shared), dim3(64), 0, s, heavy, reinterpret_cast<const char*>(scratch),
+                   reinterpret_cast<char*>(out));
+  }
+  if (nheavy > shared)
+    SNARK_DISPATCH(field, k_spmvt_heavy, dim3((unsigned)(nheavy - shared)), dim3(256), 0, s, heavy + shared, colptr, rows, cm,
+                   reinterpret_cast<const char*>(dict), reinterpret_cast<const char*>(eq), r, reinterpret_cast<char*>(out));
   return Status{};
 }
 
