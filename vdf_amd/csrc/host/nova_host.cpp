@@ -850,16 +850,6 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     if (custom && static_cast<const CustomStepCircuit*>(c1.get())->rc != 0) return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed");
     if (cs.dev_len != seg_n || (seg_n && cs.dev_begin != seg_b)) return fail(VDF_ERR_DEVICE, "device segment moved");
     t2 = now_ms();
-    if (!first) {
-      // fold the secondary witness on the device (z, E, A z, B z, C z += r2 * fresh), the instance from the circuit
-      SideState& s2 = p->r[SECONDARY];
-      const Fe rr = int_to_fe(r2, F2);
-      vdf_fe* acc[5] = {(vdf_fe*)s2.d_z, (vdf_fe*)s2.d_E, (vdf_fe*)s2.d_abc[0], (vdf_fe*)s2.d_abc[1], (vdf_fe*)s2.d_abc[2]};
-      const vdf_fe* addv[5] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T, (const vdf_fe*)s2.d_abc2[0], (const vdf_fe*)s2.d_abc2[1],
-                               (const vdf_fe*)s2.d_abc2[2]};
-      const size_t len[5] = {S2.ncols, S2.num_cons, S2.num_cons, S2.num_cons, S2.num_cons};
-      HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
-    }
     p->r[SECONDARY].inst = inst_from_elements(unew, F1, F2);       // base step: the default instance
     // the host-made variables go next to the rounds the lookahead context has written (vdf_ctx_wait at their launch)
     int rc = upload_fresh(ctx, S1, cs, p->h_stage[PRIMARY], d_z2);
@@ -898,6 +888,17 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       }
     }
     HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
+    if (!first) {
+      // behind the primary side's launches (it does not depend on them, they do not wait for it): the fold of the secondary
+      // witness on the device (z, E, A z, B z, C z += r2 * fresh); the instance came from the circuit
+      SideState& s2 = p->r[SECONDARY];
+      const Fe rr = int_to_fe(r2, F2);
+      vdf_fe* acc[5] = {(vdf_fe*)s2.d_z, (vdf_fe*)s2.d_E, (vdf_fe*)s2.d_abc[0], (vdf_fe*)s2.d_abc[1], (vdf_fe*)s2.d_abc[2]};
+      const vdf_fe* addv[5] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T, (const vdf_fe*)s2.d_abc2[0], (const vdf_fe*)s2.d_abc2[1],
+                               (const vdf_fe*)s2.d_abc2[2]};
+      const size_t len[5] = {S2.ncols, S2.num_cons, S2.num_cons, S2.num_cons, S2.num_cons};
+      HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+    }
     t3 = now_ms();
     // the host's share of this wait: the secondary circuit's inputs but for comm_W and comm_T, and what it can do with them
     in2.params = pp->params[SECONDARY];
@@ -967,18 +968,19 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   HIPCALL(ctx, vdf_ctx_mark(ctx, 3));
   {
     static const bool ahead = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
-    // the early rows of the next step's cross term: its rounds are in their ring slot (the lookahead above), its input is
-    // this step's output, the running instance is final once the fold just enqueued is done
-    if (ahead && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
-      HIPCALL(ct, vdf_ctx_wait(ct, ctx));                             // ... and the fold read T and A z, B z, C z of this step
-      int rc = early_rows(p->d_z2s[p->ahead[0].slot], p->ctx2[(k + 1) % D]);
-      if (rc != VDF_OK) return rc;
-      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
-    }
+    // first the NIFS (the next call waits for it), then -- their dozen launches under its execution -- the early rows of
+    // the next step's cross term: its rounds are in their ring slot (the lookahead above), its input is this step's
+    // output, the running instance is final once the fold is done (mark 3, not the NIFS behind it)
     if (ahead) {
       int rc = launch_nifs2();
       if (rc != VDF_OK) return rc;
       p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
+    }
+    if (ahead && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
+      HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, 3));                     // ... and the fold read T and A z, B z, C z of this step
+      int rc = early_rows(p->d_z2s[p->ahead[0].slot], p->ctx2[(k + 1) % D]);
+      if (rc != VDF_OK) return rc;
+      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
     }
   }
   HIPCALL(ctx, vdf_ctx_sync_mark(ctx, 3));
