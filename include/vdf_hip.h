@@ -216,6 +216,9 @@ int  vdf_spmv3(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z, vdf_fe* Az
 int  vdf_cross_term(vdf_ctx* ctx, int field, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1,
                     const vdf_fe* Az2, const vdf_fe* Bz2, const vdf_fe* Cz2, const vdf_fe* u1,
                     size_t n, vdf_fe* T);
+/* is_zero = 1 iff all n elements are zero, decided on the device (a verifier's residual A z o B z - u C z - E is checked
+ * where it lies instead of being copied out); synchronises. */
+int  vdf_vec_is_zero(vdf_ctx* ctx, const vdf_fe* v, size_t n, int* is_zero);
 /* out = a + r*b   (nova-snark RelaxedR1CSWitness::fold: W1 + r*W2, E1 + r*T; K6).
  * `r` is one field element (host or device).  out may alias a. */
 int  vdf_axpy(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* r, const vdf_fe* b, size_t n, vdf_fe* out);

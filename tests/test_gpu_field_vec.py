@@ -280,6 +280,20 @@ def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
     shape.free()
 
 
+def test_vec_is_zero(ctx):
+    for n in (0, 1, 255, 256, 257, 70001):
+        v = np.zeros((n, 4), dtype="<u8")
+        assert ctx.vec_is_zero(_dev(v) if n else v, n)
+        for pos in ([0, n // 2, n - 1] if n else []):
+            w = v.copy()
+            w[pos, int(pos) % 4] = 1 << (pos % 64)
+            assert not ctx.vec_is_zero(_dev(w), n)
+            assert not ctx.vec_is_zero(w, n)                       # host memory is staged
+    with pytest.raises(Exception):
+        from vdf_amd._lib import lib
+        ctx._check(lib.vdf_vec_is_zero(ctx.handle, None, 0, None))
+
+
 @pytest.mark.parametrize("field", FIELDS)
 def test_fold_many_equals_axpy_per_vector(ctx, cref, field):
     rng = np.random.default_rng(42)

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "vdf_minroot_step_z_packed": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_minroot_step_segment": (_i, [_vp, _i, _vp, _u64, _vp, _i, _vp]),
+    "vdf_vec_is_zero": (_i, [_vp, _vp, _sz, C.POINTER(C.c_int)]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term_rows": (_i, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),

@@ -1018,6 +1018,23 @@ int vdf_cross_term(vdf_ctx* ctx, int field, const vdf_fe* Az1, const vdf_fe* Bz1
   });
 }
 
+int vdf_vec_is_zero(vdf_ctx* ctx, const vdf_fe* v, size_t n, int* is_zero) {
+  return guarded(ctx, [&]() -> Status {
+    if (!is_zero) return Status{VDF_ERR_BAD_ARG, "null out"};
+    Staging st(ctx);
+    const void* dv;
+    VDF_TRY(st.in(v, n * 32, &dv));
+    if (!ctx->reduce_scratch) VDF_TRY_HIP(hipMalloc(&ctx->reduce_scratch, vdf::snark_reduce_scratch_bytes()));
+    uint32_t* d_flag = reinterpret_cast<uint32_t*>(ctx->reduce_scratch);
+    VDF_TRY(vdf::vec_any_nonzero(dv, n, d_flag, ctx->stream));
+    uint32_t flag = 1;
+    VDF_TRY_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));                 // the answer is the point of the call
+    *is_zero = flag == 0;
+    return st.finish();
+  });
+}
+
 int vdf_axpy(vdf_ctx* ctx, int field, const vdf_fe* a, const vdf_fe* r, const vdf_fe* b, size_t n, vdf_fe* out) {
   return guarded(ctx, [&]() -> Status {
     Staging st(ctx);

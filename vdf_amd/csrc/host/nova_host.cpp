@@ -282,11 +282,9 @@ int check_sat(const Side& sd, const Inst& in, const void* d_z, const void* d_E, 
   HIPCALL(ctx, vdf_cross_term(ctx, sd.field, (const vdf_fe*)d_abc[0], (const vdf_fe*)sd.d_zero, (const vdf_fe*)(d_E ? d_E : sd.d_zero),
                               (const vdf_fe*)sd.d_zero, (const vdf_fe*)d_abc[1], (const vdf_fe*)d_abc[2], (const vdf_fe*)&in.u,
                               sd.num_cons, (vdf_fe*)d_T));
-  std::vector<uint64_t> res(sd.num_cons * 4);
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, res.data(), d_T, sd.num_cons * 32));
-  uint64_t any = 0;
-  for (uint64_t w : res) any |= w;
-  *ok = any == 0;
+  int zero = 0;
+  HIPCALL(ctx, vdf_vec_is_zero(ctx, (const vdf_fe*)d_T, sd.num_cons, &zero));
+  *ok = zero != 0;
   return VDF_OK;
 }
 

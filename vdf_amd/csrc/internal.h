@@ -188,6 +188,7 @@ Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);
+Status vec_any_nonzero(const void* v, size_t n, uint32_t* d_flag, hipStream_t s);     // *d_flag = 1 iff some element is non-zero
 Status vec_to_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, hipStream_t s);

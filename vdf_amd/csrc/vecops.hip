@@ -386,6 +386,24 @@ Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const
   return Status{};
 }
 
+// flag |= 1 when any of the n 32-byte elements is not all-zero (a residual vector checked where it lies)
+__global__ __launch_bounds__(256) void k_any_nonzero(const uint4* __restrict__ v, size_t n16, uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t any = 0;
+  for (size_t k = i; k < n16; k += (size_t)gridDim.x * 256) { const uint4 w = v[k]; any |= w.x | w.y | w.z | w.w; }
+  if (__any(any != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+Status vec_any_nonzero(const void* v, size_t n, uint32_t* d_flag, hipStream_t s) {
+  VDF_TRY_HIP(hipMemsetAsync(d_flag, 0, 4, s));
+  if (n == 0) return Status{};
+  const size_t n16 = n * 2;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_any_nonzero, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(v), n16, d_flag);
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s) {
   if (n == 0) return Status{};
   FIELD_DISPATCH(field, k_mul, grid_for(n), dim3(256), 0, s, C(a), C(b), n, M(out));

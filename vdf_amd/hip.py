@@ -352,6 +352,12 @@ class Context:
     def minroot_step_segment(self, field, trace_xy, t, i0, vars_per_round, out) -> None:
         self._check(lib.vdf_minroot_step_segment(self.handle, field, _ptr(trace_xy), t, _ptr(i0), vars_per_round, _ptr(out)))
 
+    def vec_is_zero(self, v, n: int) -> bool:
+        """True iff all n field elements are zero (decided on the device)."""
+        out = C.c_int(0)
+        self._check(lib.vdf_vec_is_zero(self.handle, _ptr(v), n, C.byref(out)))
+        return bool(out.value)
+
     def nifs_cross_term(self, shape: Shape, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
         self._check(lib.vdf_nifs_cross_term(self.handle, shape.handle, _ptr(z2), _ptr(az1), _ptr(bz1), _ptr(cz1), _ptr(u1),
                                             _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
