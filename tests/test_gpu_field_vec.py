@@ -353,7 +353,7 @@ def test_ctx_marks(ctx):
     try:
         with pytest.raises(Exception):
             ctx.sync_mark(3)                          # never set
-        for bad in (-1, 4):
+        for bad in (-1, 8):
             with pytest.raises(Exception):
                 ctx.mark(bad)
         da, db = _dev(a), _dev(b)

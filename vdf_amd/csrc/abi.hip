@@ -1176,7 +1176,7 @@ int vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other) {
 
 int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
     if (!ctx->marks[slot]) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->marks[slot], hipEventDisableTiming));
     VDF_TRY_HIP(hipEventRecord(ctx->marks[slot], ctx->stream));
     return Status{};
@@ -1186,7 +1186,7 @@ int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
 int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
   if (!other) return VDF_ERR_BAD_ARG;
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
     if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
     if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     if (other == ctx) return Status{};
@@ -1197,7 +1197,7 @@ int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
 
 int vdf_ctx_sync_mark(vdf_ctx* ctx, int slot) {
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 4) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..3"};
+    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
     if (!ctx->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     for (int spin = 0; spin < 4000; ++spin) {                    // poll first, as vdf_ctx_sync does
       hipError_t q = hipEventQuery(ctx->marks[slot]);

@@ -691,7 +691,9 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
   struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
-  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2 };    // marks on a lookahead context: segment written / its commitment landed / early rows of T committed
+  // marks on a lookahead context: segment written / its commitment landed / early rows of T committed; MARK_STEP on the
+  // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
+  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4 };
   bool touched[D] = {};
   const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
   const int per = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
@@ -960,28 +962,28 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->zi[SECONDARY] = z_next;
   }
   t6 = now_ms();
-  // the staging buffers are rewritten by the next call: their copies must have left (mark 3), and nothing in flight may
+  // the staging buffers are rewritten by the next call: their copies must have left (a mark), and nothing in flight may
   // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
   // needs nothing of the next step: the NIFS of the secondary instance just made (VDF_NOVA_NIFS_AHEAD=0: left to the next call)
-  HIPCALL(ctx, vdf_ctx_mark(ctx, 3));
+  HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_STEP));
   {
     static const bool ahead = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
     // first the NIFS (the next call waits for it), then -- their dozen launches under its execution -- the early rows of
     // the next step's cross term: its rounds are in their ring slot (the lookahead above), its input is this step's
-    // output, the running instance is final once the fold is done (mark 3, not the NIFS behind it)
+    // output, the running instance is final once the fold is done (the mark, not the NIFS behind it)
     if (ahead) {
       int rc = launch_nifs2();
       if (rc != VDF_OK) return rc;
       p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
     }
     if (ahead && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
-      HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, 3));                     // ... and the fold read T and A z, B z, C z of this step
+      HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, MARK_STEP));                     // ... and the fold read T and A z, B z, C z of this step
       int rc = early_rows(p->d_z2s[p->ahead[0].slot], p->ctx2[(k + 1) % D]);
       if (rc != VDF_OK) return rc;
       p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
     }
   }
-  HIPCALL(ctx, vdf_ctx_sync_mark(ctx, 3));
+  HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   p->i += 1;
   p->last.comm_W1 = *(const vdf_affine*)&l1.comm_W;
