@@ -775,6 +775,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     return VDF_OK;
   };
   double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
+  bool looked = false, waited_w = false;
   Aff comm_T2, comm_T1;
   memset(&comm_T2, 0, sizeof(Aff)); memset(&comm_T1, 0, sizeof(Aff));
   uint64_t r2[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
@@ -900,6 +901,18 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
     }
     t3 = now_ms();
+    // The next step's MinRoot rounds and their commitment go to the second queue NOW, under this wait: their dozen launches
+    // cost the chain nothing here, and their 0.65 ms are over that much sooner (they are the next step's primary
+    // commitment; back to back the device is the co-bottleneck).  This step's own rounds were committed a step ago; their
+    // mark is waited for first, because the launch reuses it.  (VDF_NOVA_LOOKAHEAD_EARLY=0: launched after the wait.)
+    static const bool la_early = [] { const char* e = std::getenv("VDF_NOVA_LOOKAHEAD_EARLY"); return !(e && e[0] == '0'); }();
+    if (la_early && !first && !custom) {
+      if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+      waited_w = true;
+      int rc = look_ahead();
+      if (rc != VDF_OK) return rc;
+      looked = true;
+    }
     // the host's share of this wait: the secondary circuit's inputs but for comm_W and comm_T, and what it can do with them
     in2.params = pp->params[SECONDARY];
     in2.i = i_fe2;
@@ -910,7 +923,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     memset(&in2.u_W, 0, sizeof(Aff)); memset(&in2.T, 0, sizeof(Aff));
     for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in2.u_X[j]);
     early2 = synthesize_augmented_early(SECONDARY, in2, c2);
-    if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+    if (seg_n && !waited_w) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
     if (t_ahead) HIPCALL(ct, vdf_ctx_sync_mark(ct, MARK_T));
     HIPCALL(ctx, vdf_ctx_sync(ctx));
     const Field& Fb = *S1.Fb;
@@ -926,9 +939,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     }
   }
   t4 = now_ms();
-  // The next step's MinRoot rounds and their commitment go to the second context NOW: the device is idle while the host
-  // synthesises the secondary circuit below, so they do not compete with anything on the chain.
-  {
+  if (!looked) {                                  // (the base step, a custom circuit, or the switch above)
     int rc = look_ahead();
     if (rc != VDF_OK) return rc;
   }
