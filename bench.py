@@ -230,12 +230,19 @@ def strong_scaling_leg(ctx, curve, log2n, rank, world, steps, dist, always_gathe
     sh = ShardedMsm(ctx, curve, seed=11, n_total=ntot, rank=rank, world=world, table=(0, 1), family=vdf_amd.GENS_KNOWN_DLOG)
     g = torch.Generator(device="cuda")
     g.manual_seed(4321 + rank)
-    sc = torch.randint(-(2**63), 2**63 - 1, (sh.count, 4), dtype=torch.int64, device="cuda", generator=g)
-    sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
+    # two scalar vectors, alternated step by step: a step that read a stale partial or gathered buffer (an unordered
+    # collective) would return the OTHER vector's point and fail the exactness check below
+    scs = []
+    for _ in range(2):
+        v = torch.randint(-(2**63), 2**63 - 1, (sh.count, 4), dtype=torch.int64, device="cuda", generator=g)
+        v[:, 3] &= 0x3FFFFFFFFFFFFFFF
+        scs.append(v)
     partial = torch.zeros(12, dtype=torch.int64, device="cuda")
     gathered = torch.zeros(world * 12, dtype=torch.int64, device="cuda")
     result = torch.zeros(12, dtype=torch.int64, device="cuda")
     collective = world > 1 or always_gather
+    torch.cuda.synchronize()                 # the inputs were made on torch's default stream; the MSM runs on the context's
+    run_stream = torch.cuda.ExternalStream(ctx.stream) if ctx.stream else torch.cuda.current_stream()
 
     def all_gather(dst, src):
         dist.all_gather_into_tensor(dst, src)
@@ -245,14 +252,19 @@ def strong_scaling_leg(ctx, curve, log2n, rank, world, steps, dist, always_gathe
         if collective:
             dist.barrier()
             torch.cuda.synchronize()
-    for _ in range(2):
-        sh.run(sc, partial, gathered, all_gather, out=result, always_gather=always_gather)
+    # partial MSM, all-gather and point sum all on the context's stream (vdf_hip.h: the collective is ordered on the stream
+    # the library hands to the callback; hip.py makes it torch's current stream for the call)
+    with torch.cuda.stream(run_stream):
+        for i in range(2):
+            sh.run(scs[i & 1], partial, gathered, all_gather, out=result, always_gather=always_gather)
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        sh.run(sc, partial, gathered, all_gather, out=result, always_gather=always_gather)
+    with torch.cuda.stream(run_stream):
+        for i in range(steps):
+            sh.run(scs[i & 1], partial, gathered, all_gather, out=result, always_gather=always_gather)
     fence()
     elapsed = time.perf_counter() - t0
+    sc = scs[(steps - 1) & 1]                # the vector of the last step: `result` must be ITS point
     # exactness: sum s_i k_i over all ranks
     mine = _sum_s_k(sc.cpu().numpy().view("<u8"), _dlogs(11, sh.start, sh.count))
     words = torch.tensor(list(int(mine).to_bytes(48, "little")), dtype=torch.uint8, device="cuda")

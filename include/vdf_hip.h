@@ -119,6 +119,7 @@ int  vdf_bases_window(const vdf_bases* bases);            /* window of the curre
  * ranges = 0 drops the table.  VDF_MSM_DIRECT=0 in the environment disables the path (tuning). */
 int  vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int ranges, const size_t begin[], const size_t count[]);
 int  vdf_bases_digit_window(const vdf_bases* bases);      /* window of the digit table, 0 without one */
+size_t vdf_bases_digit_table_bytes(const vdf_bases* bases); /* HBM held by the digit table, 0 without one */
 int  vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out);
 size_t vdf_bases_len(const vdf_bases* bases);
 const void* vdf_bases_device_ptr(const vdf_bases* bases);

@@ -74,6 +74,24 @@ int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** 
  * VDF_GENS_LABEL_SHAKE derives the generators from the label "vdf-nova-ivc-v1 gens" through SHAKE256, the way nova-snark
  * derives its CommitGens (vdf_bases_generate_label): parameters reproducible from a string. */
 int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, vdf_pp** out);
+/* HBM a parameter set holds, and how to decline the optional part.  Beside the shapes and the generators with their
+ * fixed-base tables (2^19 Pallas generators x 16 windows x 64 B = 512 MiB for the reference's circuit at t = 2^16),
+ * public_params builds a DIGIT TABLE per side for the generators of the small commitments a step waits on
+ * (vdf_bases_precompute_digits, 852 KB per generator at the default 10-bit window): at t = 2^16 that is 8.6 GB on the
+ * secondary side (all 10,049 generators) + 9.4 GB on the primary side (the ~11 k generators outside the MinRoot rounds)
+ * = 18 GB PER PARAMETER SET, spent to take ~0.4 ms of bucket method off every step's critical path.  It is an
+ * accelerator only: results are the same group elements without it.  A table that does not fit the free HBM is skipped
+ * silently (vdf_nova_pp_memory reports it; VDF_NOVA_VERBOSE=1 logs it), and the flags below decline it up front:
+ *   VDF_PP_NO_DIGIT_TABLES  no digit tables: every commitment takes the bucket method (about +0.5 ms per step at t = 2^16)
+ *   VDF_PP_NO_EARLY_ROWS    the cross term T of a step is made and committed in one piece instead of ahead of the step
+ *                           for the rows that read only the MinRoot rounds (one MSM workspace and one queue fewer)
+ * The environment variables VDF_NOVA_DIGIT_WINDOW (0 = none, 6..12) and VDF_NOVA_T_AHEAD=0 remain as tuning overrides. */
+enum { VDF_PP_NO_DIGIT_TABLES = 1u, VDF_PP_NO_EARLY_ROWS = 2u };
+int  vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint32_t flags,
+                                  vdf_pp** out);
+/* bytes of HBM held per side: generators, their fixed-base table, the digit table (0 = none; *skipped bit s set when
+ * side s wanted one and it did not fit). */
+int  vdf_nova_pp_memory(const vdf_pp* pp, uint64_t gens_bytes[2], uint64_t table_bytes[2], uint64_t digit_bytes[2], uint32_t* skipped);
 void vdf_nova_pp_free(vdf_pp* pp);
 int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,
                        uint64_t* num_gens);

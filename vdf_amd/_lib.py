@@ -45,6 +45,7 @@ PROTOTYPES = {
     "vdf_bases_window": (_i, [_vp]),
     "vdf_bases_precompute_digits": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "vdf_bases_digit_window": (_i, [_vp]),
+    "vdf_bases_digit_table_bytes": (C.c_size_t, [_vp]),
     "vdf_bases_len": (_sz, [_vp]),
     "vdf_bases_device_ptr": (_vp, [_vp]),
     "vdf_bases_free": (None, [_vp]),

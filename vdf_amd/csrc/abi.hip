@@ -9,6 +9,7 @@
 #include <array>
 #include <new>
 #include <memory>
+#include <mutex>
 #include <initializer_list>
 #include <utility>
 #include "internal.h"
@@ -182,10 +183,14 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
       VDF_TRY(ensure_ws(ctx, vdf::direct_ws_bytes(groups, n, bases->dg_c, ctx->num_cus)));
       hipEvent_t* dev = nullptr;
       vdf_ctx::TimedCall dtc;
+      int have = 0;                                       // events taken so far: they go back to the pool if the call fails
+      struct Giveback { vdf_ctx* c; vdf_ctx::TimedCall* t; int* have; bool armed; ~Giveback() { if (armed) for (int i = 0; i < *have; ++i) c->ev_pool.push_back(t->ev[i]); } }
+          giveback{ctx, &dtc, &have, true};
       if (ctx->timing) {
         for (int i = 0; i < 4; ++i) {
           if (!ctx->ev_pool.empty()) { dtc.ev[i] = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
           else VDF_TRY_HIP(hipEventCreate(&dtc.ev[i]));
+          have = i + 1;
         }
         dev = dtc.ev;
         VDF_TRY_HIP(hipEventRecord(dev[0], ctx->stream));
@@ -198,6 +203,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
         VDF_TRY_HIP(hipEventRecord(dev[3], ctx->stream));
         ctx->timed.push_back(dtc);
       }
+      giveback.armed = false;
       return st.finish();
     }
   }
@@ -360,7 +366,10 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   }
   // a prover keeps several queues busy at once (vdf_nova.h): the runtime's default of 4 hardware queues makes streams share
   // one, and kernels then wait behind another stream's; honoured only when this is the process's first HIP call
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // -- and set at most once per process (setenv is not safe against a concurrent getenv: a second prover thread making its
+  // contexts, the runtime's own threads).  A host that makes its first HIP call elsewhere sets the variable itself.
+  static std::once_flag hwq_once;
+  std::call_once(hwq_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -602,7 +611,11 @@ int vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits,
     size_t free_b = 0, total_b = 0;
     VDF_TRY_HIP(hipMemGetInfo(&free_b, &total_b));
     if (bytes + ((size_t)1 << 30) > free_b) return Status{VDF_ERR_OOM, "the digit table does not fit the free device memory"};
-    VDF_TRY_HIP(hipMalloc(&bases->d_digits, bytes));
+    if (hipMalloc(&bases->d_digits, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      bases->d_digits = nullptr;
+      return Status{VDF_ERR_OOM, "the digit table could not be allocated"};
+    }
     size_t slot0 = 0;
     Status s{};
     for (int r = 0; r < ranges && s.ok(); ++r) {
@@ -611,12 +624,13 @@ int vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits,
       slot0 += count[r];
     }
     if (!s.ok()) { (void)hipFree(bases->d_digits); bases->d_digits = nullptr; return s; }
-    bases->dg_c = window_bits; bases->dg_ranges = ranges;
+    bases->dg_c = window_bits; bases->dg_ranges = ranges; bases->dg_bytes = bytes;
     return Status{};
   });
 }
 
 int vdf_bases_digit_window(const vdf_bases* bases) { return bases && bases->d_digits ? bases->dg_c : 0; }
+size_t vdf_bases_digit_table_bytes(const vdf_bases* bases) { return bases && bases->d_digits ? bases->dg_bytes : 0; }
 
 int vdf_bases_window(const vdf_bases* bases) { return bases && bases->d_table ? bases->tbl_c : 0; }
 
@@ -799,17 +813,18 @@ int vdf_msm_multi(vdf_ctx* const ctxs[], const vdf_bases* const bases[], const s
   vdf_jac* h = nullptr;
   int rc = vdf_host_alloc(c0, (size_t)k * sizeof(vdf_jac), reinterpret_cast<void**>(&h));
   if (rc != VDF_OK) return rc;
-  int was_async[64];
+  int was_async[64] = {};
+  bool switched[64] = {};                        // only contexts whose mode was read AND changed are restored below
   for (int i = 0; i < k && rc == VDF_OK; ++i) {
     if (!ctxs[i] || !bases[i] || bases[i]->curve != bases[0]->curve) { c0->err = "bad context / generator shard"; rc = VDF_ERR_BAD_ARG; break; }
     rc = vdf_ctx_get_async(ctxs[i], &was_async[i]);
-    if (rc == VDF_OK) rc = vdf_ctx_set_async(ctxs[i], 1);
+    if (rc == VDF_OK) { rc = vdf_ctx_set_async(ctxs[i], 1); switched[i] = rc == VDF_OK; }
     // every device works at once: enqueue all partials (results into pinned memory), then wait for each
     if (rc == VDF_OK) rc = vdf_msm(ctxs[i], bases[i], offsets ? offsets[i] : 0, scalars[i], n[i], is_mont, &h[i]);
     if (rc != VDF_OK && ctxs[i] != c0) c0->err = ctxs[i]->err;
   }
   for (int i = 0; i < k; ++i) {
-    if (!ctxs[i]) continue;
+    if (!ctxs[i] || !switched[i]) continue;
     const int r2 = vdf_ctx_sync(ctxs[i]);
     if (rc == VDF_OK && r2 != VDF_OK) { rc = r2; c0->err = ctxs[i]->err; }
     (void)vdf_ctx_set_async(ctxs[i], was_async[i]);

@@ -395,26 +395,32 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   });
 }
 
-static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out);
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
+                              vdf_pp** out);
 
-int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
+int vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, uint32_t flags, vdf_pp** out) {
   return nova_guard([&]() -> int {
     if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
     if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
       return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
-    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, out);
+    if (flags & ~(uint32_t)(VDF_PP_NO_DIGIT_TABLES | VDF_PP_NO_EARLY_ROWS)) return fail(VDF_ERR_BAD_ARG, "unknown flag");
+    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, flags, out);
   });
+}
+int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
+  return vdf_nova_public_params_flags(ctx, t, circuit_kind, gens_family, 0, out);
 }
 
 int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary, int gens_family, vdf_pp** out) {
   return nova_guard([&]() -> int {
     if (!ctx || !out || !primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64)
       return fail(VDF_ERR_BAD_ARG, "bad argument");
-    return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, out);
+    return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, 0, out);
   });
 }
 
-static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, vdf_pp** out) {
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
+                              vdf_pp** out) {
   if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG && gens_family != VDF_GENS_LABEL_SHAKE)
     return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
@@ -455,7 +461,7 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     for (size_t r = 0; r <= h.num_cons; ++r)
       if (r == h.num_cons || !early[r]) { if (r - run_b > best_n) { best_b = run_b; best_n = r - run_b; } run_b = r + 1; }
     const char* ov = std::getenv("VDF_NOVA_T_AHEAD");                 // tuning: 0 = one cross term, one commitment of T per step
-    if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0')) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
+    if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0') && !(flags & VDF_PP_NO_EARLY_ROWS)) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
     pp->ahead_mode = (ov && ov[0] == '1') ? 1 : 2;
   }
   for (int s = 0; s < 2; ++s) {
@@ -491,7 +497,11 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     // terms, committed ahead of the step, stay with the bucket method.
     {
       int digit_c = 10;
-      if (const char* ov = std::getenv("VDF_NOVA_DIGIT_WINDOW")) digit_c = atoi(ov);                 // tuning; 0 = no digit tables
+      if (const char* ov = std::getenv("VDF_NOVA_DIGIT_WINDOW")) {                                   // tuning; 0 = no digit tables
+        const int v = atoi(ov);
+        if (v == 0 || (v >= 6 && v <= 12)) digit_c = v;                                              // anything else: the default stays
+      }
+      if (flags & VDF_PP_NO_DIGIT_TABLES) digit_c = 0;
       size_t db[2] = {0, 0}, dn[2] = {0, 0};
       int nr = 0;
       const size_t top = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons;
@@ -503,7 +513,21 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
         dn[1] = top - db[1];
         nr = db[1] > dn[0] ? 2 : 0;
       }
-      if (digit_c && nr && dn[0] + dn[1] <= (1u << 16)) HIPCALL(ctx, vdf_bases_precompute_digits(ctx, sd.gens, digit_c, nr, db, dn));
+      if (digit_c && nr && dn[0] + dn[1] <= (1u << 16)) {
+        // The digit table is a latency optimisation (852 KB per generator at c = 10: 8.6 + 9.4 GB at t = 2^16), never a
+        // requirement: when it does not fit the free HBM -- a smaller GPU, several parameter sets or chains resident --
+        // or the window is refused, the parameters are made without it and vdf_msm takes the bucket method.
+        const int rc = vdf_bases_precompute_digits(ctx, sd.gens, digit_c, nr, db, dn);
+        if (rc == VDF_ERR_OOM || rc == VDF_ERR_BAD_ARG) {
+          pp->digit_tables_skipped |= 1u << s;
+          if (std::getenv("VDF_NOVA_VERBOSE"))
+            fprintf(stderr, "vdf_nova: no digit table on side %d (%s): commitments take the bucket method\n", s, vdf_last_error(ctx));
+        } else if (rc != VDF_OK) {
+          return fail(rc, std::string("vdf_bases_precompute_digits: ") + vdf_last_error(ctx));
+        } else {
+          pp->digit_table_bytes[s] = vdf_bases_digit_table_bytes(sd.gens);
+        }
+      }
     }
     vdf_bases* ub = nullptr;
     HIPCALL(ctx, make_gens(sd.curve, g, 1, &ub));
@@ -537,6 +561,18 @@ int vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* 
   if (num_io) *num_io = NUM_IO;
   if (nnz3) *nnz3 = sd.nnz3;
   if (num_gens) *num_gens = sd.num_gens;
+  return VDF_OK;
+}
+int vdf_nova_pp_memory(const vdf_pp* pp, uint64_t gens_bytes[2], uint64_t table_bytes[2], uint64_t digit_bytes[2], uint32_t* skipped) {
+  if (!pp) return fail(VDF_ERR_BAD_ARG, "null argument");
+  for (int s = 0; s < 2; ++s) {
+    const Side& sd = pp->s[s];
+    const int c = vdf_bases_window(sd.gens);
+    if (gens_bytes) gens_bytes[s] = (uint64_t)sd.num_gens * 64;
+    if (table_bytes) table_bytes[s] = c ? (uint64_t)sd.num_gens * 64 * ((255 + c - 1) / c) : 0;
+    if (digit_bytes) digit_bytes[s] = pp->digit_table_bytes[s];
+  }
+  if (skipped) *skipped = pp->digit_tables_skipped;
   return VDF_OK;
 }
 int vdf_nova_pp_digest(const vdf_pp* pp, uint8_t out[32]) {

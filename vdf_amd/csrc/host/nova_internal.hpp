@@ -90,6 +90,8 @@ struct vdf_pp {
   size_t ahead_row = 0, ahead_rows = 0;
   int ahead_mode = 2;            // when they run: 2 = from the start of the step, beside the secondary side's NIFS; 1 = after it (tuning)
   size_t arity = 3;                        // of the primary step circuit (z0, zi)
+  uint64_t digit_table_bytes[2] = {0, 0};  // HBM held by each side's digit table (vdf_nova_pp_memory)
+  unsigned digit_tables_skipped = 0;       // bit s: side s asked for a digit table and went without (no room, refused window)
 };
 
 struct Circuit {            // InverseMinRootCircuit<G1>, src/nova/proof.rs:57-66, + the forward trace

@@ -572,8 +572,11 @@ class Helpers {
   void start(int k, std::function<void()> fn) {
     Slot& s = slots_[k];
     s.fn = std::move(fn);
-    s.state.store(1, std::memory_order_release);           // 1 = posted
-    if (s.parked.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> l(s.mu); s.cv.notify_one(); }
+    // Dekker-style handshake with loop(): "store state, then load parked" here against "store parked, then load state"
+    // there.  Both pairs are seq_cst, so at least one side sees the other's store (release / acquire would allow both to
+    // read stale values: a posted job and a helper asleep for good).
+    s.state.store(1, std::memory_order_seq_cst);           // 1 = posted
+    if (s.parked.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> l(s.mu); s.cv.notify_one(); }
   }
   void wait(int k) {
     Slot& s = slots_[k];
@@ -604,9 +607,11 @@ class Helpers {
         __builtin_ia32_pause();
         if (std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
           std::unique_lock<std::mutex> l(s.mu);
-          s.parked.store(true, std::memory_order_release);
-          s.cv.wait(l, [&] { return s.state.load(std::memory_order_acquire) == 1 || quit_.load(); });
-          s.parked.store(false, std::memory_order_release);
+          s.parked.store(true, std::memory_order_seq_cst);
+          // the timeout is a backstop only (the handshake above does not need it): a parked helper looks again every 50 ms
+          while (!(s.state.load(std::memory_order_seq_cst) == 1 || quit_.load()))
+            s.cv.wait_for(l, std::chrono::milliseconds(50));
+          s.parked.store(false, std::memory_order_seq_cst);
         }
       }
       s.fn();

@@ -52,6 +52,7 @@ struct vdf_bases {
   int dg_c = 0, dg_ranges = 0;
   size_t dg_begin[4] = {0, 0, 0, 0}, dg_count[4] = {0, 0, 0, 0}, dg_slot0[4] = {0, 0, 0, 0};
   void* d_digits = nullptr;
+  size_t dg_bytes = 0;
 };
 
 struct vdf_shape {

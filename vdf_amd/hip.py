@@ -279,12 +279,20 @@ class Context:
                     is_mont: bool = False, always_gather: bool = False, offset: int = 0):
         """vdf_msm_sharded: this rank's partial, the host's all-gather of the world partials, the local point sum.
         all_gather(dst, src) is the collective on the caller's buffers `gathered` (world x 12 words) and `partial` (12),
-        both device memory; it is called once, from inside the library, ordered after the partial."""
+        both device memory; it is called once, from inside the library, ordered after the partial.  The header's contract
+        is that the collective runs ON the stream the library hands over (the one the partial was produced on and the
+        point sum will run on): when the buffers are torch tensors the callback therefore makes that stream torch's
+        current one for the duration of the call, whatever stream the caller happens to be on."""
         err = []
 
         def cb(_user, _send, _recv, _bytes, _stream):
             try:
-                all_gather(gathered, partial)
+                if hasattr(partial, "data_ptr"):
+                    import torch
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(_stream or 0), device=partial.device)):
+                        all_gather(gathered, partial)
+                else:
+                    all_gather(gathered, partial)
                 return 0
             except Exception as e:            # an exception must not unwind through the C frames
                 err.append(e)

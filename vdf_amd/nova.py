@@ -17,6 +17,8 @@ _vp, _i, _u64, _sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
 for _name, _res, _args in [
     ("vdf_nova_public_params", _i, [_vp, _u64, C.POINTER(_vp)]),
     ("vdf_nova_public_params_ex", _i, [_vp, _u64, _i, _i, C.POINTER(_vp)]),
+    ("vdf_nova_public_params_flags", _i, [_vp, _u64, _i, _i, C.c_uint, C.POINTER(_vp)]),
+    ("vdf_nova_pp_memory", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint)]),
     ("vdf_nova_pp_free", None, [_vp]),
     ("vdf_nova_pp_sizes", _i, [_vp, _i] + [C.POINTER(_u64)] * 5),
     ("vdf_nova_pp_digest", _i, [_vp, _vp]),
@@ -78,6 +80,7 @@ CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE = 0, 1
 SIDE_PRIMARY, SIDE_SECONDARY = 0, 1
 INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY, INST_FRESH_PRIMARY_LAST = 0, 1, 2, 3
 GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT, GENS_LABEL_SHAKE = 0, 1, 2
+PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS = 1, 2
 
 
 def _check(rc: int) -> None:
@@ -275,6 +278,13 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         _check(nova_lib.vdf_nova_pp_early_rows(self.handle, C.byref(b), C.byref(n)))
         return b.value, n.value
 
+    def memory(self) -> dict:
+        """HBM held per side (bytes): generators, fixed-base table, digit table; `skipped` = sides whose digit table did not fit."""
+        g, t, d = (np.zeros(2, dtype="<u8") for _ in range(3))
+        sk = C.c_uint()
+        _check(nova_lib.vdf_nova_pp_memory(self.handle, g.ctypes.data, t.ctypes.data, d.ctypes.data, C.byref(sk)))
+        return {"gens_bytes": g.tolist(), "table_bytes": t.tolist(), "digit_table_bytes": d.tolist(), "digit_tables_skipped": sk.value}
+
     def free(self) -> None:
         if self.handle and self.ctx.handle:      # a dead context took the device memory with it (see hip.Bases.free)
             for proof in list(self._proofs):     # a proof holds device buffers of this context and points at pp
@@ -290,10 +300,12 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
 
 
 def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_BOUND,
-                  gens_family: int = GENS_TRY_AND_INCREMENT) -> NovaVDFPublicParams:      # :232-237
+                  gens_family: int = GENS_TRY_AND_INCREMENT, flags: int = 0) -> NovaVDFPublicParams:      # :232-237
     h = C.c_void_p()
-    _check(nova_lib.vdf_nova_public_params_ex(ctx.handle, num_iters_per_step, circuit_kind, gens_family, C.byref(h)))
-    return NovaVDFPublicParams(ctx, h.value, num_iters_per_step)
+    _check(nova_lib.vdf_nova_public_params_flags(ctx.handle, num_iters_per_step, circuit_kind, gens_family, flags, C.byref(h)))
+    pp = NovaVDFPublicParams(ctx, h.value, num_iters_per_step)
+    pp.circuit_kind = circuit_kind
+    return pp
 
 
 class Circuits:
