@@ -186,6 +186,17 @@ int  vdf_msm_multi(vdf_ctx* const ctxs[], const vdf_bases* const bases[], const 
  * ms[2] = tail (fix-up, bucket reduction, final), ms[3] = whole pipeline; *calls = number of MSMs. */
 int  vdf_ctx_set_timing(vdf_ctx* ctx, int enable);
 int  vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls);
+/* Per-launch timing of EVERY kernel a context enqueues (bench.py's per-kernel roofline of prove_step).  While enabled,
+ * each launch is bracketed by two HIP events on the stream it runs on.  vdf_ctx_kernel_events synchronises the context's
+ * stream and drains the launches recorded since the last call: kernel name, the ALGORITHMIC bytes the launch is priced at
+ * (96 B per (base, scalar) pair on an MSM's accumulation kernel, 96 B per folded element, 64 + 32 * vars B
+ * per MinRoot round, the CSR + vector bytes of a cross term; 0 for the helper kernels of a pipeline) and start / end in
+ * milliseconds since a per-device origin shared by all contexts -- so the launches of several contexts (a prover's three
+ * queues) can be laid on one time line.  out == NULL: *n = launches waiting, nothing drained.  Costs two event records
+ * per launch while on: measure throughput with it off. */
+typedef struct { char name[24]; double bytes; double start_ms, end_ms; } vdf_kernel_event;
+int  vdf_ctx_set_kernel_timing(vdf_ctx* ctx, int enable);
+int  vdf_ctx_kernel_events(vdf_ctx* ctx, vdf_kernel_event* out, size_t cap, size_t* n);
 
 /* Drop-in shims with the upstream pasta-msm 0.1.1 shape (upload-on-call, default context on device 0).  The
  * signature returns nothing and an all-zero `out` is the identity -- a valid-looking commitment -- so a call that
@@ -261,6 +272,16 @@ int  vdf_minroot_step_z_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, 
  * combination y - i + 1 and no variable); then final_i = i0.  out has vars_per_round * t + 1 elements.  i0: host memory. */
 int  vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe* i0, int vars_per_round,
                               vdf_fe* out);
+/* The reference's allocation (vars_per_round = 4) and, in the same pass, the scalars of its commitment WITHOUT the new_x
+ * terms:   packed = [ tmp1, tmp2, new_y per round (3t) | final_i | y_0 | i_in | 1 ],  3t + 4 elements,
+ * y_0 the y the first round reads and i_in the i it reads (= i0 + t; host memory, like i0).  new_x of round j is
+ * y_j - (i_in - (j + 1)) with y_j = new_y of round j - 1 (src/nova/proof.rs:162-173), so over the generators G of `out`
+ *   sum_j new_x_j G[4j]  =  y_0 G[0] + sum_(j>=1) new_y_(j-1) G[4j] - i_in S1 + S2,   S1 = sum_j G[4j],  S2 = sum_j (j + 1) G[4j]
+ * and the commitment to `out` equals the MSM of `packed` over the derived generators
+ *   [ G[4j+1], G[4j+2], G[4j+3] + G[4j+4] (last round: G[4t-1]) per round | G[4t] | G[0] | -S1 | S2 ]
+ * -- the same group element from 3t + 4 instead of 4t + 1 terms (libvdf_nova.so commits the reference's circuit this way). */
+int  vdf_minroot_step_segment_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe* i0, const vdf_fe* i_in,
+                                     vdf_fe* out, vdf_fe* packed);
 /* vdf_spmv3(shape, z2) followed by vdf_cross_term(Az1, Bz1, Cz1, Az2, Bz2, Cz2, u1): writes Az2, Bz2, Cz2
  * (num_cons each) and T.  u1: host memory.  (nova-snark NIFS::prove -> commit_T, K4 + K5.) */
 int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1,

@@ -151,6 +151,11 @@ int  vdf_nova_proof_last_step(const vdf_proof* proof, vdf_nova_step_info* out);
  * [3] wait for them, [4] synthesis of the secondary augmented circuit, [5] upload + fold launches, [6] lookahead
  * launch, [7] total. */
 int  vdf_nova_last_step_ms(const vdf_proof* proof, double ms[8]);
+/* Per-launch timing of everything a prover enqueues (vdf_hip.h vdf_ctx_kernel_events) over its three queues -- queue[i] =
+ * 0 the step's chain (the parameters' context), 1 the lookahead (MinRoot rounds of the next step and their commitment),
+ * 2 the early rows of the cross term -- on one time line.  For bench.py's prove_step.roofline; measure rates with it off. */
+int  vdf_nova_proof_set_kernel_timing(vdf_proof* proof, int enable);
+int  vdf_nova_proof_kernel_events(vdf_proof* proof, vdf_kernel_event* out, int* queue, size_t cap, size_t* n);
 
 /* ---- the step-circuit seam (src/nova/proof.rs:79-153: `impl StepCircuit for InverseMinRootCircuit` -- arity, synthesize,
  * output) ---------------------------------------------------------------------------------------------------------
@@ -188,6 +193,10 @@ int  vdf_nova_ro_hash(int field, uint64_t tag, const vdf_fe* xs, size_t n, vdf_f
 /* digest of the parameters public_params would make (both shapes synthesised on the host), and the sizes per side:
  * sizes[side] = {num_cons, num_vars, nnz(A) + nnz(B) + nnz(C)} */
 int  vdf_nova_shape_digest(uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]);
+/* the same shape as COO triples per matrix (A, B, C), in the order the constraints were made, values in Montgomery form of the
+ * side's scalar field: call once with rows = cols = vals = NULL for nnz[3], then with arrays of those lengths. */
+int  vdf_nova_shape_export(uint64_t num_iters_per_step, int circuit_kind, int side, uint64_t nnz[3], uint32_t* const rows[3],
+                           uint32_t* const cols[3], vdf_fe* const vals[3]);
 int  vdf_nova_shape_digest_custom(const vdf_step_circuit* primary, int gens_family, uint8_t out[32], uint64_t sizes[2][3]);
 /* One augmented circuit synthesised on the host with every variable computed there (small t only).  The inputs that
  * belong to the folded side (U_u, U_X, u_X) are in Montgomery form of THAT side's scalar field, everything else in the

@@ -10,7 +10,7 @@ import pytest
 from oracle import nova as nv, pasta as o, wire as w
 from test_gpu_nova import make
 from vdf_amd.minroot import State, FIELD_FQ
-from vdf_amd.nova import NovaVDFProof, CIRCUIT_MINROOT_BOUND
+from vdf_amd.nova import NovaVDFProof, CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE
 
 pytestmark = pytest.mark.gpu
 
@@ -20,24 +20,30 @@ def _zi(init_ints):
     return [s.x, s.y, s.i]
 
 
-def oracle_proof(t, n, init_ints):
+def oracle_proof(t, n, init_ints, bound=True):
     """The same chain proven by the oracle: (public parameters, RecursiveSNARK, z0 as integers)."""
-    opp = nv.public_params(t, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
+    opp = nv.public_params(t, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=bound)
     states = [o.State(*init_ints)]
     for _ in range(n):
         states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
     z0 = [states[n].x, states[n].y, states[n].i]
     s = None
     for k in range(n):
-        s = nv.prove_step(opp, s, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1]), z0)
+        s = nv.prove_step(opp, s, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1], bound), z0)
     return opp, s, z0
 
 
-@pytest.mark.parametrize("t,n", [(3, 2), (5, 3)])
-def test_compressed_arguments_equal_the_oracles(ctx, t, n):
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=31)
+@pytest.mark.parametrize("t,n,kind", [(3, 2, CIRCUIT_MINROOT_BOUND), (5, 3, CIRCUIT_MINROOT_BOUND), (5, 3, CIRCUIT_MINROOT_REFERENCE),
+                                      (1024, 2, CIRCUIT_MINROOT_REFERENCE), (1024, 2, CIRCUIT_MINROOT_BOUND)],
+                         ids=["t3-bound", "t5-bound", "t5-reference", "t1024-reference", "t1024-bound"])
+def test_compressed_arguments_equal_the_oracles(ctx, t, n, kind):
+    """compress (src/nova/proof.rs:360-368) byte for byte against oracle/nova.py compress over oracle/spartan.py, up to
+    BASELINE config 1's step size (t = 1024: 2^14-row sum-checks, the oracle's MSMs in the C restatement) and for both
+    forms of the step circuit."""
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=31, kind=kind)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
-    opp, want_s, z0i = oracle_proof(t, n, init_ints)
+    opp, want_s, z0i = oracle_proof(t, n, init_ints, bound=(kind == CIRCUIT_MINROOT_BOUND))
+    assert pp.digest() == opp.params
     want = nv.compress(opp, want_s)
     assert nv.verify_compressed(opp, want, n, z0i) is not None
     snark = proof.compress(pp)
@@ -105,10 +111,12 @@ def test_compress_and_verify_at_t_1024_and_tampering(ctx):
         snark.set_bytes(b"\xff" * len(good))            # not canonical
 
 
-def test_compress_full_size_t_2_16(ctx):
-    """t = 2^16 (BASELINE config 3 shape: 2^18 constraints and variables on the primary side): completes and verifies."""
+@pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
+def test_compress_full_size_t_2_16(ctx, kind):
+    """t = 2^16 (BASELINE config 3 shape; the reference's circuit: 2^18 constraints, 2^19 variables and generators on the
+    primary side): completes and verifies."""
     t, n = 1 << 16, 2
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=5)
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=5, kind=kind)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
     t0 = time.perf_counter()
     snark = proof.compress(pp)
@@ -121,3 +129,41 @@ def test_compress_full_size_t_2_16(ctx):
     bad[100] ^= 1
     snark.set_bytes(bytes(bad))
     assert not snark.verify(pp, n, z0, _zi(init_ints))
+
+
+def test_config_5_compressed_snark_of_2_20_folded_iterations(ctx):
+    """BASELINE config 5's workload on one GPU: 16 steps of 2^16 MinRoot iterations (2^20 folded iterations) of the reference's
+    circuit -> compress (src/nova/proof.rs:360-368) -> verify the compressed proof (:383, the reference's test at :446-450) ->
+    wire round trip in another context, which must accept it; a wrong z_i, a wrong step count and a flipped bit are rejected."""
+    import vdf_amd
+    from vdf_amd.minroot import EvalMode
+    from vdf_amd.nova import CompressedNovaVDFProof as CompressedSNARK, public_params
+    t, n = 1 << 16, 16
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=55, i0=0, kind=CIRCUIT_MINROOT_REFERENCE, mode=EvalMode.LTRAddChainSequential)
+    circuits.upload(ctx)
+    zi = _zi(init_ints)
+    t0 = time.perf_counter()
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    t1 = time.perf_counter()
+    assert proof.num_steps() == n and proof.verify(pp, n, z0, zi)
+    t2 = time.perf_counter()
+    snark = proof.compress(pp)
+    t3 = time.perf_counter()
+    assert snark.verify(pp, n, z0, zi)
+    t4 = time.perf_counter()
+    wire = snark.serialize()
+    print(f"2^20 iterations in {n} steps: prove {1e3 * (t1 - t0):.1f} ms, compress {1e3 * (t3 - t2):.1f} ms, "
+          f"verify compressed {1e3 * (t4 - t3):.1f} ms, {len(wire)} bytes on the wire")
+    assert not snark.verify(pp, n, z0, [zi[1], zi[0], zi[2]]) and not snark.verify(pp, n - 1, z0, zi)
+    ctx_v = vdf_amd.Context(0)                       # a verifier of its own: parameters derived again, the proof from bytes
+    pp_v = public_params(ctx_v, t, CIRCUIT_MINROOT_REFERENCE)
+    assert pp_v.digest() == pp.digest()
+    got = CompressedSNARK.deserialize(pp_v, wire)
+    assert got.verify(pp_v, n, z0, zi) and got.serialize() == wire
+    bad = bytearray(wire)
+    bad[len(bad) // 2] ^= 4
+    try:
+        assert not CompressedSNARK.deserialize(pp_v, bytes(bad)).verify(pp_v, n, z0, zi)
+    except vdf_amd.VdfError:
+        pass                                         # refused at decoding: non-canonical or off the curve
+    got.free(); pp_v.free(); ctx_v.close()

@@ -249,12 +249,15 @@ def _canon(cref, field, arr):
     return out
 
 
-@pytest.mark.parametrize("t,n", [(1024, 3), (1 << 16, 2)])
-def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n):
+@pytest.mark.parametrize("t,n,kind", [(1024, 3, CIRCUIT_MINROOT_REFERENCE), (1 << 16, 2, CIRCUIT_MINROOT_REFERENCE),
+                                      (1024, 3, CIRCUIT_MINROOT_BOUND), (1 << 16, 2, CIRCUIT_MINROOT_BOUND)],
+                         ids=["t1024-n3-reference", "t65536-n2-reference", "t1024-n3-bound", "t65536-n2-bound"])
+def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n, kind):
     """BASELINE config 1 (t = 1024, 3 steps) and config 3 (t = 2^16) checked against the CPU restatements instead of the
     product's own verifier: generators with known discrete logarithms (tests only), then for the LAST step --
       * both R1CS shapes: the parameters digest equals the oracle's (every triple of both matrices triples);
-      * the MinRoot rounds of the fresh witness = the C restatement's ref_step_witness (src/nova/proof.rs:162-189);
+      * the MinRoot rounds of the fresh witness = the C restatement's ref_step_witness (src/nova/proof.rs:162-189) -- for the
+        reference's circuit (4 variables per round, :167-189) its 4t + 1 values AS THEY ARE, for the bound form without new_x;
       * commitments of the fresh witness, of the cross term T and of the folded W, E = [sum s_i k_i] G (discrete-log identity);
       * A z, B z, C z (C restatement ref_spmv over the ORACLE's shape), T (ref_cross_term), W' = W + r W2 and E' = E + r T
         (ref_axpy) element for element, u' = u + r, X' = X + r X2.
@@ -262,14 +265,15 @@ def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n):
     from vdf_amd.nova import INST_FRESH_PRIMARY_LAST
     from vdf_amd.nova import nova_lib
     L, fld, m = cref.lib(), o.FIELD_FQ, o.Q
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=3, kind=CIRCUIT_MINROOT_BOUND, family=GENS_KNOWN_DLOG,
+    reference = kind == CIRCUIT_MINROOT_REFERENCE
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=3, kind=kind, family=GENS_KNOWN_DLOG,
                                                 mode=EvalMode.LTRAddChainSequential)
-    opp = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_KNOWN_DLOG)
+    opp = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_KNOWN_DLOG, bound=not reference)
     assert pp.digest() == opp.params
     sh = opp.shapes[0]
     nvar, nc = sh.num_vars, sh.num_cons
     seg_b, seg_n = pp.segment()
-    assert seg_n == 3 * t + 1 and seg_b + seg_n <= nvar
+    assert seg_n == (4 if reference else 3) * t + 1 and seg_b + seg_n <= nvar
     proof = None
     for k in range(n - 1):
         proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
@@ -280,12 +284,13 @@ def test_one_fold_replayed_by_the_c_oracle_at_baseline_sizes(ctx, cref, t, n):
     z2, _ = proof.witness(INST_FRESH_PRIMARY_LAST)
     z_new, E_new = proof.witness(INST_RUNNING_PRIMARY)
     inst_new = proof.instance(INST_RUNNING_PRIMARY)
-    # MinRoot rounds of the fresh witness: the C restatement's 4t + 1 values without new_x
+    # MinRoot rounds of the fresh witness: the C restatement's 4t + 1 values -- unstripped for the reference's circuit
+    # (new_x, tmp1, tmp2, new_y per round, then final_i: src/nova/proof.rs:167-189, :122-126), without new_x for the bound form
     res, _inp = circuits.states(n - 1)
     st = np.frombuffer(res.x + res.y + res.i, dtype="<u8").reshape(3, 4).copy()
     Wref = cref.fe_array(4 * t + 1)
     L.ref_step_witness(fld, cref.p(st), t, cref.p(Wref))
-    want_seg = np.concatenate([Wref[:4 * t].reshape(t, 4, 4)[:, 1:, :].reshape(3 * t, 4), Wref[4 * t:]])
+    want_seg = Wref if reference else np.concatenate([Wref[:4 * t].reshape(t, 4, 4)[:, 1:, :].reshape(3 * t, 4), Wref[4 * t:]])
     assert np.array_equal(z2[seg_b:seg_b + seg_n], want_seg)
     assert unmont(z2[nvar:nvar + 1], m) == [1] and np.array_equal(z2[nvar + 1:], ls["X1"])
     # commitments by the discrete-log identity

@@ -126,10 +126,12 @@ def test_checkpoint_and_resume_gives_the_same_proof(ctx):
         pp2.free()
 
 
-def test_wire_formats_at_t_2_16(ctx):
-    """Full-size shape: sizes and timings of both encodings."""
+@pytest.mark.parametrize("kind", [1, 0], ids=["reference", "bound"])
+def test_wire_formats_at_t_2_16(ctx, kind):
+    """Full-size shape (the reference's circuit and the bound form): sizes and timings of both encodings; a checkpoint
+    taken after two steps resumes (the restored proof proves the third step and verifies)."""
     t, n = 1 << 16, 3
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=5)
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=5, kind=kind)
     zi = _zi(init_ints)
     proof = None
     for k in range(2):

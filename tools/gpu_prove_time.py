@@ -4,12 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pasta as o
 import vdf_amd
 from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode
-from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params
+from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params, CIRCUIT_MINROOT_BOUND, CIRCUIT_MINROOT_REFERENCE
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+kind = CIRCUIT_MINROOT_REFERENCE if len(sys.argv) > 3 and sys.argv[3].startswith("ref") else CIRCUIT_MINROOT_BOUND
 t = 1 << lg
 ctx = vdf_amd.Context(0)
-t0 = time.time(); pp = public_params(ctx, t); print("public_params %.2f s" % (time.time() - t0), pp.sizes(0), pp.sizes(1), "early rows", pp.early_rows())
+print("step circuit:", "reference (4 variables per round)" if kind else "bound (3 variables per round)")
+t0 = time.time(); pp = public_params(ctx, t, kind); print("memory", pp.memory()); print("public_params %.2f s" % (time.time() - t0), pp.sizes(0), pp.sizes(1), "early rows", pp.early_rows())
 initial = State.from_ints(FIELD_FQ, o.rand_fe(1, 0, o.Q), 0, 0)
 t0 = time.time(); z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new_with_mode(EvalMode.LTRAddChainSequential), t, n, initial)
 print("forward evaluation of %d x 2^%d rounds: %.2f s (host, sequential)" % (n, lg, time.time() - t0))

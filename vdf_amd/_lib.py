@@ -60,6 +60,8 @@ PROTOTYPES = {
     "vdf_msm_sharded": (_i, [_vp, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vdf_msm_multi": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz), _i, _i, _vp]),
     "vdf_msm_timing": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "vdf_ctx_set_kernel_timing": (_i, [_vp, _i]),
+    "vdf_ctx_kernel_events": (_i, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "mult_pippenger_pallas": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
     "mult_pippenger_vesta": (None, [_vp, _vp, _sz, _vp, C.c_bool]),
     "vdf_shape_create": (_i, [_vp, _i, _sz, _sz, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp)]),
@@ -71,6 +73,7 @@ PROTOTYPES = {
     "vdf_minroot_step_z": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "vdf_minroot_step_z_packed": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_minroot_step_segment": (_i, [_vp, _i, _vp, _u64, _vp, _i, _vp]),
+    "vdf_minroot_step_segment_packed": (_i, [_vp, _i, _vp, _u64, _vp, _vp, _vp, _vp]),
     "vdf_vec_is_zero": (_i, [_vp, _vp, _sz, C.POINTER(C.c_int)]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term_rows": (_i, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -106,11 +106,21 @@ int fail(vdf_ctx* ctx, const Status& s) {
   return s.code;
 }
 
+}  // namespace
+namespace vdf { thread_local KSink* tl_ksink = nullptr; }
+namespace {
+struct SinkScope {            // launches made under this call record into the context's sink (nested calls restore the outer one)
+  vdf::KSink* prev;
+  explicit SinkScope(vdf_ctx* c) : prev(vdf::tl_ksink) { vdf::tl_ksink = c->ktiming ? &c->ksink : nullptr; }
+  ~SinkScope() { vdf::tl_ksink = prev; }
+};
+
 template <class F>
 int guarded(vdf_ctx* ctx, F&& body) {
   if (!ctx) { g_create_err = "null context"; return VDF_ERR_BAD_ARG; }
   try {
     std::lock_guard<std::mutex> lock(ctx->mu);
+    SinkScope sink_scope(ctx);
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, vdf::hip_status(e, "hipSetDevice"));
     Status s = body();
@@ -835,6 +845,53 @@ int vdf_msm_multi(vdf_ctx* const ctxs[], const vdf_bases* const bases[], const s
   return rc;
 }
 
+// ---- per-launch timing (the roofline report of bench.py) ----------------------------------------------------------
+namespace {
+std::mutex g_base_mu;
+hipEvent_t g_base_ev[64] = {};          // one time origin per device, shared by every context on it
+}
+int vdf_ctx_set_kernel_timing(vdf_ctx* ctx, int enable) {
+  return guarded(ctx, [&]() -> Status {
+    if (enable && ctx->device >= 0 && ctx->device < 64) {
+      std::lock_guard<std::mutex> l(g_base_mu);
+      if (!g_base_ev[ctx->device]) {
+        hipEvent_t e = nullptr;
+        VDF_TRY_HIP(hipEventCreate(&e));
+        VDF_TRY_HIP(hipEventRecord(e, ctx->stream));
+        VDF_TRY_HIP(hipEventSynchronize(e));
+        g_base_ev[ctx->device] = e;
+      }
+    }
+    ctx->ktiming = enable != 0;
+    return Status{};
+  });
+}
+int vdf_ctx_kernel_events(vdf_ctx* ctx, vdf_kernel_event* out, size_t cap, size_t* n) {
+  return guarded(ctx, [&]() -> Status {
+    if (!n) return Status{VDF_ERR_BAD_ARG, "null count"};
+    auto& rec = ctx->ksink.rec;
+    *n = rec.size();
+    if (!out) return Status{};                                  // a query of the count only: nothing is drained
+    if (cap < rec.size()) return Status{VDF_ERR_BAD_LENGTH, "more launches recorded than the buffer holds"};
+    hipEvent_t base = (ctx->device >= 0 && ctx->device < 64) ? g_base_ev[ctx->device] : nullptr;
+    if (!base && !rec.empty()) return Status{VDF_ERR_BAD_ARG, "kernel timing was never enabled on this device"};
+    VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < rec.size(); ++i) {
+      float a = 0, b = 0;
+      // a record's stream may be another than the context's (the side streams of an MSM job): wait for its end event
+      VDF_TRY_HIP(hipEventSynchronize(rec[i].e1));
+      VDF_TRY_HIP(hipEventElapsedTime(&a, base, rec[i].e0));
+      VDF_TRY_HIP(hipEventElapsedTime(&b, base, rec[i].e1));
+      std::memset(out[i].name, 0, sizeof(out[i].name));
+      std::strncpy(out[i].name, rec[i].name, sizeof(out[i].name) - 1);
+      out[i].bytes = rec[i].bytes; out[i].start_ms = a; out[i].end_ms = b;
+      ctx->ksink.pool.push_back(rec[i].e0); ctx->ksink.pool.push_back(rec[i].e1);
+    }
+    rec.clear();
+    return Status{};
+  });
+}
+
 int vdf_ctx_set_timing(vdf_ctx* ctx, int enable) {
   return guarded(ctx, [&]() -> Status { ctx->timing = enable != 0; return Status{}; });
 }
@@ -925,6 +982,8 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
     if (e == hipSuccess) e = hipMemcpy(s->d_dict, dict.data(), dict.size() * 32, hipMemcpyHostToDevice);
     for (int k = 0; k < 3 && e == hipSuccess; ++k) {
       s->nnz[k] = nnz[k];
+      if (k == 0) s->h_nnz_prefix.assign(num_cons + 1, 0);
+      for (size_t r = 0; r <= num_cons; ++r) s->h_nnz_prefix[r] += rowptr[k][r];       // entries of A, B, C above row r
       e = hipMalloc(reinterpret_cast<void**>(&s->d_rowptr[k]), (num_cons + 1) * 4);
       if (e == hipSuccess) e = hipMemcpy(s->d_rowptr[k], rowptr[k].data(), (num_cons + 1) * 4, hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_col[k]), (nnz[k] + 1) * 4);
@@ -1111,7 +1170,20 @@ int vdf_minroot_step_segment(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, ui
     if (!i0 || ptr_is_device(i0)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
     if (!ptr_is_device(trace_xy) || !ptr_is_device(out))
       return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
-    VDF_TRY(vdf::vec_step_segment(field, trace_xy, t, i0, vars_per_round, out, ctx->stream));
+    VDF_TRY(vdf::vec_step_segment(field, trace_xy, t, i0, vars_per_round, out, nullptr, nullptr, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_minroot_step_segment_packed(vdf_ctx* ctx, int field, const vdf_fe* trace_xy, uint64_t t, const vdf_fe* i0, const vdf_fe* i_in,
+                                    vdf_fe* out, vdf_fe* packed) {
+  return guarded(ctx, [&]() -> Status {
+    if (t == 0 || t >= (1ull << 31)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
+    if (!i0 || !i_in || ptr_is_device(i0) || ptr_is_device(i_in)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    if (!ptr_is_device(trace_xy) || !ptr_is_device(out) || !ptr_is_device(packed))
+      return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    VDF_TRY(vdf::vec_step_segment(field, trace_xy, t, i0, 4, out, packed, i_in, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });
@@ -1142,8 +1214,19 @@ static Status nifs_cross_impl(vdf_ctx* ctx, const vdf_shape* shape, size_t row_b
     VDF_TRY(vdf::vec_spmv_long(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, shape->d_long,
                                shape->n_long, outs, ctx->stream));
   }
+  // algorithmic bytes of the launch: per entry of A, B, C the column and coefficient index (8 B), per
+  // row three row pointers and three results (3 x 36 B) and the seven vectors of the cross term (7 x 32 B); the gathered
+  // elements of z are not counted (they are re-reads of a vector the launch already reads once through the cache)
+  double alg_bytes = 0;
+  if (shape->h_nnz_prefix.size() == shape->num_cons + 1) {
+    const auto& pf = shape->h_nnz_prefix;
+    const double nnz_all = (double)pf[shape->num_cons];
+    const double nnz_range = (part == VDF_ROWS_ALL) ? 0.0 : (double)(pf[row_begin + row_count] - pf[row_begin]);
+    const double nnz_run = part == VDF_ROWS_INSIDE ? nnz_range : nnz_all - nnz_range;
+    alg_bytes = nnz_run * 8.0 + (double)rows * (3 * 36.0 + 7 * 32.0);
+  }
   VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
-                              u1, rows, skip_begin, skip_len, Az2, Bz2, Cz2, T, ctx->stream));
+                              u1, rows, skip_begin, skip_len, Az2, Bz2, Cz2, T, alg_bytes, ctx->stream));
   if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
   return Status{};
 }

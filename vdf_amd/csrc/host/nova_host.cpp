@@ -224,6 +224,7 @@ int alloc_proof_buffers(vdf_proof* p) {
     HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[k] + pp->s[PRIMARY].num_vars * 32, &u_one, 32));
   }
   for (int k = 0; k < vdf_proof::DEPTH; ++k) {
+    if (pp->seg_gens) HIPCALL(ctx, vdf_dev_alloc(ctx, (3 * pp->t + 4) * 32, &p->d_packed[k]));
     const int dev = vdf_ctx_device(ctx);
     if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
@@ -315,6 +316,31 @@ int vdf_nova_shape_digest(uint64_t t, int circuit_kind, int gens_family, uint8_t
         sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
         sizes[s][2] = sh[s].m[0].rows.size() + sh[s].m[1].rows.size() + sh[s].m[2].rows.size();
       }
+    return VDF_OK;
+  });
+}
+
+// The R1CS shape public_params would make, as COO triples (row-major order of the constraints' creation, values in Montgomery
+// form of the side's field): two calls, first with null arrays for the counts.
+int vdf_nova_shape_export(uint64_t t, int circuit_kind, int side, uint64_t nnz[3], uint32_t* const rows[3], uint32_t* const cols[3],
+                          vdf_fe* const vals[3]) {
+  return nova_guard([&]() -> int {
+    if (t == 0 || t > (1ull << 24) || !nnz || (side != PRIMARY && side != SECONDARY)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE) return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
+    HostShape sh[2];
+    build_shapes(t, circuit_kind, sh);
+    const HostShape& h = sh[side];
+    const bool fill = rows && cols && vals;
+    for (int k = 0; k < 3; ++k) {
+      const size_t z = h.m[k].rows.size();
+      if (fill) {
+        if (nnz[k] < z || !rows[k] || !cols[k] || !vals[k]) return fail(VDF_ERR_BAD_LENGTH, "triple arrays too short");
+        memcpy(rows[k], h.m[k].rows.data(), z * 4);
+        memcpy(cols[k], h.m[k].cols.data(), z * 4);
+        memcpy(vals[k], h.m[k].vals.data(), z * 32);
+      }
+      nnz[k] = z;
+    }
     return VDF_OK;
   });
 }
@@ -417,6 +443,46 @@ int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary,
       return fail(VDF_ERR_BAD_ARG, "bad argument");
     return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, 0, out);
   });
+}
+
+// The reference's circuit allocates new_x in every round (src/nova/proof.rs:167-173) although it is an affine image of
+// other witness values: new_x_j = y_j - (i_in - (j + 1)), y_j = new_y_(j-1).  Its share of a commitment therefore folds
+// into the generators of the new_y's and two points that depend on the generators only (include/vdf_hip.h
+// vdf_minroot_step_segment_packed): the MinRoot rounds of the reference's witness are committed by an MSM of 3t + 4 terms
+// over DERIVED generators instead of 4t + 1 -- the same group element, a quarter fewer bucket additions.
+static int make_packed_generators(vdf_pp* pp) {
+  const Side& sd = pp->s[PRIMARY];
+  const Field& Fb = *sd.Fb;
+  const size_t t = pp->t, n = 4 * t + 1;
+  std::vector<Aff> G(n);
+  HIPCALL(pp->ctx, vdf_bases_download(pp->ctx, sd.gens, pp->seg_begin, n, (vdf_affine*)G.data()));
+  std::vector<Aff> D(3 * t + 4);
+  std::vector<Pt> sums(t + 2);                    // G[4j+3] + G[4j+4] for j < t - 1, then S1 (negated below) and S2
+  Pt s1 = pt_identity(), s2 = pt_identity();
+  for (size_t j = t; j-- > 0;) {                  // suffix sums: S2 = sum_j (j + 1) G[4j]
+    s1 = pt_add(s1, pt_from_aff(G[4 * j], Fb), Fb);
+    s2 = pt_add(s2, s1, Fb);
+  }
+  for (size_t j = 0; j + 1 < t; ++j) sums[j] = pt_add(pt_from_aff(G[4 * j + 3], Fb), pt_from_aff(G[4 * j + 4], Fb), Fb);
+  sums[t - 1] = pt_from_aff(G[4 * t - 1], Fb);
+  s1.y = neg(s1.y, Fb);
+  sums[t] = s1; sums[t + 1] = s2;
+  // XYZZ -> affine with two batched inversions
+  std::vector<Fe> izz(t + 2), izzz(t + 2);
+  for (size_t j = 0; j < t + 2; ++j) { izz[j] = sums[j].is_id() ? one(Fb) : sums[j].zz; izzz[j] = sums[j].is_id() ? one(Fb) : sums[j].zzz; }
+  batch_inverse(izz.data(), izz.size(), Fb);
+  batch_inverse(izzz.data(), izzz.size(), Fb);
+  auto aff = [&](size_t j) {
+    Aff a;
+    if (sums[j].is_id()) { a.x = zero(); a.y = zero(); return a; }
+    a.x = vdfhost::canon(vdfhost::mul(sums[j].x, izz[j], Fb), Fb); a.y = vdfhost::canon(vdfhost::mul(sums[j].y, izzz[j], Fb), Fb);
+    return a;
+  };
+  for (size_t j = 0; j < t; ++j) { D[3 * j] = G[4 * j + 1]; D[3 * j + 1] = G[4 * j + 2]; D[3 * j + 2] = aff(j); }
+  D[3 * t] = G[4 * t]; D[3 * t + 1] = G[0]; D[3 * t + 2] = aff(t); D[3 * t + 3] = aff(t + 1);
+  HIPCALL(pp->ctx, vdf_bases_upload(pp->ctx, sd.curve, (const vdf_affine*)D.data(), D.size(), &pp->seg_gens));
+  HIPCALL(pp->ctx, vdf_bases_precompute(pp->ctx, pp->seg_gens, vdf_bases_window(sd.gens), 1));
+  return VDF_OK;
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
@@ -540,11 +606,16 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     memcpy(dv, pp->digest, 32);
     pp->params[s] = int_to_fe(dv, *sd.F);
   }
+  if (circuit_kind == VDF_CIRCUIT_MINROOT_REFERENCE && pp->seg_len == 4 * t + 1 && !std::getenv("VDF_NOVA_NO_PACKED_COMMIT")) {
+    int rc = make_packed_generators(pp.get());
+    if (rc != VDF_OK) return rc;
+  }
   *out = pp.release();
   return VDF_OK;
 }
 void vdf_nova_pp_free(vdf_pp* pp) {
   if (!pp) return;
+  if (pp->seg_gens) vdf_bases_free(pp->seg_gens);
   for (Side& sd : pp->s) {
     if (sd.d_zero) vdf_dev_free(pp->ctx, sd.d_zero);
     if (sd.shape) vdf_shape_free(sd.shape);
@@ -746,10 +817,15 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       d_trace = stage;
     }
     char* seg = (char*)p->d_z2s[s] + seg_b * 32;
-    HIPCALL(q, vdf_minroot_step_segment(q, S1.field, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)&cc.input.i, per, (vdf_fe*)seg));
+    void* packed = pp->seg_gens ? p->d_packed[j % D] : nullptr;
+    if (packed) HIPCALL(q, vdf_minroot_step_segment_packed(q, S1.field, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)&cc.input.i,
+                                                            (const vdf_fe*)&cc.result.i, (vdf_fe*)seg, (vdf_fe*)packed));
+    else HIPCALL(q, vdf_minroot_step_segment(q, S1.field, (const vdf_fe*)d_trace, pp->t, (const vdf_fe*)&cc.input.i, per, (vdf_fe*)seg));
     HIPCALL(q, vdf_ctx_mark(q, MARK_Z));
     HIPCALL(ctx, vdf_ctx_wait(ctx, q));          // the first context waits for the rounds only, not for their commitment
-    HIPCALL(q, vdf_msm(q, S1.gens, seg_b, (const vdf_fe*)seg, seg_n, 1, &p->h_pts[s]));
+    // the reference's circuit: the same commitment from 3t + 4 terms over the derived generators (make_packed_generators)
+    if (packed) HIPCALL(q, vdf_msm(q, pp->seg_gens, 0, (const vdf_fe*)packed, 3 * pp->t + 4, 1, &p->h_pts[s]));
+    else HIPCALL(q, vdf_msm(q, S1.gens, seg_b, (const vdf_fe*)seg, seg_n, 1, &p->h_pts[s]));
     HIPCALL(q, vdf_ctx_mark(q, MARK_W));
     touched[j % D] = true;
     vdf_proof::Ahead a;
@@ -1078,6 +1154,7 @@ void vdf_nova_proof_free(vdf_proof* p) {
     if (p->d_l2z) vdf_dev_free(ctx, p->d_l2z);
     for (void* b : p->d_z2s) if (b) vdf_dev_free(ctx, b);
     for (void* b : p->d_traces) if (b) vdf_dev_free(ctx, b);
+    for (void* b : p->d_packed) if (b) vdf_dev_free(ctx, b);
     for (vdf_ctx* q : p->ctx2) if (q) vdf_ctx_destroy(q);
     if (p->ctx3) vdf_ctx_destroy(p->ctx3);
     if (p->h_pts) vdf_host_free(ctx, p->h_pts);
@@ -1124,6 +1201,36 @@ int vdf_nova_proof_last_step(const vdf_proof* p, vdf_nova_step_info* out) {
 int vdf_nova_last_step_ms(const vdf_proof* p, double ms[8]) {
   if (!p || !ms) return fail(VDF_ERR_BAD_ARG, "null argument");
   memcpy(ms, p->ms, sizeof(p->ms));
+  return VDF_OK;
+}
+
+// Per-launch timing of a prover's three queues (its context, the lookahead's, the early rows'): the three contexts'
+// records merged on the device's common time line, queue = 0 / 1 / 2.
+int vdf_nova_proof_set_kernel_timing(vdf_proof* p, int enable) {
+  if (!p || !p->pp) return fail(VDF_ERR_BAD_ARG, "null argument");
+  vdf_ctx* cs[3] = {p->pp->ctx, p->ctx2[0], p->ctx3};
+  for (vdf_ctx* c : cs)
+    if (c) HIPCALL(c, vdf_ctx_set_kernel_timing(c, enable));
+  return VDF_OK;
+}
+int vdf_nova_proof_kernel_events(vdf_proof* p, vdf_kernel_event* out, int* queue, size_t cap, size_t* n) {
+  if (!p || !p->pp || !n) return fail(VDF_ERR_BAD_ARG, "null argument");
+  vdf_ctx* cs[3] = {p->pp->ctx, p->ctx2[0], p->ctx3};
+  size_t cnt[3] = {0, 0, 0}, total = 0;
+  for (int q = 0; q < 3; ++q)
+    if (cs[q]) { HIPCALL(cs[q], vdf_ctx_kernel_events(cs[q], nullptr, 0, &cnt[q])); total += cnt[q]; }
+  *n = total;
+  if (!out) return VDF_OK;
+  if (cap < total) return fail(VDF_ERR_BAD_LENGTH, "more launches recorded than the buffer holds");
+  size_t at = 0;
+  for (int q = 0; q < 3; ++q) {
+    if (!cs[q]) continue;
+    size_t got = 0;
+    HIPCALL(cs[q], vdf_ctx_kernel_events(cs[q], out + at, cap - at, &got));
+    if (queue) for (size_t i = 0; i < got; ++i) queue[at + i] = q;
+    at += got;
+  }
+  *n = at;
   return VDF_OK;
 }
 

@@ -90,6 +90,9 @@ struct vdf_pp {
   size_t ahead_row = 0, ahead_rows = 0;
   int ahead_mode = 2;            // when they run: 2 = from the start of the step, beside the secondary side's NIFS; 1 = after it (tuning)
   size_t arity = 3;                        // of the primary step circuit (z0, zi)
+  // the reference's step circuit only: generators of the packed commitment to the MinRoot rounds (3t + 4 points derived from
+  // the 4t + 1 of the segment: vdf_hip.h vdf_minroot_step_segment_packed), with a fixed-base table of their own
+  vdf_bases* seg_gens = nullptr;
   uint64_t digit_table_bytes[2] = {0, 0};  // HBM held by each side's digit table (vdf_nova_pp_memory)
   unsigned digit_tables_skipped = 0;       // bit s: side s asked for a digit table and went without (no room, refused window)
 };
@@ -142,6 +145,7 @@ struct vdf_proof {
                                  // they start with the step and not behind the previous lookahead's commitment
   void* d_z2s[RING] = {};
   void* d_traces[DEPTH] = {};
+  void* d_packed[DEPTH] = {};    // scalars of the packed commitment (the reference's circuit), one buffer per lookahead queue
   int slot = 0;
   struct Ahead { vdfnova::St result, input; int slot; };
   const vdf_circuits* ahead_circuits = nullptr;

@@ -7,6 +7,37 @@
 #include <vector>
 #include "../../include/vdf_hip.h"
 
+namespace vdf {
+// Per-launch timing for the roofline report (vdf_ctx_set_kernel_timing): a launch site constructs a KTimer around its
+// launch; when the calling thread has a sink (set by the ABI's guard while the context's kernel timing is on) two HIP
+// events bracket the launch on its stream.  Off by default: no events, no cost.
+struct KRecord { const char* name; double bytes; hipEvent_t e0, e1; };
+struct KSink {
+  std::vector<KRecord> rec;
+  std::vector<hipEvent_t> pool;
+};
+extern thread_local KSink* tl_ksink;
+struct KTimer {
+  hipStream_t s; KSink* k; KRecord r;
+  KTimer(hipStream_t st, const char* name, double bytes) : s(st), k(tl_ksink) {
+    if (!k) return;
+    r.name = name; r.bytes = bytes; r.e0 = r.e1 = nullptr;
+    for (hipEvent_t* e : {&r.e0, &r.e1}) {
+      if (!k->pool.empty()) { *e = k->pool.back(); k->pool.pop_back(); }
+      else if (hipEventCreate(e) != hipSuccess) { (void)hipGetLastError(); *e = nullptr; }
+    }
+    if (r.e0 && r.e1) (void)hipEventRecord(r.e0, s); else k = nullptr;
+  }
+  ~KTimer() {
+    if (!k) return;
+    (void)hipEventRecord(r.e1, s);
+    k->rec.push_back(r);
+  }
+  KTimer(const KTimer&) = delete;
+  KTimer& operator=(const KTimer&) = delete;
+};
+}  // namespace vdf
+
 struct vdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -27,6 +58,8 @@ struct vdf_ctx {
   int num_cus = 256;
   // stage timing (bench.py roofline leg)
   bool timing = false;
+  bool ktiming = false;              // per-launch events (vdf_ctx_set_kernel_timing)
+  vdf::KSink ksink;
   struct TimedCall { hipEvent_t ev[4]; };
   std::vector<TimedCall> timed;      // events of calls not yet queried
   std::vector<hipEvent_t> ev_pool;   // recycled events
@@ -74,6 +107,7 @@ struct vdf_shape {
   // rows with more than VDF_LONG_ROW entries, as row | matrix << 30: one wavefront each (vec_spmv_long) instead of one lane
   uint32_t* d_long = nullptr;
   size_t n_long = 0;
+  std::vector<uint64_t> h_nnz_prefix;                     // entries of A + B + C in the rows above r (pricing of a row range)
   std::vector<uint32_t> h_long_rows;                      // ... their row numbers, ascending (vdf_nifs_cross_term_rows)
 };
 // A row of more than this many entries is summed by a whole wavefront ahead of the lane-per-row kernels, which then
@@ -179,13 +213,14 @@ Status vec_spmv_long(int field, const uint32_t* const rowptr[3], const uint32_t*
 Status vec_spmv(int field, const uint32_t* rowptr, const uint32_t* col, const uint32_t* coef, const void* dict,
                 const void* z, size_t rows, void* out, hipStream_t s);
 // fused step kernels; vdf_fe* arguments are HOST pointers whose values travel as kernel arguments
-Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, hipStream_t s);
+Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, void* packed,
+                        const vdf_fe* i_in, hipStream_t s);
 Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in[3], const vdf_fe* i0, const vdf_fe* u,
                   const vdf_fe X[6], void* z, void* packed, hipStream_t s);
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
                       const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
-                      void* bz2, void* cz2, void* T, hipStream_t s);
+                      void* bz2, void* cz2, void* T, double alg_bytes, hipStream_t s);
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);

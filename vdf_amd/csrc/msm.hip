@@ -1205,20 +1205,27 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
 
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   // pass A
+  {
+  KTimer kt(st, "msm_sort(5 launches)", 0.0);
   hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
   hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy, heavy + 1 + nkeys + 2);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
                      p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
-  static const FixupTune tune = fixup_tune();
   // pass B
   hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
                      reinterpret_cast<uint32_t*>(base + w.tstart));
+  }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
+  {
+  KTimer kt(st, "k_accumulate", 96.0 * p.n);            // the pipeline's algorithmic bytes: 96 B per (base, scalar) pair, SURVEY.md 8d
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
                      reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.slots, p.Lfixed, p.nthreads);
+  }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
+  static const FixupTune tune = fixup_tune();
+  KTimer kt_tail(st, ext_bucket_acc ? "msm_fixup(2 launches)" : "msm_tail(fixup+reduce)", 0.0);
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
                      heavy, tune.heavy_min, tune.giant_span);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(16 * GIANT_PARTS), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,

@@ -329,9 +329,14 @@ static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, con
   }
   for (int l = 0; l < 9; ++l) a.half[l] = 0;
   for (int j = 0; j < W; ++j) { const int bit = c * j + c - 1; a.half[bit >> 5] |= 1u << (bit & 31); }
-  if (waves)
+  double nsum = 0;
+  for (int g = 0; g < groups; ++g) nsum += (double)n[g];
+  if (waves) {
+    KTimer kt(st, "k_direct_sum", 96.0 * nsum);         // a commitment's algorithmic bytes: 96 B per (base, scalar) pair
     hipLaunchKernelGGL((k_direct_sum<P, SP>), dim3(waves / 4), dim3(256), 0, st, a, is_mont ? 1 : 0, c, W,
                        reinterpret_cast<const char*>(d_digits), reinterpret_cast<char*>(ws));
+  }
+  KTimer kt(st, "k_direct_final", 0.0);
   hipLaunchKernelGGL((k_direct_final<P>), dim3(groups), dim3(256), 0, st, a, reinterpret_cast<const char*>(ws),
                      reinterpret_cast<char*>(d_out));
   VDF_TRY_HIP(hipGetLastError());

@@ -148,22 +148,36 @@ __global__ __launch_bounds__(256) void k_step_z(const char* __restrict__ trace, 
 // per = 3 the bound form without new_x (oracle/nova.py InverseMinRootCircuit).
 template <class P>
 __global__ __launch_bounds__(256) void k_step_segment(const char* __restrict__ trace, FeVal i0, uint64_t t, int per,
-                                                      char* __restrict__ out) {
+                                                      char* __restrict__ out, char* __restrict__ packed, FeVal i_in) {
   __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (j > t) return;
   if (j == t) {
     fe_store<P>(out + (size_t)per * t * 32, fe_from_val<P>(i0));
+    if (packed) {                    // [3t] final_i, [3t + 1] y of the first round, [3t + 2] i of the first round, [3t + 3] one
+      char* q = packed + (size_t)3 * t * 32;
+      fe_store<P>(q, fe_from_val<P>(i0));
+      fe_store<P>(q + 32, fe_load<P>(trace + t * 64 + 32));
+      fe_store<P>(q + 64, fe_from_val<P>(i_in));
+      fe_store<P>(q + 96, fe_one<P>());
+    }
     return;
   }
   const Fe<P> x = fe_load<P>(trace + (t - j) * 64);
   const Fe<P> t1 = fe_sqr(x);
   const Fe<P> t2 = fe_sqr(t1);
+  const Fe<P> ny = fe_load<P>(trace + (t - j - 1) * 64 + 32);
   char* o = out + j * (size_t)per * 32;
   if (per == 4) { fe_store<P>(o, fe_load<P>(trace + (t - j - 1) * 64)); o += 32; }
   fe_store<P>(o, t1);
   fe_store<P>(o + 32, t2);
-  fe_store<P>(o + 64, fe_load<P>(trace + (t - j - 1) * 64 + 32));
+  fe_store<P>(o + 64, ny);
+  if (packed) {
+    char* q = packed + j * 96;
+    fe_store<P>(q, t1);
+    fe_store<P>(q + 32, t2);
+    fe_store<P>(q + 64, ny);
+  }
 }
 
 struct Csr3 { const uint32_t* rowptr[3]; const uint32_t* col[3]; const uint32_t* coef[3]; };
@@ -304,6 +318,7 @@ __global__ __launch_bounds__(256) void k_mul_chain(const char* __restrict__ a, s
 
 Status vec_axpy(int field, const void* a, const void* r, const void* b, size_t n, void* out, hipStream_t s) {
   if (n == 0) return Status{};
+  KTimer kt(s, "k_axpy", 96.0 * n);
   FIELD_DISPATCH(field, k_axpy, grid_for(n), dim3(256), 0, s, C(a), C(r), C(b), n, M(out));
   return Status{};
 }
@@ -311,12 +326,14 @@ Status vec_axpy(int field, const void* a, const void* r, const void* b, size_t n
 Status vec_cross_term(int field, const void* az1, const void* bz1, const void* cz1, const void* az2, const void* bz2,
                       const void* cz2, const void* u1, size_t n, void* T, hipStream_t s) {
   if (n == 0) return Status{};
+  KTimer kt(s, "k_cross_term", 224.0 * n);
   FIELD_DISPATCH(field, k_cross_term, grid_for(n), dim3(256), 0, s, C(az1), C(bz1), C(cz1), C(az2), C(bz2), C(cz2),
                  C(u1), n, M(T));
   return Status{};
 }
 
 Status vec_minroot_witness(int field, const void* trace_xy, const void* i0, uint64_t t, void* W, hipStream_t s) {
+  KTimer kt(s, "k_minroot_witness", 192.0 * t);
   FIELD_DISPATCH(field, k_minroot_witness, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), C(i0), t, M(W));
   return Status{};
 }
@@ -326,6 +343,7 @@ Status vec_spmv_long(int field, const uint32_t* const rowptr[3], const uint32_t*
   if (n_long == 0) return Status{};
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
+  KTimer kt(s, "k_spmv_long", 0.0);                    // priced with the cross term that reads its results
   FIELD_DISPATCH(field, k_spmv_long, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, s, m, C(dict), C(z), long_rows, n_long,
                  M(out[0]), M(out[1]), M(out[2]));
   return Status{};
@@ -351,18 +369,22 @@ Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in
   return Status{};
 }
 
-Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, hipStream_t s) {
-  FIELD_DISPATCH(field, k_step_segment, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), to_val(i0), t, per, M(out));
+Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_fe* i0, int per, void* out, void* packed,
+                        const vdf_fe* i_in, hipStream_t s) {
+  KTimer kt(s, "k_step_segment", (64.0 + 32.0 * per) * t);    // trace (x, y) read + `per` variables written per round
+  FIELD_DISPATCH(field, k_step_segment, grid_for(t + 1), dim3(256), 0, s, C(trace_xy), to_val(i0), t, per, M(out), M(packed),
+                 to_val(i_in ? i_in : i0));
   return Status{};
 }
 
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
                       const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
-                      void* bz2, void* cz2, void* T, hipStream_t s) {
+                      void* bz2, void* cz2, void* T, double alg_bytes, hipStream_t s) {
   if (rows == 0) return Status{};
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
+  KTimer kt(s, "k_nifs_cross", alg_bytes);
   FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
                  to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
   return Status{};
@@ -382,6 +404,9 @@ Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const
     a.blk_end[i] = (uint32_t)blocks;
   }
   if (blocks == 0) return Status{};
+  double elems = 0;
+  for (int i = 0; i < k; ++i) elems += (double)n[i];
+  KTimer kt(s, "k_fold_many", 96.0 * elems);
   FIELD_DISPATCH(field, k_fold_many, dim3((unsigned)blocks), dim3(256), 0, s, a, to_val(r));
   return Status{};
 }

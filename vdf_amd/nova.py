@@ -39,9 +39,12 @@ for _name, _res, _args in [
     ("vdf_nova_proof_zi", _i, [_vp, _vp, _vp]),
     ("vdf_nova_proof_last_step", _i, [_vp, _vp]),
     ("vdf_nova_last_step_ms", _i, [_vp, C.POINTER(C.c_double * 8)]),
+    ("vdf_nova_proof_set_kernel_timing", _i, [_vp, _i]),
+    ("vdf_nova_proof_kernel_events", _i, [_vp, _vp, _vp, _sz, C.POINTER(_sz)]),
     ("vdf_nova_ro_hash", _i, [_i, _u64, _vp, _sz, _vp]),
     ("vdf_nova_shape_digest", _i, [_u64, _i, _i, _vp, _vp]),
     ("vdf_nova_shape_digest_custom", _i, [_vp, _i, _vp, _vp]),
+    ("vdf_nova_shape_export", _i, [_u64, _i, _i, _vp, _vp, _vp, _vp]),
     ("vdf_nova_aug_synthesize", _i, [_i, _u64, _i, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp, _vp]),
     ("vdf_nova_public_params_custom", _i, [_vp, _vp, _i, C.POINTER(_vp)]),
     ("vdf_nova_prove_step_custom", _i, [_vp, C.POINTER(_vp), _vp, _vp]),
@@ -81,6 +84,7 @@ SIDE_PRIMARY, SIDE_SECONDARY = 0, 1
 INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY, INST_FRESH_PRIMARY_LAST = 0, 1, 2, 3
 GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT, GENS_LABEL_SHAKE = 0, 1, 2
 PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS = 1, 2
+KERNEL_EVENT_DTYPE = np.dtype([("name", "S24"), ("bytes", "<f8"), ("start_ms", "<f8"), ("end_ms", "<f8")])     # vdf_kernel_event
 
 
 def _check(rc: int) -> None:
@@ -118,6 +122,16 @@ def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
     sizes = np.zeros((2, 3), dtype="<u8")
     _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+def shape_export(t: int, circuit_kind: int = 0, side: int = 0):
+    """[(rows uint32[nnz], cols uint32[nnz], vals uint64[nnz, 4])] x 3 (A, B, C) of the shape public_params(t) makes (host only)."""
+    nnz = np.zeros(3, dtype="<u8")
+    _check(nova_lib.vdf_nova_shape_export(t, circuit_kind, side, nnz.ctypes.data, None, None, None))
+    mats = [(np.zeros(int(z), dtype=np.uint32), np.zeros(int(z), dtype=np.uint32), np.zeros((int(z), 4), dtype="<u8")) for z in nnz]
+    arr = lambda k: (C.c_void_p * 3)(*[m[k].ctypes.data for m in mats])
+    _check(nova_lib.vdf_nova_shape_export(t, circuit_kind, side, nnz.ctypes.data, arr(0), arr(1), arr(2)))
+    return mats
 
 
 # ---- the step-circuit seam (include/vdf_nova.h vdf_step_circuit; src/nova/proof.rs:79-153) ---------------------------
@@ -454,6 +468,21 @@ class NovaVDFProof:               # enum NovaVDFProof { Recursive, Compressed },
         ms = (C.c_double * 8)()
         _check(nova_lib.vdf_nova_last_step_ms(self.handle, C.byref(ms)))
         return dict(zip(("secondary_nifs", "primary_synthesis", "primary_launch", "primary_wait", "secondary_synthesis", "secondary_launch", "lookahead", "total"), list(ms)))
+
+    def set_kernel_timing(self, flag: bool) -> None:
+        """HIP events around every launch of this prover's three queues (include/vdf_nova.h); measure rates with it off."""
+        _check(nova_lib.vdf_nova_proof_set_kernel_timing(self.handle, int(flag)))
+
+    def kernel_events(self) -> list:
+        """Drains the timed launches: [(queue, kernel, algorithmic bytes, start_ms, end_ms)] on the device's common time line."""
+        n = C.c_size_t()
+        _check(nova_lib.vdf_nova_proof_kernel_events(self.handle, None, None, 0, C.byref(n)))
+        cap = n.value + 64
+        ev = np.zeros(cap, dtype=KERNEL_EVENT_DTYPE)
+        q = np.zeros(cap, dtype=np.int32)
+        _check(nova_lib.vdf_nova_proof_kernel_events(self.handle, ev.ctypes.data, q.ctypes.data, cap, C.byref(n)))
+        return [(int(q[i]), ev["name"][i].decode(), float(ev["bytes"][i]), float(ev["start_ms"][i]), float(ev["end_ms"][i]))
+                for i in range(n.value)]
 
     def free(self) -> None:
         if self.handle and self.pp.handle and self.pp.ctx.handle:      # needs live parameters and a live context
