@@ -568,18 +568,27 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
         if (v == 0 || (v >= 6 && v <= 12)) digit_c = v;                                              // anything else: the default stays
       }
       if (flags & VDF_PP_NO_DIGIT_TABLES) digit_c = 0;
-      size_t db[2] = {0, 0}, dn[2] = {0, 0};
+      // generator ranges of the commitments a step waits for, as index intervals: the host-made variables before and after
+      // the MinRoot rounds (W) and the rows of T before and after the early rows; merged where they overlap (at most 4)
+      size_t db[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
       int nr = 0;
       const size_t top = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons;
       if (s == SECONDARY || pp->seg_len == 0) { dn[0] = top; nr = 1; }
       else if (pp->ahead_rows) {
         const size_t se = pp->seg_begin + pp->seg_len, ae = pp->ahead_row + pp->ahead_rows;
-        dn[0] = pp->seg_begin > pp->ahead_row ? pp->seg_begin : pp->ahead_row;
-        db[1] = se < ae ? se : ae;
-        dn[1] = top - db[1];
-        nr = db[1] > dn[0] ? 2 : 0;
+        std::vector<std::pair<size_t, size_t>> iv = {{0, pp->seg_begin}, {se, sd.num_vars}, {0, pp->ahead_row}, {ae, sd.num_cons}};
+        std::sort(iv.begin(), iv.end());
+        std::vector<std::pair<size_t, size_t>> merged;
+        for (const auto& x : iv) {
+          if (x.second <= x.first) continue;
+          if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
+          else merged.push_back(x);
+        }
+        for (const auto& x : merged) { db[nr] = x.first; dn[nr] = x.second - x.first; ++nr; }
       }
-      if (digit_c && nr && dn[0] + dn[1] <= (1u << 16)) {
+      size_t dtot = 0;
+      for (int r = 0; r < nr; ++r) dtot += dn[r];
+      if (digit_c && nr && dtot <= (1u << 16)) {
         // The digit table is a latency optimisation (852 KB per generator at c = 10: 8.6 + 9.4 GB at t = 2^16), never a
         // requirement: when it does not fit the free HBM -- a smaller GPU, several parameter sets or chains resident --
         // or the window is refused, the parameters are made without it and vdf_msm takes the bucket method.
