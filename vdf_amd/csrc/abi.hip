@@ -206,8 +206,12 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
         VDF_TRY_HIP(hipEventRecord(dev[0], ctx->stream));
         VDF_TRY_HIP(hipEventRecord(dev[1], ctx->stream));
       }
+      if (!ctx->direct_arrived) {
+        VDF_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->direct_arrived), 64));
+        VDF_TRY_HIP(hipMemsetAsync(ctx->direct_arrived, 0, 64, ctx->stream));
+      }
       VDF_TRY(vdf::msm_direct_run(bases->curve, groups, n, slot0, d_scalars, is_mont != 0, bases->dg_c, ctx->num_cus, bases->d_digits, ctx->ws, d_out,
-                                  ctx->stream));
+                                  ctx->direct_arrived, ctx->stream));
       if (dev) {
         VDF_TRY_HIP(hipEventRecord(dev[2], ctx->stream));
         VDF_TRY_HIP(hipEventRecord(dev[3], ctx->stream));
@@ -426,6 +430,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->small_pool) (void)hipFree(ctx->small_pool);
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->reduce_scratch) (void)hipFree(ctx->reduce_scratch);
+  if (ctx->direct_arrived) (void)hipFree(ctx->direct_arrived);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);

@@ -70,6 +70,7 @@ struct vdf_ctx {
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool job_open = false;
   void* reduce_scratch = nullptr;    // per-workgroup partial sums of vdf_reduce
+  uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
 };
 
 struct vdf_bases {
@@ -196,7 +197,7 @@ int direct_windows(int c);
 Status digits_build(int curve, const void* d_pts, size_t first, size_t nslots, size_t slot0, int c, void* d_digits, hipStream_t stream);
 size_t direct_ws_bytes(int groups, const size_t* n, int c, int num_cus);
 Status msm_direct_run(int curve, int groups, const size_t* n, const size_t* slot0, const void* const* d_scalars, bool is_mont,
-                      int c, int num_cus, const void* d_digits, void* ws, void* d_out, hipStream_t stream);
+                      int c, int num_cus, const void* d_digits, void* ws, void* d_out, uint32_t* arrived, hipStream_t stream);
 Status bases_generate_label(int curve, const uint8_t* label, size_t len, size_t start, size_t n, void* d_pts, hipStream_t stream);
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream);
 Status bases_validate(int curve, const void* d_pts, size_t n, uint32_t* d_flags, hipStream_t stream);   // d_flags: 2 words

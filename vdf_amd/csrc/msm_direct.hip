@@ -163,10 +163,11 @@ __device__ __forceinline__ void dmadd(XYZZ<P>& acc, bool& have, const Affine<P>&
 // a second wavefront on a SIMD only doubles the time of both.
 template <class P, class SP>
 __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, int c, int W, const char* __restrict__ D,
-                                                    char* __restrict__ partials) {
+                                                    char* __restrict__ partials, uint32_t* __restrict__ arrived, char* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ uint32_t limbs[9 * 256];                              // k + H, one private column per thread
   __shared__ __align__(16) char pts[256 * 128];
+  __shared__ uint32_t ticket;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6;     // a wavefront serves one group
   int g = 0;
@@ -246,11 +247,39 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
   if (qd == 0) qpoint_store<P>(pts + (size_t)wv * 128, r);
   __syncthreads();
   // the four wavefronts of a workgroup serve one group (wave_end is a multiple of 4): one point per workgroup
-  if (wv != 0 || qd != 0) return;
-  QPoint<P> t = qpoint_load<P>(pts);
+  if (wv == 0 && qd == 0) {
+    QPoint<P> t = qpoint_load<P>(pts);
 #pragma unroll 1
-  for (int m = 1; m < 4; ++m) t = qpoint_add<P>(t, qpoint_load<P>(pts + (size_t)m * 128));
-  if (live_wave) qpoint_store<P>(partials + (size_t)blockIdx.x * 128, t);
+    for (int m = 1; m < 4; ++m) t = qpoint_add<P>(t, qpoint_load<P>(pts + (size_t)m * 128));
+    if (live_wave) qpoint_store<P>(partials + (size_t)blockIdx.x * 128, t);
+    __threadfence();                                               // the point is visible device-wide before the ticket is taken
+  }
+  // The group's LAST workgroup to get here adds up the group's workgroup points (what a second launch, k_direct_final,
+  // did before: one launch and its start-up less on a path the prover waits on -- the pattern of msm.hip's giant buckets).
+  // The counter is left at zero for the next call.
+  if (threadIdx.x == 0) ticket = live_wave ? atomicAdd(&arrived[g], 1u) : 0xFFFFFFFFu;
+  __syncthreads();
+  const uint32_t p0 = g ? a.wg_end[g - 1] : 0u, p1 = a.wg_end[g];
+  if (ticket != p1 - p0 - 1u) return;
+  __threadfence();
+  if (threadIdx.x == 0) arrived[g] = 0u;
+  const uint32_t tq = threadIdx.x >> 2;
+  QPoint<P> acc2 = qpoint_identity<P>();
+  for (uint32_t p = p0 + tq; p < p1; p += 64) acc2 = qpoint_add<P>(acc2, qpoint_load<P>(partials + (size_t)p * 128));
+  acc2 = qpoint_wave_sum(acc2);
+  __syncthreads();                                                 // (the buffer's earlier readers are all past their loads)
+  if ((tq & 15u) == 0) qpoint_store<P>(pts + (size_t)wv * 128, acc2);
+  __syncthreads();
+  if (tq != 0) return;
+  QPoint<P> v = qpoint_load<P>(pts);
+#pragma unroll 1
+  for (int m = 1; m < 4; ++m) v = qpoint_add<P>(v, qpoint_load<P>(pts + (size_t)m * 128));
+  const Jac<P> jj = xyzz_to_jac(qpoint_gather(v));
+  if (threadIdx.x == 0) {
+    fe_store<P>(out + (size_t)g * 96, jj.x);
+    fe_store<P>(out + (size_t)g * 96 + 32, jj.y);
+    fe_store<P>(out + (size_t)g * 96 + 64, jj.z);
+  }
 }
 
 // one workgroup (one wavefront per SIMD) per group: 64 quads stride over the group's workgroup points, a butterfly per
@@ -310,9 +339,14 @@ size_t direct_ws_bytes(int groups, const size_t* n, int c, int num_cus) {
   return ((size_t)direct_geom(groups, n, direct_windows(c), num_cus).total_wgs + 1) * 128;
 }
 
+static bool fused_final() {          // VDF_MSM_DIRECT_FUSED=0: the final sum as a launch of its own (tuning / A-B measurements)
+  static const bool on = [] { const char* e = std::getenv("VDF_MSM_DIRECT_FUSED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <class P, class SP>
 static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, const void* const* d_scalars, bool is_mont, int c,
-                           int num_cus, const void* d_digits, void* ws, void* d_out, hipStream_t st) {
+                           int num_cus, const void* d_digits, void* ws, void* d_out, uint32_t* arrived, hipStream_t st) {
   DirectArgs a{};
   a.groups = groups;
   const int W = direct_windows(c);
@@ -331,24 +365,28 @@ static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, con
   for (int j = 0; j < W; ++j) { const int bit = c * j + c - 1; a.half[bit >> 5] |= 1u << (bit & 31); }
   double nsum = 0;
   for (int g = 0; g < groups; ++g) nsum += (double)n[g];
+  bool empty_group = false;
+  for (int g = 0; g < groups; ++g) empty_group |= geo.waves[g] == 0;
   if (waves) {
     KTimer kt(st, "k_direct_sum", 96.0 * nsum);         // a commitment's algorithmic bytes: 96 B per (base, scalar) pair
     hipLaunchKernelGGL((k_direct_sum<P, SP>), dim3(waves / 4), dim3(256), 0, st, a, is_mont ? 1 : 0, c, W,
-                       reinterpret_cast<const char*>(d_digits), reinterpret_cast<char*>(ws));
+                       reinterpret_cast<const char*>(d_digits), reinterpret_cast<char*>(ws), arrived, reinterpret_cast<char*>(d_out));
   }
-  KTimer kt(st, "k_direct_final", 0.0);
-  hipLaunchKernelGGL((k_direct_final<P>), dim3(groups), dim3(256), 0, st, a, reinterpret_cast<const char*>(ws),
-                     reinterpret_cast<char*>(d_out));
+  if (empty_group || !arrived || !fused_final()) {     // a group without scalars has no workgroup to write its identity: the second launch does
+    KTimer kt(st, "k_direct_final", 0.0);
+    hipLaunchKernelGGL((k_direct_final<P>), dim3(groups), dim3(256), 0, st, a, reinterpret_cast<const char*>(ws),
+                       reinterpret_cast<char*>(d_out));
+  }
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 
 Status msm_direct_run(int curve, int groups, const size_t* n, const size_t* slot0, const void* const* d_scalars, bool is_mont,
-                      int c, int num_cus, const void* d_digits, void* ws, void* d_out, hipStream_t stream) {
+                      int c, int num_cus, const void* d_digits, void* ws, void* d_out, uint32_t* arrived, hipStream_t stream) {
   if (curve == VDF_CURVE_PALLAS)
-    return direct_run_t<FpParams, FqParams>(groups, n, slot0, d_scalars, is_mont, c, num_cus, d_digits, ws, d_out, stream);
+    return direct_run_t<FpParams, FqParams>(groups, n, slot0, d_scalars, is_mont, c, num_cus, d_digits, ws, d_out, arrived, stream);
   if (curve == VDF_CURVE_VESTA)
-    return direct_run_t<FqParams, FpParams>(groups, n, slot0, d_scalars, is_mont, c, num_cus, d_digits, ws, d_out, stream);
+    return direct_run_t<FqParams, FpParams>(groups, n, slot0, d_scalars, is_mont, c, num_cus, d_digits, ws, d_out, arrived, stream);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 
