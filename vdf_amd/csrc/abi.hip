@@ -248,7 +248,9 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
     }
     ev = tc.ev;
   }
-  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev));
+  hipEvent_t gate = ctx->acc_gate;
+  ctx->acc_gate = nullptr;                                      // one-shot
+  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev, nullptr, gate));
   if (ev) ctx->timed.push_back(tc);
   return st.finish();
 }
@@ -1294,6 +1296,17 @@ int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
     if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     if (other == ctx) return Status{};
     VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, other->marks[slot], 0));
+    return Status{};
+  });
+}
+
+int vdf_ctx_gate_accumulate(vdf_ctx* ctx, vdf_ctx* other, int slot) {
+  if (!other) return VDF_ERR_BAD_ARG;
+  return guarded(ctx, [&]() -> Status {
+    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
+    if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
+    if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
+    ctx->acc_gate = other == ctx ? nullptr : other->marks[slot];
     return Status{};
   });
 }

@@ -809,7 +809,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
   // marks on a lookahead context: segment written / its commitment landed / early rows of T committed; MARK_STEP on the
   // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
-  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4 };
+  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5 };
+  bool gate_next_segment = false;     // the next enqueue_segment holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
   const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
   const int per = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
@@ -833,6 +834,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     HIPCALL(q, vdf_ctx_mark(q, MARK_Z));
     HIPCALL(ctx, vdf_ctx_wait(ctx, q));          // the first context waits for the rounds only, not for their commitment
     // the reference's circuit: the same commitment from 3t + 4 terms over the derived generators (make_packed_generators)
+    if (gate_next_segment) { HIPCALL(q, vdf_ctx_gate_accumulate(q, ctx, MARK_PRIMARY)); gate_next_segment = false; }
     if (packed) HIPCALL(q, vdf_msm(q, pp->seg_gens, 0, (const vdf_fe*)packed, 3 * pp->t + 4, 1, &p->h_pts[s]));
     else HIPCALL(q, vdf_msm(q, S1.gens, seg_b, (const vdf_fe*)seg, seg_n, 1, &p->h_pts[s]));
     HIPCALL(q, vdf_ctx_mark(q, MARK_W));
@@ -1010,6 +1012,10 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       }
     }
     HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
+    // the lookahead launched under this wait sorts beside these commitments but holds its bucket accumulation -- every SIMD
+    // for 0.25 ms -- until they are done: it then runs while the host synthesises the secondary circuit (VDF_NOVA_GATE=0: no hold)
+    static const bool gate = [] { const char* e = std::getenv("VDF_NOVA_GATE"); return !(e && e[0] == '0'); }();
+    if (gate && !first && !custom) { HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_PRIMARY)); gate_next_segment = true; }
     if (!first) {
       // behind the primary side's launches (it does not depend on them, they do not wait for it): the fold of the secondary
       // witness on the device (z, E, A z, B z, C z += r2 * fresh); the instance came from the circuit

@@ -70,6 +70,7 @@ struct vdf_ctx {
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool job_open = false;
   void* reduce_scratch = nullptr;    // per-workgroup partial sums of vdf_reduce
+  hipEvent_t acc_gate = nullptr;     // one-shot: the next bucket-method MSM's accumulation waits for this event (vdf_ctx_gate_accumulate)
   uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
 };
 
@@ -187,7 +188,8 @@ bool msm_plan_feasible(int groups, int c, int sets);       // sets <= 0: one buc
 // ext_bucket_acc (optional): the bucket accumulators of this plan's key range inside a job's shared array; the
 // run then stops after the fix-up and msm_tail reduces all groups of the job at once.
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont,
-               void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr, void* ext_bucket_acc = nullptr);
+               void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr, void* ext_bucket_acc = nullptr,
+               hipEvent_t acc_gate = nullptr);
 size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);

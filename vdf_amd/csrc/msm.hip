@@ -47,7 +47,25 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 // grid that keeps every SIMD's issue port busy.  When two MSMs run on two streams (prove_step commits W and T
 // side by side) the light kernels of one would starve behind the other's accumulate waves, which the
 // oldest-first arbiter favours; a raised wave priority lets them through.
-__device__ __forceinline__ void raise_wave_priority() { __builtin_amdgcn_s_setprio(3); }
+// Wave priority of the pipeline's light kernels (sort, fix-up, bucket reduction): above the bucket accumulation (0), and --
+// VDF_MSM_LIGHT_PRIO=2 -- optionally below the short kernels a prover's main queue waits for (3).
+__constant__ int c_light_prio = 3;
+__device__ __forceinline__ void raise_wave_priority() {
+  const int p = c_light_prio;
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+}
+static void init_light_prio() {
+  static const bool done = [] {
+    if (const char* e = std::getenv("VDF_MSM_LIGHT_PRIO")) {
+      const int v = atoi(e);
+      if (v >= 0 && v <= 3) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_light_prio), &v, sizeof(int));
+    }
+    return true;
+  }();
+  (void)done;
+}
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
 static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many: two waves per SIMD already issue at ~99 % of three,
                                             // and a third fewer slices means a third fewer slice heads for k_fixup to add
@@ -1179,7 +1197,7 @@ static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* 
 // fix-up; the reduction of all groups follows in msm_tail.
 template <class P, class SP>
 static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-                        void* d_out, hipStream_t st, hipEvent_t* ev, char* ext_bucket_acc) {
+                        void* d_out, hipStream_t st, hipEvent_t* ev, char* ext_bucket_acc, hipEvent_t acc_gate) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* countsA = reinterpret_cast<uint32_t*>(base + w.countsA);
@@ -1203,6 +1221,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   }
   const size_t lds_bins = (size_t)p.bins * 4;
 
+  init_light_prio();
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   // pass A
   {
@@ -1218,6 +1237,9 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
                      reinterpret_cast<uint32_t*>(base + w.tstart));
   }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
+  // the sort is light; the accumulation fills every SIMD: a caller that knows of latency-critical work on another queue
+  // holds it back until that work's mark (vdf_ctx_gate_accumulate)
+  if (acc_gate) VDF_TRY_HIP(hipStreamWaitEvent(st, acc_gate, 0));
   {
   KTimer kt(st, "k_accumulate", 96.0 * p.n);            // the pipeline's algorithmic bytes: 96 B per (base, scalar) pair, SURVEY.md 8d
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
@@ -1237,13 +1259,13 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
 }
 
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-               void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc) {
+               void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc, hipEvent_t acc_gate) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
   char* ext = reinterpret_cast<char*>(ext_bucket_acc);
   if (curve == VDF_CURVE_PALLAS)
-    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext);
+    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate);
   if (curve == VDF_CURVE_VESTA)
-    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext);
+    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 

@@ -262,6 +262,73 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
   fe_store<P>(T + r * 32, t);
 }
 
+// The same with LPR lanes per row (4 or 8): lane l of a row's group takes the entries l, l + LPR, ... of each of the three
+// sparse rows, so that all gathers of a row are in flight at once instead of one dependent round trip per entry, and a
+// butterfly over the group's lanes (log2 LPR steps) adds the terms up; the group's first lane finishes the cross term.
+// What it buys is LATENCY: the ~10^4 rows of an augmented circuit that a step waits for take 12 us instead of 26-48 (a lane
+// that walks 8 entries of 3 matrices in turn pays 24 round trips); for the 2 x 10^5 uniform rows of the MinRoot rounds
+// (1 + 1 + 4 entries) four lanes per row issue the four gathers of C together.
+template <class P, int LPR>
+__global__ __launch_bounds__(256) void k_nifs_cross_w(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
+                                                      const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                      const char* __restrict__ cz1, FeVal u1, size_t rows,
+                                                      size_t skip_begin, size_t skip_len,
+                                                      char* __restrict__ az2, char* __restrict__ bz2,
+                                                      char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);
+  constexpr uint32_t RPB = 256 / LPR;                                // rows per workgroup
+  const uint32_t l = threadIdx.x & (LPR - 1);
+  size_t r = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = r < rows;
+  if (!live) r = rows ? rows - 1 : 0;                                // keeps the group's lanes together for the butterfly
+  if (r >= skip_begin) r += skip_len;
+  uint32_t lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
+  Fe<P> a1, b1, c1;
+  if (l == 0) { a1 = fe_load<P>(az1 + r * 32); b1 = fe_load<P>(bz1 + r * 32); c1 = fe_load<P>(cz1 + r * 32); }
+  char* const outs[3] = {az2, bz2, cz2};
+  Fe<P> acc[3], v[3];
+  uint32_t cc[3], kk[3];
+  bool has[3], longrow[3];
+  // every lane's first entry of each matrix: column and coefficient of all three issued together, then the three gathers
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    longrow[k] = hi[k] - lo[k] > VDF_LONG_ROW;
+    has[k] = !longrow[k] && lo[k] + l < hi[k];
+    const uint32_t e = has[k] ? lo[k] + l : lo[k];                   // (arrays are nnz + 1 long: lo is always readable)
+    cc[k] = m.col[k][e];
+    kk[k] = m.coef[k][e];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = fe_load<P>(z2 + (size_t)(has[k] ? cc[k] : 0u) * 32);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    acc[k] = has[k] ? spmv_term<P>(v[k], kk[k], dict) : fe_zero<P>();
+    if (longrow[k]) { if (l == 0) acc[k] = fe_load<P>(outs[k] + r * 32); continue; }       // k_spmv_long ran first
+    for (uint32_t e = lo[k] + l + LPR; e < hi[k]; e += LPR)
+      acc[k] = fe_add(acc[k], spmv_term<P>(fe_load<P>(z2 + (size_t)m.col[k][e] * 32), m.coef[k][e], dict));
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) {
+      Fe<P> o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(acc[k].v[i], off, 64);
+      acc[k] = fe_add(acc[k], o);
+    }
+  }
+  if (l != 0 || !live) return;
+  fe_store<P>(az2 + r * 32, acc[0]);
+  fe_store<P>(bz2 + r * 32, acc[1]);
+  fe_store<P>(cz2 + r * 32, acc[2]);
+  Fe<P> t = fe_add(fe_mul(a1, acc[1]), fe_mul(acc[0], b1));
+  t = fe_sub(t, fe_mul(fe_from_val<P>(u1), acc[2]));
+  t = fe_sub(t, c1);
+  fe_store<P>(T + r * 32, t);
+}
+
 // acc_k <- acc_k + r * add_k for up to 8 vectors in one launch (the witness fold W, E and the running Az, Bz, Cz)
 struct FoldArgs { char* acc[8]; const char* add[8]; uint32_t blk_end[8]; uint64_t n[8]; int k; };
 template <class P>
@@ -384,9 +451,31 @@ Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t
   if (rows == 0) return Status{};
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
-  KTimer kt(s, "k_nifs_cross", alg_bytes);
-  FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
-                 to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+  // lanes per row: 8 for the ~10^4 rows a step waits for (latency), 4 for long runs of short rows (the MinRoot rounds: all
+  // gathers of a row at once), 1 = the lane-per-row kernel.  VDF_NIFS_LANES=1|4|8 forces one (tuning / A-B measurements).
+  static const int forced = [] { const char* e = std::getenv("VDF_NIFS_LANES"); return e ? atoi(e) : 0; }();
+  const int lpr = forced == 1 || forced == 4 || forced == 8 ? forced : (rows <= (1u << 15) ? 8 : 1);
+  KTimer kt(s, lpr == 1 ? "k_nifs_cross" : (lpr == 4 ? "k_nifs_cross_w4" : "k_nifs_cross_w8"), alg_bytes);
+  if (lpr == 1) {
+    FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                   to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+  } else if (lpr == 4) {
+    const dim3 grid((unsigned)((rows + 63) / 64));
+    if (field == VDF_FIELD_FP) hipLaunchKernelGGL((k_nifs_cross_w<FpParams, 4>), grid, dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                                                  to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+    else if (field == VDF_FIELD_FQ) hipLaunchKernelGGL((k_nifs_cross_w<FqParams, 4>), grid, dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                                                       to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+    else return Status{VDF_ERR_BAD_ARG, "unknown field"};
+    VDF_TRY_HIP(hipGetLastError());
+  } else {
+    const dim3 grid((unsigned)((rows + 31) / 32));
+    if (field == VDF_FIELD_FP) hipLaunchKernelGGL((k_nifs_cross_w<FpParams, 8>), grid, dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                                                  to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+    else if (field == VDF_FIELD_FQ) hipLaunchKernelGGL((k_nifs_cross_w<FqParams, 8>), grid, dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
+                                                       to_val(u1), rows, skip_begin, skip_len, M(az2), M(bz2), M(cz2), M(T));
+    else return Status{VDF_ERR_BAD_ARG, "unknown field"};
+    VDF_TRY_HIP(hipGetLastError());
+  }
   return Status{};
 }
 
