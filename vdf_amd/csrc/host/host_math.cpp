@@ -1,7 +1,17 @@
 #include "host_math.hpp"
 #include "../pasta_constants.h"
 
+#include <cstdlib>
+
 namespace vdfhost {
+
+// BMI2 (mulx) and ADX (adcx / adox) by cpuid, once, before main: selects the product of fe_mul_x86_adx.inc
+static bool detect_adx() {
+  if (const char* e = std::getenv("VDF_HOST_NO_ADX")) if (e[0] == '1') return false;
+  __builtin_cpu_init();
+  return __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+}
+const bool g_has_adx = detect_adx();
 
 static Field make_field(const uint32_t mod[8], const uint32_t one_[8], const uint32_t r2_[8]) {
   static_assert(FpParams::MOD[4] == 0 && FpParams::MOD[5] == 0 && FpParams::MOD[6] == 0 && FpParams::MOD[7] == 0x40000000u &&

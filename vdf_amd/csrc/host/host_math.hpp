@@ -119,8 +119,22 @@ inline Fe canon(Fe r, const Field& F) {               // [0, 2m) -> [0, m)
   if (geq(r.l, F.m)) sub4(r.l, F.m);
   return r;
 }
+// The same product as one block of mulx / adcx / adox where the CPU has BMI2 and ADX (every x86-64 server core since
+// Broadwell / Zen): generated by tools/gen_host_mul.py.  The compiler's own code for the portable form below keeps two
+// serial carry chains in flags and spends ~50 cycles per product; this one overlaps them (g_has_adx: host_math.cpp, cpuid
+// at load time; VDF_HOST_NO_ADX=1 forces the portable form).
+extern const bool g_has_adx;
+template <bool LAZY = false>
+inline Fe mul_adx(const Fe& a, const Fe& b, const Field& F) {
+  uint64_t t0, t1, t2, t3, t4, t5, lo, hi, lo2, hi2;
+  Fe r;
+#include "fe_mul_x86_adx.inc"
+  if (!LAZY && geq(r.l, F.m)) sub4(r.l, F.m);
+  return r;
+}
 template <bool LAZY = false>
 inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
+  if (g_has_adx) return mul_adx<LAZY>(a, b, F);
   uint64_t t[8];
   {
     u128 c = 0;
@@ -138,6 +152,7 @@ inline Fe mul(const Fe& a, const Fe& b, const Field& F) {
 // 16.  (On the GPU the same trick does not pay, DESIGN.md 4.2: there a carry costs what a multiplication does.)
 template <bool LAZY = false>
 inline Fe sqr(const Fe& a, const Field& F) {
+  if (g_has_adx) return mul_adx<LAZY>(a, a, F);
   uint64_t t[8];
   u128 c = (u128)a.l[0] * a.l[1];
   t[1] = (uint64_t)c;
