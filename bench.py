@@ -905,7 +905,7 @@ def main():
             issue = lambda ms: (per_add * n * windows_eff / 64.0) / (ctx_num_simds * ms * 1e-3 * ghz * 1e9 / cyc)
             valu = {"valu_issue_frac": issue(acc_iso_ms), "of_timed_region_accumulate_only": issue(elapsed / args.steps * 1e3),
                     "valu_per_bucket_addition": per_add, "cycles_per_valu_wave_instruction_per_simd": cyc,
-                    "sustained_shader_clock_ghz": ghz, "source": "profiles/" + vfile, "provenance": vm.get("provenance")}
+                    "sustained_shader_clock_ghz": ghz, "source": "profiles/" + vfile, "produced_at_commit": vm.get("produced_at_commit"), "provenance": vm.get("provenance")}
         line = {
             "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step); prove_step/s in `prove_step`",
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -926,6 +926,7 @@ def main():
             "stage_ms_one_step_at_a_time": iso,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": ("profiles/" + tfile) if tfile else None,
+                         "traffic_produced_at_commit": (tj or {}).get("produced_at_commit"),
                          "kernel": "k_accumulate", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": acc_iso_ms, "launch_timing": "HIP events on the launching stream, one step at a time",
                          "overlapped_avg_launch_ms": acc_avg_ms, "overlapped_achieved": achieved_overlapped,
