@@ -466,3 +466,97 @@ def test_minroot_step_segment(ctx, cref, field, t, per):
     rounds = W[:4 * t].reshape(t, 4, 4)
     want = rounds if per == 4 else rounds[:, 1:, :]
     assert np.array_equal(got[:per * t], want.reshape(per * t, 4)) and np.array_equal(got[per * t], W[4 * t])
+
+
+@pytest.mark.parametrize("t", [1, 2, 7, 1024, 4097])
+def test_packed_commitment_of_the_reference_rounds(ctx, cref, t):
+    """vdf_minroot_step_segment_packed (include/vdf_hip.h): the reference's 4t + 1 round variables (src/nova/proof.rs:167-189)
+    and the 3t + 4 scalars whose MSM over the DERIVED generators is the same Pedersen commitment -- new_x_j = y_j - (i_in - j - 1)
+    folds into the generators of the new_y's.  Checked three ways: `out` equals the C restatement's witness, `packed` equals its
+    definition, and the two commitments (C restatement's MSM over 4t + 1 generators, device MSM over the 3t + 4 derived ones)
+    are the same point."""
+    field, curve, m, bm = o.FIELD_FQ, o.CURVE_PALLAS, o.Q, o.P
+    L = cref.lib()
+    st = mont([o.rand_fe(15, 0, m), 0, 3], m)
+    so, tr = cref.fe_array(3), cref.fe_array(2 * (t + 1))
+    L.ref_minroot_eval(field, 1, cref.p(st), t, cref.p(so), cref.p(tr))
+    W = cref.fe_array(4 * t + 1)
+    L.ref_step_witness(field, cref.p(so), t, cref.p(W))
+    out, packed = _dev(np.zeros((4 * t + 1, 4), dtype="<u8")), _dev(np.zeros((3 * t + 4, 4), dtype="<u8"))
+    i0, i_in = st[2:3].copy(), so[2:3].copy()                  # final_i = the input state's i; the first round reads the result's i
+    ctx.minroot_step_segment_packed(field, _dev(tr), t, i0, i_in, out, packed)
+    ctx.sync()
+    got, pk = _host(out), _host(packed)
+    assert np.array_equal(got, W)
+    rounds = W[:4 * t].reshape(t, 4, 4)
+    assert np.array_equal(pk[:3 * t], rounds[:, 1:, :].reshape(3 * t, 4)) and np.array_equal(pk[3 * t], W[4 * t])
+    assert np.array_equal(pk[3 * t + 1], tr[2 * t + 1]) and np.array_equal(pk[3 * t + 2], so[2]) and unmont(pk[3 * t + 3:3 * t + 4], m) == [1]
+    # the commitment both ways
+    seed, n = 21, 4 * t + 1
+    G = cref.fe_array(2 * n).reshape(n, 8)
+    L.ref_tai_bases(curve, seed, 0, n, cref.p(G))
+    want = np.zeros(12, dtype="<u8")
+    L.ref_msm(curve, cref.p(G), cref.p(W), n, 1, 4, 0, cref.p(want))
+    pt = lambda row: None if not row.any() else tuple(unmont(row.reshape(2, 4), bm))
+    Gi = [pt(G[k]) for k in range(n)]
+    add = lambda a, b: o.pt_add(a, b, bm)
+    neg = lambda a: None if a is None else (a[0], (-a[1]) % bm)
+    D = []
+    for j in range(t):
+        D += [Gi[4 * j + 1], Gi[4 * j + 2], add(Gi[4 * j + 3], Gi[4 * j + 4]) if j + 1 < t else Gi[4 * t - 1]]
+    s1, s2 = None, None
+    for j in range(t - 1, -1, -1):
+        s1 = add(s1, Gi[4 * j]); s2 = add(s2, s1)
+    D += [Gi[4 * t], Gi[0], neg(s1), s2]
+    Dl = mont([c for p_ in D for c in (p_ or (0, 0))], bm).reshape(3 * t + 4, 8)
+    bases = ctx.bases_upload(curve, Dl)
+    got_pt = np.ascontiguousarray(ctx.msm(bases, packed, n=3 * t + 4, is_mont=True))
+    ga, wa = np.zeros(8, dtype="<u8"), np.zeros(8, dtype="<u8")
+    L.ref_jac_to_affine(curve, cref.p(got_pt), cref.p(ga))
+    L.ref_jac_to_affine(curve, cref.p(want), cref.p(wa))
+    assert np.array_equal(ga, wa)
+    bases.free()
+
+
+def test_kernel_events_and_the_accumulate_gate(ctx):
+    """vdf_ctx_set_kernel_timing / vdf_ctx_kernel_events: every launch of a bucket-method MSM shows up once, in order, with the
+    pipeline's algorithmic bytes on its accumulation kernel; vdf_ctx_gate_accumulate holds that kernel of the NEXT MSM of a
+    context behind another context's mark (results unchanged), one-shot."""
+    import vdf_amd
+    n = 1 << 14
+    rng = np.random.default_rng(3)
+    sc = rand_limbs(rng, n)
+    bases = ctx.bases_generate(o.CURVE_PALLAS, 5, n)
+    bases.precompute(13, 1)
+    want = np.ascontiguousarray(ctx.msm(bases, sc))
+    other = vdf_amd.Context(0)
+    was = ctx.get_async()
+    try:
+        ctx.set_kernel_timing(True)
+        ctx.kernel_events()
+        dsc, dout = _dev(sc), _dev(np.zeros(12, dtype="<u8"))
+        ctx.set_async(True); other.set_async(True)
+        da = _dev(rand_limbs(rng, 1 << 14))
+        dlong = _dev(np.zeros((1 << 14, 4), dtype="<u8"))
+        other.fe_mul_chain(o.FIELD_FQ, da, 1 << 14, 3000, dlong)   # ~ms of work on the other queue
+        other.mark(2)
+        ctx.gate_accumulate(other, 2)
+        ctx.msm(bases, dsc, n=n, out=dout)
+        ctx.msm(bases, dsc, n=n, out=dout)                          # the gate was for one MSM only
+        other.sync(); ctx.sync()
+        ev = ctx.kernel_events()
+        names = [e[0] for e in ev]
+        assert names == ["msm_sort(5 launches)", "k_accumulate", "msm_tail(fixup+reduce)"] * 2
+        assert ev[1][1] == 96.0 * n and ev[0][1] == 0.0
+        assert all(e[3] >= e[2] for e in ev) and all(ev[i + 1][2] >= ev[i][2] for i in range(len(ev) - 1))
+        # the gated accumulation started after its own sort by about the other queue's work; the second MSM's did not wait
+        assert ev[1][2] - ev[0][3] > 5 * max(ev[4][2] - ev[3][3], 0.01)
+        assert np.array_equal(_host(dout), want)
+        assert ctx.kernel_events() == []
+        with pytest.raises(Exception):
+            ctx.gate_accumulate(other, 3)                           # never set
+    finally:
+        ctx.set_kernel_timing(False)
+        ctx.set_async(was)
+        other.close()
+        bases.free()

@@ -203,6 +203,37 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
     assert a.verify(pp, n, z0, [initial.x, initial.y, initial.i])
 
 
+@pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
+def test_public_params_flags_decline_the_accelerators_and_change_nothing(ctx, kind):
+    """vdf_nova_public_params_flags (include/vdf_nova.h): VDF_PP_NO_DIGIT_TABLES / VDF_PP_NO_EARLY_ROWS decline the HBM-hungry
+    digit tables and the early rows of T; vdf_nova_pp_memory reports what a parameter set holds.  Parameters (digest) and
+    every instance and witness of a proof are the same with and without them -- they are accelerators, not protocol."""
+    from vdf_amd.nova import PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS
+    t, n = 96, 4
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=14, kind=kind)
+    mem = pp.memory()
+    assert mem["digit_tables_skipped"] == 0 and min(mem["digit_table_bytes"]) > 0 and pp.early_rows()[1] > 0
+    assert mem["gens_bytes"][0] == 64 * pp.sizes(0)["num_gens"] and mem["table_bytes"][0] >= 15 * mem["gens_bytes"][0]
+    a = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    for flags in (PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS, PP_NO_DIGIT_TABLES | PP_NO_EARLY_ROWS):
+        pp1 = public_params(ctx, t, kind, GENS_TRY_AND_INCREMENT, flags)
+        assert pp1.digest() == pp.digest()
+        m1 = pp1.memory()
+        assert (m1["digit_table_bytes"] == [0, 0]) == bool(flags & PP_NO_DIGIT_TABLES)
+        assert (pp1.early_rows() == (0, 0)) == bool(flags & PP_NO_EARLY_ROWS)
+        b = NovaVDFProof.prove_recursively(pp1, circuits, t, z0)
+        for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+            ia, ib = a.instance(which), b.instance(which)
+            for key in ia:
+                assert np.array_equal(ia[key], ib[key]), (flags, which, key)
+            for va, vb in zip(a.witness(which), b.witness(which)):
+                assert (va is None and vb is None) or np.array_equal(va, vb)
+        assert b.verify(pp1, n, z0, [initial.x, initial.y, initial.i])
+        b.free(); pp1.free()
+    with pytest.raises(Exception):
+        public_params(ctx, t, kind, GENS_TRY_AND_INCREMENT, 64)          # unknown flag
+
+
 def test_two_chains_proven_concurrently(ctx):
     """Two host threads, two contexts, two chains at once (the bench's aggregate leg): the helper threads of the witness
     synthesis are taken by one prover at a time and the other synthesises inline -- both must give the proofs they give

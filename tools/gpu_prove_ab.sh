@@ -3,6 +3,6 @@
 mkdir -p gpurun_out/r3
 for cfg in "" "$@"; do
   for rep in 1 2; do
-    echo "== [$cfg] run $rep: $(env $cfg python tools/gpu_prove_time.py 16 60 ref 2>&1 | grep 'steady state')"
+    echo "== [$cfg] run $rep: $(env $cfg python tools/gpu_prove_time.py 16 100 ref 2>&1 | grep 'steady state')"
   done
 done

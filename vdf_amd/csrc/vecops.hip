@@ -233,24 +233,38 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
   size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
   if (r >= skip_begin) r += skip_len;  // `rows` rows of the matrix, leaving out [skip_begin, skip_begin + skip_len)
-  uint32_t lo[3], hi[3], c0[3], k0[3];
+  uint32_t lo[3], hi[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
   const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+  // Loads in three waves instead of one dependent round trip per entry: the row pointers; then column and coefficient of
+  // the first PRE[k] entries of each matrix (a MinRoot row is 1 + 1 + at most 4 entries: src/nova/proof.rs:219-227); then
+  // all their z values at once.  Entries past PRE[k] (rows of the augmented circuit, at most VDF_LONG_ROW) follow in a loop.
+  constexpr int PRE[3] = {2, 2, 4};
+  uint32_t cc[3][4], kk[3][4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {      // hi > lo is the common case; an empty row reads a padding slot (arrays are nnz + 1 long)
-    c0[k] = m.col[k][lo[k]];
-    k0[k] = m.coef[k][lo[k]];
-  }
-  Fe<P> v[3], acc[3];
+  for (int k = 0; k < 3; ++k)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v[k] = fe_load<P>(z2 + (size_t)(hi[k] > lo[k] ? c0[k] : 0u) * 32);
+    for (int j = 0; j < PRE[k]; ++j) {
+      const uint32_t e = lo[k] + j < hi[k] ? lo[k] + j : lo[k];       // (arrays are nnz + 1 long: lo is always readable)
+      cc[k][j] = m.col[k][e];
+      kk[k][j] = m.coef[k][e];
+    }
+  Fe<P> v[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < PRE[k]; ++j) v[k][j] = fe_load<P>(z2 + (size_t)(lo[k] + j < hi[k] ? cc[k][j] : 0u) * 32);
+  Fe<P> acc[3];
   char* const outs[3] = {az2, bz2, cz2};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     if (hi[k] - lo[k] > VDF_LONG_ROW) { acc[k] = fe_load<P>(outs[k] + r * 32); continue; }      // k_spmv_long ran first
-    acc[k] = hi[k] > lo[k] ? spmv_term<P>(v[k], k0[k], dict) : fe_zero<P>();
-    for (uint32_t e = lo[k] + 1; e < hi[k]; ++e)
+    acc[k] = hi[k] > lo[k] ? spmv_term<P>(v[k][0], kk[k][0], dict) : fe_zero<P>();
+#pragma unroll
+    for (int j = 1; j < PRE[k]; ++j)
+      if (lo[k] + j < hi[k]) acc[k] = fe_add(acc[k], spmv_term<P>(v[k][j], kk[k][j], dict));
+    for (uint32_t e = lo[k] + PRE[k]; e < hi[k]; ++e)
       acc[k] = fe_add(acc[k], spmv_term<P>(fe_load<P>(z2 + (size_t)m.col[k][e] * 32), m.coef[k][e], dict));
   }
   fe_store<P>(az2 + r * 32, acc[0]);

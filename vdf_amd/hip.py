@@ -360,6 +360,25 @@ class Context:
     def minroot_step_segment(self, field, trace_xy, t, i0, vars_per_round, out) -> None:
         self._check(lib.vdf_minroot_step_segment(self.handle, field, _ptr(trace_xy), t, _ptr(i0), vars_per_round, _ptr(out)))
 
+    def minroot_step_segment_packed(self, field, trace_xy, t, i0, i_in, out, packed) -> None:
+        """The reference's allocation (4 variables per round) and the 3t + 4 scalars of its commitment without new_x."""
+        self._check(lib.vdf_minroot_step_segment_packed(self.handle, field, _ptr(trace_xy), t, _ptr(i0), _ptr(i_in), _ptr(out), _ptr(packed)))
+
+    def gate_accumulate(self, other: "Context", slot: int) -> None:
+        """The next bucket-method MSM on this context accumulates only after `other`'s mark `slot` (vdf_ctx_gate_accumulate)."""
+        self._check(lib.vdf_ctx_gate_accumulate(self.handle, other.handle, slot))
+
+    def set_kernel_timing(self, flag: bool) -> None:
+        self._check(lib.vdf_ctx_set_kernel_timing(self.handle, int(flag)))
+
+    def kernel_events(self) -> list:
+        """Drains the timed launches of this context: [(kernel, algorithmic bytes, start_ms, end_ms)]."""
+        n = C.c_size_t()
+        self._check(lib.vdf_ctx_kernel_events(self.handle, None, 0, C.byref(n)))
+        ev = np.zeros(n.value + 16, dtype=np.dtype([("name", "S24"), ("bytes", "<f8"), ("start_ms", "<f8"), ("end_ms", "<f8")]))
+        self._check(lib.vdf_ctx_kernel_events(self.handle, ev.ctypes.data, ev.shape[0], C.byref(n)))
+        return [(ev["name"][i].decode(), float(ev["bytes"][i]), float(ev["start_ms"][i]), float(ev["end_ms"][i])) for i in range(n.value)]
+
     def vec_is_zero(self, v, n: int) -> bool:
         """True iff all n field elements are zero (decided on the device)."""
         out = C.c_int(0)
