@@ -56,11 +56,15 @@ typedef struct vdf_circuits vdf_circuits; /* Vec<InverseMinRootCircuit<G1>>, :57
 typedef struct vdf_proof vdf_proof;       /* NovaVDFProof::Recursive, :51-55 */
 typedef struct vdf_snark vdf_snark;       /* NovaVDFProof::Compressed, :54 */
 
-/* The primary step circuit (the seam of :79-153).  BOUND (the default): InverseMinRootCircuit with new_x carried as
- * the linear combination y - i + 1 instead of a variable -- 3 variables and 3 constraints per round.  REFERENCE: the
- * circuit exactly as the reference writes it (4 variables per round; new_x allocated at :167-173 and used by no
- * constraint, :219-227 takes y - i + 1 directly), kept for shape / witness parity; a prover may set its new_x freely,
- * so a proof over it does not attest the VDF (tests/test_oracle_nova.py shows the forgery). */
+/* The primary step circuit (the seam of :79-153).  REFERENCE (the default: what vdf_nova_public_params builds, what
+ * the bench measures and the parity tests check first): the circuit exactly as the reference writes it -- 4 variables
+ * per round, new_x allocated at :167-173 and used by no constraint (:219-227 takes y - i + 1 directly), 4t + 1 step
+ * variables, 3t + 1 constraints; 2^19 generators at t = 2^16.  Because nothing binds new_x a prover may set it freely, so
+ * a proof over this circuit does not attest the VDF (tests/test_oracle_nova.py builds the forgery): a weakness of the
+ * work-in-progress reference that a drop-in reproduces.  BOUND: the sound variant, offered as an option -- new_x carried
+ * as the linear combination y - i + 1 instead of a variable, 3 variables and the same 3 constraints per round.
+ * The witness of the reference's circuit is committed WITHOUT a term per new_x: new_x_j is an affine image of new_y_(j-1),
+ * so its share folds into derived generators (vdf_hip.h vdf_minroot_step_segment_packed) -- same commitment, 3t + 4 terms. */
 enum { VDF_CIRCUIT_MINROOT_BOUND = 0, VDF_CIRCUIT_MINROOT_REFERENCE = 1, VDF_CIRCUIT_CUSTOM = 2 /* vdf_step_circuit, below */ };
 enum { VDF_SIDE_PRIMARY = 0, VDF_SIDE_SECONDARY = 1 };
 
@@ -68,7 +72,7 @@ enum { VDF_SIDE_PRIMARY = 0, VDF_SIDE_SECONDARY = 1 };
  * Pedersen generators per curve (next_pow2(max(vars, cons)) of them, seeded try-and-increment -- unknown discrete
  * logarithms; nova-snark's own label -> hash derivation is unpinned) with their fixed-base tables, and the digest of
  * all of it that every hash of the protocol absorbs.  One-time; outside every timed region (benches/nova.rs:51-58). */
-int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** out);
+int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** out);      /* the reference's circuit */
 /* The same with the step circuit and the generator family chosen.  gens_family = VDF_GENS_KNOWN_DLOG is for tests only
  * (commitments checkable by the discrete-log identity at full size; such commitments are not binding);
  * VDF_GENS_LABEL_SHAKE derives the generators from the label "vdf-nova-ivc-v1 gens" through SHAKE256, the way nova-snark

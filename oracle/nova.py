@@ -332,10 +332,10 @@ def fold_foreign(cs: CS, a_lo: Num, a_hi: Num, b_bits: Sequence[Num], r_bits: Se
 class InverseMinRootCircuit:
     """src/nova/proof.rs:57-230.  `bound` = False restates the reference's circuit exactly (4 aux per round, new_x
     allocated at :167-173 but bound by no constraint -- the third constraint uses y - i + 1 directly, :219-227);
-    `bound` = True is the sound form the product proves by default: new_x is not a variable at all, the next round's x
+    `bound` = True is the sound variant the product offers as an option (VDF_CIRCUIT_MINROOT_BOUND): new_x is not a variable at all, the next round's x
     is the linear combination y - i + 1 itself (3 aux per round, the same three constraints)."""
 
-    def __init__(self, t: int, result: Optional[o.State], inp: Optional[o.State], bound: bool = True):
+    def __init__(self, t: int, result: Optional[o.State], inp: Optional[o.State], bound: bool = False):
         self.t, self.result, self.input, self.bound = t, result, inp, bound
 
     def arity(self) -> int:
@@ -547,7 +547,7 @@ class PublicParams:
     commit: Callable[[int, Sequence[int]], Aff]               # commit(side, vector) under that side's generators
 
 
-def public_params(t: int, commit, gens_seed: int, gens_family: int, bound: bool = True, primary=None) -> PublicParams:
+def public_params(t: int, commit, gens_seed: int, gens_family: int, bound: bool = False, primary=None) -> PublicParams:
     """src/nova/proof.rs:232-237: both augmented circuits synthesised once for their shapes.  `primary`: another step
     circuit than InverseMinRootCircuit on the primary side (anything with arity / synthesize / output; t is then 0)."""
     shapes = []

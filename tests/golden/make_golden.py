@@ -122,27 +122,30 @@ out["spartan_t6"] = {"comm_W": [H(cW3[0]), H(cW3[1])], "comm_E": [H(cE3[0]), H(c
 import hashlib  # noqa: E402
 from oracle import nova as nv, wire  # noqa: E402
 wt, wn = 2, 2
-wpp = nv.public_params(wt, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
 winit = o.State(o.rand_fe(31, 0, o.Q), 0, 1)
 wstates = [winit]
 for _ in range(wn):
     wstates.append(o.minroot_eval(wstates[-1], wt, o.FIELD_FQ))
 wz0 = [wstates[wn].x, wstates[wn].y, wstates[wn].i]
-wsn = None
-for k in range(wn):
-    wsn = nv.prove_step(wpp, wsn, nv.InverseMinRootCircuit(wt, wstates[wn - k], wstates[wn - k - 1]), wz0)
-wc = nv.compress(wpp, wsn)
-assert nv.verify_compressed(wpp, wc, wn, wz0) == ([winit.x, winit.y, winit.i], [0])
-wire_snark = wire.encode_compressed_proof(wt, wpp.params, wc)
-wire_running = wire.encode_running_proof(wt, wpp.params, wsn, wz0)
-out["wire_ivc_t2"] = {"t": wt, "steps": wn, "seed": 31, "i0": 1, "params": H(wpp.params),
-                      "compressed_proof_sha256": hashlib.sha256(wire_snark).hexdigest(), "compressed_proof_len": len(wire_snark),
-                      "compressed_proof_head_hex": wire_snark[:48 + 5 * 32 * 2 + 3 * 32 + 32 + 128].hex(),
-                      "running_proof_sha256": hashlib.sha256(wire_running).hexdigest(), "running_proof_len": len(wire_running)}
+# the reference's step circuit (src/nova/proof.rs:155-230: 4 variables per round) and the bound form (3 per round)
+for key, bound in (("wire_ivc_t2_reference", False), ("wire_ivc_t2", True)):
+    wpp = nv.public_params(wt, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=bound)
+    wsn = None
+    for k in range(wn):
+        wsn = nv.prove_step(wpp, wsn, nv.InverseMinRootCircuit(wt, wstates[wn - k], wstates[wn - k - 1], bound), wz0)
+    wc = nv.compress(wpp, wsn)
+    assert nv.verify_compressed(wpp, wc, wn, wz0) == ([winit.x, winit.y, winit.i], [0])
+    wire_snark = wire.encode_compressed_proof(wt, wpp.params, wc)
+    wire_running = wire.encode_running_proof(wt, wpp.params, wsn, wz0)
+    out[key] = {"t": wt, "steps": wn, "seed": 31, "i0": 1, "bound": bound, "params": H(wpp.params),
+                "compressed_proof_sha256": hashlib.sha256(wire_snark).hexdigest(), "compressed_proof_len": len(wire_snark),
+                "compressed_proof_head_hex": wire_snark[:48 + 5 * 32 * 2 + 3 * 32 + 32 + 128].hex(),
+                "running_proof_sha256": hashlib.sha256(wire_running).hexdigest(), "running_proof_len": len(wire_running)}
 # --- the random oracle (oracle/poseidon.py): a known answer per field and the parameters digest at t = 1 ---------------
 from oracle import poseidon as ps  # noqa: E402
 out["ro"] = {str(f): H(ps.hash_elements(1, [1, 2, 3, 4, 5], f)) for f in (o.FIELD_FP, o.FIELD_FQ)}
-out["params_t1"] = H(nv.public_params(1, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT).params)
+out["params_t1"] = H(nv.public_params(1, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=True).params)
+out["params_t1_reference"] = H(nv.public_params(1, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=False).params)
 
 path = os.path.join(os.path.dirname(__file__), "vectors.json")
 json.dump(out, open(path, "w"), indent=0)

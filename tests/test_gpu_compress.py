@@ -20,7 +20,7 @@ def _zi(init_ints):
     return [s.x, s.y, s.i]
 
 
-def oracle_proof(t, n, init_ints, bound=True):
+def oracle_proof(t, n, init_ints, bound=False):
     """The same chain proven by the oracle: (public parameters, RecursiveSNARK, z0 as integers)."""
     opp = nv.public_params(t, nv.CCommit(), nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=bound)
     states = [o.State(*init_ints)]

@@ -23,7 +23,7 @@ def aff_ints(arr, side):
     return tuple(unmont(np.asarray(arr).reshape(2, 4), BASE[side]))
 
 
-def make(ctx, t, n, seed=42, i0=1, kind=CIRCUIT_MINROOT_BOUND, family=GENS_TRY_AND_INCREMENT, mode=None):
+def make(ctx, t, n, seed=42, i0=1, kind=CIRCUIT_MINROOT_REFERENCE, family=GENS_TRY_AND_INCREMENT, mode=None):
     x = o.rand_fe(seed, 0, o.Q)
     initial = State.from_ints(FIELD_FQ, x, 0, i0)             # y = 0, i = 1: src/nova/proof.rs:417-421
     pp = public_params(ctx, t, kind, family)
@@ -89,7 +89,8 @@ def test_eval_and_make_circuits_order(ctx):
         InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, 0, initial)
 
 
-@pytest.mark.parametrize("t,n,kind", [(5, 3, CIRCUIT_MINROOT_BOUND), (24, 3, CIRCUIT_MINROOT_BOUND), (7, 2, CIRCUIT_MINROOT_REFERENCE)])
+@pytest.mark.parametrize("t,n,kind", [(5, 3, CIRCUIT_MINROOT_REFERENCE), (24, 3, CIRCUIT_MINROOT_REFERENCE), (7, 2, CIRCUIT_MINROOT_BOUND),
+                                      (24, 3, CIRCUIT_MINROOT_BOUND)], ids=["t5-reference", "t24-reference", "t7-bound", "t24-bound"])
 def test_prove_steps_replayed_by_the_oracle(ctx, t, n, kind):
     """Every quantity of every step, bit-exact against oracle/nova.py: parameters digest, the fresh primary instance,
     both cross-term commitments, both challenges, the three instances a proof carries and their witnesses."""
@@ -190,7 +191,7 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
     assert 3 * t - 8 <= rn <= 3 * t + 2 and rb > 0
     a = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
     monkeypatch.setenv("VDF_NOVA_T_AHEAD", "0")
-    pp1 = public_params(ctx, t, CIRCUIT_MINROOT_BOUND, GENS_TRY_AND_INCREMENT)
+    pp1 = public_params(ctx, t, CIRCUIT_MINROOT_REFERENCE, GENS_TRY_AND_INCREMENT)
     monkeypatch.delenv("VDF_NOVA_T_AHEAD")
     assert pp1.early_rows() == (0, 0) and pp1.digest() == pp.digest()
     b = NovaVDFProof.prove_recursively(pp1, circuits, t, z0)

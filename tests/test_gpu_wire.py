@@ -33,11 +33,13 @@ def test_proof_bytes_equal_the_oracles(ctx):
     assert again.verify(pp, n, z0, _zi(init_ints))
 
 
-def test_product_bytes_equal_the_committed_vector(ctx, golden):
-    """tests/golden/vectors.json "wire_ivc_t2" (made on the CPU by the oracle alone): the product's bytes for that chain."""
-    g = golden["wire_ivc_t2"]
+@pytest.mark.parametrize("key", ["wire_ivc_t2_reference", "wire_ivc_t2"])
+def test_product_bytes_equal_the_committed_vector(ctx, golden, key):
+    """tests/golden/vectors.json "wire_ivc_t2_reference" / "wire_ivc_t2" (made on the CPU by the oracle alone, for the
+    reference's step circuit and for the bound form): the product's bytes for that chain."""
+    g = golden[key]
     t, n = g["t"], g["steps"]
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=g["seed"], i0=g["i0"])
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=g["seed"], i0=g["i0"], kind=0 if g["bound"] else 1)
     assert pp.digest() == int(g["params"], 16)
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
     wire = proof.compress(pp).serialize()

@@ -108,7 +108,7 @@ def test_augmented_circuit_witness_equals_the_restatement(oracle_run):
         f = nv.SIDE_FIELD[side]
         res = st(step.result) if side == 0 else None
         inn = st(step.input) if side == 0 else None
-        W, X, zn, nc = vn.aug_synthesize(side, t, 0, c_inputs(side, inp), res, inn)
+        W, X, zn, nc = vn.aug_synthesize(side, t, 1, c_inputs(side, inp), res, inn)        # 1: the reference's circuit (the oracle's default)
         assert nc == pp.shapes[side].num_cons and W.shape[0] == pp.shapes[side].num_vars
         assert unmont(X, f) == fresh.X
         assert unmont(zn, f) == z_next
@@ -119,16 +119,16 @@ def test_augmented_circuit_witness_equals_the_restatement(oracle_run):
         assert vn.synthesis_stats() == (512, 0)
 
 
-def test_reference_circuit_witness(oracle_run):
-    """The reference's own allocation (4 variables per round, src/nova/proof.rs:167-181) through the same seam."""
+def test_bound_circuit_witness(oracle_run):
+    """The bound form (3 variables per round: new_x as the linear combination y - i + 1) through the same seam."""
     t, pp, rec = oracle_run
     side, inp, step, fresh, z_next = rec[2]                     # a folding step of the primary side
-    ref_step = nv.InverseMinRootCircuit(t, step.result, step.input, bound=False)
+    bound_step = nv.InverseMinRootCircuit(t, step.result, step.input, bound=True)
     cs = nv.CS(nv.SIDE_FIELD[0])
-    z = nv.synthesize_augmented(cs, 0, inp, ref_step)
-    W, X, zn, nc = vn.aug_synthesize(0, t, 1, c_inputs(0, inp), st(step.result), st(step.input))
+    z = nv.synthesize_augmented(cs, 0, inp, bound_step)
+    W, X, zn, nc = vn.aug_synthesize(0, t, 0, c_inputs(0, inp), st(step.result), st(step.input))
     assert unmont(W, o.FIELD_FQ) == cs.W and unmont(zn, o.FIELD_FQ) == z and nc == cs.rows
-    assert len(cs.W) == len(fresh.W) + t
+    assert len(cs.W) == len(fresh.W) - t                        # the reference's allocation (4 per round, src/nova/proof.rs:167-181) has t more
 
 
 def test_committed_known_answers(golden):
@@ -138,6 +138,7 @@ def test_committed_known_answers(golden):
         assert ps.hash_elements(1, [1, 2, 3, 4, 5], field) == want
         assert unmont(vn.ro_hash(field, 1, mont([1, 2, 3, 4, 5], field)), field)[0] == want
     assert vn.shape_digest(1, 0, 1)[0] == int(golden["params_t1"], 16)
+    assert vn.shape_digest(1, 1, 1)[0] == int(golden["params_t1_reference"], 16) == vn.shape_digest(1)[0]      # the default: the reference's circuit
 
 
 def test_custom_step_circuit_shape_through_the_seam():

@@ -153,9 +153,12 @@ def test_nova_proof_5_iterations_3_steps(proof_5_3):
         assert zi is not None and zi[1] == [0]
     assert nv.verify(pp, snaps[2], 2, z0) is None                                 # wrong step count
     assert nv.verify(pp, snaps[2], 3, [z0[0], z0[1], (z0[2] + 1) % o.Q]) is None   # other z0
-    # shapes: the step circuit contributes 3t + 1 constraints and 3t + 1 variables (bound form)
+    # shapes: the reference's step circuit contributes 3t + 1 constraints and 4t + 1 variables (src/nova/proof.rs:155-230, :122-133);
+    # the bound form 3t + 1 and 3t + 1
     pp1 = nv.public_params(1, pp.commit, nv.GENS_SEED, 1)
-    assert pp.shapes[0].num_cons - pp1.shapes[0].num_cons == 3 * 4 and pp.shapes[0].num_vars - pp1.shapes[0].num_vars == 3 * 4
+    assert pp.shapes[0].num_cons - pp1.shapes[0].num_cons == 3 * 4 and pp.shapes[0].num_vars - pp1.shapes[0].num_vars == 4 * 4
+    ppb, ppb1 = (nv.public_params(t_, pp.commit, nv.GENS_SEED, 1, bound=True) for t_ in (5, 1))
+    assert ppb.shapes[0].num_cons - ppb1.shapes[0].num_cons == 3 * 4 and ppb.shapes[0].num_vars - ppb1.shapes[0].num_vars == 3 * 4
 
 
 def test_tampered_proofs_are_rejected(proof_5_3):

@@ -417,7 +417,8 @@ int vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses) {
 // ---- public parameters -------------------------------------------------------------------------------
 int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   return nova_guard([&]() -> int {
-    return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_BOUND, VDF_GENS_TRY_AND_INCREMENT, out);
+    // the reference's own step circuit (src/nova/proof.rs:155-230), as public_params(num_iters_per_step) builds it (:232-237)
+    return vdf_nova_public_params_ex(ctx, t, VDF_CIRCUIT_MINROOT_REFERENCE, VDF_GENS_TRY_AND_INCREMENT, out);
   });
 }
 

@@ -116,7 +116,7 @@ def ro_hash(field: int, tag: int, xs: np.ndarray) -> np.ndarray:
     return out
 
 
-def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
+def shape_digest(t: int, circuit_kind: int = 1, gens_family: int = 1):
     """(digest as an integer, sizes[side] = (num_cons, num_vars, nnz)) of the parameters public_params(t) would make."""
     d = (C.c_uint8 * 32)()
     sizes = np.zeros((2, 3), dtype="<u8")
@@ -124,7 +124,7 @@ def shape_digest(t: int, circuit_kind: int = 0, gens_family: int = 1):
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
 
 
-def shape_export(t: int, circuit_kind: int = 0, side: int = 0):
+def shape_export(t: int, circuit_kind: int = 1, side: int = 0):
     """[(rows uint32[nnz], cols uint32[nnz], vals uint64[nnz, 4])] x 3 (A, B, C) of the shape public_params(t) makes (host only)."""
     nnz = np.zeros(3, dtype="<u8")
     _check(nova_lib.vdf_nova_shape_export(t, circuit_kind, side, nnz.ctypes.data, None, None, None))
@@ -313,7 +313,7 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
             pass
 
 
-def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_BOUND,
+def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_REFERENCE,
                   gens_family: int = GENS_TRY_AND_INCREMENT, flags: int = 0) -> NovaVDFPublicParams:      # :232-237
     h = C.c_void_p()
     _check(nova_lib.vdf_nova_public_params_flags(ctx.handle, num_iters_per_step, circuit_kind, gens_family, flags, C.byref(h)))
