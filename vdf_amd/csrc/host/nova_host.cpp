@@ -171,9 +171,6 @@ void digest_shapes(uint64_t t, int gens_family, const HostShape sh[2], uint8_t o
   out[31] &= 0x03;                                 // 250 bits
 }
 
-Aff jac_aff(const vdf_jac& j, const Field& Fb) { return jac_to_aff(j, Fb); }
-Aff aff_add(const Aff& a, const Aff& b, const Field& Fb) { return pt_to_aff(pt_add(pt_from_aff(a, Fb), pt_from_aff(b, Fb), Fb), Fb); }
-
 // the running instance a circuit hands back: nine native values -> (commitments, u, X) in the instance's own field
 Inst inst_from_elements(const Fe e[9], const Field& circuit_field, const Field& own) {
   Inst in;
@@ -1165,7 +1162,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   p->i += 1;
-  p->last.comm_W1 = *(const vdf_affine*)&l1.comm_W;
+  memcpy(&p->last.comm_W1, &l1.comm_W, sizeof(vdf_affine));
   memcpy(p->last.X1, l1.X, 64);
   memcpy(&p->last.comm_T1, &comm_T1, 64);
   memcpy(&p->last.comm_T2, &comm_T2, 64);
