@@ -320,6 +320,11 @@ int  vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot);
  * latency-critical kernel on its main queue (measured: a 10^4-term direct sum takes 190 us beside an accumulation and
  * 110 us alone).  Results are unchanged; an MSM that takes the direct-sum path ignores the hint. */
 int  vdf_ctx_gate_accumulate(vdf_ctx* ctx, vdf_ctx* other, int slot);
+/* Wave priority (0..3, default 3) of the latency-bound kernels of this context's bucket-method MSMs -- the sort and the
+ * bucket reduction; the bucket accumulation always runs at 0 and a direct sum at 2.  A prover that commits on several
+ * queues gives the queue whose result it needs LAST a lower priority than the one on its longest dependent path
+ * (libvdf_nova.so: the lookahead's MSM at 1, the early rows' at 3).  Scheduling only: results are unchanged. */
+int  vdf_ctx_set_light_priority(vdf_ctx* ctx, int priority);
 
 /* ---- compression SNARK building blocks ------------------------------------------------------ */
 /* The passes behind `NovaVDFProof::compress` and the verification of a compressed proof

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "vdf_ctx_sync_mark": (_i, [_vp, _i]),
     "vdf_ctx_wait_mark": (_i, [_vp, _vp, _i]),
     "vdf_ctx_gate_accumulate": (_i, [_vp, _vp, _i]),
+    "vdf_ctx_set_light_priority": (_i, [_vp, _i]),
     "vdf_ctx_device": (_i, [_vp]),
     "vdf_last_error": (C.c_char_p, [_vp]),
     "vdf_bases_upload": (_i, [_vp, _i, _vp, _sz, C.POINTER(_vp)]),

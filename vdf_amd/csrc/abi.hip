@@ -250,7 +250,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
   }
   hipEvent_t gate = ctx->acc_gate;
   ctx->acc_gate = nullptr;                                      // one-shot
-  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev, nullptr, gate));
+  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev, nullptr, gate, ctx->light_prio));
   if (ev) ctx->timed.push_back(tc);
   return st.finish();
 }
@@ -1296,6 +1296,14 @@ int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
     if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     if (other == ctx) return Status{};
     VDF_TRY_HIP(hipStreamWaitEvent(ctx->stream, other->marks[slot], 0));
+    return Status{};
+  });
+}
+
+int vdf_ctx_set_light_priority(vdf_ctx* ctx, int priority) {
+  return guarded(ctx, [&]() -> Status {
+    if (priority < 0 || priority > 3) return Status{VDF_ERR_BAD_ARG, "wave priority is 0..3"};
+    ctx->light_prio = priority;
     return Status{};
   });
 }

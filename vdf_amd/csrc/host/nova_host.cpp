@@ -226,6 +226,10 @@ int alloc_proof_buffers(vdf_proof* p) {
     if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
+    // the lookahead's commitment is needed a whole step later: its sort and bucket reduction yield to the early rows' (the
+    // step's longest dependent path, priority 3) and to the chain's direct sums (2).  VDF_NOVA_LOOKAHEAD_PRIO=0..3 (tuning)
+    static const int la_prio = [] { const char* e = std::getenv("VDF_NOVA_LOOKAHEAD_PRIO"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
+    HIPCALL(p->ctx2[k], vdf_ctx_set_light_priority(p->ctx2[k], la_prio));
   }
   {
     const int dev = vdf_ctx_device(ctx);

@@ -70,6 +70,7 @@ struct vdf_ctx {
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool job_open = false;
   void* reduce_scratch = nullptr;    // per-workgroup partial sums of vdf_reduce
+  int light_prio = 3;                // wave priority of this context's sort / bucket-reduction kernels (vdf_ctx_set_light_priority)
   hipEvent_t acc_gate = nullptr;     // one-shot: the next bucket-method MSM's accumulation waits for this event (vdf_ctx_gate_accumulate)
   uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
 };
@@ -189,9 +190,9 @@ bool msm_plan_feasible(int groups, int c, int sets);       // sets <= 0: one buc
 // run then stops after the fix-up and msm_tail reduces all groups of the job at once.
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont,
                void* ws, void* d_out, hipStream_t stream, hipEvent_t* ev = nullptr, void* ext_bucket_acc = nullptr,
-               hipEvent_t acc_gate = nullptr);
+               hipEvent_t acc_gate = nullptr, int prio = 3);
 size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk);
-Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream);
+Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream, int prio = 3);
 Status bases_generate(int curve, int family, uint64_t seed, size_t start, size_t n, void* d_pts, hipStream_t stream);
 // msm_direct.hip: the digit table of generators [first, first + nslots) into slots [slot0, ...) of d_digits, and the
 // direct sum over it (groups x 96 B Jacobian to d_out; ws: direct_ws_bytes)

@@ -50,8 +50,8 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 // Wave priority of the pipeline's light kernels (sort, fix-up, bucket reduction): above the bucket accumulation (0), and --
 // VDF_MSM_LIGHT_PRIO=2 -- optionally below the short kernels a prover's main queue waits for (3).
 __constant__ int c_light_prio = 3;
-__device__ __forceinline__ void raise_wave_priority() {
-  const int p = c_light_prio;
+__device__ __forceinline__ void raise_wave_priority(int wave_prio = 3) {
+  const int p = wave_prio < c_light_prio ? wave_prio : c_light_prio;
   if (p >= 3) __builtin_amdgcn_s_setprio(3);
   else if (p == 2) __builtin_amdgcn_s_setprio(2);
   else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -309,8 +309,8 @@ template <class SP, bool SCATTER>
 __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c, int windows, int sets, int pb, int fb,
                                               uint32_t bins, uint32_t chA, uint32_t tstride,
                                               uint32_t* __restrict__ countsA, const uint32_t* __restrict__ pstart,
-                                              uint64_t* __restrict__ recs) {
-  raise_wave_priority();
+                                              uint64_t* __restrict__ recs, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ uint32_t limbs[9 * 256];
   extern __shared__ uint32_t cur[];                   // bins counters (histogram) or cursors (scatter)
   uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c,
 // a time through LDS (a thread per bin walking hundreds of counts would be one L2 round trip each).
 __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ countsA, uint32_t bins, uint32_t nblk,
                                                    uint32_t* __restrict__ pcount, uint32_t* __restrict__ heavy,
-                                                   uint32_t* __restrict__ giant_done) {
-  raise_wave_priority();
+                                                   uint32_t* __restrict__ giant_done, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ uint32_t sc[256];
   const uint32_t b = blockIdx.x;
   uint32_t carry = 0;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ counts
 // single workgroup exclusive scan: out[0..n], out[n] = total.  Each thread owns a contiguous run; loads are
 // issued eight at a time so the run is a few L2 round trips instead of one per element.
 __global__ __launch_bounds__(1024) void k_scan_keys(const uint32_t* __restrict__ bcount, uint32_t nkeys,
-                                                    uint32_t* __restrict__ bstart) {
-  raise_wave_priority();
+                                                    uint32_t* __restrict__ bstart, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ uint32_t part[1024];
   const uint32_t per = (nkeys + 1023) / 1024;
   const uint32_t lo = threadIdx.x * per < nkeys ? threadIdx.x * per : nkeys;
@@ -445,8 +445,8 @@ __device__ __forceinline__ uint32_t lds_take_slot(uint32_t* h, uint32_t key) {
 __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
                                                uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
                                                uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc,
-                                               uint32_t slots, uint32_t Lfixed, uint32_t* __restrict__ tstart) {
-  raise_wave_priority();
+                                               uint32_t slots, uint32_t Lfixed, uint32_t* __restrict__ tstart, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ uint32_t h[1024];
   __shared__ uint32_t sc[1024];
   const uint32_t bin = blockIdx.x, f = threadIdx.x;
@@ -639,8 +639,8 @@ template <class P>
 __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
                                                uint32_t Lfixed, char* __restrict__ bucket_acc,
                                                const char* __restrict__ heads, uint32_t* __restrict__ heavy,
-                                               uint32_t heavy_min, uint32_t giant_span) {
-  raise_wave_priority();
+                                               uint32_t heavy_min, uint32_t giant_span, int wave_prio) {
+  raise_wave_priority(wave_prio);
   const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 2;
   if (g >= nkeys) return;                                          // quad-uniform from here on
   const uint32_t ne = bstart[nkeys];
@@ -683,8 +683,8 @@ template <class P>
 __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
                                                     uint32_t Lfixed, char* __restrict__ bucket_acc,
                                                     const char* __restrict__ heads, uint32_t* __restrict__ heavy,
-                                                    char* __restrict__ giant) {
-  raise_wave_priority();
+                                                    char* __restrict__ giant, int wave_prio) {
+  raise_wave_priority(wave_prio);
   const HeavyLayout q = heavy_layout(heavy, nkeys);
   const uint32_t count = *q.count;
   uint32_t ngiant = *q.giant_count;
@@ -744,8 +744,8 @@ __global__ __launch_bounds__(64) void k_fixup_heavy(const uint32_t* __restrict__
 template <class P>
 __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket_acc, uint32_t nbk, uint32_t nseg,
                                                  uint32_t threads_per_set, uint32_t blocks_per_set,
-                                                 char* __restrict__ partials) {
-  raise_wave_priority();
+                                                 char* __restrict__ partials, int wave_prio) {
+  raise_wave_priority(wave_prio);
   extern __shared__ __align__(16) char lds_raw[];
   const uint32_t nlog = blockDim.x >> 2;                          // logical threads (quads) per block
   const uint32_t lt = threadIdx.x >> 2;
@@ -785,8 +785,8 @@ __global__ __launch_bounds__(256) void k_reduce1(const char* __restrict__ bucket
 // one workgroup of 64 quads per set: strided partial sums, then an LDS tree
 template <class P>
 __global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partials, uint32_t blocks_per_set,
-                                                 char* __restrict__ wsum) {
-  raise_wave_priority();
+                                                 char* __restrict__ wsum, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t set = blockIdx.x;
   const uint32_t lt = threadIdx.x >> 2;
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(256) void k_reduce2(const char* __restrict__ partia
 // phase 1: every row sum and column sum of every set; Q quads share a sum (strided), LDS tree within the Q quads
 template <class P>
 __global__ __launch_bounds__(256) void k_red_sums(const char* __restrict__ bucket_acc, uint32_t nbk, uint32_t Lb, uint32_t Q,
-                                                  uint32_t wgs_per_set, char* __restrict__ sums) {
-  raise_wave_priority();
+                                                  uint32_t wgs_per_set, char* __restrict__ sums, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t ncols = 1u << Lb, nrows = nbk >> Lb, nsums = nrows + ncols;
   const uint32_t set = blockIdx.x / wgs_per_set, blk = blockIdx.x % wgs_per_set;
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(256) void k_red_sums(const char* __restrict__ bucke
 // kind of one set, so the two kinds come out as separate partials (the rows still lack their common factor 2^Lb)
 template <class P>
 __global__ __launch_bounds__(256) void k_red_weights(const char* __restrict__ sums, uint32_t nbk, uint32_t Lb, uint32_t bA,
-                                                     uint32_t bB, char* __restrict__ partials) {
-  raise_wave_priority();
+                                                     uint32_t bB, char* __restrict__ partials, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t ncols = 1u << Lb, nrows = nbk >> Lb, nsums = nrows + ncols;
   const uint32_t set = blockIdx.x / (bA + bB), blk = blockIdx.x % (bA + bB);
@@ -879,8 +879,8 @@ __global__ __launch_bounds__(256) void k_red_weights(const char* __restrict__ su
 // k_final's work for that case
 template <class P>
 __global__ __launch_bounds__(256) void k_red_combine(const char* __restrict__ partials, uint32_t Lb, uint32_t bA, uint32_t bB,
-                                                     char* __restrict__ wsum, char* __restrict__ out_jac) {
-  raise_wave_priority();
+                                                     char* __restrict__ wsum, char* __restrict__ out_jac, int wave_prio) {
+  raise_wave_priority(wave_prio);
   __shared__ __align__(16) char lds_raw[64 * 128];
   const uint32_t set = blockIdx.x;
   const uint32_t lt = threadIdx.x >> 2, half = lt >> 5, qi = lt & 31u;
@@ -919,8 +919,8 @@ __global__ __launch_bounds__(256) void k_red_combine(const char* __restrict__ pa
 
 // Horner over a group's bucket sets (one quad per group, one workgroup each), XYZZ -> Jacobian
 template <class P>
-__global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum_all, int sets, int c, char* __restrict__ out_all) {
-  raise_wave_priority();
+__global__ __launch_bounds__(64) void k_final(const char* __restrict__ wsum_all, int sets, int c, char* __restrict__ out_all, int wave_prio) {
+  raise_wave_priority(wave_prio);
   if (threadIdx.x >= 4) return;
   const char* wsum = wsum_all + (size_t)blockIdx.x * sets * 128;
   char* out_jac = out_all + (size_t)blockIdx.x * 96;
@@ -1168,16 +1168,16 @@ __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts
 // ------------------------------------------------------------------------------------------
 template <class P>
 static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* bucket_acc, char* partials, char* wsum,
-                         void* d_out, hipStream_t st) {
+                         void* d_out, hipStream_t st, int prio) {
   const uint32_t gsets = (uint32_t)(groups * sets);
   if (use_matrix_reduction(nbk)) {
     const MatGeom g = mat_geom(gsets, nbk);
     char* sums = partials;
     char* parts = partials + g.sums_bytes;
-    hipLaunchKernelGGL((k_red_sums<P>), dim3(gsets * g.wgs_per_set), dim3(256), 0, st, bucket_acc, nbk, g.Lb, g.Q, g.wgs_per_set, sums);
-    hipLaunchKernelGGL((k_red_weights<P>), dim3(gsets * (g.bA + g.bB)), dim3(256), 0, st, sums, nbk, g.Lb, g.bA, g.bB, parts);
+    hipLaunchKernelGGL((k_red_sums<P>), dim3(gsets * g.wgs_per_set), dim3(256), 0, st, bucket_acc, nbk, g.Lb, g.Q, g.wgs_per_set, sums, prio);
+    hipLaunchKernelGGL((k_red_weights<P>), dim3(gsets * (g.bA + g.bB)), dim3(256), 0, st, sums, nbk, g.Lb, g.bA, g.bB, parts, prio);
     char* direct = sets == 1 ? reinterpret_cast<char*>(d_out) : nullptr;
-    hipLaunchKernelGGL((k_red_combine<P>), dim3(gsets), dim3(256), 0, st, parts, g.Lb, g.bA, g.bB, wsum, direct);
+    hipLaunchKernelGGL((k_red_combine<P>), dim3(gsets), dim3(256), 0, st, parts, g.Lb, g.bA, g.bB, wsum, direct, prio);
     if (direct) {
       VDF_TRY_HIP(hipGetLastError());
       return Status{};
@@ -1185,10 +1185,10 @@ static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* 
   } else {
     const RedGeom rg = red_geom((size_t)gsets * nbk, nbk);
     hipLaunchKernelGGL((k_reduce1<P>), dim3(gsets * rg.blocks_per_set), dim3(rg.block * 4), (size_t)rg.block * 128, st,
-                       bucket_acc, nbk, rg.seg, rg.threads_per_set, rg.blocks_per_set, partials);
-    hipLaunchKernelGGL((k_reduce2<P>), dim3(gsets), dim3(256), 0, st, partials, rg.blocks_per_set, wsum);
+                       bucket_acc, nbk, rg.seg, rg.threads_per_set, rg.blocks_per_set, partials, prio);
+    hipLaunchKernelGGL((k_reduce2<P>), dim3(gsets), dim3(256), 0, st, partials, rg.blocks_per_set, wsum, prio);
   }
-  hipLaunchKernelGGL((k_final<P>), dim3(groups), dim3(64), 0, st, wsum, sets, c, reinterpret_cast<char*>(d_out));
+  hipLaunchKernelGGL((k_final<P>), dim3(groups), dim3(64), 0, st, wsum, sets, c, reinterpret_cast<char*>(d_out), prio);
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
@@ -1197,7 +1197,7 @@ static Status msm_tail_t(int c, int sets, int groups, uint32_t nbk, const char* 
 // fix-up; the reduction of all groups follows in msm_tail.
 template <class P, class SP>
 static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-                        void* d_out, hipStream_t st, hipEvent_t* ev, char* ext_bucket_acc, hipEvent_t acc_gate) {
+                        void* d_out, hipStream_t st, hipEvent_t* ev, char* ext_bucket_acc, hipEvent_t acc_gate, int prio) {
   const WsLayout w = ws_layout(p);
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* countsA = reinterpret_cast<uint32_t*>(base + w.countsA);
@@ -1227,14 +1227,14 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   {
   KTimer kt(st, "msm_sort(5 launches)", 0.0);
   hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
-                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
-  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy, heavy + 1 + nkeys + 2);
-  hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart);
+                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs, prio);
+  hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy, heavy + 1 + nkeys + 2, prio);
+  hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart, prio);
   hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
-                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs);
+                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs, prio);
   // pass B
   hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
-                     reinterpret_cast<uint32_t*>(base + w.tstart));
+                     reinterpret_cast<uint32_t*>(base + w.tstart), prio);
   }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   // the sort is light; the accumulation fills every SIMD: a caller that knows of latency-critical work on another queue
@@ -1249,23 +1249,23 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   static const FixupTune tune = fixup_tune();
   KTimer kt_tail(st, ext_bucket_acc ? "msm_fixup(2 launches)" : "msm_tail(fixup+reduce)", 0.0);
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
-                     heavy, tune.heavy_min, tune.giant_span);
+                     heavy, tune.heavy_min, tune.giant_span, prio);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(16 * GIANT_PARTS), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
-                     base + w.giant);
-  if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st));
+                     base + w.giant, prio);
+  if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st, prio));
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[3], st));
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 
 Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void* const* d_scalars, bool is_mont, void* ws,
-               void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc, hipEvent_t acc_gate) {
+               void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc, hipEvent_t acc_gate, int prio) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
   char* ext = reinterpret_cast<char*>(ext_bucket_acc);
   if (curve == VDF_CURVE_PALLAS)
-    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate);
+    return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate, prio);
   if (curve == VDF_CURVE_VESTA)
-    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate);
+    return msm_run_t<FqParams, FpParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate, prio);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 
@@ -1280,13 +1280,13 @@ size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk) {
   const size_t gsets = (size_t)groups * sets;
   return align_up(gsets * nbk * 128, 256) + tail_scratch_bytes(gsets, nbk) + align_up(gsets * 128, 256);
 }
-Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream) {
+Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream, int prio) {
   const size_t gsets = (size_t)groups * sets;
   char* bucket_acc = reinterpret_cast<char*>(tail_ws);
   char* partials = bucket_acc + align_up(gsets * nbk * 128, 256);
   char* wsum = partials + tail_scratch_bytes(gsets, nbk);
-  if (curve == VDF_CURVE_PALLAS) return msm_tail_t<FpParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
-  if (curve == VDF_CURVE_VESTA) return msm_tail_t<FqParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream);
+  if (curve == VDF_CURVE_PALLAS) return msm_tail_t<FpParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream, prio);
+  if (curve == VDF_CURVE_VESTA) return msm_tail_t<FqParams>(c, sets, groups, nbk, bucket_acc, partials, wsum, d_out, stream, prio);
   return Status{VDF_ERR_BAD_ARG, "unknown curve"};
 }
 

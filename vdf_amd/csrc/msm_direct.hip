@@ -161,10 +161,16 @@ __device__ __forceinline__ void dmadd(XYZZ<P>& acc, bool& have, const Affine<P>&
 // (whole wavefronts); lane x takes the entries x, x + L, x + 2L, ... (per_lane of them at most): consecutive lanes read
 // consecutive scalars, and the launch is ONE round of one wavefront per SIMD -- the additions are VALU-issue bound, so
 // a second wavefront on a SIMD only doubles the time of both.
+// Wave priority of the direct sum: 2 -- above a bucket accumulation (0), below the sort and bucket-reduction kernels of an
+// MSM pipeline (3).  A prover's direct sums are its main queue's, but the longest dependent path of a step runs through the
+// side queue that commits the early rows of the cross term (sort, accumulation, bucket reduction): at equal priority the
+// direct sum's one wavefront per SIMD takes half of the issue slots those latency-bound kernels need.  Measured r3, one box:
+// 0.942 ms per step at 3, 0.906 at 2, 0.910 at 1, 0.902 at 0 (VDF_MSM_DIRECT_PRIO=0..3).
+__constant__ int c_direct_prio = 2;
 template <class P, class SP>
 __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, int c, int W, const char* __restrict__ D,
                                                     char* __restrict__ partials, uint32_t* __restrict__ arrived, char* __restrict__ out) {
-  __builtin_amdgcn_s_setprio(3);
+  { const int p_ = c_direct_prio; if (p_ >= 3) __builtin_amdgcn_s_setprio(3); else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); }
   __shared__ uint32_t limbs[9 * 256];                              // k + H, one private column per thread
   __shared__ __align__(16) char pts[256 * 128];
   __shared__ uint32_t ticket;
@@ -339,6 +345,16 @@ size_t direct_ws_bytes(int groups, const size_t* n, int c, int num_cus) {
   return ((size_t)direct_geom(groups, n, direct_windows(c), num_cus).total_wgs + 1) * 128;
 }
 
+static void init_direct_prio() {
+  static const bool done = [] {
+    if (const char* e = std::getenv("VDF_MSM_DIRECT_PRIO")) {
+      const int v = atoi(e);
+      if (v >= 0 && v <= 3) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_direct_prio), &v, sizeof(int));
+    }
+    return true;
+  }();
+  (void)done;
+}
 static bool fused_final() {          // VDF_MSM_DIRECT_FUSED=0: the final sum as a launch of its own (tuning / A-B measurements)
   static const bool on = [] { const char* e = std::getenv("VDF_MSM_DIRECT_FUSED"); return !(e && e[0] == '0'); }();
   return on;
@@ -365,6 +381,7 @@ static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, con
   for (int j = 0; j < W; ++j) { const int bit = c * j + c - 1; a.half[bit >> 5] |= 1u << (bit & 31); }
   double nsum = 0;
   for (int g = 0; g < groups; ++g) nsum += (double)n[g];
+  init_direct_prio();
   bool empty_group = false;
   for (int g = 0; g < groups; ++g) empty_group |= geo.waves[g] == 0;
   if (waves) {
