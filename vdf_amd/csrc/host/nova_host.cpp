@@ -296,6 +296,7 @@ extern "C" {
 
 const char* vdf_nova_last_error(void) { return vdfnova::g_err.c_str(); }
 
+
 // ---- host-only entry points ------------------------------------------------------------------------------------
 int vdf_nova_ro_hash(int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) {
   return nova_guard([&]() -> int {
@@ -811,7 +812,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
   // marks on a lookahead context: segment written / its commitment landed / early rows of T committed; MARK_STEP on the
   // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
-  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5 };
+  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6 };
+  std::function<int()> rows_deferred;  // the launches of the next step's early rows: set up behind the fold, issued after the NIFS's
   bool gate_next_segment = false;     // the next enqueue_segment holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
   const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
@@ -1118,6 +1120,27 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       HIPCALL(ctx, vdf_fold_many(ctx, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
     }
     p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
+    // (the folded instance is in place: the launches below read its u)
+    // The early rows of the NEXT step's cross term, as soon as this fold is on its queue: from the fold to their commitment
+    // they are a step's longest dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms).  Its rounds are
+    // in their ring slot (the lookahead), its input z_in is this step's output (uploaded here, behind the fold), the running
+    // instance is final once the fold is done: they wait for MARK_FOLD, not for the uploads and the NIFS that follow.  Their
+    // dozen launches are issued after the NIFS's (below); a helper thread issuing them at once was measured and bought
+    // nothing (0.882-0.888 ms per step either way).
+    static const bool ahead_rows = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
+    if (ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
+      void* d_next = p->d_z2s[p->ahead[0].slot];
+      vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
+      memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)d_next + (seg_b - arity) * 32, p->h_zin, arity * 32));
+      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_FOLD));
+      auto launch_rows = [&, d_next, cq_next]() -> int {
+        HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, MARK_FOLD));
+        return early_rows(d_next, cq_next, true);
+      };
+      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
+      rows_deferred = launch_rows;
+    }
     int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
     if (rc != VDF_OK) return rc;
     p->l2.X[0] = cs.X[0]; p->l2.X[1] = cs.X[1];
@@ -1132,37 +1155,13 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
   // needs nothing of the next step: the NIFS of the secondary instance just made (VDF_NOVA_NIFS_AHEAD=0: left to the next call)
   static const bool ahead = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
-  const bool rows_next = ahead && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
-  if (rows_next) {
-    // the next step's z_in (this step's output) goes to its place in the next fresh witness with this step's last uploads,
-    // so that the early rows below start with a kernel and not with a copy of their own
-    memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);
-    HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin, arity * 32));
-  }
   HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_STEP));
-  {
-    // The early rows of the next step's cross term FIRST: from the fold to their commitment they are the step's longest
-    // dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms), so their launches go out before anything
-    // else.  Its rounds are in their ring slot (the lookahead above), its input is this step's output, the running instance
-    // is final once the fold is done (the mark, not the NIFS behind it).  Then the NIFS of the secondary instance just made
-    // (the next call waits for it; its direct sum has slack).  (VDF_NOVA_ROWS_FIRST=0: the other order.)
-    static const bool rows_first = [] { const char* e = std::getenv("VDF_NOVA_ROWS_FIRST"); return !(e && e[0] == '0'); }();
-    auto launch_rows = [&]() -> int {
-      if (!rows_next) return VDF_OK;
-      HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, MARK_STEP));                     // ... and the fold read T and A z, B z, C z of this step
-      int rc = early_rows(p->d_z2s[p->ahead[0].slot], p->ctx2[(k + 1) % D], true);
-      if (rc != VDF_OK) return rc;
-      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
-      return VDF_OK;
-    };
-    if (rows_first) { int rc = launch_rows(); if (rc != VDF_OK) return rc; }
-    if (ahead) {
-      int rc = launch_nifs2();
-      if (rc != VDF_OK) return rc;
-      p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
-    }
-    if (!rows_first) { int rc = launch_rows(); if (rc != VDF_OK) return rc; }
+  if (ahead) {
+    int rc = launch_nifs2();
+    if (rc != VDF_OK) return rc;
+    p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
   }
+  if (rows_deferred) { int rc = rows_deferred(); if (rc != VDF_OK) return rc; }
   HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   p->i += 1;

@@ -3,6 +3,7 @@
 #pragma once
 #include <array>
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <initializer_list>
