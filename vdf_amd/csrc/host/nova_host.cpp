@@ -812,7 +812,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
   // marks on a lookahead context: segment written / its commitment landed / early rows of T committed; MARK_STEP on the
   // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
-  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6 };
+  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6, MARK_ZIN = 7 };
+  int zin_slot = -1;                   // ring slot whose z_in this step has already uploaded (for the next step's early rows)
+  // (tuning) VDF_NOVA_FOLD_ON_ROWS=0: the primary fold on the main queue, the early rows waiting for its mark
+  static const bool fold_on_rows = [] { const char* e = std::getenv("VDF_NOVA_FOLD_ON_ROWS"); return !(e && e[0] == '0'); }();
+  bool fold_elsewhere = false;        // the primary fold ran on the early rows' queue: the main queue waits for it before the step ends
   std::function<int()> rows_deferred;  // the launches of the next step's early rows: set up behind the fold, issued after the NIFS's
   bool gate_next_segment = false;     // the next enqueue_segment holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
@@ -1007,6 +1011,14 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     // the host-made variables go next to the rounds the lookahead context has written (vdf_ctx_wait at their launch)
     int rc = upload_fresh(ctx, S1, cs, p->h_stage[PRIMARY], d_z2);
     if (rc != VDF_OK) return rc;
+    if (!first && !custom && pp->ahead_rows != 0 && seg_n) {
+      // the NEXT step's z_in = this step's output, known now: into its place in the next ring slot's fresh witness, half a
+      // step before the early rows of that step read it
+      zin_slot = (slot + 1) % R;
+      memcpy(p->h_zin, z_next.data(), arity * 32);
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[zin_slot] + (seg_b - arity) * 32, p->h_zin, arity * 32));
+      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
+    }
     l1.X[0] = cs.X[0]; l1.X[1] = cs.X[1];
     l1.u = one(F1);
     memset(&l1.comm_E, 0, sizeof(Aff));
@@ -1110,6 +1122,19 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
     early2.reset();
     t5 = now_ms();
+    static const bool ahead_rows = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
+    const bool rows_next = ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
+    if (rows_next && p->ahead[0].slot != zin_slot) {
+      // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
+      memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin, arity * 32));
+      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
+    }
+    // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
+    // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
+    // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
+    // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
+    vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
     if (!first) {
       SideState& s1 = p->r[PRIMARY];
       const Fe rr = int_to_fe(r1, F1);
@@ -1117,27 +1142,26 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
                                (const vdf_fe*)s1.d_abc2[2]};
       const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
-      HIPCALL(ctx, vdf_fold_many(ctx, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+      if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
+      HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
     }
     p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
     // (the folded instance is in place: the launches below read its u)
     // The early rows of the NEXT step's cross term, as soon as this fold is on its queue: from the fold to their commitment
     // they are a step's longest dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms).  Its rounds are
-    // in their ring slot (the lookahead), its input z_in is this step's output (uploaded here, behind the fold), the running
+    // in their ring slot (the lookahead), its input z_in is this step's output (uploaded above, in front of the fold), the running
     // instance is final once the fold is done: they wait for MARK_FOLD, not for the uploads and the NIFS that follow.  Their
     // dozen launches are issued after the NIFS's (below); a helper thread issuing them at once was measured and bought
     // nothing (0.882-0.888 ms per step either way).
-    static const bool ahead_rows = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
-    if (ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty()) {
+    if (rows_next) {
       void* d_next = p->d_z2s[p->ahead[0].slot];
       vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
-      memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)d_next + (seg_b - arity) * 32, p->h_zin, arity * 32));
-      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_FOLD));
-      auto launch_rows = [&, d_next, cq_next]() -> int {
-        HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, MARK_FOLD));
+      HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
+      auto launch_rows = [&, d_next, cq_next, fq]() -> int {
+        if (fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, fq, MARK_FOLD));
         return early_rows(d_next, cq_next, true);
       };
+      fold_elsewhere = fq != ctx;
       p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
       rows_deferred = launch_rows;
     }
@@ -1161,6 +1185,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     if (rc != VDF_OK) return rc;
     p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
   }
+  if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
   if (rows_deferred) { int rc = rows_deferred(); if (rc != VDF_OK) return rc; }
   HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
