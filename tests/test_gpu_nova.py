@@ -205,11 +205,13 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
-def test_public_params_flags_decline_the_accelerators_and_change_nothing(ctx, kind):
+def test_public_params_flags_decline_the_accelerators_and_change_nothing(ctx, kind, monkeypatch):
     """vdf_nova_public_params_flags (include/vdf_nova.h): VDF_PP_NO_DIGIT_TABLES / VDF_PP_NO_EARLY_ROWS decline the HBM-hungry
     digit tables and the early rows of T; vdf_nova_pp_memory reports what a parameter set holds.  Parameters (digest) and
     every instance and witness of a proof are the same with and without them -- they are accelerators, not protocol."""
     from vdf_amd.nova import PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS
+    for var in ("VDF_NOVA_T_AHEAD", "VDF_NOVA_DIGIT_WINDOW"):      # the defaults are what is under test (tools/gpu_env_matrix.sh sets these)
+        monkeypatch.delenv(var, raising=False)
     t, n = 96, 4
     pp, z0, circuits, initial, _ = make(ctx, t, n, seed=14, kind=kind)
     mem = pp.memory()
