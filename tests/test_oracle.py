@@ -270,3 +270,33 @@ def test_vectorised_dlog_identity_equals_the_plain_one():
     for curve, seed, start, n in ((o.CURVE_PALLAS, 7, 0, 1000), (o.CURVE_VESTA, 3, 12345, 257), (o.CURVE_PALLAS, 9, 1 << 23, 1)):
         sc = rand_limbs(rng, n)
         assert o.msm_by_dlog_limbs(sc, curve, seed, start) == o.msm_by_dlog(ints(sc), curve, seed, start)
+
+
+@pytest.mark.parametrize("t", [1, 2, 5, 17])
+def test_packed_commitment_identity_of_the_reference_rounds(t):
+    """The identity behind vdf_minroot_step_segment_packed (include/vdf_hip.h) and libvdf_nova.so's make_packed_generators,
+    in the oracle's own integers: the reference allocates new_x in every round (src/nova/proof.rs:167-173) although
+    new_x_j = y_j - (i_in - (j + 1)) with y_j = new_y_(j-1) (:162-173), so the Pedersen commitment to the 4t + 1 round
+    variables equals an MSM of 3t + 4 scalars [tmp1, tmp2, new_y per round | final_i | y_0 | i_in | 1] over the derived
+    generators [G[4j+1], G[4j+2], G[4j+3] + G[4j+4] (last round: G[4t-1]) | G[4t] | G[0] | -S1 | S2]."""
+    field, curve, m, bm = o.FIELD_FQ, o.CURVE_PALLAS, o.Q, o.P
+    init = o.State(o.rand_fe(77, 0, m), 0, 5)
+    result = o.minroot_eval(init, t, field)
+    W = o.step_witness_segment(result, t, field)                 # new_x, tmp1, tmp2, new_y per round, then final_i
+    assert len(W) == 4 * t + 1 and W[4 * t] == init.i
+    G = o.tai_bases(curve, 9, 4 * t + 1)
+    want = o.msm_naive(W, G, curve)
+    add = lambda a, b: o.pt_add(a, b, bm)
+    packed, D = [], []
+    for j in range(t):
+        packed += [W[4 * j + 1], W[4 * j + 2], W[4 * j + 3]]
+        D += [G[4 * j + 1], G[4 * j + 2], add(G[4 * j + 3], G[4 * j + 4]) if j + 1 < t else G[4 * t - 1]]
+    s1 = s2 = None
+    for j in range(t - 1, -1, -1):
+        s1 = add(s1, G[4 * j]); s2 = add(s2, s1)
+    packed += [W[4 * t], result.y, result.i, 1]                  # final_i, the y and the i the first round reads, one
+    D += [G[4 * t], G[0], o.pt_neg(s1, bm), s2]
+    assert o.msm_naive(packed, D, curve) == want
+    for j in range(t):                                           # the relation itself
+        y_j = result.y if j == 0 else W[4 * (j - 1) + 3]
+        assert W[4 * j] == (y_j - (result.i - (j + 1))) % m
