@@ -126,7 +126,7 @@ inline Fe canon(Fe r, const Field& F) {               // [0, 2m) -> [0, m)
 extern const bool g_has_adx;
 template <bool LAZY = false>
 inline Fe mul_adx(const Fe& a, const Fe& b, const Field& F) {
-  uint64_t t0, t1, t2, t3, t4, t5, lo, hi, lo2, hi2;
+  uint64_t t0, t1, t2, t3, t4, t5, lo, hi;
   Fe r;
 #include "fe_mul_x86_adx.inc"
   if (!LAZY && geq(r.l, F.m)) sub4(r.l, F.m);

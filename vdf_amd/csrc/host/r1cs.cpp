@@ -608,9 +608,11 @@ class Helpers {
         if (std::chrono::steady_clock::now() - idle_since > std::chrono::milliseconds(2)) {
           std::unique_lock<std::mutex> l(s.mu);
           s.parked.store(true, std::memory_order_seq_cst);
-          // the timeout is a backstop only (the handshake above does not need it): a parked helper looks again every 50 ms
+          // the timeout is a backstop only (the handshake above does not need it): a parked helper looks again every 50 ms.
+          // (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer intercepts; wait_for goes through
+          // pthread_cond_clockwait, which gcc 11's does not, and it then reports the waiter's mutex as locked twice)
           while (!(s.state.load(std::memory_order_seq_cst) == 1 || quit_.load()))
-            s.cv.wait_for(l, std::chrono::milliseconds(50));
+            s.cv.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(50));
           s.parked.store(false, std::memory_order_seq_cst);
         }
       }
