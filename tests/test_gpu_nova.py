@@ -70,6 +70,33 @@ def test_nova_proof(ctx):
     assert unmont(zs, o.P) == [0] and [bytes(zp[k]) for k in range(3)] == zi
 
 
+@pytest.mark.parametrize("t,n", [(10, 200), (100, 20), (1000, 2)])
+def test_reference_bench_cases(ctx, t, n):
+    """The only measurement cases the reference defines (benches/nova.rs:62-66): (num_iters_per_step, num_steps) = (10, 200),
+    (100, 20), (1000, 2), initial state x = element, y = 0, i = 0 (:24-26), the whole n-step proof (:28-59) -- here as a
+    correctness case over the reference's own step circuit: prove_recursively, verify (Ok(true), and Ok(false) for a wrong z_i
+    or step count), the long chain also through compress / verify / the wire (bench.py times the same three cases)."""
+    x = o.rand_fe(4, t, o.Q)
+    initial = State.from_ints(FIELD_FQ, x, 0, 0)
+    pp = public_params(ctx, t)                                              # the default: the reference's circuit
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    zi = [initial.x, initial.y, initial.i]
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    assert proof.num_steps() == n and proof.verify(pp, n, z0, zi) is True
+    assert proof.verify(pp, n - 1, z0, zi) is False and proof.verify(pp, n, z0, [zi[1], zi[0], zi[2]]) is False
+    # the chain's end state is the forward evaluation's (src/minroot.rs:352-359), the proof walks it backwards to the start
+    s = o.State(x, 0, 0)
+    for _ in range(min(n, 3)):
+        s = o.minroot_eval(s, t, o.FIELD_FQ)
+    if n <= 3:
+        assert State(*z0).to_ints(FIELD_FQ) == (s.x, s.y, s.i)
+    if n == 200:
+        from vdf_amd.nova import CompressedNovaVDFProof
+        snark = proof.compress(pp)
+        assert snark.verify(pp, n, z0, zi)
+        assert CompressedNovaVDFProof.deserialize(pp, snark.serialize()).verify(pp, n, z0, zi)
+
+
 def test_eval_and_make_circuits_order(ctx):
     """Circuits come back reversed and z0 is the FINAL state (src/nova/proof.rs:278-294)."""
     t, n = 4, 3
