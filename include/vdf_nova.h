@@ -81,9 +81,10 @@ int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int ci
 /* HBM a parameter set holds, and how to decline the optional part.  Beside the shapes and the generators with their
  * fixed-base tables (2^19 Pallas generators x 16 windows x 64 B = 512 MiB for the reference's circuit at t = 2^16),
  * public_params builds a DIGIT TABLE per side for the generators of the small commitments a step waits on
- * (vdf_bases_precompute_digits, 852 KB per generator at the default 10-bit window): at t = 2^16 that is 8.6 GB on the
- * secondary side (all 10,049 generators) + 9.4 GB on the primary side (the ~11 k generators outside the MinRoot rounds)
- * = 18 GB PER PARAMETER SET, spent to take ~0.4 ms of bucket method off every step's critical path.  It is an
+ * (vdf_bases_precompute_digits, 2.9 MB per generator at the 12-bit window this library asks for): at t = 2^16 that is
+ * 29 GB on the secondary side (all 10,049 generators) + 36 GB on the primary side (the ~12.5 k generators outside the
+ * MinRoot rounds and the early rows) = 65 GB PER PARAMETER SET (a quarter of that, 19 GB, with VDF_NOVA_DIGIT_WINDOW=10, for
+ * ~2.5 % of a step), spent to take ~0.4 ms of bucket method off every step's critical path.  It is an
  * accelerator only: results are the same group elements without it.  A table that does not fit the free HBM is skipped
  * silently (vdf_nova_pp_memory reports it; VDF_NOVA_VERBOSE=1 logs it), and the flags below decline it up front:
  *   VDF_PP_NO_DIGIT_TABLES  no digit tables: every commitment takes the bucket method (about +0.5 ms per step at t = 2^16)

@@ -740,7 +740,7 @@ def _digit_edge_scalars(sm, c, n, rng):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("c", [8, 9, 10, 11])
+@pytest.mark.parametrize("c", [8, 9, 10, 11, 12])
 def test_digit_table_msm_equals_the_bucket_method(ctx, cref, curve, c):
     nb = 700
     sm = o.curve_scalar_modulus(curve)

@@ -565,7 +565,11 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     // a digit table (vdf_bases_precompute_digits: a plain sum of gathered multiples, no buckets); the rounds' 2 x 10^5
     // terms, committed ahead of the step, stay with the bucket method.
     {
-      int digit_c = 10;
+      // 12-bit digits: 22 windows instead of the 26 of a 10-bit table -- 15 % fewer additions in every direct sum of a step
+      // (0.90 -> 0.87 ms per step: with the device at its issue limit the additions count, not only the latency) for 4 x
+      // the table: 3.3 MB per generator, 42.8 + 34.2 GB at t = 2^16.  A table that does not fit is skipped (below), a host
+      // declines it with VDF_PP_NO_DIGIT_TABLES, VDF_NOVA_DIGIT_WINDOW=10 gives the round-2 size back.
+      int digit_c = 12;
       if (const char* ov = std::getenv("VDF_NOVA_DIGIT_WINDOW")) {                                   // tuning; 0 = no digit tables
         const int v = atoi(ov);
         if (v == 0 || (v >= 6 && v <= 12)) digit_c = v;                                              // anything else: the default stays
