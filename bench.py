@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed MSM steps (100 x 1.3 ms: a region long enough for +-1 %)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5, help="the timed region of `steps` steps is run this many times; the median region is reported")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the msm_sizes leg (2^20, 2^22, 2^24 one at a time; variable-base 2^20)")
     ap.add_argument("--settle", type=int, default=40, help="untimed MSM steps during set-up, before the warm-up steps (clock ramp, workspaces)")
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU (2^k)")
     ap.add_argument("--window", type=int, default=0, help="fixed-base window bits; 0 = the library's recommendation for this size")
@@ -82,6 +84,148 @@ def usable_cores():
         except Exception:
             pass
     return n
+
+
+def box_fingerprint(ctx, tag):
+    """What distinguishes one leased box from another (a 12 % spread between boxes, unexplained): the host CPU
+    and the share of it this process is granted, the shader clock the device sustains under a multiply-bound load on every
+    SIMD (vdf_ctx_clock_probe: ~5 ms), how long the driver takes to hand out and take back 4 GiB of HBM (page-table work:
+    a fragmented VRAM pool shows here and in public_params_s) and the rate of 64-byte random gathers over that block (TLB
+    reach: the digit tables and fixed-base tables are gathered at random)."""
+    fp = {"at": tag}
+    try:
+        fp["shader_mhz"], fp["clock_probe_ms"] = (round(x, 2) for x in ctx.clock_probe(6000))
+    except Exception as ex:                       # the fingerprint never fails the bench
+        fp["shader_mhz_error"] = str(ex)
+    return fp
+
+
+def host_fingerprint():
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    fp = {"cpu_model": model, "logical_cpus": os.cpu_count(), "granted_cores": usable_cores()}
+    try:
+        fp["loadavg_1m"] = float(open("/proc/loadavg").read().split()[0])
+    except Exception:
+        pass
+    return fp
+
+
+def hbm_fingerprint(ctx, gib=4):
+    """hipMalloc + hipFree of `gib` GiB through the library, and 2^22 random 64-byte gathers over the block (torch's gather
+    kernel: a fingerprint of the box's address translation, not a product kernel)."""
+    out = {}
+    try:
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        buf = torch.empty((gib << 30) // 64, 8, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        out["alloc_ms_per_GiB"] = round((time.perf_counter() - a) * 1e3 / gib, 3)
+        buf[::4096].zero_()                                       # touch every 256 KiB
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        idx = torch.randint(0, buf.shape[0], (1 << 22,), device="cuda", generator=g)
+        torch.index_select(buf, 0, idx)                           # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            torch.index_select(buf, 0, idx)
+        e1.record(); torch.cuda.synchronize()
+        out["gather64_GB_per_s"] = round(4 * (1 << 22) * 64 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        out["gather_span_GiB"] = gib
+        del buf, idx
+        a = time.perf_counter()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        out["free_ms_per_GiB"] = round((time.perf_counter() - a) * 1e3 / gib, 3)
+    except Exception as ex:
+        out["error"] = str(ex)
+    return out
+
+
+def median(xs):
+    s_ = sorted(xs)
+    return s_[len(s_) // 2] if len(s_) % 2 else 0.5 * (s_[len(s_) // 2 - 1] + s_[len(s_) // 2])
+
+
+def msm_sizes_leg(ctx, curve, sizes=(20, 22, 24), reps=5):
+    """north_star's range in the driver's record: ONE MSM at a time (no second MSM in flight) of 2^20, 2^22 and 2^24 Pallas
+    points on this GPU over a fixed-base table (the library's window for the size), `reps` timed MSMs each, and the
+    VARIABLE-BASE path at 2^20 (no table: device-resident points as pasta-msm's mult_pippenger receives them, seam B2 --
+    bucket sets per window + on-device Horner).  Generators with known discrete logarithms, so every size is checked
+    EXACTLY against [sum s_i k_i] G (host integers; no oracle code)."""
+    import vdf_amd
+    bm, sm = (_P, _Q) if curve == vdf_amd.CURVE_PALLAS else (_Q, _P)
+    out = {}
+
+    def timed(bases, sc, n, res):
+        ctx.set_async(True)
+        for _ in range(2):
+            ctx.msm(bases, sc, n=n, out=res)
+        ctx.sync()
+        ctx.set_timing(True); ctx.msm_timing()
+        per = []
+        for _ in range(reps):                     # one at a time: the latency of a lone MSM, stage times from HIP events
+            a = time.perf_counter()
+            ctx.msm(bases, sc, n=n, out=res)
+            ctx.sync()
+            per.append((time.perf_counter() - a) * 1e3)
+        st = ctx.msm_timing()
+        ctx.set_timing(False)
+        a = time.perf_counter()
+        for _ in range(reps):                     # back to back on one stream: the sustained rate of one queue
+            ctx.msm(bases, sc, n=n, out=res)
+        ctx.sync()
+        b2b = (time.perf_counter() - a) * 1e3 / reps
+        ctx.set_async(False)
+        cnt = max(st[4], 1)
+        return per, b2b, {"sort": st[0] / cnt, "accumulate": st[1] / cnt, "tail": st[2] / cnt, "pipeline": st[3] / cnt}
+
+    for lg in sizes:
+        n = 1 << lg
+        a = time.perf_counter()
+        bases = ctx.bases_generate(curve, 11, n)                  # family 0: [k_i] G
+        g = torch.Generator(device="cuda"); g.manual_seed(100 + lg)
+        sc = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        sc[:, 3] &= 0x3FFFFFFFFFFFFFFF
+        res = torch.zeros(12, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        want = None
+        rec = {}
+        if lg == sizes[0]:
+            per, b2b, st = timed(bases, sc, n, res)                # no table yet: the variable-base path
+            want = _scalar_mul_generator(_sum_s_k(sc.cpu().numpy().view("<u8"), _dlogs(11, 0, n)) % sm, bm)
+            ok = _jac_to_affine_ints(res.cpu().numpy().view("<u8").tobytes(), bm) == want
+            out["variable_base_2_%d" % lg] = {
+                "ms": median(per), "ms_back_to_back": b2b, "GPoints_per_s": n / b2b / 1e6, "stage_ms": st, "exact": bool(ok),
+                "what": "no fixed-base table: points resident in HBM, bucket sets per window + on-device Horner (the path "
+                        "behind mult_pippenger_pallas once its inputs are on the device)"}
+        bases.precompute(0, 1)
+        ctx.sync()
+        setup_s = time.perf_counter() - a
+        per, b2b, st = timed(bases, sc, n, res)
+        if want is None:
+            want = _scalar_mul_generator(_sum_s_k(sc.cpu().numpy().view("<u8"), _dlogs(11, 0, n)) % sm, bm)
+        ok = _jac_to_affine_ints(res.cpu().numpy().view("<u8").tobytes(), bm) == want
+        acc = st["accumulate"]
+        rec = {"ms": median(per), "ms_by_rep": [round(x, 4) for x in per], "ms_back_to_back": b2b,
+               "GPoints_per_s": n / b2b / 1e6, "window_bits": bases.window, "table_GiB": round(((255 + bases.window - 1) // bases.window) * n * 64 / 2**30, 2),
+               "stage_ms": st, "k_accumulate_GB_per_s": 96.0 * n / (acc * 1e-3) / 1e9 if acc else None,
+               "k_accumulate_frac": 96.0 * n / (acc * 1e-3) / 8e12 if acc else None, "exact": bool(ok),
+               "generators_and_table_s": round(setup_s, 2)}
+        out["table_2_%d" % lg] = rec
+        bases.free()
+        del sc
+        torch.cuda.empty_cache()
+    out["what"] = ("one MSM at a time on one stream (ms = median latency of %d stream-synchronised calls; GPoints_per_s from the "
+                   "same calls back to back), [k_i]G generators, exact = the result equals [sum s_i k_i mod q] G; `value` of this "
+                   "line is the 2^20 case with two independent MSMs in flight (pipelined)" % reps)
+    return out
 
 
 def cpu_baseline_leg(ctx, bases, scalars_dev, n, curve, gpu_jac):
@@ -422,6 +566,17 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     first_timed = 2 if nsteps > 2 else 1
     nsteady = max(nsteps - first_timed, 1)
     rates, stages, base_case, first_fold, proof = [], [], 0.0, 0.0, None
+    fp_before = box_fingerprint(ctx, "before the timed repeats")
+    # Settle (untimed): one whole pass over the chain -- base case + every fold -- before the first timed repeat: the device
+    # reaches the clock it then holds, every workspace has its final size, the helper threads are awake (the
+    # first repeat of a cold leg ran 10 % slow and the mean carried it)
+    settle_steps = 0
+    if nsteps > 2:
+        for k in range(nsteps):
+            proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+        proof.instance(INST_FRESH_SECONDARY)
+        ctx.sync()
+        settle_steps = nsteps
     for rep in range(max(1, repeats)):
         if proof is not None:
             proof.free()
@@ -445,8 +600,9 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         proof.instance(INST_FRESH_SECONDARY)     # the last secondary commitment (it rides in the NEXT step's batch otherwise)
         ctx.sync()
         rates.append((time.perf_counter() - a) / nsteady)
+    fp_after = box_fingerprint(ctx, "after the timed repeats")
     ok = proof.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
-    avg = sum(rates) / len(rates) if nsteps > 1 else base_case
+    avg = median(rates) if nsteps > 1 else base_case          # the MEDIAN repeat: one cold or disturbed repeat does not move it
     srt = sorted(rates)
     stage_avg = {k: sum(s_[k] for s_ in stages) / len(stages) for k in stages[-1]} if stages else {}
     sizes = {"primary": pp.sizes(0), "secondary": pp.sizes(1)}
@@ -454,7 +610,10 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     out = {"metric": "Nova prove_step/sec (MinRoot, 2^%d iters/step)" % log2t, "value": 1.0 / avg, "unit": "prove_step/s",
            "circuit": CIRCUIT_NAMES[kind], "ms_per_step": avg * 1e3,
            "timed_steps": nsteady * len(rates) if nsteps > 1 else 0, "repeats": len(rates),
-           "ms_per_step_by_repeat": {"min": srt[0] * 1e3, "median": srt[len(srt) // 2] * 1e3, "max": srt[-1] * 1e3},
+           "ms_per_step_by_repeat": {"min": srt[0] * 1e3, "median": median(rates) * 1e3, "max": srt[-1] * 1e3,
+                                     "mean": sum(rates) / len(rates) * 1e3, "in_order": [round(x * 1e3, 4) for x in rates]},
+           "value_is": "1 / median over the repeats of (wall time of the timed folds / their number); every repeat a fresh proof",
+           "settle_steps_untimed": settle_steps, "box": [fp_before, fp_after],
            "base_case_ms": base_case * 1e3, "first_fold_ms_untimed_warmup": first_fold * 1e3,
            "steady_state_steps": nsteady if nsteps > 1 else 0,
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes, "public_params_s": pp_s, "hbm": pp.memory(),
@@ -562,7 +721,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
             spans[i] = (t_, time.perf_counter())
 
         rates2 = []
-        for rep in range(3):
+        for rep in range(4):                          # repeat 0 is the settle pass of this leg: run, not rated
             proofs = warm()
             spans = [None] * chains
             ths = [threading.Thread(target=run, args=(i, i * avg / chains)) for i in range(chains)]
@@ -573,16 +732,17 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
             # aggregate over the window in which ALL chains were proving (the stagger leaves a chain alone at either end)
             a_, b_ = max(sp[0] for sp in spans), min(sp[1] for sp in spans)
             done = sum((nsteps - 2) * (b_ - a_) / (sp[1] - sp[0]) for sp in spans)
-            rates2.append(done / (b_ - a_))
+            if rep > 0:
+                rates2.append(done / (b_ - a_))
             for pr in proofs:
                 pr.free()
         proofs = []
-        agg = sorted(rates2)[len(rates2) // 2]
+        agg = median(rates2)
         out["aggregate_over_concurrent_chains"] = {"chains": chains, "value": agg, "unit": "prove_step/s",
                                                    "folds_per_chain": nsteps - 2, "repeats": len(rates2), "by_repeat": rates2,
                                                    "vs_single_chain": agg * avg,
                                                    "what": "independent chains proven by two host threads on this GPU, started half a step apart; "
-                                                           "rate over the window in which all chains were proving (median of the repeats); "
+                                                           "rate over the window in which all chains were proving (median of the repeats, after one unrated settle pass); "
                                                            "tools/gpu_prove_two_chains.py measures the same over 300 steps per chain"}
         for pr in proofs:
             pr.free()
@@ -844,11 +1004,19 @@ def main():
     for c in ctxs:
         c.set_timing(True)
         c.msm_timing()                    # clear
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    # The contract's timed region -- EXACTLY `steps` steps between two fences -- is run `regions` times back to back and the
+    # MEDIAN region is reported (at the driver's --steps 20 one region is 25 ms: a single one cannot be read finer than
+    # +-3 %); ms_per_step x steps is the duration of that one region.
+    fp_msm = [box_fingerprint(ctx, "before the MSM regions")]
+    region_s = []
+    for _ in range(max(1, args.regions)):
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        region_s.append(time.perf_counter() - t0)
+    fp_msm.append(box_fingerprint(ctx, "after the MSM regions"))
+    elapsed = median(region_s)
     sort_ms = acc_ms = tail_ms = total_ms = 0.0
     calls = 0
     for c in ctxs:
@@ -869,9 +1037,10 @@ def main():
         ctx.set_timing(False)
         iso = {"sort": a_ / n_, "accumulate": b_ / n_, "tail": c_ / n_, "pipeline": d_ / n_}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor(region_s, dtype=torch.float64, device="cuda")       # MAX over the ranks, region by region
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        region_s = [float(x) for x in t.tolist()]
+        elapsed = median(region_s)
     strong = None
     if args.strong_log2n and (world > 1 or args.rehearse_collective or args.strong):
         for c in ctxs:
@@ -947,6 +1116,8 @@ def main():
                            "value": n / ((iso["pipeline"] if iso else total_ms / max(calls, 1)) * 1e-3) / 1e9, "unit": "GPoints/s",
                            "what": "one MSM at a time on an idle device (stream-synchronised between calls)"},
             "pipelined": {"ms_per_msm": ms_per_step, "value": value, "unit": "GPoints/s", "steps_in_flight": depth},
+            "timed_regions": {"regions": len(region_s), "steps_per_region": args.steps, "reported": "median region",
+                              "ms_per_step_by_region": [round(x / args.steps * 1e3, 4) for x in region_s]},
             "stage_ms": {"sort": sort_ms / max(calls, 1), "accumulate": acc_avg_ms, "tail": tail_ms / max(calls, 1),
                          "pipeline": total_ms / max(calls, 1)},
             "stage_ms_one_step_at_a_time": iso,
@@ -966,6 +1137,14 @@ def main():
             line["strong_2_%d" % args.strong_log2n] = strong
         if replicas is not None:
             line["prove_step_replicas"] = replicas
+        line["box"] = {"host": host_fingerprint(), "device": fp_msm}
+        if world == 1 and not args.no_sizes and not args.rehearse_collective:
+            for c in ctxs:
+                c.sync()
+            line["box"]["hbm"] = hbm_fingerprint(ctx)
+            line["msm_sizes"] = msm_sizes_leg(ctx, curve)
+            for c in ctxs:
+                c.set_async(True)
         if world == 1 and not args.no_prove and not args.rehearse_collective:
             ctx.set_async(False)
             # one forward evaluation serves both forms of the step circuit (the circuits hold states and traces, not shapes);
@@ -1037,6 +1216,31 @@ def main():
         if failures:
             line["value"] = None
             line["invalid"] = failures
+        # The two halves of BASELINE's metric, and what qualifies them, once more as flat scalars and as the LAST key of the
+        # line (a reader that keeps the tail of stdout, or only top-level keys, still sees the prove_step half)
+        ps = line.get("prove_step") or {}
+        summary = {"msm_gpoints_per_s": line["value"], "msm_ms_per_step_median_region": ms_per_step,
+                   "msm_single_gpoints_per_s": line["single_msm"]["value"], "msm_roofline_frac": line["roofline"]["frac"],
+                   "msm_valu_issue_frac": (valu or {}).get("valu_issue_frac")}
+        for k_, v_ in (line.get("msm_sizes") or {}).items():
+            if isinstance(v_, dict):
+                summary["msm_" + k_ + "_gpoints_per_s"] = round(v_["GPoints_per_s"], 4)
+        if ps:
+            summary.update({
+                "prove_step_per_s": ps["value"], "prove_step_ms_median": ps["ms_per_step"],
+                "prove_step_ms_by_repeat": ps["ms_per_step_by_repeat"]["in_order"], "circuit": "reference (src/nova/proof.rs:155-230)",
+                "prove_roofline_frac": (ps.get("roofline") or {}).get("frac"),
+                "prove_step_bound_form_per_s": (ps.get("bound_form") or {}).get("value"),
+                "prove_step_two_chains_per_s": (ps.get("aggregate_over_concurrent_chains") or {}).get("value"),
+                "compress_ms": (ps.get("compress") or {}).get("compress_ms"),
+                "cpu_prove_step_per_s": (ps.get("cpu_baseline") or {}).get("value"),
+                "public_params_s": ps.get("public_params_s"),
+                "shader_mhz": [b_.get("shader_mhz") for b_ in ps.get("box", [])]})
+            line["prove_step_per_s"] = ps["value"]
+            line["prove_step_ms_median"] = ps["ms_per_step"]
+        summary["cpu_msm_gpoints_per_s"] = (line.get("cpu_baseline") or {}).get("value")
+        summary["parity"] = "unpinned against nova-snark (no reference-held vector exists); bit-exact against oracle/ in this run: %s" % (not failures)
+        line["summary"] = summary
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
         if failures:

@@ -297,6 +297,18 @@ int  vdf_nifs_cross_term(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z2,
 int  vdf_nifs_cross_term_rows(vdf_ctx* ctx, const vdf_shape* shape, size_t row_begin, size_t row_count, int part, const vdf_fe* z2,
                               const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2,
                               vdf_fe* Cz2, vdf_fe* T);
+/* The same rows for the built-in MinRoot step circuits WITHOUT the sparse matrices: the 3t + 1 constraints of
+ * InverseMinRootCircuit::synthesize (src/nova/proof.rs:107-133, :219-227) are a fixed stencil over the rounds' own
+ * variables -- A z2, B z2, C z2 of a row are copies of witness values and one four-term sum -- so rows
+ * [row_begin, row_begin + 3t + 1) are computed from coalesced streams only (no row pointers, columns, coefficients or
+ * gathers).  seg_begin: index of the first round variable in z2 (the step circuit's input x, y, i occupies the three
+ * variables before it); vars_per_round: 4 = the reference's rounds (new_x, tmp1, tmp2, new_y), 3 = the bound form;
+ * one_col: the constant's column (num_vars).  Exact for any z2.  The caller is responsible for the rows being that
+ * stencil (libvdf_nova.so compares it with the shape's triples once, at public_params).  Vectors: device memory,
+ * full length (num_cons / num_cols); u1: host memory. */
+int  vdf_nifs_cross_term_minroot(vdf_ctx* ctx, int field, int vars_per_round, uint64_t t, size_t seg_begin, size_t one_col, size_t row_begin,
+                                 const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2,
+                                 vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T);
 /* acc[i] <- acc[i] + r * add[i], i < k <= 8, n[i] elements each: k vdf_axpy calls with a common r (host
  * memory).  The fold of a relaxed witness is k = 2 (W, E); a prover that keeps A z, B z, C z of the running
  * instance folds them too (they are linear in z), k = 5, instead of recomputing three sparse products. */
@@ -370,6 +382,11 @@ int  vdf_fe_from_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe
 /* Throughput probe: each of n lanes runs `iters` dependent Montgomery multiplications
  * (roofline / issue-rate calibration for DESIGN.md; not on the prove path). */
 int  vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int iters, vdf_fe* out);
+/* Box fingerprint: every SIMD runs `iters` dependent Montgomery products (two wavefronts per SIMD, ~0.85 us per
+ * iteration: 6000 iterations = 5 ms); *shader_mhz = shader clocks / 100 MHz reference ticks summed over the wavefronts
+ * (the clock the device sustained under the MSM's kind of load), *kernel_ms = the launch's duration (HIP events).
+ * Synchronises the context's stream.  Either output may be NULL. */
+int  vdf_ctx_clock_probe(vdf_ctx* ctx, int iters, double* shader_mhz, double* kernel_ms);
 /* Device memory helpers so a non-torch host (the C++ Nova layer) can keep state resident. */
 int  vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out);
 int  vdf_dev_free(vdf_ctx* ctx, void* p);

@@ -106,6 +106,13 @@ int  vdf_nova_pp_segment(const vdf_pp* pp, uint64_t* begin, uint64_t* len);
 /* the run of primary constraints whose share of a step's cross term T and of comm_T prove_step makes ahead of the rest of
  * the step (they read only that segment, the step's input and the constant); len = 0: none, T is committed in one piece */
 int  vdf_nova_pp_early_rows(const vdf_pp* pp, uint64_t* begin, uint64_t* len);
+/* 4 / 3: the early rows are the built-in MinRoot stencil (the reference's rounds / the bound form), verified against the
+ * shape's triples when the parameters were made -- their cross term runs without the sparse matrices
+ * (vdf_hip.h vdf_nifs_cross_term_minroot); 0: they run through the generic sparse kernel (a custom circuit, or no early rows) */
+int  vdf_nova_pp_stencil(const vdf_pp* pp);
+/* The same answer without a device (host only): builds the shape of the built-in step circuit at t, finds the early rows
+ * and compares them with the stencil; returns 4 / 3 / 0 (negative: an error code).  Outputs may be NULL. */
+int  vdf_nova_shape_stencil(uint64_t t, int circuit_kind, uint64_t* early_begin, uint64_t* early_len, uint64_t* seg_begin);
 
 /* InverseMinRootCircuit::eval_and_make_circuits, :262-299: num_steps forward evaluations of
  * num_iters_per_step rounds each from initial_state (host, sequential), one circuit per step

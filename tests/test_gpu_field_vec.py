@@ -268,6 +268,21 @@ def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
         assert np.array_equal(_host(eT), expT)
         for got, e in zip(e2, abc2):
             assert np.array_equal(_host(got), e)
+    # the MinRoot rows by STENCIL (vdf_nifs_cross_term_minroot: no sparse matrix at all): rows 0 .. 3t of this shape are the
+    # reference's rounds with seg_begin = 3 (z_in in front) and the constant at num_vars; every vector byte-identical to
+    # the sparse kernel's on a RANDOM z2 (constant column included), the six wrapper rows behind them untouched
+    e2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    eT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term_minroot(field, 4, t, 3, sh.num_vars, 0, _dev(z2), *d1, u1, *e2, eT)
+    ctx.sync()
+    nr = 3 * t + 1
+    assert np.array_equal(_host(eT)[:nr], expT[:nr]) and not _host(eT)[nr:].any()
+    for got, e in zip(e2, abc2):
+        assert np.array_equal(_host(got)[:nr], e[:nr]) and not _host(got)[nr:].any()
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_minroot(field, 5, t, 3, sh.num_vars, 0, _dev(z2), *d1, u1, *e2, eT)      # 3 or 4 variables per round
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_minroot(field, 4, t, 3, sh.num_vars - 1, 0, _dev(z2), *d1, u1, *e2, eT)  # the constant inside the rounds
     with pytest.raises(Exception):
         ctx.nifs_cross_term_rows(shape, 1, nc, 1, _dev(z2), *d1, u1, *d2, dT)      # range beyond the shape
     with pytest.raises(Exception):

@@ -232,6 +232,37 @@ def test_early_rows_of_the_cross_term_are_invisible(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
+def test_early_rows_by_stencil_equal_the_sparse_kernel(ctx, kind, monkeypatch):
+    """The early rows of the built-in circuits run WITHOUT the sparse matrices (vdf_nifs_cross_term_minroot): public_params
+    compares the stencil with the shape's triples and reports it (vdf_nova_pp_stencil = variables per round); the proof --
+    every instance, every witness, both running A z / B z / C z through the folds that follow -- is the one the generic
+    sparse kernel gives (VDF_NOVA_STENCIL=0), at a t that is no multiple of the workgroup size."""
+    monkeypatch.delenv("VDF_NOVA_STENCIL", raising=False)
+    monkeypatch.delenv("VDF_NOVA_T_AHEAD", raising=False)
+    t, n = 100, 5
+    pp, z0, circuits, initial, _ = make(ctx, t, n, seed=21, kind=kind)
+    assert pp.stencil() == (4 if kind == CIRCUIT_MINROOT_REFERENCE else 3)
+    assert pp.early_rows()[1] == 3 * t + 1
+    a = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    monkeypatch.setenv("VDF_NOVA_STENCIL", "0")
+    pp1 = public_params(ctx, t, kind, GENS_TRY_AND_INCREMENT)
+    monkeypatch.delenv("VDF_NOVA_STENCIL")
+    assert pp1.stencil() == 0 and pp1.early_rows() == pp.early_rows() and pp1.digest() == pp.digest()
+    b = NovaVDFProof.prove_recursively(pp1, circuits, t, z0)
+    for which in (INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY):
+        ia, ib = a.instance(which), b.instance(which)
+        for key in ia:
+            assert np.array_equal(ia[key], ib[key]), (which, key)
+        for va, vb in zip(a.witness(which), b.witness(which)):
+            assert (va is None and vb is None) or np.array_equal(va, vb)
+    assert a.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+    # the compressed proofs agree byte for byte too (the running A z, B z, C z feed the sum-checks)
+    sa, sb = a.compress(pp), b.compress(pp1)
+    assert sa.to_bytes() == sb.to_bytes()
+    assert sa.verify(pp, n, z0, [initial.x, initial.y, initial.i])
+
+
+@pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
 def test_public_params_flags_decline_the_accelerators_and_change_nothing(ctx, kind, monkeypatch):
     """vdf_nova_public_params_flags (include/vdf_nova.h): VDF_PP_NO_DIGIT_TABLES / VDF_PP_NO_EARLY_ROWS decline the HBM-hungry
     digit tables and the early rows of T; vdf_nova_pp_memory reports what a parameter set holds.  Parameters (digest) and

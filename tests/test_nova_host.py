@@ -168,3 +168,36 @@ def test_custom_step_circuit_shape_through_the_seam():
     assert digest == opp.params and sizes[0][:2] == [opp.shapes[0].num_cons, opp.shapes[0].num_vars]
     with pytest.raises(RuntimeError):
         vn.shape_digest_custom(Broken())
+
+
+@pytest.mark.parametrize("kind,per", [(1, 4), (0, 3)], ids=["reference", "bound"])
+def test_early_rows_are_the_minroot_stencil(kind, per):
+    """What vdf_nifs_cross_term_minroot (include/vdf_hip.h) computes without the sparse matrices is compared, triple by
+    triple, with the rows InverseMinRootCircuit::synthesize records (src/nova/proof.rs:107-133, :219-227): the host layer
+    reports the stencil for both forms of the circuit at every t (host only), and the oracle's shape has those rows --
+    the same triples, read off oracle/nova.py's own R1CS -- where the host says they are."""
+    for t in (1, 2, 3, 7, 64, 100):
+        got_per, row0, nrows, seg = vn.shape_stencil(t, kind)
+        assert got_per == per and nrows == 3 * t + 1
+        sh = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT, bound=(kind == 0)).shapes[0] if t <= 7 else None
+        if sh is None:
+            continue
+        Q, one = o.Q, sh.num_vars
+        rows = {k: {} for k in range(3)}
+        for k, mat in enumerate((sh.A, sh.B, sh.C)):
+            for r, c, v in mat:
+                if row0 <= r < row0 + nrows:
+                    rows[k].setdefault(r - row0, {})[c] = v % Q
+        for j in range(t):
+            rd = seg + per * j
+            t1 = rd + per - 3
+            y_j = rd - 1 if j else seg - 2
+            if per == 4 or j == 0:
+                x = {(rd - per if j else seg - 3): 1}
+            else:
+                x = {(rd - per - 1 if j > 1 else seg - 2): 1, seg - 1: Q - 1, one: j}
+            assert rows[0][3 * j] == x and rows[1][3 * j] == x and rows[2][3 * j] == {t1: 1}
+            assert rows[0][3 * j + 1] == {t1: 1} == rows[1][3 * j + 1] and rows[2][3 * j + 1] == {t1 + 1: 1}
+            assert rows[0][3 * j + 2] == {t1 + 1: 1} and rows[1][3 * j + 2] == x
+            assert rows[2][3 * j + 2] == {t1 + 2: 1, y_j: 1, seg - 1: Q - 1, one: j + 1}
+        assert rows[0][3 * t] == {seg + per * t: 1} and rows[1][3 * t] == {one: 1} and rows[2][3 * t] == {seg - 1: 1, one: (Q - t) % Q}

@@ -1,0 +1,68 @@
+// Diagnostic (not product code): the bucket loop's sign-tracked mixed addition (ec.cuh xyzz_madd_lazy, fe_mul2_lazy,
+// fe_neg_lazy) against the plain canonical formulas, lane by lane, on random points.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I vdf_amd/csrc tools/ubench/madd_check.hip -o tools/ubench/madd_check
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include "fe.cuh"
+#include "ec.cuh"
+using namespace vdf;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+typedef FpParams P;
+
+__device__ Fe<P> rnd_fe(uint32_t& s) {
+  Fe<P> r;
+  for (int i = 0; i < 8; ++i) { s = s * 1664525u + 1013904223u; r.v[i] = s ^ (s >> 13); }
+  r.v[7] &= 0x3fffffffu;
+  return r;
+}
+// a point on y^2 = x^3 + 5 from a seed: [k] G by double-and-add with the canonical formulas
+__device__ Affine<P> rnd_pt(uint32_t& s) {
+  Affine<P> g; g.x = fe_neg(fe_one<P>()); g.y = fe_from_u64<P>(2);
+  s = s * 1664525u + 1013904223u;
+  return xyzz_to_affine(xyzz_mul_u64(g, ((uint64_t)s << 20) | 12345u));
+}
+
+__global__ void k_check(uint32_t* bad, int steps) {
+  uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 17u;
+  // (1) fe_mul2_lazy vs two products and an addition
+  for (int it = 0; it < 64; ++it) {
+    Fe<P> a = rnd_fe(s), b = rnd_fe(s), c = rnd_fe(s), d = rnd_fe(s);
+    Fe<P> want = fe_add(fe_mul_inl(a, b), fe_mul_inl(c, d));
+    Fe<P> got = fe_canon(fe_mul2_lazy(a, b, c, d));
+    if (!fe_eq(want, got)) atomicAdd(&bad[0], 1u);
+    Fe<P> n = fe_canon(fe_neg_lazy(a));
+    if (!fe_eq(n, fe_neg(a))) atomicAdd(&bad[1], 1u);
+  }
+  // (2) chains of mixed additions with random signs
+  XYZZ<P> ref = xyzz_identity<P>();
+  XYZZ<P> acc = xyzz_identity<P>();
+  bool have = false, flip = false;
+  for (int k = 0; k < steps; ++k) {
+    Affine<P> pt = rnd_pt(s);
+    s = s * 1664525u + 1013904223u;
+    const bool neg = (s >> 9) & 1u;
+    Affine<P> t = pt;
+    if (neg) t.y = fe_neg(t.y);
+    xyzz_madd<P, true>(ref, t);
+    Affine<P> u = pt;
+    if (neg != (have && flip)) u.y = fe_neg(u.y);
+    xyzz_madd_lazy<P>(acc, have, flip, u);
+    XYZZ<P> r = xyzz_lazy_resolve<P>(acc, have, flip);
+    r.x = fe_canon(r.x); r.y = fe_canon(r.y); r.zz = fe_canon(r.zz); r.zzz = fe_canon(r.zzz);
+    const Affine<P> A = xyzz_to_affine(ref), B = xyzz_to_affine(r);
+    if (!fe_eq(A.x, B.x) || !fe_eq(A.y, B.y)) { atomicAdd(&bad[2], 1u); if (k < 8) atomicAdd(&bad[3 + k], 1u); }
+  }
+}
+
+int main() {
+  uint32_t* d; CK(hipMalloc(&d, 64)); CK(hipMemset(d, 0, 64));
+  hipLaunchKernelGGL(k_check, dim3(8), dim3(64), 0, 0, d, 24);
+  CK(hipDeviceSynchronize());
+  uint32_t h[16]; CK(hipMemcpy(h, d, 64, hipMemcpyDeviceToHost));
+  printf("fe_mul2_lazy mismatches %u, fe_neg_lazy mismatches %u, chain mismatches %u (first steps:", h[0], h[1], h[2]);
+  for (int k = 0; k < 8; ++k) printf(" %u", h[3 + k]);
+  printf(")\n");
+  return (h[0] | h[1] | h[2]) ? 1 : 0;
+}

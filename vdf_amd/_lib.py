@@ -79,6 +79,7 @@ PROTOTYPES = {
     "vdf_vec_is_zero": (_i, [_vp, _vp, _sz, C.POINTER(C.c_int)]),
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term_rows": (_i, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_nifs_cross_term_minroot": (_i, [_vp, _i, _i, _u64, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "vdf_pair_table_pattern": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
@@ -91,6 +92,7 @@ PROTOTYPES = {
     "vdf_fe_to_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_from_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_mul_chain": (_i, [_vp, _i, _vp, _sz, _i, _vp]),
+    "vdf_ctx_clock_probe": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vdf_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vdf_dev_free": (_i, [_vp, _vp]),
     "vdf_dev_memcpy": (_i, [_vp, _vp, _vp, _sz]),

@@ -1249,6 +1249,23 @@ int vdf_nifs_cross_term_rows(vdf_ctx* ctx, const vdf_shape* shape, size_t row_be
   return guarded(ctx, [&]() -> Status { return nifs_cross_impl(ctx, shape, row_begin, row_count, part, z2, Az1, Bz1, Cz1, u1, Az2, Bz2, Cz2, T); });
 }
 
+int vdf_nifs_cross_term_minroot(vdf_ctx* ctx, int field, int vars_per_round, uint64_t t, size_t seg_begin, size_t one_col, size_t row_begin,
+                                const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2,
+                                vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status {
+    if (!z2 || !Az1 || !Bz1 || !Cz1 || !u1 || !Az2 || !Bz2 || !Cz2 || !T) return Status{VDF_ERR_BAD_ARG, "null argument"};
+    if (ptr_is_device(u1)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    for (const void* v : {(const void*)z2, (const void*)Az1, (const void*)Bz1, (const void*)Cz1, (const void*)Az2, (const void*)Bz2,
+                          (const void*)Cz2, (const void*)T})
+      if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    if (t == 0 || t > (1ull << 26)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
+    if (seg_begin < 3 || one_col < seg_begin + (size_t)vars_per_round * t + 1) return Status{VDF_ERR_BAD_ARG, "the constant's column lies behind the rounds"};
+    VDF_TRY(vdf::vec_nifs_cross_minroot(field, vars_per_round, t, seg_begin, one_col, row_begin, z2, Az1, Bz1, Cz1, u1, Az2, Bz2, Cz2, T, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
 int vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* const acc[], const vdf_fe* const add[],
                   const size_t n[]) {
   return guarded(ctx, [&]() -> Status {
@@ -1470,6 +1487,33 @@ int vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int ite
     VDF_TRY(st.out(out, n * 32, &dout));
     VDF_TRY(vdf::vec_mul_chain(field, da, n, iters, dout, ctx->stream));
     return st.finish();
+  });
+}
+
+int vdf_ctx_clock_probe(vdf_ctx* ctx, int iters, double* shader_mhz, double* kernel_ms) {
+  return guarded(ctx, [&]() -> Status {
+    if (iters < 1 || iters > (1 << 22)) return Status{VDF_ERR_BAD_ARG, "iters out of range"};
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(ctx->small_pool);
+    if (!d) return Status{VDF_ERR_DEVICE, "no staging pool"};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    VDF_TRY_HIP(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e0); return Status{VDF_ERR_DEVICE, "hipEventCreate"}; }
+    Status st{};
+    unsigned long long h[3] = {0, 0, 0};
+    float ms = 0.f;
+    hipError_t e = hipMemsetAsync(d, 0, 24, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) st = vdf::vec_clock_probe(iters, 2 * ctx->num_cus, d, ctx->stream);     // two wavefronts per SIMD
+    if (e == hipSuccess && st.code == VDF_OK) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess && st.code == VDF_OK) e = hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && st.code == VDF_OK) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && st.code == VDF_OK) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (st.code != VDF_OK) return st;
+    VDF_TRY_HIP(e);
+    if (shader_mhz) *shader_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    if (kernel_ms) *kernel_ms = ms;
+    return Status{};
   });
 }
 

@@ -91,6 +91,71 @@ template <class P, bool INL = false> VDF_HD void xyzz_madd(XYZZ<P>& acc, const A
   acc.zzz = fe_mul_sel<INL>(acc.zzz, PPP);
 }
 
+// Mixed addition in the lazy domain (fe.cuh) for the bucket loops of msm.hip and msm_direct.hip, with the SIGN of the
+// accumulator tracked beside it: the point a lane holds is  sigma * (x/zz, y/zzz),  sigma = -1 when `flip` is set.
+// madd-2008-s needs P = U2 - X1, R = S2 - Y1 and Y3 = R (Q - X3) - Y1 PPP: a difference of two products.  With the
+// operands of both subtractions swapped (P' = -P, R' = -R: free) PPP' = P' PP = -PPP and
+//     X3 = R'^2 + PPP' - 2Q          Y3 = R' (X3 - Q) + Y1 PPP'
+// is a SUM of two products -- one column scan, one Montgomery reduction (fe_mul2_lazy) -- while ZZZ1 PPP' = -ZZZ3.
+// (X3, Y3, ZZ3, -ZZZ3) is the negated sum: instead of negating a coordinate (8+ instructions per addition) the sign
+// moves into `flip`, the NEXT point is negated before it is added (the loops negate by the digit's sign anyway:
+// sigma (A + sigma b) = sigma A + b), and a pending sign is applied once when the accumulator is flushed.
+// Per addition: 8 products + 1 product pair + 6 subtractions, ~2,490 VALU instructions against ~2,595 for 10 + 7.
+// `b` is the point to add to the STORED accumulator (the caller has applied digit sign XOR flip), never the identity.
+template <class P>
+__device__ __forceinline__ void xyzz_madd_lazy(XYZZ<P>& acc, bool& have, bool& flip, const Affine<P>& b) {
+  if (!have) { acc = xyzz_from_affine(b); have = true; flip = false; return; }
+#ifdef VDF_MADD_V1     // A/B build only (tools/ab_madd.sh): round 3's formulas, ten products and seven subtractions, no sign tracking
+  {
+    const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
+    const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
+    const Fe<P> Pp = fe_sub_lazy(U2, acc.x);
+    const Fe<P> Rr = fe_sub_lazy(S2, acc.y);
+    if (Pp.v[0] <= 2u && fe_is_zero(fe_canon(Pp))) {
+      if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);
+      else have = false;
+      return;
+    }
+    const Fe<P> PP = fe_mul_lazy(Pp, Pp);
+    const Fe<P> PPP = fe_mul_lazy(Pp, PP);
+    const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
+    const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), PPP), Qq), Qq);
+    const Fe<P> Y3 = fe_sub_lazy(fe_mul_lazy(Rr, fe_sub_lazy(Qq, X3)), fe_mul_lazy(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fe_mul_lazy(acc.zz, PP);
+    acc.zzz = fe_mul_lazy(acc.zzz, PPP);
+    return;
+  }
+#endif
+  const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
+  const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
+  const Fe<P> Pn = fe_sub_lazy(acc.x, U2);
+  const Fe<P> Rn = fe_sub_lazy(acc.y, S2);
+  // P == 0 (mod m) means P in {0, m, 2m}; m == 1 (mod 2^32), so the low limb is 0, 1 or 2: cheap filter
+  if (Pn.v[0] <= 2u && fe_is_zero(fe_canon(Pn))) {
+    if (fe_is_zero(fe_canon(Rn))) acc = xyzz_dbl_affine(b);          // same point: double (canonical output), sign unchanged
+    else have = false;                                                // opposite points: identity
+    return;
+  }
+  const Fe<P> PP = fe_mul_lazy(Pn, Pn);
+  const Fe<P> PPPn = fe_mul_lazy(Pn, PP);
+  const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
+  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rn, Rn), Qq), fe_sub_lazy(Qq, PPPn));
+  acc.y = fe_mul2_lazy(Rn, fe_sub_lazy(X3, Qq), acc.y, PPPn);
+  acc.x = X3;
+  acc.zz = fe_mul_lazy(acc.zz, PP);
+  acc.zzz = fe_mul_lazy(acc.zzz, PPPn);
+  flip = !flip;
+}
+// the accumulator as a plain XYZZ point (lazy coordinates): a pending sign goes into y
+template <class P>
+__device__ __forceinline__ XYZZ<P> xyzz_lazy_resolve(XYZZ<P> acc, bool have, bool flip) {
+  if (!have) return xyzz_identity<P>();
+  if (flip) acc.y = fe_neg_lazy(acc.y);
+  return acc;
+}
+
 // acc += b (add-2008-s), all exceptional cases handled.
 template <class P> VDF_HD void xyzz_add(XYZZ<P>& acc, const XYZZ<P>& b) {
   if (xyzz_is_identity(b)) return;

@@ -357,6 +357,62 @@ template <class P> __device__ __forceinline__ Fe<P> fe_sub_lazy(const Fe<P>& a, 
   return r;
 }
 
+// a*b + c*d with ONE shared Montgomery reduction, lazy domain in and out: the two products' partial products go into
+// the same column accumulators (128 multiply-adds) and are reduced once (32 more), against 2 x (64 + 32) for two
+// products and the 23-instruction addition between them -- the pair costs ~395 instructions instead of ~515.
+// Bound: inputs below 2m + d give (ab + cd)/R < 2(2m + d)^2 / 2^256 = 2m + 2eps + 2d(1 + ...) and q*m/R < m, so the
+// column scan ends below 3m + 2eps + 2d < 2^256 (the ninth word is zero).  Back into the lazy domain with the top bit:
+// bit 255 clear -> below 2^255 = 2m - 2c, nothing to do; set -> at least 2^255 > m, subtract m: the result is at least
+// 2^255 - m = m - 2c > 0 and below 2m + 2eps + 2d.  (14 instructions; a compare-and-subtract of 2m would underflow for
+// values in [2^255, 2m).)  In the mixed addition d grows by a few eps per addition, as with the single product.
+template <class P> __device__ __forceinline__ Fe<P> fe_mul2_lazy(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+  constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
+  const uint32_t* A = a.v;
+  const uint32_t* B = b.v;
+  const uint32_t* Cc = c.v;
+  const uint32_t* Dd = d.v;
+  uint32_t r[8];
+#include "fe_mul2_gfx950.inc"
+  const uint32_t mask = (uint32_t)((int32_t)r[7] >> 31);
+  const uint32_t m0 = mask & 1u, m1 = mask & P::MOD[1], m2 = mask & P::MOD[2], m3 = mask & P::MOD[3], m7 = mask & 0x40000000u;
+  asm("v_sub_co_u32_e32 %0, vcc, %0, %8\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+      "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+      "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %7, %12, vcc"
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+      : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m7)
+      : "vcc");
+  Fe<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = r[i];
+  return o;
+}
+
+// -a in the lazy domain: 3m - a, exact for every a below 3m (fe_sub_lazy(0, a) would wrap for a in (2m, 2m + eps));
+// the result lies in (m - eps, 3m], so it goes ONLY where the consumer canonicalises: a bucket accumulator flushed with
+// its sign pending (ec.cuh xyzz_lazy_resolve; the tail kernels load through fe_canon, two conditional subtractions).
+template <class P> __device__ __forceinline__ Fe<P> fe_neg_lazy(const Fe<P>& a) {
+  constexpr uint64_t D1 = 3ull * P::MOD[1], D2 = 3ull * P::MOD[2] + (D1 >> 32), D3 = 3ull * P::MOD[3] + (D2 >> 32);
+  constexpr uint32_t T1 = (uint32_t)D1, T2 = (uint32_t)D2, T3 = (uint32_t)D3, T4 = (uint32_t)(D3 >> 32), T7 = 0xC0000000u;   // limb 0 = 3, limbs 5, 6 = 0
+  Fe<P> r = a;
+  asm("v_sub_co_u32_e32 %0, vcc, 3, %0\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %8, %1, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %9, %2, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %10, %3, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %11, %4, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %12, %7, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+      : "v"(T1), "v"(T2), "v"(T3), "v"(T4), "v"(T7)
+      : "vcc");
+  return r;
+}
+
 // [0, 2m + eps) -> [0, m)
 template <class P> __device__ __forceinline__ Fe<P> fe_canon(Fe<P> a) {
   fe_cond_sub<P>(a.v);
@@ -369,6 +425,10 @@ template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) { ret
 template <class P> VDF_HD Fe<P> fe_mul_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
 template <class P> VDF_HD Fe<P> fe_canon(Fe<P> a) { return a; }
 template <class P> VDF_HD Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_sub(a, b); }
+template <class P> VDF_HD Fe<P> fe_mul2_lazy(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+  return fe_add(fe_mul_generic(a, b), fe_mul_generic(c, d));
+}
+template <class P> VDF_HD Fe<P> fe_neg_lazy(const Fe<P>& a) { return fe_neg(a); }
 #endif
 
 // Out-of-line multiply (by-value arguments travel in VGPRs): one copy per field per TU.

@@ -488,6 +488,67 @@ static int make_packed_generators(vdf_pp* pp) {
   return VDF_OK;
 }
 
+// the longest run of constraints that read nothing of a witness but [seg_begin - arity, seg_begin + seg_len) and the constant, none
+// of them longer than 8 entries in any matrix (public_params_impl)
+static void longest_early_run(const HostShape& h, size_t seg_begin, size_t seg_len, size_t arity, size_t* best_b, size_t* best_n) {
+  const size_t sb = seg_begin - arity, se = seg_begin + seg_len;
+  std::vector<uint8_t> early(h.num_cons, 1);
+  for (int k = 0; k < 3; ++k) {
+    std::vector<uint32_t> per_row(h.num_cons, 0);
+    for (size_t e = 0; e < h.m[k].rows.size(); ++e) {
+      const uint32_t r = h.m[k].rows[e], c = h.m[k].cols[e];
+      if (!((c >= sb && c < se) || c == h.num_vars) || ++per_row[r] > 8) early[r] = 0;
+    }
+  }
+  *best_b = 0; *best_n = 0;
+  size_t run_b = 0;
+  for (size_t r = 0; r <= h.num_cons; ++r)
+    if (r == h.num_cons || !early[r]) { if (r - run_b > *best_n) { *best_b = run_b; *best_n = r - run_b; } run_b = r + 1; }
+}
+
+// Are the rows [row0, row0 + 3t + 1) of the primary shape EXACTLY the stencil vdf_nifs_cross_term_minroot computes
+// (include/vdf_hip.h; src/nova/proof.rs:107-133, :219-227)?  Every triple of the three matrices in those rows is compared
+// with the stencil's own list: a circuit that differs in one coefficient keeps the generic sparse kernel.
+static bool minroot_stencil_matches(const HostShape& h, const Field& F, uint64_t t, int per, size_t S, size_t row0) {
+  const size_t nrows = 3 * (size_t)t + 1, one_col = h.num_vars;
+  if (S < 3 || row0 + nrows > h.num_cons || S + (size_t)per * t + 1 > h.num_vars) return false;
+  typedef std::vector<std::pair<uint32_t, Fe>> Row;
+  const Fe p1 = one(F), m1 = neg(one(F), F);
+  for (int k = 0; k < 3; ++k) {
+    std::vector<Row> got(nrows);
+    const Coo& m = h.m[k];
+    for (size_t e = 0; e < m.rows.size(); ++e)
+      if (m.rows[e] >= row0 && m.rows[e] < row0 + nrows) got[m.rows[e] - row0].push_back({m.cols[e], vdfhost::canon(m.vals[e], F)});
+    for (size_t i = 0; i < nrows; ++i) {
+      Row want;
+      if (i == nrows - 1) {
+        if (k == 0) want = {{(uint32_t)(S + (size_t)per * t), p1}};
+        else if (k == 1) want = {{(uint32_t)one_col, p1}};
+        else want = {{(uint32_t)(S - 1), p1}, {(uint32_t)one_col, neg(from_u64(t, F), F)}};
+      } else {
+        const size_t j = i / 3, role = i - 3 * j, rd = S + (size_t)per * j, t1 = rd + (per - 3);
+        const uint32_t y_j = (uint32_t)(j ? rd - 1 : S - 2);
+        Row x;                                                       // the linear combination that is x_j
+        if (per == 4 || j == 0) x = {{(uint32_t)(j ? rd - per : S - 3), p1}};
+        else x = {{(uint32_t)(j > 1 ? rd - per - 1 : S - 2), p1}, {(uint32_t)(S - 1), m1}, {(uint32_t)one_col, from_u64(j, F)}};
+        if (role == 0) want = k < 2 ? x : Row{{(uint32_t)t1, p1}};
+        else if (role == 1) want = k < 2 ? Row{{(uint32_t)t1, p1}} : Row{{(uint32_t)(t1 + 1), p1}};
+        else if (k == 0) want = {{(uint32_t)(t1 + 1), p1}};
+        else if (k == 1) want = x;
+        else want = {{(uint32_t)(t1 + 2), p1}, {y_j, p1}, {(uint32_t)(S - 1), m1}, {(uint32_t)one_col, from_u64(j + 1, F)}};
+      }
+      Row& g = got[i];
+      if (g.size() != want.size()) return false;
+      auto by_col = [](const std::pair<uint32_t, Fe>& a, const std::pair<uint32_t, Fe>& b) { return a.first < b.first; };
+      std::sort(g.begin(), g.end(), by_col);
+      std::sort(want.begin(), want.end(), by_col);
+      for (size_t e = 0; e < g.size(); ++e)
+        if (g[e].first != want[e].first || g[e].second != vdfhost::canon(want[e].second, F)) return false;
+    }
+  }
+  return true;
+}
+
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
                               vdf_pp** out) {
   if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG && gens_family != VDF_GENS_LABEL_SHAKE)
@@ -517,21 +578,18 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     // (the `arity` variables allocated right before it, synthesize_augmented; known when a step begins) and the constant,
     // none of them a row the device sums by a wavefront (vdf_nifs_cross_term_rows)
     const HostShape& h = sh[PRIMARY];
-    const size_t sb = pp->seg_begin - pp->arity, se = pp->seg_begin + pp->seg_len;
-    std::vector<uint8_t> early(h.num_cons, 1);
-    for (int k = 0; k < 3; ++k) {
-      std::vector<uint32_t> per_row(h.num_cons, 0);
-      for (size_t e = 0; e < h.m[k].rows.size(); ++e) {
-        const uint32_t r = h.m[k].rows[e], c = h.m[k].cols[e];
-        if (!((c >= sb && c < se) || c == h.num_vars) || ++per_row[r] > 8) early[r] = 0;
-      }
-    }
-    size_t best_b = 0, best_n = 0, run_b = 0;
-    for (size_t r = 0; r <= h.num_cons; ++r)
-      if (r == h.num_cons || !early[r]) { if (r - run_b > best_n) { best_b = run_b; best_n = r - run_b; } run_b = r + 1; }
+    size_t best_b = 0, best_n = 0;
+    longest_early_run(h, pp->seg_begin, pp->seg_len, pp->arity, &best_b, &best_n);
     const char* ov = std::getenv("VDF_NOVA_T_AHEAD");                 // tuning: 0 = one cross term, one commitment of T per step
     if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0') && !(flags & VDF_PP_NO_EARLY_ROWS)) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
     pp->ahead_mode = (ov && ov[0] == '1') ? 1 : 2;
+    // the built-in circuits' early rows are a fixed stencil over the rounds' variables: compared with the shape triple by triple
+    // once, here; from then on their cross term reads no sparse matrix (VDF_NOVA_STENCIL=0: the generic kernel, for A/B runs)
+    const int per = circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
+    const char* sv = std::getenv("VDF_NOVA_STENCIL");
+    if (!custom && pp->ahead_rows == 3 * t + 1 && !(sv && sv[0] == '0') &&
+        minroot_stencil_matches(h, field(side_field(PRIMARY)), t, per, pp->seg_begin, pp->ahead_row))
+      pp->stencil_per = per;
   }
   for (int s = 0; s < 2; ++s) {
     Side& sd = pp->s[s];
@@ -678,6 +736,26 @@ int vdf_nova_pp_early_rows(const vdf_pp* pp, uint64_t* begin, uint64_t* len) {
   if (begin) *begin = pp->ahead_row;
   if (len) *len = pp->ahead_rows;
   return VDF_OK;
+}
+int vdf_nova_pp_stencil(const vdf_pp* pp) { return pp ? pp->stencil_per : 0; }
+// host only (no device): what vdf_nova_public_params would find for the built-in step circuit `circuit_kind` at `t`
+int vdf_nova_shape_stencil(uint64_t t, int circuit_kind, uint64_t* early_begin, uint64_t* early_len, uint64_t* seg_begin) {
+  return nova_guard([&]() -> int {
+    if (t == 0 || t > (1ull << 24) || (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE))
+      return -fail(VDF_ERR_BAD_ARG, "bad argument");
+    HostShape sh[2];
+    if (build_shapes(t, circuit_kind, sh) != VDF_OK) return -VDF_ERR_DEVICE;
+    const HostShape& h = sh[PRIMARY];
+    const size_t sb = h.step_begin, sl = h.step_end - h.step_begin;
+    size_t b = 0, n = 0;
+    if (sb < 3) return 0;
+    longest_early_run(h, sb, sl, 3, &b, &n);
+    if (early_begin) *early_begin = b;
+    if (early_len) *early_len = n;
+    if (seg_begin) *seg_begin = sb;
+    const int per = circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
+    return (n == 3 * t + 1 && minroot_stencil_matches(h, field(side_field(PRIMARY)), t, per, sb, b)) ? per : 0;
+  });
 }
 
 // ---- circuits ----------------------------------------------------------------------------------------
@@ -908,6 +986,13 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       HIPCALL(ct, vdf_dev_memcpy(ct, (char*)d_z2 + (seg_b - arity) * 32, p->h_zin, arity * 32));
     }
     auto rows = [&](size_t b, size_t n) -> int {
+      if (pp->stencil_per && b == ta_b && n == ta_n) {               // the MinRoot stencil: streams only (vdf_hip.h)
+        HIPCALL(ct, vdf_nifs_cross_term_minroot(ct, S1.field, pp->stencil_per, pp->t, seg_b, S1.num_vars, b, (const vdf_fe*)d_z2,
+                                                (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2],
+                                                (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
+                                                (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+        return VDF_OK;
+      }
       HIPCALL(ct, vdf_nifs_cross_term_rows(ct, S1.shape, b, n, VDF_ROWS_INSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
                                            (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
                                            (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));

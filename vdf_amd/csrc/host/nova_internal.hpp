@@ -89,6 +89,8 @@ struct vdf_pp {
   // constraints of the primary shape that read nothing of a fresh witness but that segment (and the constant): their
   // share of a step's cross term and of its commitment is made ahead of the rest, [ahead_row, ahead_row + ahead_rows)
   size_t ahead_row = 0, ahead_rows = 0;
+  int stencil_per = 0;           // 3 / 4: the early rows are the built-in MinRoot stencil with that many variables per round, checked against
+                                 // the shape at public_params -- their cross term needs no sparse matrix (vdf_nifs_cross_term_minroot); 0: generic rows
   int ahead_mode = 2;            // when they run: 2 = from the start of the step, beside the secondary side's NIFS; 1 = after it (tuning)
   size_t arity = 3;                        // of the primary step circuit (z0, zi)
   // the reference's step circuit only: generators of the packed commitment to the MinRoot rounds (3t + 4 points derived from

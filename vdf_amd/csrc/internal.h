@@ -225,6 +225,9 @@ Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
                       const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
                       void* bz2, void* cz2, void* T, double alg_bytes, hipStream_t s);
+Status vec_nifs_cross_minroot(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
+                              const void* az1, const void* bz1, const void* cz1, const vdf_fe* u1, void* az2, void* bz2, void* cz2,
+                              void* T, hipStream_t s);
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);
@@ -232,6 +235,7 @@ Status vec_any_nonzero(const void* v, size_t n, uint32_t* d_flag, hipStream_t s)
 Status vec_to_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t s);
 Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, hipStream_t s);
+Status vec_clock_probe(int iters, int workgroups, unsigned long long* d_out3, hipStream_t s);   // d_out3 zeroed by the caller
 
 // ---- snark.hip -------------------------------------------------------------------------
 // vdf_fe* arguments are HOST pointers whose values travel as kernel arguments; void* are device vectors

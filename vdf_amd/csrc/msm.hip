@@ -515,38 +515,12 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
   }
 }
 
-// Mixed addition acc += b in the lazy domain (fe.cuh): coordinates of acc in [0, 2m + eps), b canonical.
-// `have` says whether acc holds a point yet (the identity has no lazy encoding).
+// The mixed addition of the bucket loop is ec.cuh's xyzz_madd_lazy (sign-tracked, product pair for Y3).
 template <class P>
-__device__ __forceinline__ void madd_lazy(XYZZ<P>& acc, bool& have, const Affine<P>& b) {
-  if (affine_is_identity(b)) return;
-  if (!have) { acc = xyzz_from_affine(b); have = true; return; }
-  const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
-  const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
-  const Fe<P> Pp = fe_sub_lazy(U2, acc.x);
-  const Fe<P> Rr = fe_sub_lazy(S2, acc.y);
-  // P == 0 (mod m) means P in {0, m, 2m}; m == 1 (mod 2^32), so the low limb is 0, 1 or 2: cheap filter
-  if (Pp.v[0] <= 2u && fe_is_zero(fe_canon(Pp))) {
-    if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);        // same point: double (canonical output)
-    else have = false;                                              // opposite points: identity
-    return;
-  }
-  const Fe<P> PP = fe_mul_lazy(Pp, Pp);
-  const Fe<P> PPP = fe_mul_lazy(Pp, PP);
-  const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
-  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), PPP), Qq), Qq);
-  const Fe<P> Y3 = fe_sub_lazy(fe_mul_lazy(Rr, fe_sub_lazy(Qq, X3)), fe_mul_lazy(acc.y, PPP));
-  acc.x = X3;
-  acc.y = Y3;
-  acc.zz = fe_mul_lazy(acc.zz, PP);
-  acc.zzz = fe_mul_lazy(acc.zzz, PPP);
-}
-
-template <class P>
-__device__ __forceinline__ void flush_lazy(const XYZZ<P>& acc, bool have, char* dst) {
+__device__ __forceinline__ void flush_lazy(const XYZZ<P>& acc, bool have, bool flip, char* dst) {
   // stored as is, in the lazy domain: the tail kernels canonicalise on load (qpoint_load_lazy), each lane its
   // own coordinate, which takes ~140 instructions out of a path most iterations execute for a few lanes
-  xyzz_store<P>(dst, have ? acc : xyzz_identity<P>());
+  xyzz_store<P>(dst, xyzz_lazy_resolve<P>(acc, have, flip));
 }
 
 template <class P>
@@ -568,7 +542,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
   uint32_t next = bstart[g + 1];
   bool is_head = bstart[g] < lo;
   XYZZ<P> acc = xyzz_identity<P>();
-  bool have = false;
+  bool have = false, flip = false;            // flip: the accumulator holds the NEGATED partial sum (ec.cuh xyzz_madd_lazy)
   // software pipeline: while entry `pos` is added, the point of entry pos+1 is in flight.  Entry indices arrive
   // four at a time as one aligned dwordx4 (every sorted line is then fetched from HBM once; one dword per
   // iteration re-fetched lines the L1 had already dropped: +20 % FETCH_SIZE); the chunk for positions 4k..4k+3
@@ -586,7 +560,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
     const uint32_t en = (pn < hi) ? pick(cq, pn & 3u) : e;
     Affine<P> ptn = affine_load<P>(points + (size_t)(en & ~SIGN_BIT) * 64);
     if (pos >= next) {
-      flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
+      flush_lazy<P>(acc, have, flip, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
       is_head = false;
       have = false;
       ++g;
@@ -600,12 +574,14 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
       }
       next = bstart[g + 1];
     }
-    if (e & SIGN_BIT) pt.y = fe_neg(pt.y);
-    madd_lazy<P>(acc, have, pt);
+    if (!affine_is_identity(pt)) {
+      if (((e & SIGN_BIT) != 0) != (have && flip)) pt.y = fe_neg(pt.y);      // digit sign XOR the accumulator's pending sign
+      xyzz_madd_lazy<P>(acc, have, flip, pt);
+    }
     e = en;
     pt = ptn;
   }
-  flush_lazy<P>(acc, have, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
+  flush_lazy<P>(acc, have, flip, is_head ? heads + (size_t)t * 128 : bucket_acc + (size_t)g * 128);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1242,7 +1218,11 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   if (acc_gate) VDF_TRY_HIP(hipStreamWaitEvent(st, acc_gate, 0));
   {
   KTimer kt(st, "k_accumulate", 96.0 * p.n);            // the pipeline's algorithmic bytes: 96 B per (base, scalar) pair, SURVEY.md 8d
-  hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), 0, st, sorted, bstart, nkeys,
+  // (tuning) VDF_MSM_ACC_LDS=bytes: unused dynamic LDS per workgroup, which caps how many accumulate workgroups a CU
+  // takes (160 KB per CU: 54 KB -> two) whatever their register count allows -- the dispatcher then cannot pack three onto
+  // one CU and one onto another when other queues hold slots (a CU with three takes 1.5 x as long: the launch's tail)
+  static const unsigned acc_lds = [] { const char* e = std::getenv("VDF_MSM_ACC_LDS"); const long v = e ? std::atol(e) : 0; return (unsigned)(v >= 0 && v <= 65536 ? v : 0); }();
+  hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), acc_lds, st, sorted, bstart, nkeys,
                      reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.slots, p.Lfixed, p.nthreads);
   }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));

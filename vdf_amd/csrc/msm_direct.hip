@@ -133,30 +133,6 @@ struct DirectArgs {
   int groups;
 };
 
-// mixed addition in the lazy domain, as k_accumulate's (msm.hip madd_lazy)
-template <class P>
-__device__ __forceinline__ void dmadd(XYZZ<P>& acc, bool& have, const Affine<P>& b) {
-  if (!have) { acc = xyzz_from_affine(b); have = true; return; }
-  const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
-  const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
-  const Fe<P> Pp = fe_sub_lazy(U2, acc.x);
-  const Fe<P> Rr = fe_sub_lazy(S2, acc.y);
-  if (Pp.v[0] <= 2u && fe_is_zero(fe_canon(Pp))) {
-    if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);
-    else have = false;
-    return;
-  }
-  const Fe<P> PP = fe_mul_lazy(Pp, Pp);
-  const Fe<P> PPP = fe_mul_lazy(Pp, PP);
-  const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
-  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), PPP), Qq), Qq);
-  const Fe<P> Y3 = fe_sub_lazy(fe_mul_lazy(Rr, fe_sub_lazy(Qq, X3)), fe_mul_lazy(acc.y, PPP));
-  acc.x = X3;
-  acc.y = Y3;
-  acc.zz = fe_mul_lazy(acc.zz, PP);
-  acc.zzz = fe_mul_lazy(acc.zzz, PPP);
-}
-
 // The entries of a group are its (window, scalar) pairs, window-major: entry e = j * n + s.  A group owns L lanes
 // (whole wavefronts); lane x takes the entries x, x + L, x + 2L, ... (per_lane of them at most): consecutive lanes read
 // consecutive scalars, and the launch is ONE round of one wavefront per SIMD -- the additions are VALU-issue bound, so
@@ -181,7 +157,7 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
   const uint32_t w0 = g ? a.wave_end[g - 1] : 0u;
   const bool live_wave = wave < a.wave_end[a.groups - 1];
   XYZZ<P> acc = xyzz_identity<P>();
-  bool have = false;
+  bool have = false, flip = false;            // ec.cuh xyzz_madd_lazy: the mixed addition of the bucket loop, sign-tracked
   if (live_wave) {
     const uint32_t n = a.n[g];
     const uint32_t E = n * (uint32_t)W;                            // entries of the group (at most 2^17 x 33)
@@ -234,13 +210,13 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
       Affine<P> ptn;
       if (ptrn) ptn = affine_load<P>(ptrn);
       if (ptr) {
-        if (neg) pt.y = fe_neg(pt.y);
-        dmadd<P>(acc, have, pt);
+        if (neg != (have && flip)) pt.y = fe_neg(pt.y);
+        xyzz_madd_lazy<P>(acc, have, flip, pt);
       }
       e += L; ptr = ptrn; neg = negn; pt = ptn; k1 = k2;
     }
   }
-  xyzz_store<P>(pts + (size_t)threadIdx.x * 128, have ? acc : xyzz_identity<P>());
+  xyzz_store<P>(pts + (size_t)threadIdx.x * 128, xyzz_lazy_resolve<P>(acc, have, flip));
   __syncthreads();
   // the wavefront's 64 points: each of its 16 quads adds four, then a butterfly over the quads
   const uint32_t qd = lane >> 2, wv = threadIdx.x >> 6;

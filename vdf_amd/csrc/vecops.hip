@@ -343,6 +343,70 @@ __global__ __launch_bounds__(256) void k_nifs_cross_w(Csr3 m, const char* __rest
   fe_store<P>(T + r * 32, t);
 }
 
+// The cross term over the rows of the built-in MinRoot step circuits WITHOUT the sparse matrices: the 3t + 1 constraints
+// InverseMinRootCircuit::synthesize records (src/nova/proof.rs:107-133, :219-227) are a fixed stencil over the round's own
+// variables, so A z2, B z2, C z2 of a row are copies of witness values (and one four-term sum): no row pointers, no
+// column / coefficient loads, no dependent gathers.  With S = seg_begin (first round variable), the step circuit's input
+// z_in = (x, y, i) in the three variables before S, `one` the constant's column, PER = 4 (the reference's rounds: new_x,
+// tmp1, tmp2, new_y) or 3 (bound form: tmp1, tmp2, new_y), round j and y_j = new_y_(j-1) (y_0 = z_in.y):
+//   row 3j     x_j * x_j   = tmp1_j             x_j = new_x_(j-1)  (PER = 4; x_0 = z_in.x)
+//   row 3j + 1 tmp1 * tmp1 = tmp2                   = y_(j-1) - i + j * one  (PER = 3, j > 0)
+//   row 3j + 2 tmp2 * x_j  = new_y_j + y_j - i + (j + 1) * one
+//   row 3t     final_i * one = i - t * one
+// One row per lane (every running / fresh vector is read and written as contiguous 32-byte elements, like k_fold_many);
+// the witness values a row needs sit in the 128 (96) bytes of its round and the one before.  Exact for ANY z2: the
+// constant's coefficient is multiplied by z2[one] (1 in a fresh instance).  The host checks the stencil against the
+// shape's triples before it uses this kernel (libvdf_nova.so public_params); other circuits keep k_nifs_cross.
+template <class P, int PER>
+__global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restrict__ z2, size_t S, size_t one_col, uint64_t t,
+                                                            size_t row0, const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                            const char* __restrict__ cz1, FeVal u1, char* __restrict__ az2,
+                                                            char* __restrict__ bz2, char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > 3 * t) return;
+  const size_t r = row0 + i;
+  const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+  const Fe<P> onev = fe_load<P>(z2 + one_col * 32);
+  const Fe<P> i_in = fe_load<P>(z2 + (S - 1) * 32);
+  Fe<P> a2, b2, c2;
+  if (i == 3 * t) {
+    a2 = fe_load<P>(z2 + (S + (size_t)PER * t) * 32);
+    b2 = onev;
+    c2 = fe_sub(i_in, fe_mul(fe_from_u64<P>(t), onev));
+  } else {
+    const uint64_t j = i / 3;
+    const uint32_t role = (uint32_t)(i - 3 * j);
+    const char* rd = z2 + (S + (size_t)PER * j) * 32;              // this round's variables
+    const char* t1p = rd + (PER - 3) * 32;                          // tmp1, tmp2, new_y
+    // y_j and (PER = 3) the value below x_j: new_y of earlier rounds, or z_in
+    const char* yp = j ? rd - 32 : z2 + (S - 2) * 32;               // y_j = new_y_(j-1): the element right before this round
+    Fe<P> x;
+    if (role != 1) {
+      if (PER == 4) x = fe_load<P>(j ? rd - (size_t)PER * 32 : z2 + (S - 3) * 32);      // new_x_(j-1)
+      else if (j == 0) x = fe_load<P>(z2 + (S - 3) * 32);
+      else {                                                        // y_(j-1) - i + j * one
+        const Fe<P> yprev = fe_load<P>(j > 1 ? rd - (size_t)PER * 32 - 32 : z2 + (S - 2) * 32);
+        x = fe_add(fe_sub(yprev, i_in), fe_mul(fe_from_u64<P>(j), onev));
+      }
+    }
+    if (role == 0) { a2 = x; b2 = x; c2 = fe_load<P>(t1p); }
+    else if (role == 1) { a2 = fe_load<P>(t1p); b2 = a2; c2 = fe_load<P>(t1p + 32); }
+    else {
+      a2 = fe_load<P>(t1p + 32); b2 = x;
+      const Fe<P> ny = fe_load<P>(t1p + 64), y = fe_load<P>(yp);
+      c2 = fe_add(fe_sub(fe_add(ny, y), i_in), fe_mul(fe_from_u64<P>(j + 1), onev));
+    }
+  }
+  fe_store<P>(az2 + r * 32, a2);
+  fe_store<P>(bz2 + r * 32, b2);
+  fe_store<P>(cz2 + r * 32, c2);
+  Fe<P> tt = fe_add(fe_mul(a1, b2), fe_mul(a2, b1));
+  tt = fe_sub(tt, fe_mul(fe_from_val<P>(u1), c2));
+  tt = fe_sub(tt, c1);
+  fe_store<P>(T + r * 32, tt);
+}
+
 // acc_k <- acc_k + r * add_k for up to 8 vectors in one launch (the witness fold W, E and the running Az, Bz, Cz)
 struct FoldArgs { char* acc[8]; const char* add[8]; uint32_t blk_end[8]; uint64_t n[8]; int k; };
 template <class P>
@@ -384,6 +448,24 @@ __global__ __launch_bounds__(256) void k_mul_chain(const char* __restrict__ a, s
   Fe<P> y = x;
   for (int k = 0; k < iters; ++k) y = fe_mul(y, x);
   fe_store<P>(out + i * 32, y);
+}
+
+// Box fingerprint (bench.py): every SIMD runs `iters` dependent Montgomery products; s_memtime counts shader clocks,
+// s_memrealtime the constant 100 MHz reference, so their ratio over all wavefronts is the clock the device sustained
+// under the integer load the MSM puts on it.  out[0] += shader cycles, out[1] += reference ticks (one add per wavefront).
+__global__ __launch_bounds__(256) void k_clock_probe(int iters, unsigned long long* __restrict__ out) {
+  Fe<FpParams> x, y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x.v[i] = threadIdx.x * 2654435761u + i; y.v[i] = blockIdx.x * 40503u + i * 7 + 1; }
+  x.v[7] &= 0x3fffffffu; y.v[7] &= 0x3fffffffu;
+  const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int k = 0; k < iters; ++k) y = fe_mul_lazy(y, x);
+  const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, (unsigned long long)(c1 - c0));
+    atomicAdd(out + 1, (unsigned long long)(r1 - r0));
+  }
+  if (y.v[0] == 0x12345678u && y.v[5] == 0x9abcdef0u) out[2] = y.v[1];          // keeps the chain alive
 }
 
 #define FIELD_DISPATCH(field, KERNEL, ...)                                                       \
@@ -493,6 +575,26 @@ Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t
   return Status{};
 }
 
+Status vec_nifs_cross_minroot(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
+                              const void* az1, const void* bz1, const void* cz1, const vdf_fe* u1, void* az2, void* bz2, void* cz2,
+                              void* T, hipStream_t s) {
+  if (per != 3 && per != 4) return Status{VDF_ERR_BAD_ARG, "variables per round must be 3 or 4"};
+  if (t == 0 || seg_begin < 3) return Status{VDF_ERR_BAD_ARG, "bad segment"};
+  const size_t rows = 3 * (size_t)t + 1;
+  // algorithmic bytes: 3 running + 3 fresh + T elements per row, and the round's variables once (SURVEY 8d counts 224 B per
+  // row for the cross term alone and the sparse products apart; here the products are the witness copies themselves)
+  KTimer kt(s, "k_nifs_cross_minroot", (double)rows * 7 * 32 + (double)per * t * 32);
+  const dim3 grid = grid_for(rows);
+#define LAUNCH_MR(PP, PERV) hipLaunchKernelGGL((k_nifs_cross_minroot<PP, PERV>), grid, dim3(256), 0, s, C(z2), seg_begin, one_col, t, row0, \
+                                               C(az1), C(bz1), C(cz1), to_val(u1), M(az2), M(bz2), M(cz2), M(T))
+  if (field == VDF_FIELD_FP) { if (per == 4) LAUNCH_MR(FpParams, 4); else LAUNCH_MR(FpParams, 3); }
+  else if (field == VDF_FIELD_FQ) { if (per == 4) LAUNCH_MR(FqParams, 4); else LAUNCH_MR(FqParams, 3); }
+  else return Status{VDF_ERR_BAD_ARG, "unknown field"};
+#undef LAUNCH_MR
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s) {
   if (k <= 0) return Status{};
@@ -559,6 +661,12 @@ Status vec_from_mont(int field, const void* a, size_t n, void* out, hipStream_t 
 Status vec_mul_chain(int field, const void* a, size_t n, int iters, void* out, hipStream_t s) {
   if (n == 0) return Status{};
   FIELD_DISPATCH(field, k_mul_chain, grid_for(n), dim3(256), 0, s, C(a), n, iters, M(out));
+  return Status{};
+}
+
+Status vec_clock_probe(int iters, int workgroups, unsigned long long* d_out3, hipStream_t s) {
+  hipLaunchKernelGGL(k_clock_probe, dim3(workgroups), dim3(256), 0, s, iters, d_out3);
+  VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }
 

@@ -394,6 +394,11 @@ class Context:
         self._check(lib.vdf_nifs_cross_term_rows(self.handle, shape.handle, row_begin, row_count, part, _ptr(z2), _ptr(az1), _ptr(bz1),
                                                  _ptr(cz1), _ptr(u1), _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
 
+    def nifs_cross_term_minroot(self, field, per, t, seg_begin, one_col, row_begin, z2, az1, bz1, cz1, u1, az2, bz2, cz2, T) -> None:
+        """The 3t + 1 rows of a built-in MinRoot step circuit from row_begin on, by stencil (vdf_hip.h)."""
+        self._check(lib.vdf_nifs_cross_term_minroot(self.handle, field, per, t, seg_begin, one_col, row_begin, _ptr(z2), _ptr(az1),
+                                                    _ptr(bz1), _ptr(cz1), _ptr(u1), _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
+
     def fold_many(self, field, r, acc, add, n) -> None:
         k = len(acc)
         a = (C.c_void_p * k)(*[_ptr(x) for x in acc])
@@ -437,6 +442,12 @@ class Context:
 
     def fe_from_mont(self, field, a, n, out) -> None:
         self._check(lib.vdf_fe_from_mont(self.handle, field, _ptr(a), n, _ptr(out)))
+
+    def clock_probe(self, iters: int = 6000):
+        """(shader MHz sustained under a multiply-bound load on every SIMD, the probe kernel's duration in ms)."""
+        mhz, ms = C.c_double(), C.c_double()
+        self._check(lib.vdf_ctx_clock_probe(self.handle, iters, C.byref(mhz), C.byref(ms)))
+        return mhz.value, ms.value
 
     def fe_mul_chain(self, field, a, n, iters, out) -> None:
         self._check(lib.vdf_fe_mul_chain(self.handle, field, _ptr(a), n, iters, _ptr(out)))

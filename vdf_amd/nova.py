@@ -24,6 +24,8 @@ for _name, _res, _args in [
     ("vdf_nova_pp_digest", _i, [_vp, _vp]),
     ("vdf_nova_pp_segment", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_pp_early_rows", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    ("vdf_nova_pp_stencil", _i, [_vp]),
+    ("vdf_nova_shape_stencil", _i, [_u64, _i, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     ("vdf_nova_eval_and_make_circuits", _i, [_i, _u64, _sz, C.POINTER(_State), C.POINTER(_Fe * 3), C.POINTER(_vp)]),
     ("vdf_nova_circuits_len", _sz, [_vp]),
     ("vdf_nova_circuits_upload", _i, [_vp, _vp]),
@@ -122,6 +124,16 @@ def shape_digest(t: int, circuit_kind: int = 1, gens_family: int = 1):
     sizes = np.zeros((2, 3), dtype="<u8")
     _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
+
+
+def shape_stencil(t: int, circuit_kind: int = 1):
+    """(variables per round of the MinRoot stencil the early rows match, or 0; first early row; early rows; first round variable)
+    -- host only: what public_params(t) would use for the early rows' cross term."""
+    b, n, s_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    per = nova_lib.vdf_nova_shape_stencil(t, circuit_kind, C.byref(b), C.byref(n), C.byref(s_))
+    if per < 0:
+        _check(-per)
+    return per, b.value, n.value, s_.value
 
 
 def shape_export(t: int, circuit_kind: int = 1, side: int = 0):
@@ -291,6 +303,10 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         b, n = C.c_uint64(), C.c_uint64()
         _check(nova_lib.vdf_nova_pp_early_rows(self.handle, C.byref(b), C.byref(n)))
         return b.value, n.value
+
+    def stencil(self) -> int:
+        """4 / 3: the early rows run as the MinRoot stencil (reference / bound rounds), 0: through the sparse kernel."""
+        return int(nova_lib.vdf_nova_pp_stencil(self.handle))
 
     def memory(self) -> dict:
         """HBM held per side (bytes): generators, fixed-base table, digit table; `skipped` = sides whose digit table did not fit."""
