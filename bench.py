@@ -62,6 +62,10 @@ def parse():
                     help="also report the aggregate rate of this many independent chains proven concurrently (1 = skip)")
     ap.add_argument("--prove-steps", type=int, default=26, help="1 base case + 1 warm-up fold + timed steady-state folds")
     ap.add_argument("--prove-repeats", type=int, default=5, help="the steady state is timed this many times (a fresh proof each): 5 x 24 = 120 timed steps")
+    ap.add_argument("--digit-budget-gib", type=int, default=72,
+                    help="HBM the prove_step leg lets the digit tables of a parameter set take (vdf_nova_tuning.digit_budget_bytes): 72 GiB "
+                         "buys the 12-bit tables (65 GB at t = 2^16) -- an opt-in of a host with 288 GB; the library's own default, 20 GiB "
+                         "(10-bit tables, 19 GB), is measured beside it as prove_step.library_default_budget")
     ap.add_argument("--no-bound-form", action="store_true", help="skip the bound-form sub-record of the prove_step leg")
     ap.add_argument("--no-reference-cases", action="store_true", help="skip the reference's own bench cases (benches/nova.rs:62-66)")
     return ap.parse_args()
@@ -537,7 +541,7 @@ def kernel_report(events, nsteps):
 
 
 def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compress=True, with_roofline=True, seed_offset=0,
-                   circuits_in=None, chain2=None):
+                   circuits_in=None, chain2=None, digit_budget_gib=72):
     """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU -- a full IVC step on the
     Pallas / Vesta cycle (both augmented circuits, in-circuit NIFS verifier, see include/vdf_nova.h) over the step circuit
     `kind`.  Forward evaluation and public parameters are outside the timed region (benches/nova.rs:28-59); step 0 (base
@@ -548,7 +552,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     from vdf_amd.nova import InverseMinRootCircuit, NovaVDFProof, public_params, INST_FRESH_SECONDARY
     t = 1 << log2t
     t0 = time.perf_counter()
-    pp = public_params(ctx, t, kind)
+    pp = public_params(ctx, t, kind, digit_budget_bytes=digit_budget_gib << 30)
     pp_s = time.perf_counter() - t0
     initial = State.from_ints(FIELD_FQ, 0x1234567890ABCDEF1234567890ABCDEF + (seed_offset << 64), 0, 0)   # y = 0, i = 0: benches/nova.rs:24-26
     if circuits_in is None:
@@ -616,7 +620,9 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
            "settle_steps_untimed": settle_steps, "box": [fp_before, fp_after],
            "base_case_ms": base_case * 1e3, "first_fold_ms_untimed_warmup": first_fold * 1e3,
            "steady_state_steps": nsteady if nsteps > 1 else 0,
-           "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes, "public_params_s": pp_s, "hbm": pp.memory(),
+           "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes, "public_params_s": pp_s,
+           "public_params_ms_split": {k_: round(v_, 1) for k_, v_ in pp.setup_ms().items()}, "hbm": pp.memory(),
+           "tuning": {k_: v_ for k_, v_ in pp.tuning().items() if k_ != "struct_size"}, "early_rows_stencil": pp.stencil(),
            "segment_commitment": "the MinRoot rounds' 4t + 1 variables committed as an MSM of 3t + 4 terms over derived generators "
                                  "(new_x is an affine image of new_y: same group element; vdf_hip.h vdf_minroot_step_segment_packed)" if kind == 1 else
                                  "the MinRoot rounds' 3t + 1 variables, one MSM",
@@ -689,7 +695,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         work = [(ctx, pp, circuits, z0)]
         for c in range(1, chains):
             ctx2 = vdf_amd.Context(ctx.device)
-            pp2 = public_params(ctx2, t, kind)
+            pp2 = public_params(ctx2, t, kind, digit_budget_bytes=digit_budget_gib << 30)
             if chain2 is not None and c == 1:
                 z02, circ2 = chain2()
             else:
@@ -1053,7 +1059,7 @@ def main():
     if (world > 1 or args.rehearse_collective) and not args.no_prove:
         ctx.set_async(False)
         mine = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=1, chains=1, with_compress=False,
-                              with_roofline=False, seed_offset=rank)
+                              with_roofline=False, seed_offset=rank, digit_budget_gib=args.digit_budget_gib)
         r = torch.tensor([mine["value"], -mine["value"], mine["value"], 1.0 if mine["verified"] else 0.0],
                          dtype=torch.float64, device="cuda")
         agg = r.clone()
@@ -1174,10 +1180,20 @@ def main():
                 return second["z0"], second["circuits"]
             # the headline: the REFERENCE's step circuit (src/nova/proof.rs:155-230: 4 variables per round, 2^19 generators)
             line["prove_step"] = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=args.prove_repeats,
-                                                chains=args.prove_chains, circuits_in=shared, chain2=chain2 if th2 else None)
+                                                chains=args.prove_chains, circuits_in=shared, chain2=chain2 if th2 else None,
+                                                digit_budget_gib=args.digit_budget_gib)
+            line["prove_step"]["config"] = {"digit_budget_gib": args.digit_budget_gib,
+                                            "note": "digit tables opted in beyond the library's 20 GiB default (vdf_nova.h); "
+                                                    "library_default_budget is the same leg on the default"}
+            if args.digit_budget_gib != 20:
+                dflt = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=3, chains=1, with_compress=False,
+                                      with_roofline=False, circuits_in=shared, digit_budget_gib=20)
+                line["prove_step"]["library_default_budget"] = {k_: dflt[k_] for k_ in ("value", "unit", "ms_per_step", "ms_per_step_by_repeat", "hbm",
+                                                                                       "verified", "public_params_s", "public_params_ms_split")}
             if not args.no_bound_form:
                 line["prove_step"]["bound_form"] = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=0, repeats=3, chains=1,
-                                                                  with_compress=False, with_roofline=False, circuits_in=shared)
+                                                                  with_compress=False, with_roofline=False, circuits_in=shared,
+                                                                  digit_budget_gib=args.digit_budget_gib)
                 line["prove_step"]["bound_form"]["note"] = ("the sound variant of the step circuit (3 variables per round), measured after the "
                                                             "reference's circuit in the same process on parameters of its own")
             if not args.no_reference_cases:
@@ -1235,6 +1251,8 @@ def main():
                 "compress_ms": (ps.get("compress") or {}).get("compress_ms"),
                 "cpu_prove_step_per_s": (ps.get("cpu_baseline") or {}).get("value"),
                 "public_params_s": ps.get("public_params_s"),
+                "prove_step_library_default_budget_per_s": (ps.get("library_default_budget") or {}).get("value"),
+                "digit_table_GB": round(sum((ps.get("hbm") or {}).get("digit_table_bytes", [0])) / 1e9, 1),
                 "shader_mhz": [b_.get("shader_mhz") for b_ in ps.get("box", [])]})
             line["prove_step_per_s"] = ps["value"]
             line["prove_step_ms_median"] = ps["ms_per_step"]

@@ -118,6 +118,10 @@ int  vdf_bases_window(const vdf_bases* bases);            /* window of the curre
  * ceil(256 / window_bits) (+1 when the top digit could overflow): 852 KB per generator at window_bits = 10 (0 = that).
  * ranges = 0 drops the table.  VDF_MSM_DIRECT=0 in the environment disables the path (tuning). */
 int  vdf_bases_precompute_digits(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int ranges, const size_t begin[], const size_t count[]);
+/* HBM a digit table at window c over `generators` generators takes (64 B x windows(c) x 2^(c-1) each), 0 for a window the
+ * library refuses; and what the fixed-base table of `bases` holds (0 without one).  No device work. */
+size_t vdf_digit_table_bytes(int window_bits, size_t generators);
+size_t vdf_bases_table_bytes(const vdf_bases* bases);
 int  vdf_bases_digit_window(const vdf_bases* bases);      /* window of the digit table, 0 without one */
 size_t vdf_bases_digit_table_bytes(const vdf_bases* bases); /* HBM held by the digit table, 0 without one */
 int  vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out);
@@ -382,6 +386,35 @@ int  vdf_fe_from_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe
 /* Throughput probe: each of n lanes runs `iters` dependent Montgomery multiplications
  * (roofline / issue-rate calibration for DESIGN.md; not on the prove path). */
 int  vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int iters, vdf_fe* out);
+/* Process-wide tuning of the kernels (every field has a measured default; DESIGN.md says what each was worth).  The
+ * environment variables of earlier rounds (VDF_MSM_*, VDF_NIFS_LANES, VDF_SHIM_CACHE) are read ONCE, the first time the
+ * library needs a value, as overrides of these defaults; a host sets them here instead.  Set before the first MSM of the
+ * process (values are read at launch time; changing them between calls is allowed, not while a call is in flight). */
+typedef struct vdf_hip_tuning {
+  uint32_t struct_size;        /* sizeof(vdf_hip_tuning) as the caller compiled it */
+  int32_t msm_direct;          /* 1: MSMs inside a digit table's ranges are direct sums (msm_direct.hip); 0: bucket method only */
+  int32_t direct_priority;     /* wave priority of the direct sum, 0..3 (2) */
+  int32_t direct_fused;        /* 1: the direct sum's last workgroup adds the workgroup points; 0: a second launch does */
+  int32_t light_priority;      /* ceiling of the wave priority of sort / fix-up / bucket-reduction kernels, 0..3 (3);
+                                  a context lowers its own with vdf_ctx_set_light_priority */
+  int32_t accumulate_fill;     /* resident bucket-accumulation workgroups per CU one launch is sized for, 1..3 (2);
+                                  a context overrides it with vdf_ctx_set_accumulate_fill */
+  int32_t accumulate_lds;      /* bytes of unused LDS per accumulation workgroup: caps its occupancy per CU (0) */
+  int32_t slice_len;           /* fixed slice length of the bucket accumulation, 1..65536; 0 = from the entry count */
+  int32_t part_bits;           /* high bucket bits of the sort's first pass; -1 = about one partition per CU */
+  int32_t reduction;           /* 1: bucket reduction as a matrix (k_red_sums / weights / combine); 0: segments */
+  int32_t reduction_quads;     /* quads of the segment reduction, 64..65536; 0 = 8192 */
+  int32_t heavy_min;           /* a bucket spanning more slices than max(this, 2 x average + 4) goes to a wavefront; 0 = 6 */
+  int32_t giant_span;          /* ... and more than this to several wavefronts; 0 = 64 */
+  int32_t nifs_lanes;          /* lanes per row of the fused cross term: 1, 4, 8; 0 = 8 up to 2^15 rows, else 1 */
+  int32_t shim_cache;          /* generator arrays the mult_pippenger shims keep resident, 0..64 (0; vdf_shim_set_cache) */
+} vdf_hip_tuning;
+int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
+int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */
+/* Per context: how many resident accumulation workgroups per CU its bucket-method MSMs fill (1..3; 0 = the process-wide
+ * value).  A prover's side queues fill all three (their launches share the device with other queues' kernels, and a
+ * grid sized for two is packed three-and-one by the dispatcher); independent MSMs in flight do better with two. */
+int  vdf_ctx_set_accumulate_fill(vdf_ctx* ctx, int workgroups_per_cu);
 /* Box fingerprint: every SIMD runs `iters` dependent Montgomery products (two wavefronts per SIMD, ~0.85 us per
  * iteration: 6000 iterations = 5 ms); *shader_mhz = shader clocks / 100 MHz reference ticks summed over the wavefronts
  * (the clock the device sustained under the MSM's kind of load), *kernel_ms = the launch's duration (HIP events).
@@ -390,6 +423,7 @@ int  vdf_ctx_clock_probe(vdf_ctx* ctx, int iters, double* shader_mhz, double* ke
 /* Device memory helpers so a non-torch host (the C++ Nova layer) can keep state resident. */
 int  vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out);
 int  vdf_dev_free(vdf_ctx* ctx, void* p);
+int  vdf_dev_mem_info(vdf_ctx* ctx, size_t* free_bytes, size_t* total_bytes);   /* HBM of the context's device; either may be NULL */
 int  vdf_dev_memcpy(vdf_ctx* ctx, void* dst, const void* src, size_t bytes);   /* any direction */
 /* Pinned host memory mapped into the device's address space.  Calls treat such a pointer like device memory
  * (used in place, no staging, no implicit synchronisation): a kernel's small result -- an MSM's point -- lands

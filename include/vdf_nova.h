@@ -78,24 +78,57 @@ int  vdf_nova_public_params(vdf_ctx* ctx, uint64_t num_iters_per_step, vdf_pp** 
  * VDF_GENS_LABEL_SHAKE derives the generators from the label "vdf-nova-ivc-v1 gens" through SHAKE256, the way nova-snark
  * derives its CommitGens (vdf_bases_generate_label): parameters reproducible from a string. */
 int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, vdf_pp** out);
-/* HBM a parameter set holds, and how to decline the optional part.  Beside the shapes and the generators with their
- * fixed-base tables (2^19 Pallas generators x 16 windows x 64 B = 512 MiB for the reference's circuit at t = 2^16),
- * public_params builds a DIGIT TABLE per side for the generators of the small commitments a step waits on
- * (vdf_bases_precompute_digits, 2.9 MB per generator at the 12-bit window this library asks for): at t = 2^16 that is
- * 29 GB on the secondary side (all 10,049 generators) + 36 GB on the primary side (the ~12.5 k generators outside the
- * MinRoot rounds and the early rows) = 65 GB PER PARAMETER SET (a quarter of that, 19 GB, with VDF_NOVA_DIGIT_WINDOW=10, for
- * ~2.5 % of a step), spent to take ~0.4 ms of bucket method off every step's critical path.  It is an
- * accelerator only: results are the same group elements without it.  A table that does not fit the free HBM is skipped
- * silently (vdf_nova_pp_memory reports it; VDF_NOVA_VERBOSE=1 logs it), and the flags below decline it up front:
+/* HBM a parameter set holds, and how to bound the optional part.  Beside the shapes and the generators with their
+ * fixed-base tables (2^19 Pallas generators x 16 windows x 64 B = 512 MiB for the reference's circuit at t = 2^16, plus the
+ * derived generators of the packed commitment), public_params builds a DIGIT TABLE per side for the generators of the
+ * small commitments a step waits on (vdf_bases_precompute_digits: 0.85 MB per generator at a 10-bit window, 2.9 MB at 12):
+ * all 10,049 generators of the secondary side and the ~12.5 k of the primary side outside the MinRoot rounds and the early
+ * rows.  It is an accelerator only (results are the same group elements without it) and it is BUDGETED: the tables of both
+ * sides together take at most vdf_nova_tuning.digit_budget_bytes -- 20 GiB by default, which buys the 10-bit tables
+ * (19 GB at t = 2^16); 72 GiB buys the 12-bit ones (65 GB) for ~2.5 % of a step -- and never more than the free HBM less a
+ * reserve for what is allocated afterwards (proof buffers, MSM workspaces).  A table that does not fit is skipped
+ * (vdf_nova_pp_memory reports it; tuning.verbose logs it).  Flags:
  *   VDF_PP_NO_DIGIT_TABLES  no digit tables: every commitment takes the bucket method (about +0.5 ms per step at t = 2^16)
  *   VDF_PP_NO_EARLY_ROWS    the cross term T of a step is made and committed in one piece instead of ahead of the step
- *                           for the rows that read only the MinRoot rounds (one MSM workspace and one queue fewer)
- * The environment variables VDF_NOVA_DIGIT_WINDOW (0 = none, 6..12) and VDF_NOVA_T_AHEAD=0 remain as tuning overrides. */
+ *                           for the rows that read only the MinRoot rounds (one MSM workspace and one queue fewer) */
 enum { VDF_PP_NO_DIGIT_TABLES = 1u, VDF_PP_NO_EARLY_ROWS = 2u };
 int  vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint32_t flags,
                                   vdf_pp** out);
+/* Everything tunable about a parameter set and the prover that runs over it, in one struct (DESIGN.md says what each
+ * choice measured).  vdf_nova_tuning_default fills in the defaults; the environment variables of earlier rounds
+ * (VDF_NOVA_*) are read once, by that function's first call, as overrides of those defaults.  A parameter set keeps its
+ * copy: two sets in one process may differ. */
+typedef struct vdf_nova_tuning {
+  uint32_t struct_size;          /* sizeof(vdf_nova_tuning) as the caller compiled it */
+  uint32_t flags;                /* VDF_PP_* */
+  uint64_t digit_budget_bytes;   /* HBM for the digit tables of both sides together (20 GiB) */
+  int32_t  digit_window;         /* 0 = the widest window of 12 .. 8 whose tables fit the budget; 6..12 = exactly this one
+                                    (still subject to the free HBM); -1 = none */
+  int32_t  early_rows;           /* 2 = the early rows of T start with the step (default), 1 = after the secondary NIFS, 0 = none */
+  int32_t  stencil;              /* 1 = the built-in circuits' early rows without the sparse matrices (vdf_nova_pp_stencil) */
+  int32_t  small_window;         /* fixed-base window of a side with fewer than 2^17 generators, 6..16 (15) */
+  int32_t  big_window;           /* ... with 2^17 and more, 12..20 (16) */
+  int32_t  packed_commit;        /* 1 = the reference circuit's rounds committed over derived generators (3t + 4 terms) */
+  int32_t  lookahead_early;      /* 1 = the next step's rounds are launched under the primary side's wait */
+  int32_t  gate_accumulate;      /* 1 = the lookahead's bucket accumulation is held behind the primary side's direct sum */
+  int32_t  fold_on_rows;         /* 1 = the primary fold runs on the early rows' queue */
+  int32_t  nifs_ahead;           /* 1 = a step launches the next step's first device phases on its way out */
+  int32_t  early_row_parts;      /* 1..3: the early rows as an MSM job of that many parts (1) */
+  int32_t  lookahead_priority;   /* wave priority of the lookahead's sort and bucket reduction, 0..3 (1) */
+  int32_t  side_accumulate_fill; /* accumulation workgroups per CU the two side queues' MSMs fill, 1..3 (3) */
+  int32_t  verbose;              /* 1 = decisions (skipped tables, the window chosen) on stderr */
+} vdf_nova_tuning;
+void vdf_nova_tuning_default(vdf_nova_tuning* out);
+/* public_params with the tuning given (NULL = the defaults); VDF_ERR_BAD_ARG for a field out of range */
+int  vdf_nova_public_params_tuned(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family,
+                                  const vdf_nova_tuning* tuning, vdf_pp** out);
+int  vdf_nova_pp_tuning(const vdf_pp* pp, vdf_nova_tuning* out);            /* the copy this parameter set runs with */
+/* wall-clock milliseconds of the stages of the call that made `pp`: [0] both shapes + digest (host), [1] shapes to the
+ * device, [2] generators, [3] fixed-base tables (the packed commitment's included), [4] digit tables, [5] the rest, [6] total */
+int  vdf_nova_pp_setup_ms(const vdf_pp* pp, double ms[7]);
 /* bytes of HBM held per side: generators, their fixed-base table, the digit table (0 = none; *skipped bit s set when
- * side s wanted one and it did not fit). */
+ * side s wanted one and it did not fit).  The primary side's figures include the derived generators of the packed
+ * commitment and their table. */
 int  vdf_nova_pp_memory(const vdf_pp* pp, uint64_t gens_bytes[2], uint64_t table_bytes[2], uint64_t digit_bytes[2], uint32_t* skipped);
 void vdf_nova_pp_free(vdf_pp* pp);
 int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,

@@ -48,6 +48,8 @@ PROTOTYPES = {
     "vdf_bases_precompute_digits": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "vdf_bases_digit_window": (_i, [_vp]),
     "vdf_bases_digit_table_bytes": (C.c_size_t, [_vp]),
+    "vdf_digit_table_bytes": (C.c_size_t, [_i, _sz]),
+    "vdf_bases_table_bytes": (C.c_size_t, [_vp]),
     "vdf_bases_len": (_sz, [_vp]),
     "vdf_bases_device_ptr": (_vp, [_vp]),
     "vdf_bases_free": (None, [_vp]),
@@ -92,9 +94,13 @@ PROTOTYPES = {
     "vdf_fe_to_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_from_mont": (_i, [_vp, _i, _vp, _sz, _vp]),
     "vdf_fe_mul_chain": (_i, [_vp, _i, _vp, _sz, _i, _vp]),
+    "vdf_hip_tuning_get": (_i, [_vp]),
+    "vdf_hip_tuning_set": (_i, [_vp]),
+    "vdf_ctx_set_accumulate_fill": (_i, [_vp, _i]),
     "vdf_ctx_clock_probe": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vdf_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vdf_dev_free": (_i, [_vp, _vp]),
+    "vdf_dev_mem_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "vdf_dev_memcpy": (_i, [_vp, _vp, _vp, _sz]),
     "vdf_dev_memset": (_i, [_vp, _vp, _i, _sz]),
     "vdf_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

@@ -106,8 +106,67 @@ int fail(vdf_ctx* ctx, const Status& s) {
   return s.code;
 }
 
+
+// ---- process-wide tuning (include/vdf_hip.h vdf_hip_tuning) ---------------------------------------------------------
+std::once_flag g_tune_once;
+std::mutex g_tune_mu;
+vdf_hip_tuning g_tune;
+vdf_hip_tuning tuning_defaults() {
+  vdf_hip_tuning t{};
+  t.struct_size = (uint32_t)sizeof(vdf_hip_tuning);
+  t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
+  t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
+  t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0;
+  return t;
+}
+bool tuning_valid(const vdf_hip_tuning& t) {
+  auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+  return in(t.msm_direct, 0, 1) && in(t.direct_priority, 0, 3) && in(t.direct_fused, 0, 1) && in(t.light_priority, 0, 3) &&
+         in(t.accumulate_fill, 1, 3) && in(t.accumulate_lds, 0, 65536) && in(t.slice_len, 0, 65536) && in(t.part_bits, -1, 19) &&
+         in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
+         (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
+         (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64);
+}
+// the environment overrides of earlier rounds, read once: the only place this library looks at the environment for tuning
+void tuning_from_env() {
+  g_tune = tuning_defaults();
+  const struct { const char* name; int32_t* field; } vars[] = {
+      {"VDF_MSM_DIRECT", &g_tune.msm_direct}, {"VDF_MSM_DIRECT_PRIO", &g_tune.direct_priority}, {"VDF_MSM_DIRECT_FUSED", &g_tune.direct_fused},
+      {"VDF_MSM_LIGHT_PRIO", &g_tune.light_priority}, {"VDF_MSM_ACC_WG", &g_tune.accumulate_fill}, {"VDF_MSM_ACC_LDS", &g_tune.accumulate_lds},
+      {"VDF_MSM_L", &g_tune.slice_len}, {"VDF_MSM_PB", &g_tune.part_bits}, {"VDF_MSM_RED", &g_tune.reduction},
+      {"VDF_MSM_RED_QUADS", &g_tune.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &g_tune.heavy_min}, {"VDF_MSM_GIANT_SPAN", &g_tune.giant_span},
+      {"VDF_NIFS_LANES", &g_tune.nifs_lanes}, {"VDF_SHIM_CACHE", &g_tune.shim_cache}};
+  for (const auto& v : vars) {
+    const char* e = std::getenv(v.name);
+    if (!e || !*e) continue;
+    const int32_t old = *v.field;
+    *v.field = (int32_t)std::atol(e);
+    if (!tuning_valid(g_tune)) *v.field = old;          // an out-of-range override is ignored, as before
+  }
+}
 }  // namespace
-namespace vdf { thread_local KSink* tl_ksink = nullptr; }
+namespace vdf {
+thread_local KSink* tl_ksink = nullptr;
+const vdf_hip_tuning& tuning() {
+  std::call_once(g_tune_once, tuning_from_env);
+  return g_tune;
+}
+}  // namespace vdf
+extern "C" int vdf_hip_tuning_get(vdf_hip_tuning* out) {
+  if (!out) return VDF_ERR_BAD_ARG;
+  (void)vdf::tuning();
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  *out = g_tune;
+  out->struct_size = (uint32_t)sizeof(vdf_hip_tuning);
+  return VDF_OK;
+}
+extern "C" int vdf_hip_tuning_set(const vdf_hip_tuning* in) {
+  if (!in || in->struct_size != sizeof(vdf_hip_tuning) || !tuning_valid(*in)) return VDF_ERR_BAD_ARG;
+  (void)vdf::tuning();
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  g_tune = *in;
+  return VDF_OK;
+}
 namespace {
 struct SinkScope {            // launches made under this call record into the context's sink (nested calls restore the outer one)
   vdf::KSink* prev;
@@ -149,10 +208,7 @@ Status ensure_ws(vdf_ctx* ctx, size_t bytes) {
 
 // the direct sum is for commitments a host waits on; beyond this many scalars per call the bucket method's throughput wins
 constexpr size_t DIRECT_MAX_SCALARS = (size_t)1 << 17;
-bool direct_enabled() {
-  static const bool on = [] { const char* e = std::getenv("VDF_MSM_DIRECT"); return !(e && e[0] == '0'); }();   // tuning: 0 = bucket method only
-  return on;
-}
+bool direct_enabled() { return vdf::tuning().msm_direct != 0; }       // (tuning: 0 = bucket method only)
 
 size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 
@@ -226,13 +282,13 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
   if (bases->d_table && (ctx->msm_window == 0 || ctx->msm_window == bases->tbl_c)) {
     if (!vdf::msm_plan_feasible(groups, bases->tbl_c, bases->tbl_sets))
       return Status{VDF_ERR_BAD_ARG, "a batch this wide does not fit the sort under this table's window and bucket sets: fewer MSMs per call"};
-    plan = vdf::msm_make_plan(groups, n, offset, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus);
+    plan = vdf::msm_make_plan(groups, n, offset, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus, ctx->acc_fill);
     plan.tstride = (uint32_t)bases->n;
     pts = reinterpret_cast<const char*>(bases->d_table);
   } else {
     int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(nmax);
     while (c > 4 && !vdf::msm_plan_feasible(groups, c, 0)) --c;     // a table-less window is a tuning knob: lowered to what fits
-    plan = vdf::msm_make_plan(groups, n, offset, c, 0, 0, ctx->num_cus);
+    plan = vdf::msm_make_plan(groups, n, offset, c, 0, 0, ctx->num_cus, ctx->acc_fill);
     plan.tstride = 0;
     pts = reinterpret_cast<const char*>(bases->d_pts);
   }
@@ -250,7 +306,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
   }
   hipEvent_t gate = ctx->acc_gate;
   ctx->acc_gate = nullptr;                                      // one-shot
-  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev, nullptr, gate, ctx->light_prio));
+  VDF_TRY(vdf::msm_run(bases->curve, plan, pts, d_scalars, is_mont != 0, ctx->ws, d_out, ctx->stream, ev, nullptr, gate, std::min(ctx->light_prio, (int)vdf::tuning().light_priority)));
   if (ev) ctx->timed.push_back(tc);
   return st.finish();
 }
@@ -306,9 +362,7 @@ uint64_t shim_fingerprint(const vdf_affine* points, size_t n) {
 
 int shim_cache_capacity() {          // caller holds g_shim_mu
   if (g_shim_cap < 0) {
-    const char* ov = std::getenv("VDF_SHIM_CACHE");
-    const long v = ov ? std::atol(ov) : 0;
-    g_shim_cap = v > 0 ? (v > 64 ? 64 : (int)v) : 0;
+    g_shim_cap = vdf::tuning().shim_cache;
   }
   return g_shim_cap;
 }
@@ -382,7 +436,7 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   }
   // a prover keeps several queues busy at once (vdf_nova.h): the runtime's default of 4 hardware queues makes streams share
   // one, and kernels then wait behind another stream's; honoured only when this is the process's first HIP call
-  // -- and set at most once per process (setenv is not safe against a concurrent getenv: a second prover thread making its
+  // -- and set at most once per process (setenv is not safe against concurrent readers of the environment: a second prover thread making its
   // contexts, the runtime's own threads).  A host that makes its first HIP call elsewhere sets the variable itself.
   static std::once_flag hwq_once;
   std::call_once(hwq_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
@@ -650,6 +704,11 @@ int vdf_bases_digit_window(const vdf_bases* bases) { return bases && bases->d_di
 size_t vdf_bases_digit_table_bytes(const vdf_bases* bases) { return bases && bases->d_digits ? bases->dg_bytes : 0; }
 
 int vdf_bases_window(const vdf_bases* bases) { return bases && bases->d_table ? bases->tbl_c : 0; }
+size_t vdf_bases_table_bytes(const vdf_bases* bases) { return bases && bases->d_table ? (size_t)bases->tbl_tables * bases->n * 64 : 0; }
+size_t vdf_digit_table_bytes(int window_bits, size_t generators) {
+  if (window_bits < 4 || window_bits > 12) return 0;
+  return generators * (size_t)vdf::direct_windows(window_bits) * ((size_t)64 << (window_bits - 1));
+}
 
 int vdf_bases_download(vdf_ctx* ctx, const vdf_bases* bases, size_t offset, size_t n, vdf_affine* out) {
   return guarded(ctx, [&]() -> Status {
@@ -718,7 +777,7 @@ int vdf_msm_job_begin(vdf_ctx* ctx, const vdf_bases* bases, int k, const size_t 
     for (int g = 0; g < k; ++g) {
       if (offset[g] > bases->n || n[g] > bases->n - offset[g]) return Status{VDF_ERR_BAD_LENGTH, "offset + n exceeds the generator table"};
       if (n[g] == 0 || n[g] >= (1ull << 27)) return Status{VDF_ERR_BAD_LENGTH, "every vector of a job needs 1 .. 2^27 - 1 elements"};
-      job->plan[g] = vdf::msm_make_plan(1, &n[g], &offset[g], bases->tbl_c, 1, bases->tbl_tables, ctx->num_cus);
+      job->plan[g] = vdf::msm_make_plan(1, &n[g], &offset[g], bases->tbl_c, 1, bases->tbl_tables, ctx->num_cus, ctx->acc_fill);
       job->plan[g].tstride = (uint32_t)bases->n;
       if ((uint64_t)n[g] * job->plan[g].windows >= 0xFFF00000ull) return Status{VDF_ERR_BAD_LENGTH, "n * windows exceeds 32-bit entry positions"};
       job->ws_off[g] = off;
@@ -1317,6 +1376,14 @@ int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
   });
 }
 
+int vdf_ctx_set_accumulate_fill(vdf_ctx* ctx, int workgroups_per_cu) {
+  return guarded(ctx, [&]() -> Status {
+    if (workgroups_per_cu < 0 || workgroups_per_cu > 3) return Status{VDF_ERR_BAD_ARG, "accumulate fill must be 0 (process-wide) or 1..3"};
+    ctx->acc_fill = workgroups_per_cu;
+    return Status{};
+  });
+}
+
 int vdf_ctx_set_light_priority(vdf_ctx* ctx, int priority) {
   return guarded(ctx, [&]() -> Status {
     if (priority < 0 || priority > 3) return Status{VDF_ERR_BAD_ARG, "wave priority is 0..3"};
@@ -1523,6 +1590,16 @@ int vdf_dev_alloc(vdf_ctx* ctx, size_t bytes, void** out) {
     if (!out) return Status{VDF_ERR_BAD_ARG, "null out"};
     *out = nullptr;
     VDF_TRY_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return Status{};
+  });
+}
+
+int vdf_dev_mem_info(vdf_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  return guarded(ctx, [&]() -> Status {
+    size_t f = 0, t = 0;
+    VDF_TRY_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return Status{};
   });
 }

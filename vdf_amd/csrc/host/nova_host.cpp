@@ -227,17 +227,22 @@ int alloc_proof_buffers(vdf_proof* p) {
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
     // the lookahead's commitment is needed a whole step later: its sort and bucket reduction yield to the early rows' (the
-    // step's longest dependent path, priority 3) and to the chain's direct sums (2).  VDF_NOVA_LOOKAHEAD_PRIO=0..3 (tuning)
-    static const int la_prio = [] { const char* e = std::getenv("VDF_NOVA_LOOKAHEAD_PRIO"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
-    HIPCALL(p->ctx2[k], vdf_ctx_set_light_priority(p->ctx2[k], la_prio));
+    // step's longest dependent path, priority 3) and to the chain's direct sums (2).  vdf_nova_tuning.lookahead_priority
+    HIPCALL(p->ctx2[k], vdf_ctx_set_light_priority(p->ctx2[k], pp->tune.lookahead_priority));
+    // both side queues' bucket accumulations share the device with other queues' kernels: a grid sized for all three resident
+    // workgroups per CU (a grid sized for two is packed three-and-one by the dispatcher; r4: 0.917 -> 0.867 ms per step)
+    HIPCALL(p->ctx2[k], vdf_ctx_set_accumulate_fill(p->ctx2[k], pp->tune.side_accumulate_fill));
   }
   {
     const int dev = vdf_ctx_device(ctx);
     if (vdf_ctx_create(&dev, 1, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx3, vdf_ctx_set_async(p->ctx3, 1));
+    HIPCALL(p->ctx3, vdf_ctx_set_accumulate_fill(p->ctx3, pp->tune.side_accumulate_fill));
   }
   HIPCALL(ctx, vdf_host_alloc(ctx, (vdf_proof::RING + 8) * sizeof(vdf_jac), (void**)&p->h_pts));
-  HIPCALL(ctx, vdf_host_alloc(ctx, pp->arity * 32, (void**)&p->h_zin));
+  // two pinned slots: [0, arity) this step's z_in when its early rows start with the step, [arity, 2 arity) the NEXT step's, written
+  // half a step early -- one buffer had two writers whose async copies were not ordered against each other
+  HIPCALL(ctx, vdf_host_alloc(ctx, 2 * pp->arity * 32, (void**)&p->h_zin));
   memset(&p->last, 0, sizeof(p->last));
   return VDF_OK;
 }
@@ -416,6 +421,58 @@ int vdf_nova_synthesis_stats(uint64_t* queued, uint64_t* misses) {
   return VDF_OK;
 }
 
+// ---- tuning --------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace vdfnova {
+bool tuning_valid(const vdf_nova_tuning& t) {
+  auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+  return (t.flags & ~(uint32_t)(VDF_PP_NO_DIGIT_TABLES | VDF_PP_NO_EARLY_ROWS)) == 0 &&
+         (t.digit_window == -1 || t.digit_window == 0 || in(t.digit_window, 6, 12)) && in(t.early_rows, 0, 2) && in(t.stencil, 0, 1) &&
+         in(t.small_window, 6, 16) && in(t.big_window, 12, 20) && in(t.packed_commit, 0, 1) && in(t.lookahead_early, 0, 1) &&
+         in(t.gate_accumulate, 0, 1) && in(t.fold_on_rows, 0, 1) && in(t.nifs_ahead, 0, 1) && in(t.early_row_parts, 1, 3) &&
+         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1);
+}
+const vdf_nova_tuning& default_tuning() {
+  static const vdf_nova_tuning d = [] {
+    vdf_nova_tuning t{};
+    t.struct_size = (uint32_t)sizeof(vdf_nova_tuning);
+    t.flags = 0; t.digit_budget_bytes = (uint64_t)20 << 30; t.digit_window = 0; t.early_rows = 2; t.stencil = 1; t.small_window = 15;
+    t.big_window = 16; t.packed_commit = 1; t.lookahead_early = 1; t.gate_accumulate = 1; t.fold_on_rows = 1; t.nifs_ahead = 1;
+    t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0;
+    // the environment overrides of earlier rounds, read once: the only place the prover looks at the environment for tuning
+    const struct { const char* name; int32_t* field; } vars[] = {
+        {"VDF_NOVA_DIGIT_WINDOW", &t.digit_window}, {"VDF_NOVA_T_AHEAD", &t.early_rows}, {"VDF_NOVA_STENCIL", &t.stencil},
+        {"VDF_NOVA_SMALL_WINDOW", &t.small_window}, {"VDF_NOVA_BIG_WINDOW", &t.big_window}, {"VDF_NOVA_PACKED_COMMIT", &t.packed_commit},
+        {"VDF_NOVA_LOOKAHEAD_EARLY", &t.lookahead_early}, {"VDF_NOVA_GATE", &t.gate_accumulate}, {"VDF_NOVA_FOLD_ON_ROWS", &t.fold_on_rows},
+        {"VDF_NOVA_NIFS_AHEAD", &t.nifs_ahead}, {"VDF_NOVA_T_PARTS", &t.early_row_parts}, {"VDF_NOVA_LOOKAHEAD_PRIO", &t.lookahead_priority},
+        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}};
+    for (const auto& v : vars) {
+      const char* e = env_override(v.name);
+      if (!e || !*e) continue;
+      const int32_t old = *v.field;
+      *v.field = (int32_t)atol(e);
+      if (v.field == &t.digit_window && *v.field == 0) *v.field = -1;            // VDF_NOVA_DIGIT_WINDOW=0 has always meant "none"
+      if (!tuning_valid(t)) *v.field = old;                                     // an out-of-range override is ignored
+    }
+    if (const char* e = env_override("VDF_NOVA_DIGIT_BUDGET_GIB")) { const long g = atol(e); if (g >= 0 && g <= 1024) t.digit_budget_bytes = (uint64_t)g << 30; }
+    return t;
+  }();
+  return d;
+}
+}  // namespace vdfnova
+extern "C" {
+void vdf_nova_tuning_default(vdf_nova_tuning* out) { if (out) *out = default_tuning(); }
+int vdf_nova_pp_tuning(const vdf_pp* pp, vdf_nova_tuning* out) {
+  if (!pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  *out = pp->tune;
+  return VDF_OK;
+}
+int vdf_nova_pp_setup_ms(const vdf_pp* pp, double ms[7]) {
+  if (!pp || !ms) return fail(VDF_ERR_BAD_ARG, "null argument");
+  memcpy(ms, pp->setup_ms, sizeof(pp->setup_ms));
+  return VDF_OK;
+}
+
 // ---- public parameters -------------------------------------------------------------------------------
 int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   return nova_guard([&]() -> int {
@@ -424,17 +481,23 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
   });
 }
 
-static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
-                              vdf_pp** out);
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family,
+                              const vdf_nova_tuning& tune, vdf_pp** out);
 
-int vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, uint32_t flags, vdf_pp** out) {
+int vdf_nova_public_params_tuned(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, const vdf_nova_tuning* tuning, vdf_pp** out) {
   return nova_guard([&]() -> int {
     if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
     if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
       return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
-    if (flags & ~(uint32_t)(VDF_PP_NO_DIGIT_TABLES | VDF_PP_NO_EARLY_ROWS)) return fail(VDF_ERR_BAD_ARG, "unknown flag");
-    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, flags, out);
+    if (tuning && (tuning->struct_size != sizeof(vdf_nova_tuning) || !tuning_valid(*tuning))) return fail(VDF_ERR_BAD_ARG, "tuning: a field is out of range");
+    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, tuning ? *tuning : default_tuning(), out);
   });
+}
+int vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, uint32_t flags, vdf_pp** out) {
+  if (flags & ~(uint32_t)(VDF_PP_NO_DIGIT_TABLES | VDF_PP_NO_EARLY_ROWS)) return fail(VDF_ERR_BAD_ARG, "unknown flag");
+  vdf_nova_tuning tn = default_tuning();
+  tn.flags |= flags;
+  return vdf_nova_public_params_tuned(ctx, t, circuit_kind, gens_family, &tn, out);
 }
 int vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, vdf_pp** out) {
   return vdf_nova_public_params_flags(ctx, t, circuit_kind, gens_family, 0, out);
@@ -444,7 +507,7 @@ int vdf_nova_public_params_custom(vdf_ctx* ctx, const vdf_step_circuit* primary,
   return nova_guard([&]() -> int {
     if (!ctx || !out || !primary || !primary->synthesize || primary->arity == 0 || primary->arity > 64)
       return fail(VDF_ERR_BAD_ARG, "bad argument");
-    return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, 0, out);
+    return public_params_impl(ctx, 0, VDF_CIRCUIT_CUSTOM, primary, gens_family, default_tuning(), out);
   });
 }
 
@@ -549,11 +612,12 @@ static bool minroot_stencil_matches(const HostShape& h, const Field& F, uint64_t
   return true;
 }
 
-static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family, uint32_t flags,
-                              vdf_pp** out) {
+static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family,
+                              const vdf_nova_tuning& tune, vdf_pp** out) {
   if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG && gens_family != VDF_GENS_LABEL_SHAKE)
     return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
+  const double t_start = now_ms();
   // family 2: CommitGens from a label, as nova-snark makes them (PublicParams::setup, src/nova/proof.rs:236)
   static const char GENS_LABEL[] = "vdf-nova-ivc-v1 gens";
   auto make_gens = [&](int curve, size_t start, size_t n, vdf_bases** b) {
@@ -567,6 +631,10 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
   pp->circuit_kind = circuit_kind;
   pp->gens_family = gens_family;
   pp->arity = custom ? custom->arity : 3;
+  pp->tune = tune;
+  double* ms = pp->setup_ms;                       // [0] shapes + digest, [1] shapes to the device, [2] generators, [3] tables, [4] digit tables
+  double mark = t_start;
+  auto lap = [&](int k) -> int { HIPCALL(ctx, vdf_ctx_sync(ctx)); const double now = now_ms(); ms[k] += now - mark; mark = now; return VDF_OK; };
   HostShape sh[2];
   { int rc = build_shapes(t, circuit_kind, sh, custom); if (rc != VDF_OK) return rc; }
   digest_shapes(t, gens_family, sh, pp->digest);
@@ -580,17 +648,16 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     const HostShape& h = sh[PRIMARY];
     size_t best_b = 0, best_n = 0;
     longest_early_run(h, pp->seg_begin, pp->seg_len, pp->arity, &best_b, &best_n);
-    const char* ov = std::getenv("VDF_NOVA_T_AHEAD");                 // tuning: 0 = one cross term, one commitment of T per step
-    if (best_n >= 64 && pp->seg_begin >= pp->arity && !(ov && ov[0] == '0') && !(flags & VDF_PP_NO_EARLY_ROWS)) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
-    pp->ahead_mode = (ov && ov[0] == '1') ? 1 : 2;
+    if (best_n >= 64 && pp->seg_begin >= pp->arity && tune.early_rows != 0 && !(tune.flags & VDF_PP_NO_EARLY_ROWS)) { pp->ahead_row = best_b; pp->ahead_rows = best_n; }
+    pp->ahead_mode = tune.early_rows == 1 ? 1 : 2;
     // the built-in circuits' early rows are a fixed stencil over the rounds' variables: compared with the shape triple by triple
-    // once, here; from then on their cross term reads no sparse matrix (VDF_NOVA_STENCIL=0: the generic kernel, for A/B runs)
+    // once, here; from then on their cross term reads no sparse matrix (tuning.stencil = 0: the generic kernel, for A/B runs)
     const int per = circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
-    const char* sv = std::getenv("VDF_NOVA_STENCIL");
-    if (!custom && pp->ahead_rows == 3 * t + 1 && !(sv && sv[0] == '0') &&
+    if (!custom && pp->ahead_rows == 3 * t + 1 && tune.stencil &&
         minroot_stencil_matches(h, field(side_field(PRIMARY)), t, per, pp->seg_begin, pp->ahead_row))
       pp->stencil_per = per;
   }
+  ms[0] = now_ms() - mark; mark = now_ms();
   for (int s = 0; s < 2; ++s) {
     Side& sd = pp->s[s];
     sd.side = s; sd.field = side_field(s); sd.curve = side_curve(s);
@@ -607,83 +674,96 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     const vdf_fe* vals[3] = {(const vdf_fe*)m[0].vals.data(), (const vdf_fe*)m[1].vals.data(), (const vdf_fe*)m[2].vals.data()};
     const size_t nnz[3] = {m[0].rows.size(), m[1].rows.size(), m[2].rows.size()};
     HIPCALL(ctx, vdf_shape_create(ctx, sd.field, sd.num_cons, sd.ncols, rows, cols, vals, nnz, &sd.shape));
+    { int rc = lap(1); if (rc != VDF_OK) return rc; }
     size_t need = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons, g = 1;
     while (g < need) g <<= 1;                                        // next_pow2(max(vars, cons)), SURVEY.md App. C
     sd.num_gens = g;
     HIPCALL(ctx, make_gens(sd.curve, 0, g, &sd.gens));
-    // window of the fixed-base table by the size of the MSMs taken over it: 2^17 terms and more -> 16 bits, the
-    // ~10^4-term witnesses of an augmented circuit -> 15 (measured: 10, 11, 13 and 15 within 4 %, 15 best)
-    int small_c = 15;
-    if (const char* ov = std::getenv("VDF_NOVA_SMALL_WINDOW")) { const int v = atoi(ov); if (v >= 6 && v <= 16) small_c = v; }   // tuning
-    int big_c = 16;
-    if (const char* ov = std::getenv("VDF_NOVA_BIG_WINDOW")) { const int v = atoi(ov); if (v >= 12 && v <= 20) big_c = v; }       // tuning
-    HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? big_c : small_c, 1));
-    // The commitments a step WAITS for are small: the secondary circuit's witness and cross term (~10^4 terms each), and
-    // on the primary side what the host made of the witness and the rows of T that depend on it.  Their generators get
-    // a digit table (vdf_bases_precompute_digits: a plain sum of gathered multiples, no buckets); the rounds' 2 x 10^5
-    // terms, committed ahead of the step, stay with the bucket method.
-    {
-      // 12-bit digits: 22 windows instead of the 26 of a 10-bit table -- 15 % fewer additions in every direct sum of a step
-      // (0.90 -> 0.87 ms per step: with the device at its issue limit the additions count, not only the latency) for 4 x
-      // the table: 3.3 MB per generator, 42.8 + 34.2 GB at t = 2^16.  A table that does not fit is skipped (below), a host
-      // declines it with VDF_PP_NO_DIGIT_TABLES, VDF_NOVA_DIGIT_WINDOW=10 gives the round-2 size back.
-      int digit_c = 12;
-      if (const char* ov = std::getenv("VDF_NOVA_DIGIT_WINDOW")) {                                   // tuning; 0 = no digit tables
-        const int v = atoi(ov);
-        if (v == 0 || (v >= 6 && v <= 12)) digit_c = v;                                              // anything else: the default stays
-      }
-      if (flags & VDF_PP_NO_DIGIT_TABLES) digit_c = 0;
-      // generator ranges of the commitments a step waits for, as index intervals: the host-made variables before and after
-      // the MinRoot rounds (W) and the rows of T before and after the early rows; merged where they overlap (at most 4)
-      size_t db[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
-      int nr = 0;
-      const size_t top = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons;
-      if (s == SECONDARY || pp->seg_len == 0) { dn[0] = top; nr = 1; }
-      else if (pp->ahead_rows) {
-        const size_t se = pp->seg_begin + pp->seg_len, ae = pp->ahead_row + pp->ahead_rows;
-        std::vector<std::pair<size_t, size_t>> iv = {{0, pp->seg_begin}, {se, sd.num_vars}, {0, pp->ahead_row}, {ae, sd.num_cons}};
-        std::sort(iv.begin(), iv.end());
-        std::vector<std::pair<size_t, size_t>> merged;
-        for (const auto& x : iv) {
-          if (x.second <= x.first) continue;
-          if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
-          else merged.push_back(x);
-        }
-        for (const auto& x : merged) { db[nr] = x.first; dn[nr] = x.second - x.first; ++nr; }
-      }
-      size_t dtot = 0;
-      for (int r = 0; r < nr; ++r) dtot += dn[r];
-      if (digit_c && nr && dtot <= (1u << 16)) {
-        // The digit table is a latency optimisation (852 KB per generator at c = 10: 8.6 + 9.4 GB at t = 2^16), never a
-        // requirement: when it does not fit the free HBM -- a smaller GPU, several parameter sets or chains resident --
-        // or the window is refused, the parameters are made without it and vdf_msm takes the bucket method.
-        const int rc = vdf_bases_precompute_digits(ctx, sd.gens, digit_c, nr, db, dn);
-        if (rc == VDF_ERR_OOM || rc == VDF_ERR_BAD_ARG) {
-          pp->digit_tables_skipped |= 1u << s;
-          if (std::getenv("VDF_NOVA_VERBOSE"))
-            fprintf(stderr, "vdf_nova: no digit table on side %d (%s): commitments take the bucket method\n", s, vdf_last_error(ctx));
-        } else if (rc != VDF_OK) {
-          return fail(rc, std::string("vdf_bases_precompute_digits: ") + vdf_last_error(ctx));
-        } else {
-          pp->digit_table_bytes[s] = vdf_bases_digit_table_bytes(sd.gens);
-        }
-      }
-    }
     vdf_bases* ub = nullptr;
     HIPCALL(ctx, make_gens(sd.curve, g, 1, &ub));
     const int rc = vdf_bases_download(ctx, ub, 0, 1, (vdf_affine*)&sd.gen_u);
     vdf_bases_free(ub);
     if (rc != VDF_OK) return fail(rc, std::string("generator download: ") + vdf_last_error(ctx));
+    { int rc2 = lap(2); if (rc2 != VDF_OK) return rc2; }
+    // window of the fixed-base table by the size of the MSMs taken over it: 2^17 terms and more -> 16 bits, the
+    // ~10^4-term witnesses of an augmented circuit -> 15 (measured: 10, 11, 13 and 15 within 4 %, 15 best)
+    HIPCALL(ctx, vdf_bases_precompute(ctx, sd.gens, g >= (1u << 17) ? tune.big_window : tune.small_window, 1));
+    { int rc2 = lap(3); if (rc2 != VDF_OK) return rc2; }
     HIPCALL(ctx, vdf_dev_alloc(ctx, sd.num_cons * 32, &sd.d_zero));
     HIPCALL(ctx, vdf_dev_memset(ctx, sd.d_zero, 0, sd.num_cons * 32));
     uint64_t dv[4];
     memcpy(dv, pp->digest, 32);
     pp->params[s] = int_to_fe(dv, *sd.F);
   }
-  if (circuit_kind == VDF_CIRCUIT_MINROOT_REFERENCE && pp->seg_len == 4 * t + 1 && !std::getenv("VDF_NOVA_NO_PACKED_COMMIT")) {
+  // the derived generators of the packed commitment and their table come BEFORE the optional digit tables
+  if (circuit_kind == VDF_CIRCUIT_MINROOT_REFERENCE && pp->seg_len == 4 * t + 1 && tune.packed_commit) {
+    mark = now_ms();
     int rc = make_packed_generators(pp.get());
     if (rc != VDF_OK) return rc;
+    { int rc2 = lap(3); if (rc2 != VDF_OK) return rc2; }
   }
+  // The commitments a step WAITS for are small: the secondary circuit's witness and cross term (~10^4 terms each), and
+  // on the primary side what the host made of the witness and the rows of T that depend on it.  Their generators get
+  // a digit table (vdf_bases_precompute_digits: a plain sum of gathered multiples, no buckets); the rounds' 2 x 10^5
+  // terms, committed ahead of the step, stay with the bucket method.  Generator ranges as index intervals: the host-made
+  // variables before and after the MinRoot rounds (W) and the rows of T before and after the early rows; merged where they
+  // overlap (at most 4).
+  mark = now_ms();
+  size_t db[2][4] = {}, dn[2][4] = {}, dtot[2] = {0, 0};
+  int nr[2] = {0, 0};
+  for (int s = 0; s < 2; ++s) {
+    const Side& sd = pp->s[s];
+    const size_t top = sd.num_vars > sd.num_cons ? sd.num_vars : sd.num_cons;
+    if (s == SECONDARY || pp->seg_len == 0) { dn[s][0] = top; nr[s] = 1; }
+    else if (pp->ahead_rows) {
+      const size_t se = pp->seg_begin + pp->seg_len, ae = pp->ahead_row + pp->ahead_rows;
+      std::vector<std::pair<size_t, size_t>> iv = {{0, pp->seg_begin}, {se, sd.num_vars}, {0, pp->ahead_row}, {ae, sd.num_cons}};
+      std::sort(iv.begin(), iv.end());
+      std::vector<std::pair<size_t, size_t>> merged;
+      for (const auto& x : iv) {
+        if (x.second <= x.first) continue;
+        if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
+        else merged.push_back(x);
+      }
+      for (const auto& x : merged) { db[s][nr[s]] = x.first; dn[s][nr[s]] = x.second - x.first; ++nr[s]; }
+    }
+    for (int r = 0; r < nr[s]; ++r) dtot[s] += dn[s][r];
+    if (!(nr[s] && dtot[s] <= (1u << 16))) { nr[s] = 0; dtot[s] = 0; }
+  }
+  // The window: what the caller fixed, or the widest of 12 .. 8 whose tables (both sides) fit the budget -- 20 GiB by default,
+  // i.e. the 10-bit tables at t = 2^16 (19 GB; the 12-bit ones, 65 GB, buy ~2.5 % of a step and are for a host that says so) --
+  // and the free HBM less a reserve for what comes after this call: proof buffers, three MSM workspaces, a second chain's share.
+  int digit_c = (tune.flags & VDF_PP_NO_DIGIT_TABLES) ? -1 : tune.digit_window;
+  if (digit_c == 0) {
+    size_t free_b = 0;
+    HIPCALL(ctx, vdf_dev_mem_info(ctx, &free_b, nullptr));
+    const uint64_t reserve = (uint64_t)4 << 30;
+    const uint64_t room = free_b > reserve ? free_b - reserve : 0;
+    const uint64_t budget = tune.digit_budget_bytes < room ? tune.digit_budget_bytes : room;
+    digit_c = -1;
+    for (int c = 12; c >= 8; --c)
+      if ((uint64_t)vdf_digit_table_bytes(c, dtot[0] + dtot[1]) <= budget) { digit_c = c; break; }
+    if (tune.verbose) fprintf(stderr, "vdf_nova: digit window %d (%zu generators, budget %.1f GiB, free %.1f GiB)\n", digit_c, dtot[0] + dtot[1],
+                              budget / 1073741824.0, free_b / 1073741824.0);
+    if (digit_c < 0) for (int s = 0; s < 2; ++s) if (nr[s]) pp->digit_tables_skipped |= 1u << s;
+  }
+  for (int s = 0; s < 2 && digit_c > 0; ++s) {
+    if (!nr[s]) continue;
+    // never a requirement: when it does not fit the free HBM or the window is refused, the parameters are made without
+    // it and vdf_msm takes the bucket method
+    const int rc = vdf_bases_precompute_digits(ctx, pp->s[s].gens, digit_c, nr[s], db[s], dn[s]);
+    if (rc == VDF_ERR_OOM || rc == VDF_ERR_BAD_ARG) {
+      pp->digit_tables_skipped |= 1u << s;
+      if (tune.verbose) fprintf(stderr, "vdf_nova: no digit table on side %d (%s): commitments take the bucket method\n", s, vdf_last_error(ctx));
+    } else if (rc != VDF_OK) {
+      return fail(rc, std::string("vdf_bases_precompute_digits: ") + vdf_last_error(ctx));
+    } else {
+      pp->digit_table_bytes[s] = vdf_bases_digit_table_bytes(pp->s[s].gens);
+    }
+  }
+  { int rc2 = lap(4); if (rc2 != VDF_OK) return rc2; }
+  ms[6] = now_ms() - t_start;
+  ms[5] = ms[6] - (ms[0] + ms[1] + ms[2] + ms[3] + ms[4]);
   *out = pp.release();
   return VDF_OK;
 }
@@ -712,9 +792,10 @@ int vdf_nova_pp_memory(const vdf_pp* pp, uint64_t gens_bytes[2], uint64_t table_
   if (!pp) return fail(VDF_ERR_BAD_ARG, "null argument");
   for (int s = 0; s < 2; ++s) {
     const Side& sd = pp->s[s];
-    const int c = vdf_bases_window(sd.gens);
-    if (gens_bytes) gens_bytes[s] = (uint64_t)sd.num_gens * 64;
-    if (table_bytes) table_bytes[s] = c ? (uint64_t)sd.num_gens * 64 * ((255 + c - 1) / c) : 0;
+    // sizes as the library holds them (tables x generators x 64 B); the primary side includes the packed commitment's derived generators
+    const vdf_bases* extra = s == PRIMARY ? pp->seg_gens : nullptr;
+    if (gens_bytes) gens_bytes[s] = ((uint64_t)sd.num_gens + (extra ? vdf_bases_len(extra) : 0)) * 64;
+    if (table_bytes) table_bytes[s] = (uint64_t)vdf_bases_table_bytes(sd.gens) + (extra ? vdf_bases_table_bytes(extra) : 0);
     if (digit_bytes) digit_bytes[s] = pp->digit_table_bytes[s];
   }
   if (skipped) *skipped = pp->digit_tables_skipped;
@@ -896,10 +977,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
   enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6, MARK_ZIN = 7 };
   int zin_slot = -1;                   // ring slot whose z_in this step has already uploaded (for the next step's early rows)
-  // (tuning) VDF_NOVA_FOLD_ON_ROWS=0: the primary fold on the main queue, the early rows waiting for its mark
-  static const bool fold_on_rows = [] { const char* e = std::getenv("VDF_NOVA_FOLD_ON_ROWS"); return !(e && e[0] == '0'); }();
+  // (tuning.fold_on_rows = 0: the primary fold on the main queue, the early rows waiting for its mark)
+  const bool fold_on_rows = pp->tune.fold_on_rows != 0;
   bool fold_elsewhere = false;        // the primary fold ran on the early rows' queue: the main queue waits for it before the step ends
   std::function<int()> rows_deferred;  // the launches of the next step's early rows: set up behind the fold, issued after the NIFS's
+  int rows_deferred_slot = -1;
   bool gate_next_segment = false;     // the next enqueue_segment holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
   const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
@@ -974,9 +1056,9 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   const bool t_ahead = !first && !custom && pp->ahead_rows != 0;
   const size_t ta_b = pp->ahead_row, ta_n = pp->ahead_rows, ta_e = ta_b + ta_n;
   vdf_ctx* ct = p->ctx3;
-  // (tuning) VDF_NOVA_T_PARTS=2 or 3: the early rows as an MSM job of that many parts (vdf_msm_job_*): a later part's rows and sort
-  // run under an earlier part's bucket accumulation, one shared bucket reduction.  Measured r3: 1.10 ms per step against 0.95 as ONE MSM (default)
-  static const int t_parts = [] { const char* e = std::getenv("VDF_NOVA_T_PARTS"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 3 ? v : 1; }();
+  // (tuning.early_row_parts = 2 or 3: the early rows as an MSM job of that many parts (vdf_msm_job_*): a later part's rows and sort
+  // run under an earlier part's bucket accumulation, one shared bucket reduction.  Measured r3: 1.10 ms per step against 0.95 as ONE MSM, the default)
+  const int t_parts = pp->tune.early_row_parts;
   auto early_rows = [&](void* d_z2, vdf_ctx* cq, bool zin_in_place) -> int {            // for the step whose fresh witness lives in d_z2
     SideState& s1 = p->r[PRIMARY];
     HIPCALL(ct, vdf_ctx_wait_mark(ct, cq, MARK_Z));                 // the rounds are in place (written a step ago, normally)
@@ -1104,8 +1186,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       // the NEXT step's z_in = this step's output, known now: into its place in the next ring slot's fresh witness, half a
       // step before the early rows of that step read it
       zin_slot = (slot + 1) % R;
-      memcpy(p->h_zin, z_next.data(), arity * 32);
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[zin_slot] + (seg_b - arity) * 32, p->h_zin, arity * 32));
+      memcpy(p->h_zin + arity, z_next.data(), arity * 32);          // the second pinned slot (the first may still feed this step's early rows)
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[zin_slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
       HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
     }
     l1.X[0] = cs.X[0]; l1.X[1] = cs.X[1];
@@ -1143,8 +1225,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     }
     HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
     // the lookahead launched under this wait sorts beside these commitments but holds its bucket accumulation -- every SIMD
-    // for 0.25 ms -- until they are done: it then runs while the host synthesises the secondary circuit (VDF_NOVA_GATE=0: no hold)
-    static const bool gate = [] { const char* e = std::getenv("VDF_NOVA_GATE"); return !(e && e[0] == '0'); }();
+    // for 0.25 ms -- until they are done: it then runs while the host synthesises the secondary circuit (tuning.gate_accumulate = 0: no hold)
+    const bool gate = pp->tune.gate_accumulate != 0;
     if (gate && !first && !custom) { HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_PRIMARY)); gate_next_segment = true; }
     if (!first) {
       // behind the primary side's launches (it does not depend on them, they do not wait for it): the fold of the secondary
@@ -1161,8 +1243,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     // The next step's MinRoot rounds and their commitment go to the second queue NOW, under this wait: their dozen launches
     // cost the chain nothing here, and their 0.65 ms are over that much sooner (they are the next step's primary
     // commitment; back to back the device is the co-bottleneck).  This step's own rounds were committed a step ago; their
-    // mark is waited for first, because the launch reuses it.  (VDF_NOVA_LOOKAHEAD_EARLY=0: launched after the wait.)
-    static const bool la_early = [] { const char* e = std::getenv("VDF_NOVA_LOOKAHEAD_EARLY"); return !(e && e[0] == '0'); }();
+    // mark is waited for first, because the launch reuses it.  (tuning.lookahead_early = 0: launched after the wait.)
+    const bool la_early = pp->tune.lookahead_early != 0;
     if (la_early && !first && !custom) {
       if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
       waited_w = true;
@@ -1211,12 +1293,12 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
     early2.reset();
     t5 = now_ms();
-    static const bool ahead_rows = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
+    const bool ahead_rows = pp->tune.nifs_ahead != 0;
     const bool rows_next = ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
     if (rows_next && p->ahead[0].slot != zin_slot) {
       // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
-      memcpy(p->h_zin, p->zi[PRIMARY].data(), arity * 32);
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin, arity * 32));
+      memcpy(p->h_zin + arity, p->zi[PRIMARY].data(), arity * 32);   // (this thread has waited for the primary side's launches: the slot's last copy is over)
+      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
       HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
     }
     // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
@@ -1251,7 +1333,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
         return early_rows(d_next, cq_next, true);
       };
       fold_elsewhere = fq != ctx;
-      p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
+      rows_deferred_slot = p->ahead[0].slot;                         // (tahead_* are set once the rows are really on their queue)
       rows_deferred = launch_rows;
     }
     int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
@@ -1266,8 +1348,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   t6 = now_ms();
   // the staging buffers are rewritten by the next call: their copies must have left (a mark), and nothing in flight may
   // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
-  // needs nothing of the next step: the NIFS of the secondary instance just made (VDF_NOVA_NIFS_AHEAD=0: left to the next call)
-  static const bool ahead = [] { const char* e = std::getenv("VDF_NOVA_NIFS_AHEAD"); return !(e && e[0] == '0'); }();
+  // needs nothing of the next step: the NIFS of the secondary instance just made (tuning.nifs_ahead = 0: left to the next call)
+  const bool ahead = pp->tune.nifs_ahead != 0;
   HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_STEP));
   if (ahead) {
     int rc = launch_nifs2();
@@ -1275,7 +1357,11 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
   }
   if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
-  if (rows_deferred) { int rc = rows_deferred(); if (rc != VDF_OK) return rc; }
+  if (rows_deferred) {
+    int rc = rows_deferred();
+    if (rc != VDF_OK) return rc;                  // tahead_valid stays false: a retried step launches its rows itself
+    p->tahead_valid = true; p->tahead_slot = rows_deferred_slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
+  }
   HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
   for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
   p->i += 1;

@@ -96,6 +96,8 @@ struct vdf_pp {
   // the reference's step circuit only: generators of the packed commitment to the MinRoot rounds (3t + 4 points derived from
   // the 4t + 1 of the segment: vdf_hip.h vdf_minroot_step_segment_packed), with a fixed-base table of their own
   vdf_bases* seg_gens = nullptr;
+  vdf_nova_tuning tune;                    // the tuning this set was made with, and that its prover runs with
+  double setup_ms[7] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t digit_table_bytes[2] = {0, 0};  // HBM held by each side's digit table (vdf_nova_pp_memory)
   unsigned digit_tables_skipped = 0;       // bit s: side s asked for a digit table and went without (no room, refused window)
 };
@@ -163,6 +165,8 @@ struct vdf_proof {
 };
 
 namespace vdfnova {
+const vdf_nova_tuning& default_tuning();   // defaults + the VDF_NOVA_* environment overrides, read once
+bool tuning_valid(const vdf_nova_tuning& t);
 int alloc_proof_buffers(vdf_proof* p);
 int finalize_l2(const vdf_proof* p);      // commits to the last secondary witness if that is still pending
 std::unique_ptr<StepCircuit> make_primary_circuit(const vdf_pp* pp, const Circuit* c, bool device_rounds);

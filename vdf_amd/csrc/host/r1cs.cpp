@@ -1025,7 +1025,7 @@ struct AugEarly {
 void aug_early_free(AugEarly* e) { delete e; }
 
 AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const StepCircuit& step) {
-  static const bool trace = [] { const char* e = std::getenv("VDF_NOVA_SYNTH_TRACE"); return e && e[0] == '1'; }();
+  static const bool trace = [] { const char* e = env_override("VDF_NOVA_SYNTH_TRACE"); return e && e[0] == '1'; }();
   const auto T0 = std::chrono::steady_clock::now();
   AugEarlyPtr e(new AugEarly(), aug_early_free);
   const int fid = side_field(side);
@@ -1087,7 +1087,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   const int fid = cs.field_id;
   const size_t a = step.arity();
   const Fe ONE = one(F), ZERO = vdfhost::zero();
-  static const bool trace = [] { const char* e = std::getenv("VDF_NOVA_SYNTH_TRACE"); return e && e[0] == '1'; }();
+  static const bool trace = [] { const char* e = env_override("VDF_NOVA_SYNTH_TRACE"); return e && e[0] == '1'; }();
   const auto T0 = std::chrono::steady_clock::now();
   auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
   double tr[8] = {0};
@@ -1242,7 +1242,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
 
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out, uint64_t* r_out,
                                      AugEarly* early) {
-  static const bool sequential = [] { const char* e = std::getenv("VDF_NOVA_SEQ_SYNTH"); return e && e[0] == '1'; }();
+  static const bool sequential = [] { const char* e = env_override("VDF_NOVA_SEQ_SYNTH"); return e && e[0] == '1'; }();
   if (!cs.shape && !sequential) return synthesize_augmented_blocks(cs, side, in, step, unew_out, r_out, early);
   const Field& F = cs.F;
   const Field& PF = field(side_field(1 - side));

@@ -7,6 +7,7 @@
 // One code path serves both uses of a circuit: SHAPE mode records the R1CS matrices (public_params, once), WITNESS
 // mode only computes the variable assignment (every prove_step) -- linear combinations are then empty and cost nothing.
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -14,6 +15,11 @@
 
 namespace vdfnova {
 using namespace vdfhost;
+
+// the one place libvdf_nova.so reads the environment: tuning overrides (default_tuning, once) and two debugging switches of
+// the synthesis (VDF_NOVA_SYNTH_TRACE, VDF_NOVA_SEQ_SYNTH), each read once into a static
+inline const char* env_override(const char* name) { return std::getenv(name); }
+
 
 // variable keys: W index k -> k; the constant column -> KEY_ONE; public IO k -> KEY_ONE + 1 + k.  Ascending key order is
 // the column order of z = (W, u, X).

@@ -38,6 +38,8 @@ struct KTimer {
 };
 }  // namespace vdf
 
+namespace vdf { const vdf_hip_tuning& tuning(); }     // process-wide tuning (abi.hip), environment overrides applied once
+
 struct vdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -70,6 +72,7 @@ struct vdf_ctx {
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};
   bool job_open = false;
   void* reduce_scratch = nullptr;    // per-workgroup partial sums of vdf_reduce
+  int acc_fill = 0;                  // accumulate workgroups per CU this context's MSMs fill (vdf_ctx_set_accumulate_fill; 0 = process-wide)
   int light_prio = 3;                // wave priority of this context's sort / bucket-reduction kernels (vdf_ctx_set_light_priority)
   hipEvent_t acc_gate = nullptr;     // one-shot: the next bucket-method MSM's accumulation waits for this event (vdf_ctx_gate_accumulate)
   uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
@@ -176,7 +179,7 @@ struct MsmPlan {
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)
   size_t ws_bytes = 0;
 };
-MsmPlan msm_make_plan(int groups, const size_t* n, const size_t* offsets, int c, int sets, int tables, int num_cus);
+MsmPlan msm_make_plan(int groups, const size_t* n, const size_t* offsets, int c, int sets, int tables, int num_cus, int acc_fill = 0);
 inline MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
   const size_t zero = 0;
   return msm_make_plan(1, &n, &zero, c, sets, tables, num_cus);

@@ -47,24 +47,13 @@ static constexpr uint32_t SIGN_BIT = 0x80000000u;
 // grid that keeps every SIMD's issue port busy.  When two MSMs run on two streams (prove_step commits W and T
 // side by side) the light kernels of one would starve behind the other's accumulate waves, which the
 // oldest-first arbiter favours; a raised wave priority lets them through.
-// Wave priority of the pipeline's light kernels (sort, fix-up, bucket reduction): above the bucket accumulation (0), and --
-// VDF_MSM_LIGHT_PRIO=2 -- optionally below the short kernels a prover's main queue waits for (3).
-__constant__ int c_light_prio = 3;
+// Wave priority of the pipeline's light kernels (sort, fix-up, bucket reduction): above the bucket accumulation (0); a
+// context lowers its own (vdf_ctx_set_light_priority), the process-wide ceiling is vdf_hip_tuning.light_priority -- both
+// are folded into the `wave_prio` argument on the host (msm_run).
 __device__ __forceinline__ void raise_wave_priority(int wave_prio = 3) {
-  const int p = wave_prio < c_light_prio ? wave_prio : c_light_prio;
-  if (p >= 3) __builtin_amdgcn_s_setprio(3);
-  else if (p == 2) __builtin_amdgcn_s_setprio(2);
-  else if (p == 1) __builtin_amdgcn_s_setprio(1);
-}
-static void init_light_prio() {
-  static const bool done = [] {
-    if (const char* e = std::getenv("VDF_MSM_LIGHT_PRIO")) {
-      const int v = atoi(e);
-      if (v >= 0 && v <= 3) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_light_prio), &v, sizeof(int));
-    }
-    return true;
-  }();
-  (void)done;
+  if (wave_prio >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
 }
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
 static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many: two waves per SIMD already issue at ~99 % of three,
@@ -106,11 +95,7 @@ struct RedGeom { uint32_t seg, threads_per_set, block, blocks_per_set; };
 static RedGeom red_geom(size_t nkeys, uint32_t nbk) {
   RedGeom r;
   uint32_t seg = 2;                            // buckets per quad in k_reduce1 (serial depth 2*seg), power of two
-  uint32_t quads = RED_QUADS;
-  if (const char* ov = std::getenv("VDF_MSM_RED_QUADS")) {              // tuning override
-    const long v = std::atol(ov);
-    if (v >= 64 && v <= 65536) quads = (uint32_t)v;
-  }
+  const uint32_t quads = tuning().reduction_quads ? (uint32_t)tuning().reduction_quads : RED_QUADS;
   while (seg < 64 && nkeys / seg > quads) seg <<= 1;
   if (seg > nbk) seg = nbk;
   r.seg = seg;
@@ -151,8 +136,7 @@ static MatGeom mat_geom(size_t gsets, uint32_t nbk) {
   return g;
 }
 static bool use_matrix_reduction(uint32_t nbk) {
-  static const int mode = [] { const char* ov = std::getenv("VDF_MSM_RED"); return ov ? std::atoi(ov) : 1; }();   // tuning override: 0 = segments
-  return mode != 0 && nbk >= 16;
+  return tuning().reduction != 0 && nbk >= 16;         // (tuning: 0 = segments)
 }
 
 static WsLayout ws_layout(const MsmPlan& p) {
@@ -203,7 +187,7 @@ bool msm_plan_feasible(int groups, int c, int sets) {
   return ((uint64_t)groups * sets << (over > 0 ? over : 0)) <= 8192u;
 }
 
-MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus) {
+MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus, int acc_fill) {
   MsmPlan p;
   p.groups = groups;
   size_t n = 0, nmax = 0;
@@ -227,7 +211,7 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // fine bits <= 10 (one thread per fine bucket in k_fine)
   p.pb = 0;
   while (p.pb < c - 1 && ((uint32_t)p.gsets << p.pb) < (uint32_t)num_cus) ++p.pb;
-  if (const char* ov = std::getenv("VDF_MSM_PB")) { int v = std::atoi(ov); if (v >= 0 && v <= c - 1) p.pb = v; }   // tuning override
+  if (tuning().part_bits >= 0 && tuning().part_bits <= c - 1) p.pb = tuning().part_bits;      // tuning override
   while (c - 1 - p.pb > 10) ++p.pb;
   while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) --p.pb;
   p.fb = c - 1 - p.pb;
@@ -248,11 +232,8 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // single workgroup more costs a whole extra round.  So: one round, every slot used, L = ceil(entries / slots)
   // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
-  int acc_wg = ACC_WG_FILL;
-  if (const char* ov = std::getenv("VDF_MSM_ACC_WG")) {                 // tuning override: resident workgroups per CU to fill
-    const long v = std::atol(ov);
-    if (v >= 1 && v <= ACC_WG_PER_CU) acc_wg = (int)v;
-  }
+  int acc_wg = acc_fill ? acc_fill : tuning().accumulate_fill;         // the context's choice, else the process-wide one
+  if (acc_wg < 1 || acc_wg > ACC_WG_PER_CU) acc_wg = ACC_WG_FILL;
   const size_t slots = (size_t)num_cus * acc_wg * 256;
   size_t L = (ne + slots - 1) / slots;           // upper bound: the kernels shorten it to the actual entry count
   if (L < 8) L = 8;
@@ -260,9 +241,9 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.Lfixed = 0;
   p.slots = (uint32_t)slots;
   p.nthreads = (uint32_t)slots;
-  if (const char* ov = std::getenv("VDF_MSM_L")) {                      // tuning override: a fixed slice length
-    long v = std::atol(ov);
-    if (v >= 1 && v <= 65536) { p.L = p.Lfixed = (uint32_t)v; p.nthreads = (uint32_t)((ne + v - 1) / v); if (p.nthreads < 1) p.nthreads = 1; }
+  if (tuning().slice_len >= 1 && tuning().slice_len <= 65536) {          // tuning override: a fixed slice length
+    const long v = tuning().slice_len;
+    p.L = p.Lfixed = (uint32_t)v; p.nthreads = (uint32_t)((ne + v - 1) / v); if (p.nthreads < 1) p.nthreads = 1;
   }
   p.ws_bytes = ws_layout(p).total;
   return p;
@@ -605,8 +586,8 @@ __host__ __device__ __forceinline__ HeavyLayout heavy_layout(uint32_t* heavy, ui
 struct FixupTune { uint32_t heavy_min, giant_span; };
 static FixupTune fixup_tune() {                                     // tuning overrides
   FixupTune t{HEAVY_MIN, GIANT_SPAN};
-  if (const char* e = std::getenv("VDF_MSM_HEAVY_MIN")) { const long v = std::atol(e); if (v >= 1 && v <= 4096) t.heavy_min = (uint32_t)v; }
-  if (const char* e = std::getenv("VDF_MSM_GIANT_SPAN")) { const long v = std::atol(e); if (v >= 16 && v <= (1 << 20)) t.giant_span = (uint32_t)v; }
+  if (tuning().heavy_min >= 1 && tuning().heavy_min <= 4096) t.heavy_min = (uint32_t)tuning().heavy_min;
+  if (tuning().giant_span >= 16 && tuning().giant_span <= (1 << 20)) t.giant_span = (uint32_t)tuning().giant_span;
   return t;
 }
 
@@ -1197,7 +1178,6 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   }
   const size_t lds_bins = (size_t)p.bins * 4;
 
-  init_light_prio();
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[0], st));
   // pass A
   {
@@ -1218,15 +1198,15 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   if (acc_gate) VDF_TRY_HIP(hipStreamWaitEvent(st, acc_gate, 0));
   {
   KTimer kt(st, "k_accumulate", 96.0 * p.n);            // the pipeline's algorithmic bytes: 96 B per (base, scalar) pair, SURVEY.md 8d
-  // (tuning) VDF_MSM_ACC_LDS=bytes: unused dynamic LDS per workgroup, which caps how many accumulate workgroups a CU
+  // (tuning) vdf_hip_tuning.accumulate_lds: unused dynamic LDS per workgroup, which caps how many accumulate workgroups a CU
   // takes (160 KB per CU: 54 KB -> two) whatever their register count allows -- the dispatcher then cannot pack three onto
   // one CU and one onto another when other queues hold slots (a CU with three takes 1.5 x as long: the launch's tail)
-  static const unsigned acc_lds = [] { const char* e = std::getenv("VDF_MSM_ACC_LDS"); const long v = e ? std::atol(e) : 0; return (unsigned)(v >= 0 && v <= 65536 ? v : 0); }();
+  const unsigned acc_lds = (unsigned)(tuning().accumulate_lds >= 0 && tuning().accumulate_lds <= 65536 ? tuning().accumulate_lds : 0);
   hipLaunchKernelGGL((k_accumulate<P>), dim3((p.nthreads + 255) / 256), dim3(256), acc_lds, st, sorted, bstart, nkeys,
                      reinterpret_cast<const uint32_t*>(base + w.tstart), reinterpret_cast<const char*>(d_points), bucket_acc, heads, p.slots, p.Lfixed, p.nthreads);
   }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
-  static const FixupTune tune = fixup_tune();
+  const FixupTune tune = fixup_tune();
   KTimer kt_tail(st, ext_bucket_acc ? "msm_fixup(2 launches)" : "msm_tail(fixup+reduce)", 0.0);
   hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
                      heavy, tune.heavy_min, tune.giant_span, prio);

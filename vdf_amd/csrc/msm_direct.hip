@@ -141,12 +141,14 @@ struct DirectArgs {
 // MSM pipeline (3).  A prover's direct sums are its main queue's, but the longest dependent path of a step runs through the
 // side queue that commits the early rows of the cross term (sort, accumulation, bucket reduction): at equal priority the
 // direct sum's one wavefront per SIMD takes half of the issue slots those latency-bound kernels need.  Measured r3, one box:
-// 0.942 ms per step at 3, 0.906 at 2, 0.910 at 1, 0.902 at 0 (VDF_MSM_DIRECT_PRIO=0..3).
-__constant__ int c_direct_prio = 2;
+// 0.942 ms per step at 3, 0.906 at 2, 0.910 at 1, 0.902 at 0 (vdf_hip_tuning.direct_priority, a kernel argument).
+// fused = 0 (vdf_hip_tuning.direct_fused, or no arrival counters): the launch ends with the workgroup points and
+// k_direct_final adds them up.
 template <class P, class SP>
 __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, int c, int W, const char* __restrict__ D,
-                                                    char* __restrict__ partials, uint32_t* __restrict__ arrived, char* __restrict__ out) {
-  { const int p_ = c_direct_prio; if (p_ >= 3) __builtin_amdgcn_s_setprio(3); else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else if (p_ == 1) __builtin_amdgcn_s_setprio(1); }
+                                                    char* __restrict__ partials, uint32_t* __restrict__ arrived, char* __restrict__ out,
+                                                    int wave_prio, int fused) {
+  if (wave_prio >= 3) __builtin_amdgcn_s_setprio(3); else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2); else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
   __shared__ uint32_t limbs[9 * 256];                              // k + H, one private column per thread
   __shared__ __align__(16) char pts[256 * 128];
   __shared__ uint32_t ticket;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
     if (live_wave) qpoint_store<P>(partials + (size_t)blockIdx.x * 128, t);
     __threadfence();                                               // the point is visible device-wide before the ticket is taken
   }
+  if (!fused) return;                                              // (uniform: a kernel argument) k_direct_final follows
   // The group's LAST workgroup to get here adds up the group's workgroup points (what a second launch, k_direct_final,
   // did before: one launch and its start-up less on a path the prover waits on -- the pattern of msm.hip's giant buckets).
   // The counter is left at zero for the next call.
@@ -321,21 +324,6 @@ size_t direct_ws_bytes(int groups, const size_t* n, int c, int num_cus) {
   return ((size_t)direct_geom(groups, n, direct_windows(c), num_cus).total_wgs + 1) * 128;
 }
 
-static void init_direct_prio() {
-  static const bool done = [] {
-    if (const char* e = std::getenv("VDF_MSM_DIRECT_PRIO")) {
-      const int v = atoi(e);
-      if (v >= 0 && v <= 3) (void)hipMemcpyToSymbol(HIP_SYMBOL(c_direct_prio), &v, sizeof(int));
-    }
-    return true;
-  }();
-  (void)done;
-}
-static bool fused_final() {          // VDF_MSM_DIRECT_FUSED=0: the final sum as a launch of its own (tuning / A-B measurements)
-  static const bool on = [] { const char* e = std::getenv("VDF_MSM_DIRECT_FUSED"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 template <class P, class SP>
 static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, const void* const* d_scalars, bool is_mont, int c,
                            int num_cus, const void* d_digits, void* ws, void* d_out, uint32_t* arrived, hipStream_t st) {
@@ -357,15 +345,16 @@ static Status direct_run_t(int groups, const size_t* n, const size_t* slot0, con
   for (int j = 0; j < W; ++j) { const int bit = c * j + c - 1; a.half[bit >> 5] |= 1u << (bit & 31); }
   double nsum = 0;
   for (int g = 0; g < groups; ++g) nsum += (double)n[g];
-  init_direct_prio();
+  const int fused = (arrived && tuning().direct_fused) ? 1 : 0;
   bool empty_group = false;
   for (int g = 0; g < groups; ++g) empty_group |= geo.waves[g] == 0;
   if (waves) {
     KTimer kt(st, "k_direct_sum", 96.0 * nsum);         // a commitment's algorithmic bytes: 96 B per (base, scalar) pair
     hipLaunchKernelGGL((k_direct_sum<P, SP>), dim3(waves / 4), dim3(256), 0, st, a, is_mont ? 1 : 0, c, W,
-                       reinterpret_cast<const char*>(d_digits), reinterpret_cast<char*>(ws), arrived, reinterpret_cast<char*>(d_out));
+                       reinterpret_cast<const char*>(d_digits), reinterpret_cast<char*>(ws), arrived, reinterpret_cast<char*>(d_out),
+                       tuning().direct_priority, fused);
   }
-  if (empty_group || !arrived || !fused_final()) {     // a group without scalars has no workgroup to write its identity: the second launch does
+  if (empty_group || !fused) {     // a group without scalars has no workgroup to write its identity: the second launch does
     KTimer kt(st, "k_direct_final", 0.0);
     hipLaunchKernelGGL((k_direct_final<P>), dim3(groups), dim3(256), 0, st, a, reinterpret_cast<const char*>(ws),
                        reinterpret_cast<char*>(d_out));

@@ -548,8 +548,8 @@ Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
   // lanes per row: 8 for the ~10^4 rows a step waits for (latency), 4 for long runs of short rows (the MinRoot rounds: all
-  // gathers of a row at once), 1 = the lane-per-row kernel.  VDF_NIFS_LANES=1|4|8 forces one (tuning / A-B measurements).
-  static const int forced = [] { const char* e = std::getenv("VDF_NIFS_LANES"); return e ? atoi(e) : 0; }();
+  // gathers of a row at once), 1 = the lane-per-row kernel.  vdf_hip_tuning.nifs_lanes = 1 | 4 | 8 forces one (tuning / A-B measurements).
+  const int forced = tuning().nifs_lanes;
   const int lpr = forced == 1 || forced == 4 || forced == 8 ? forced : (rows <= (1u << 15) ? 8 : 1);
   KTimer kt(s, lpr == 1 ? "k_nifs_cross" : (lpr == 4 ? "k_nifs_cross_w4" : "k_nifs_cross_w8"), alg_bytes);
   if (lpr == 1) {

@@ -13,6 +13,34 @@ from . import _lib
 from ._lib import lib, CURVE_PALLAS, CURVE_VESTA, FIELD_FP, FIELD_FQ  # noqa: F401
 
 
+class HipTuning(C.Structure):
+    """vdf_hip_tuning (include/vdf_hip.h): process-wide tuning of the kernels."""
+    _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in (
+        "msm_direct", "direct_priority", "direct_fused", "light_priority", "accumulate_fill", "accumulate_lds", "slice_len", "part_bits",
+        "reduction", "reduction_quads", "heavy_min", "giant_span", "nifs_lanes", "shim_cache")]
+
+
+def tuning_get() -> HipTuning:
+    t = HipTuning()
+    rc = lib.vdf_hip_tuning_get(C.byref(t))
+    if rc != 0:
+        raise VdfError(rc, "vdf_hip_tuning_get")
+    return t
+
+
+def tuning_set(**fields) -> HipTuning:
+    """Changes the named fields of the process-wide tuning; returns the values now in force."""
+    t = tuning_get()
+    for k, v in fields.items():
+        if k not in dict(HipTuning._fields_):
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    rc = lib.vdf_hip_tuning_set(C.byref(t))
+    if rc != 0:
+        raise VdfError(rc, "vdf_hip_tuning_set: a field is out of range")
+    return t
+
+
 class VdfError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"vdf_hip error {code}: {msg}")
@@ -220,6 +248,10 @@ class Context:
         """Work enqueued on this context from now on starts after `other` has reached its mark `slot` (not after what
         `other` was given since)."""
         self._check(lib.vdf_ctx_wait_mark(self.handle, other.handle, slot))
+
+    def set_accumulate_fill(self, workgroups_per_cu: int) -> None:
+        """Resident accumulation workgroups per CU this context's bucket-method MSMs fill (1..3; 0 = the process-wide value)."""
+        self._check(lib.vdf_ctx_set_accumulate_fill(self.handle, workgroups_per_cu))
 
     def set_msm_window(self, c: int) -> None:
         self._check(lib.vdf_ctx_set_msm_window(self.handle, c))

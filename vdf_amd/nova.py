@@ -18,6 +18,10 @@ for _name, _res, _args in [
     ("vdf_nova_public_params", _i, [_vp, _u64, C.POINTER(_vp)]),
     ("vdf_nova_public_params_ex", _i, [_vp, _u64, _i, _i, C.POINTER(_vp)]),
     ("vdf_nova_public_params_flags", _i, [_vp, _u64, _i, _i, C.c_uint, C.POINTER(_vp)]),
+    ("vdf_nova_public_params_tuned", _i, [_vp, _u64, _i, _i, _vp, C.POINTER(_vp)]),
+    ("vdf_nova_tuning_default", None, [_vp]),
+    ("vdf_nova_pp_tuning", _i, [_vp, _vp]),
+    ("vdf_nova_pp_setup_ms", _i, [_vp, C.POINTER(C.c_double * 7)]),
     ("vdf_nova_pp_memory", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint)]),
     ("vdf_nova_pp_free", None, [_vp]),
     ("vdf_nova_pp_sizes", _i, [_vp, _i] + [C.POINTER(_u64)] * 5),
@@ -87,6 +91,27 @@ INST_RUNNING_PRIMARY, INST_RUNNING_SECONDARY, INST_FRESH_SECONDARY, INST_FRESH_P
 GENS_KNOWN_DLOG, GENS_TRY_AND_INCREMENT, GENS_LABEL_SHAKE = 0, 1, 2
 PP_NO_DIGIT_TABLES, PP_NO_EARLY_ROWS = 1, 2
 KERNEL_EVENT_DTYPE = np.dtype([("name", "S24"), ("bytes", "<f8"), ("start_ms", "<f8"), ("end_ms", "<f8")])     # vdf_kernel_event
+
+
+class NovaTuning(C.Structure):
+    """vdf_nova_tuning (include/vdf_nova.h): everything tunable about a parameter set and the prover over it."""
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("digit_budget_bytes", C.c_uint64)] + [(k, C.c_int32) for k in (
+        "digit_window", "early_rows", "stencil", "small_window", "big_window", "packed_commit", "lookahead_early", "gate_accumulate",
+        "fold_on_rows", "nifs_ahead", "early_row_parts", "lookahead_priority", "side_accumulate_fill", "verbose")]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def tuning_default(**fields) -> NovaTuning:
+    """The library's defaults (environment overrides applied once per process), with the named fields replaced."""
+    t = NovaTuning()
+    nova_lib.vdf_nova_tuning_default(C.byref(t))
+    for k, v in fields.items():
+        if k not in dict(NovaTuning._fields_):
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    return t
 
 
 def _check(rc: int) -> None:
@@ -308,6 +333,18 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         """4 / 3: the early rows run as the MinRoot stencil (reference / bound rounds), 0: through the sparse kernel."""
         return int(nova_lib.vdf_nova_pp_stencil(self.handle))
 
+    def tuning(self) -> dict:
+        t = NovaTuning()
+        _check(nova_lib.vdf_nova_pp_tuning(self.handle, C.byref(t)))
+        return t.as_dict()
+
+    def setup_ms(self) -> dict:
+        """Wall-clock of the stages of the public_params call that made this set (vdf_nova_pp_setup_ms)."""
+        ms = (C.c_double * 7)()
+        _check(nova_lib.vdf_nova_pp_setup_ms(self.handle, C.byref(ms)))
+        return dict(zip(("shapes_and_digest_host", "shapes_to_device", "generators", "fixed_base_tables", "digit_tables", "other", "total"),
+                        [float(x) for x in ms]))
+
     def memory(self) -> dict:
         """HBM held per side (bytes): generators, fixed-base table, digit table; `skipped` = sides whose digit table did not fit."""
         g, t, d = (np.zeros(2, dtype="<u8") for _ in range(3))
@@ -330,9 +367,20 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
 
 
 def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_REFERENCE,
-                  gens_family: int = GENS_TRY_AND_INCREMENT, flags: int = 0) -> NovaVDFPublicParams:      # :232-237
+                  gens_family: int = GENS_TRY_AND_INCREMENT, flags: int = 0, tuning: "NovaTuning | None" = None,
+                  **tune) -> NovaVDFPublicParams:      # :232-237
+    """`tuning` / keyword fields of vdf_nova_tuning (e.g. digit_window=12, early_rows=0): vdf_nova_public_params_tuned."""
     h = C.c_void_p()
-    _check(nova_lib.vdf_nova_public_params_flags(ctx.handle, num_iters_per_step, circuit_kind, gens_family, flags, C.byref(h)))
+    if tuning is not None or tune:
+        t = tuning if tuning is not None else tuning_default()
+        for k, v in tune.items():
+            if k not in dict(NovaTuning._fields_):
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        t.flags |= flags
+        _check(nova_lib.vdf_nova_public_params_tuned(ctx.handle, num_iters_per_step, circuit_kind, gens_family, C.byref(t), C.byref(h)))
+    else:
+        _check(nova_lib.vdf_nova_public_params_flags(ctx.handle, num_iters_per_step, circuit_kind, gens_family, flags, C.byref(h)))
     pp = NovaVDFPublicParams(ctx, h.value, num_iters_per_step)
     pp.circuit_kind = circuit_kind
     return pp
