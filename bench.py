@@ -680,7 +680,33 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     a = time.perf_counter()
     ok_c = snark.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
     verify_c_ms = (time.perf_counter() - a) * 1e3
+    # the same compression once more with HIP events around every launch (a pass of its own, not the figure above): where
+    # the time goes, pass by pass, each priced by its own bytes against the 8 TB/s roof (the sum-check passes are
+    # the genuinely HBM-bound work of this library)
+    ctx.sync()
+    ctx.set_kernel_timing(True); ctx.kernel_events()
+    a = time.perf_counter()
+    snark2 = proof.compress(pp)
+    ctx.sync()
+    timed_ms = (time.perf_counter() - a) * 1e3
+    cev = ctx.kernel_events()
+    ctx.set_kernel_timing(False)
+    snark2.free()
+    agg = {}
+    for name, nbytes, s0, s1 in cev:
+        e = agg.setdefault(name, {"kernel": name, "calls": 0, "ms": 0.0, "bytes": 0.0})
+        e["calls"] += 1; e["ms"] += s1 - s0; e["bytes"] += nbytes
+    crow = []
+    for e in sorted(agg.values(), key=lambda e: -e["ms"]):
+        gbs = e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["bytes"] and e["ms"] else None
+        crow.append({"kernel": e["kernel"], "calls": e["calls"], "ms": round(e["ms"], 3), "avg_us": round(e["ms"] / e["calls"] * 1e3, 1),
+                     "MB": round(e["bytes"] / 1e6, 1), "GB_per_s": gbs and round(gbs, 1), "frac_of_8TBs": gbs and round(gbs / 8000.0, 4)})
+    dev_ms = sum(e["ms"] for e in agg.values())
+    msm_ms = sum(e["ms"] for e in agg.values() if e["kernel"].startswith(("msm_", "k_accumulate", "k_direct")))
     out["compress"] = {"compress_ms": compress_ms, "verify_compressed_ms": verify_c_ms, "verified": bool(ok_c),
+                       "per_kernel": crow, "per_kernel_pass_ms": round(timed_ms, 2), "device_ms_sum_of_launches": round(dev_ms, 2),
+                       "msm_share_of_device_time": round(msm_ms / dev_ms, 3) if dev_ms else None,
+                       "host_and_idle_ms": round(timed_ms - dev_ms, 2),
                        "argument_bytes": len(snark.to_bytes()),
                        "wire_bytes": len(snark.serialize()),
                        "what": "one Spartan-style argument with inner-product-argument openings per side of the cycle (vdf_nova.h)"}

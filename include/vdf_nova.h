@@ -94,6 +94,25 @@ int  vdf_nova_public_params_ex(vdf_ctx* ctx, uint64_t num_iters_per_step, int ci
 enum { VDF_PP_NO_DIGIT_TABLES = 1u, VDF_PP_NO_EARLY_ROWS = 2u };
 int  vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint32_t flags,
                                   vdf_pp** out);
+/* The random oracle as a PARAMETER BLOCK, covered by the parameters' digest.  The reference reaches
+ * its RO through nova-snark 0.8.0 -> neptune 7.2.0 (Cargo.toml:14-15), neither of which is in the reference tree: nothing
+ * pins their constants here, so this library's default is its own permutation -- and everything the RO is made of is data:
+ *   family 0 (VDF_RO_POSEIDON2): Poseidon2-style, width 4, 8 + 56 rounds, constants from SHAKE256 (the default; the only
+ *            block of this family the build supports);
+ *   family 1 (VDF_RO_POSEIDON):  the original Poseidon permutation -- dense Cauchy MDS matrix 1 / (i + t + j), round
+ *            constants from the paper's Grain LFSR, any width 2..25 (a sponge of rate width - 1), even full_rounds <= 16,
+ *            partial_rounds <= 128.  vdf_nova_ro_preset(1) is the shape [UPSTREAM-RECALL] neptune gives nova-snark: width 25,
+ *            8 + 57 rounds.  Recalled, unpinned, NOT claimed interoperable: it shows that adopting the upstream constants
+ *            is a change of this block, not of code.
+ * alpha must be 5, challenge_bits 128, hash_bits 250 (what the circuits of this build are written for); any other value is
+ * refused.  A block other than the default changes both R1CS shapes and the digest. */
+enum { VDF_RO_POSEIDON2 = 0, VDF_RO_POSEIDON = 1 };
+typedef struct vdf_nova_ro_params {
+  uint32_t struct_size;          /* sizeof(vdf_nova_ro_params) as the caller compiled it */
+  int32_t  family, width, full_rounds, partial_rounds, alpha, challenge_bits, hash_bits;
+} vdf_nova_ro_params;
+int  vdf_nova_ro_preset(int which, vdf_nova_ro_params* out);        /* 0 = this build's default, 1 = the neptune-shaped block */
+int  vdf_nova_pp_ro(const vdf_pp* pp, vdf_nova_ro_params* out);     /* the block a parameter set was made under */
 /* Everything tunable about a parameter set and the prover that runs over it, in one struct (DESIGN.md says what each
  * choice measured).  vdf_nova_tuning_default fills in the defaults; the environment variables of earlier rounds
  * (VDF_NOVA_*) are read once, by that function's first call, as overrides of those defaults.  A parameter set keeps its
@@ -123,6 +142,9 @@ void vdf_nova_tuning_default(vdf_nova_tuning* out);
 int  vdf_nova_public_params_tuned(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family,
                                   const vdf_nova_tuning* tuning, vdf_pp** out);
 int  vdf_nova_pp_tuning(const vdf_pp* pp, vdf_nova_tuning* out);            /* the copy this parameter set runs with */
+/* public_params under the given random-oracle block (NULL = the default) and tuning (NULL = the defaults) */
+int  vdf_nova_public_params_ro(vdf_ctx* ctx, uint64_t num_iters_per_step, int circuit_kind, int gens_family,
+                               const vdf_nova_ro_params* ro, const vdf_nova_tuning* tuning, vdf_pp** out);
 /* wall-clock milliseconds of the stages of the call that made `pp`: [0] both shapes + digest (host), [1] shapes to the
  * device, [2] generators, [3] fixed-base tables (the packed commitment's included), [4] digit tables, [5] the rest, [6] total */
 int  vdf_nova_pp_setup_ms(const vdf_pp* pp, double ms[7]);
@@ -255,6 +277,13 @@ typedef struct {
 int  vdf_nova_aug_synthesize(int side, uint64_t num_iters_per_step, int circuit_kind, const vdf_nova_aug_inputs* in,
                              const vdf_state* result, const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars,
                              size_t* num_cons, vdf_fe X[2], vdf_fe z_next[3]);
+/* the host-only entry points under another random-oracle block (NULL = the default): sponge, shape digest, synthesis */
+int  vdf_nova_ro_hash_ro(const vdf_nova_ro_params* ro, int field, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out);
+int  vdf_nova_shape_digest_ro(const vdf_nova_ro_params* ro, uint64_t num_iters_per_step, int circuit_kind, int gens_family, uint8_t out[32],
+                              uint64_t sizes[2][3]);
+int  vdf_nova_aug_synthesize_ro(const vdf_nova_ro_params* ro, int side, uint64_t num_iters_per_step, int circuit_kind,
+                                const vdf_nova_aug_inputs* in, const vdf_state* result, const vdf_state* input, vdf_fe* W, size_t w_cap,
+                                size_t* num_vars, size_t* num_cons, vdf_fe X[2], vdf_fe z_next[3]);
 
 /* of the calling thread's last augmented-circuit synthesis: how many slope inverses the native pre-pass queued (batched
  * inversion) and how many of them were wrong or unused (0 for well-formed inputs: the queue is only an accelerator) */

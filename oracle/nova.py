@@ -184,7 +184,30 @@ def strict_bits(cs: CS, a: Num) -> List[Num]:
     return bits
 
 
+def poseidon_permute_classic(cs: CS, s: List[Num]) -> List[Num]:
+    """The original Poseidon permutation in R1CS (ps.RoSpec family 1): add the round constants, x^5 on every lane (full rounds)
+    or on lane 0 (partial rounds: the other lanes stay linear combinations), then the dense MDS matrix as linear combinations."""
+    spec = ps.current()
+    rc, mds = ps.classic_constants(cs.field, spec)
+    t, half = spec.width, spec.full_rounds // 2
+
+    def sbox(x):
+        x2 = cs.mul(x, x)
+        x4 = cs.mul(x2, x2)
+        return cs.mul(x4, x)
+    for r in range(spec.full_rounds + spec.partial_rounds):
+        s = [cs.add(s[i], cs.const(rc[r][i])) for i in range(t)]
+        if r < half or r >= half + spec.partial_rounds:
+            s = [sbox(x) for x in s]
+        else:
+            s = [sbox(s[0])] + s[1:]
+        s = [cs.lin([(mds[i][j], s[j]) for j in range(t)]) for i in range(t)]
+    return s
+
+
 def poseidon_permute(cs: CS, s: List[Num]) -> List[Num]:
+    if ps.current().family == 1:
+        return poseidon_permute_classic(cs, s)
     f, m = cs.field, cs.m
     rc = ps.round_constants(f)
     mu = ps.MU[f]
@@ -209,9 +232,9 @@ def poseidon_permute(cs: CS, s: List[Num]) -> List[Num]:
 
 
 def poseidon_hash(cs: CS, tag: int, xs: Sequence[Num]) -> Num:
-    s = [cs.const(tag + (len(xs) << 32)), cs.const(0), cs.const(0), cs.const(0)]
-    for k in range(0, len(xs), ps.RATE):
-        for j, x in enumerate(xs[k:k + ps.RATE]):
+    s = [cs.const(tag + (len(xs) << 32))] + [cs.const(0)] * (ps.width() - 1)
+    for k in range(0, len(xs), ps.rate()):
+        for j, x in enumerate(xs[k:k + ps.rate()]):
             s[1 + j] = cs.add(s[1 + j], x)
         s = poseidon_permute(cs, s)
     return s[1]
@@ -526,7 +549,7 @@ def dummy_inputs(arity: int) -> AugInputs:
 def digest_shapes(t: int, shapes: Sequence[o.R1CSShape], gens_seed: int, gens_family: int) -> int:
     """`params`: SHAKE256 over both shapes, the generator family and the RO label, truncated to 250 bits."""
     h = hashlib.shake_256()
-    h.update(b"vdf-nova-ivc-v1" + ps.LABEL)
+    h.update(b"vdf-nova-ivc-v1" + ps.label())
     h.update(int(t).to_bytes(8, "little") + int(gens_seed).to_bytes(8, "little") + int(gens_family).to_bytes(8, "little"))
     for sh in shapes:
         for v in (sh.num_cons, sh.num_vars, sh.num_io):

@@ -18,7 +18,126 @@ import hashlib
 from functools import lru_cache
 from typing import List, Sequence
 
+from contextlib import contextmanager
+from dataclasses import dataclass
+
 from . import pasta as o
+
+
+# ---- the random oracle as a PARAMETER BLOCK -----------------------------------------------
+# Everything the RO is made of, as data that the parameters' digest covers (digest_shapes absorbs `label()`, and the
+# shapes themselves change with it): the permutation family, width, round numbers, S-box exponent, and the two
+# truncations of the protocol.  Two instances ship:
+#   DEFAULT         this build's own: Poseidon2-style, width 4, 8 + 56 rounds, constants from SHAKE256 (below);
+#   NEPTUNE_SHAPED  [UPSTREAM-RECALL] the shape nova-snark 0.8.0 reaches through neptune 7.2.0 (Cargo.toml:14-15): the
+#                   original Poseidon permutation (Grassi et al., 2019) of width 25 (a sponge of rate 24), x^5, 8 full and 57
+#                   partial rounds, Cauchy MDS matrix M[i][j] = 1 / (x_i + y_j) with x_i = i, y_j = t + j, round constants
+#                   from the paper's Grain LFSR.  Neither crate is in /root/reference: the numbers are recalled, nothing
+#                   pins them, and interoperability is NOT claimed -- what the instance proves is that the day the upstream
+#                   constants are available, adopting them is a change of DATA (this block), not of code.
+@dataclass(frozen=True)
+class RoSpec:
+    family: int = 0              # 0 = Poseidon2-style (this build), 1 = original Poseidon (Cauchy MDS, Grain constants)
+    width: int = 4
+    full_rounds: int = 8
+    partial_rounds: int = 56
+    alpha: int = 5
+    challenge_bits: int = 128
+    hash_bits: int = 250
+
+
+DEFAULT = RoSpec()
+NEPTUNE_SHAPED = RoSpec(family=1, width=25, full_rounds=8, partial_rounds=57)
+_current = DEFAULT
+
+
+@contextmanager
+def using(spec: RoSpec):
+    """Every hash of the oracle (native and in-circuit) under `spec` inside the block."""
+    global _current
+    prev, _current = _current, spec
+    try:
+        yield spec
+    finally:
+        _current = prev
+
+
+def current() -> RoSpec:
+    return _current
+
+
+def label() -> bytes:
+    """What the parameters' digest absorbs for the RO: the historical label for the default, the whole block otherwise."""
+    s = _current
+    if s == DEFAULT:
+        return LABEL
+    return b"vdf-ro-block-v1:" + bytes([s.family, s.width, s.full_rounds, s.partial_rounds, s.alpha, s.challenge_bits, s.hash_bits])
+
+
+def width() -> int:
+    return _current.width
+
+
+def rate() -> int:
+    return _current.width - 1
+
+
+@lru_cache(maxsize=None)
+def classic_constants(field: int, spec: RoSpec):
+    """(round constants [R][t], MDS [t][t]) of the original Poseidon over `field` [UPSTREAM-RECALL: the paper's
+    generate_parameters_grain]: an 80-bit Grain LFSR seeded with (field type 1 : 2 bits, S-box 0 : 4, n = 255 : 12, t : 12,
+    R_F : 10, R_P : 10, thirty ones), taps b[i+80] = b[i+62] ^ b[i+51] ^ b[i+38] ^ b[i+23] ^ b[i+13] ^ b[i], the first 160
+    bits discarded, then bits taken in pairs (first bit 1: keep the second); a constant = 255 bits, most significant first,
+    rejected when not below the modulus.  MDS: Cauchy, M[i][j] = 1 / (i + t + j)."""
+    m = o.modulus(field)
+    t, rf, rp, n = spec.width, spec.full_rounds, spec.partial_rounds, 255
+    bits = []
+    for v, w in ((1, 2), (0, 4), (n, 12), (t, 12), (rf, 10), (rp, 10)):
+        bits += [(v >> (w - 1 - k)) & 1 for k in range(w)]
+    bits += [1] * 30
+    assert len(bits) == 80
+    st = bits
+
+    def step():
+        nonlocal st
+        b = st[62] ^ st[51] ^ st[38] ^ st[23] ^ st[13] ^ st[0]
+        st = st[1:] + [b]
+        return b
+    for _ in range(160):
+        step()
+
+    def next_bit():
+        while True:
+            a, b = step(), step()
+            if a:
+                return b
+
+    def next_fe():
+        while True:
+            v = 0
+            for _ in range(n):
+                v = (v << 1) | next_bit()
+            if v < m:
+                return v
+    rc = [[next_fe() for _ in range(t)] for _ in range(rf + rp)]
+    mds = [[pow((i + t + j) % m, -1, m) for j in range(t)] for i in range(t)]
+    return rc, mds
+
+
+def _classic_permute(state: Sequence[int], field: int, spec: RoSpec) -> List[int]:
+    m = o.modulus(field)
+    rc, mds = classic_constants(field, spec)
+    t, half = spec.width, spec.full_rounds // 2
+    s = list(state)
+    for r in range(spec.full_rounds + spec.partial_rounds):
+        s = [(s[i] + rc[r][i]) % m for i in range(t)]
+        if r < half or r >= half + spec.partial_rounds:
+            s = [pow(x, 5, m) for x in s]
+        else:
+            s[0] = pow(s[0], 5, m)
+        s = [sum(mds[i][j] * s[j] for j in range(t)) % m for i in range(t)]
+    return s
+
 
 T = 4
 RATE = 3
@@ -56,6 +175,8 @@ def int_layer(s: Sequence[int], field: int, m: int) -> List[int]:
 
 
 def permute(state: Sequence[int], field: int) -> List[int]:
+    if _current.family == 1:
+        return _classic_permute(state, field, _current)
     m = o.modulus(field)
     rc = round_constants(field)
     s = ext_layer(state, m)
@@ -73,9 +194,10 @@ def hash_elements(tag: int, xs: Sequence[int], field: int) -> int:
     """Sponge: capacity lane 0 starts at tag + 2^32 * len(xs); the inputs are added to lanes 1..3 three at a time,
     one permutation per chunk; the output is lane 1 (a full field element; truncation is the caller's)."""
     m = o.modulus(field)
-    s = [(tag + (len(xs) << 32)) % m, 0, 0, 0]
-    for k in range(0, len(xs), RATE):
-        chunk = xs[k:k + RATE]
+    w, r = width(), rate()                       # (4, 3) for the default block
+    s = [(tag + (len(xs) << 32)) % m] + [0] * (w - 1)
+    for k in range(0, len(xs), r):
+        chunk = xs[k:k + r]
         for j, v in enumerate(chunk):
             s[1 + j] = (s[1 + j] + v) % m
         s = permute(s, field)

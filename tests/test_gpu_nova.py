@@ -152,6 +152,61 @@ def test_prove_steps_replayed_by_the_oracle(ctx, t, n, kind):
     assert proof.verify(pp, n, z0, zi)
 
 
+@pytest.mark.parametrize("which", ["neptune-shaped", "small"])
+def test_prove_steps_under_another_random_oracle_block(ctx, which):
+    """The random oracle is a parameter block covered by the digest (vdf_nova_ro_params): under the
+    neptune-shaped block (original Poseidon, width 25, 8 + 57 rounds: [UPSTREAM-RECALL], unpinned) and under a smaller
+    instance of the same family, every quantity of every step is the oracle's under the same block, bit for bit -- shapes,
+    digest, commitments, challenges, instances, witnesses -- the proof verifies, compresses and survives the wire; and the
+    parameters differ from the default block's."""
+    from oracle import poseidon as ps
+    from vdf_amd.nova import ro_preset, RO_NEPTUNE_SHAPED
+    t, n, kind = 5, 2, CIRCUIT_MINROOT_REFERENCE
+    if which == "small":
+        spec, ro = ps.RoSpec(family=1, width=9, full_rounds=8, partial_rounds=30), ro_preset(RO_NEPTUNE_SHAPED, width=9, partial_rounds=30)
+    else:
+        spec, ro = ps.NEPTUNE_SHAPED, ro_preset(RO_NEPTUNE_SHAPED)
+    x = o.rand_fe(78, 0, o.Q)
+    initial = State.from_ints(FIELD_FQ, x, 0, 1)
+    pp = public_params(ctx, t, kind, GENS_TRY_AND_INCREMENT, ro=ro)
+    assert pp.ro() == ro.as_dict()
+    pp0 = public_params(ctx, t, kind, GENS_TRY_AND_INCREMENT)
+    assert pp0.digest() != pp.digest() and pp0.sizes(0) != pp.sizes(0) and pp0.ro()["family"] == 0
+    pp0.free()
+    z0, circuits = InverseMinRootCircuit.eval_and_make_circuits(PallasVDF.new(), t, n, initial)
+    com = nv.CCommit()
+    with ps.using(spec):
+        opp = nv.public_params(t, com, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
+        assert pp.digest() == opp.params
+        for side in (0, 1):
+            sz, sh = pp.sizes(side), opp.shapes[side]
+            assert (sz["num_cons"], sz["num_vars"], sz["nnz"]) == (sh.num_cons, sh.num_vars, len(sh.A) + len(sh.B) + len(sh.C))
+        states = [o.State(x, 0, 1)]
+        for _ in range(n):
+            states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+        z0i = [states[n].x, states[n].y, states[n].i]
+        proof, want = None, None
+        for k in range(n):
+            proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+            want = nv.prove_step(opp, want, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1]), z0i)
+            tr, ls = want.trace[-1], proof.last_step()
+            assert aff_ints(ls["comm_W1"], 0) == tuple(tr["l1"].comm_W) and unmont(ls["X1"], o.Q) == tr["l1"].X
+            if k:
+                assert aff_ints(ls["comm_T1"], 0) == tuple(tr["T1"]) and aff_ints(ls["comm_T2"], 1) == tuple(tr["T2"])
+                assert (ls["r1"], ls["r2"]) == (tr["r1"], tr["r2"])
+            check_instance(proof, INST_RUNNING_PRIMARY, 0, want.r[0])
+            check_instance(proof, INST_RUNNING_SECONDARY, 1, want.r[1])
+            check_instance(proof, INST_FRESH_SECONDARY, 1, want.l2)
+        assert nv.verify(opp, want, n, z0i) is not None
+    zi = [initial.x, initial.y, initial.i]
+    assert proof.verify(pp, n, z0, zi)
+    snark = proof.compress(pp)
+    assert snark.verify(pp, n, z0, zi)
+    from vdf_amd.nova import CompressedNovaVDFProof
+    again = CompressedNovaVDFProof.deserialize(pp, snark.serialize())
+    assert again.verify(pp, n, z0, zi)
+
+
 def test_tampered_witness_is_rejected(ctx):
     """Corrupting one word of any of the five witness vectors on the device must fail verification."""
     from vdf_amd._lib import lib

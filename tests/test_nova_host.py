@@ -201,3 +201,90 @@ def test_early_rows_are_the_minroot_stencil(kind, per):
             assert rows[0][3 * j + 2] == {t1 + 1: 1} and rows[1][3 * j + 2] == x
             assert rows[2][3 * j + 2] == {t1 + 2: 1, y_j: 1, seg - 1: Q - 1, one: j + 1}
         assert rows[0][3 * t] == {seg + per * t: 1} and rows[1][3 * t] == {one: 1} and rows[2][3 * t] == {seg - 1: 1, one: (Q - t) % Q}
+
+
+# ---- the random oracle as a parameter block (vdf_nova_ro_params; oracle/poseidon.py RoSpec) -------------------------
+RO_SMALL = (ps.RoSpec(family=1, width=9, full_rounds=8, partial_rounds=30), dict(width=9, partial_rounds=30))
+
+
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+def test_ro_block_native_hash_equals_the_restatement(field):
+    """The original Poseidon permutation (family 1: Grain-LFSR constants, Cauchy MDS) in the host library against the oracle's,
+    for the neptune-shaped block (width 25, 8 + 57 rounds) and a smaller instance; the default block is untouched by it."""
+    rng = random.Random(100 + field)
+    m = o.modulus(field)
+    for spec, ro in ((ps.NEPTUNE_SHAPED, vn.ro_preset(vn.RO_NEPTUNE_SHAPED)), (RO_SMALL[0], vn.ro_preset(vn.RO_NEPTUNE_SHAPED, **RO_SMALL[1]))):
+        assert ro.as_dict() == dict(family=spec.family, width=spec.width, full_rounds=spec.full_rounds, partial_rounds=spec.partial_rounds,
+                                    alpha=5, challenge_bits=128, hash_bits=250)
+        for n in (0, 1, spec.width - 2, spec.width - 1, spec.width, 2 * spec.width + 3):
+            xs = [rng.randrange(m) for _ in range(n)]
+            with ps.using(spec):
+                want = ps.hash_elements(7, xs, field)
+            got = unmont(vn.ro_hash(field, 7, mont(xs, field) if n else np.zeros((0, 4), dtype="<u8"), ro), field)[0]
+            assert got == want
+            assert n == 0 or got != unmont(vn.ro_hash(field, 7, mont(xs, field)), field)[0]         # another oracle than the default
+    xs = [1, 2, 3, 4, 5]
+    assert unmont(vn.ro_hash(field, 1, mont(xs, field), vn.ro_preset(vn.RO_DEFAULT)), field)[0] == ps.hash_elements(1, xs, field)
+    for bad in (dict(alpha=3), dict(challenge_bits=120), dict(hash_bits=248), dict(width=26), dict(width=1), dict(full_rounds=7), dict(family=2)):
+        with pytest.raises(Exception):
+            vn.ro_hash(field, 1, mont(xs, field), vn.ro_preset(vn.RO_NEPTUNE_SHAPED, **bad))
+    with pytest.raises(Exception):                                          # family 0 supports the default numbers only
+        vn.ro_hash(field, 1, mont(xs, field), vn.ro_preset(vn.RO_DEFAULT, partial_rounds=57))
+
+
+def test_ro_block_changes_shapes_and_digest_as_the_restatement_says():
+    """A parameter set under another block: both augmented circuits hold that block's permutations (other sizes, other
+    triples), and the digest -- which absorbs the block itself -- equals the oracle's under the same block."""
+    t, kind = 3, 1
+    spec, fields = RO_SMALL
+    ro = vn.ro_preset(vn.RO_NEPTUNE_SHAPED, **fields)
+    with ps.using(spec):
+        pp = nv.public_params(t, None, nv.GENS_SEED, nv.FAMILY_TRY_AND_INCREMENT)
+    digest, sizes = vn.shape_digest(t, kind, 1, ro)
+    assert digest == pp.params
+    for s in (0, 1):
+        sh = pp.shapes[s]
+        assert sizes[s] == [sh.num_cons, sh.num_vars, len(sh.A) + len(sh.B) + len(sh.C)]
+    d0, s0 = vn.shape_digest(t, kind, 1)
+    assert d0 != digest and s0 != sizes
+    assert vn.shape_digest(t, kind, 1, vn.ro_preset(vn.RO_DEFAULT)) == (d0, s0)
+
+
+def test_ro_block_augmented_witness_equals_the_restatement():
+    """Two oracle steps at t = 3 under the small classic-Poseidon block: every variable of the four augmented circuits."""
+    t, n = 3, 2
+    spec, fields = RO_SMALL
+    ro = vn.ro_preset(vn.RO_NEPTUNE_SHAPED, **fields)
+    com = nv.CCommit()
+    rec = []
+    orig = nv.synth_fresh
+
+    def spy(pp, side, inp, step):
+        fresh, z = orig(pp, side, inp, step)
+        rec.append((side, copy.deepcopy(inp), step, fresh, z))
+        return fresh, z
+    nv.synth_fresh = spy
+    try:
+        with ps.using(spec):
+            pp = nv.public_params(t, com, nv.GENS_SEED, 1)
+            states = [o.State(0x4321, 0, 1)]
+            for _ in range(n):
+                states.append(o.minroot_eval(states[-1], t, o.FIELD_FQ))
+            z0 = [states[n].x, states[n].y, states[n].i]
+            s = None
+            for k in range(n):
+                s = nv.prove_step(pp, s, nv.InverseMinRootCircuit(t, states[n - k], states[n - k - 1]), z0)
+            assert nv.verify(pp, s, n, z0) is not None
+    finally:
+        nv.synth_fresh = orig
+    assert len(rec) == 4
+    for side, inp, step, fresh, z_next in rec:
+        f = nv.SIDE_FIELD[side]
+        res = st(step.result) if side == 0 else None
+        inn = st(step.input) if side == 0 else None
+        W, X, zn, nc = vn.aug_synthesize(side, t, 1, c_inputs(side, inp), res, inn, ro=ro)
+        assert nc == pp.shapes[side].num_cons and W.shape[0] == pp.shapes[side].num_vars
+        assert unmont(X, f) == fresh.X and unmont(zn, f) == z_next
+        got = unmont(W, f)
+        bad = [k for k in range(len(got)) if got[k] != fresh.W[k]]
+        assert not bad, (side, inp.i, bad[:5])

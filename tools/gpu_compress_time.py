@@ -16,3 +16,19 @@ for rep in range(3):
     a = time.perf_counter(); s = proof.compress(pp); b = time.perf_counter(); ok = s.verify(pp, n, z0, zi); c = time.perf_counter()
     print(f"compress {1e3*(b-a):.1f} ms, verify {1e3*(c-b):.1f} ms, ok {ok}, {len(s.to_bytes())} bytes", flush=True)
     s.free()
+# where the time goes: HIP events around every launch of one more compression (a pass of its own)
+ctx.sync(); ctx.set_kernel_timing(True); ctx.kernel_events()
+a = time.perf_counter(); s = proof.compress(pp); ctx.sync(); wall = (time.perf_counter() - a) * 1e3
+ev = ctx.kernel_events(); ctx.set_kernel_timing(False); s.free()
+agg = {}
+for name, nbytes, s0, s1 in ev:
+    e = agg.setdefault(name, [0, 0.0, 0.0]); e[0] += 1; e[1] += s1 - s0; e[2] += nbytes
+dev = sum(e[1] for e in agg.values())
+print(f"timed pass {wall:.1f} ms, device (sum of launches) {dev:.1f} ms, host + idle {wall - dev:.1f} ms")
+print("%-26s %6s %9s %9s %9s %8s" % ("kernel", "calls", "ms", "avg us", "MB", "GB/s"))
+for name, (calls, ms, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-26s %6d %9.3f %9.1f %9.1f %8s" % (name, calls, ms, ms / calls * 1e3, nb / 1e6, ("%.0f" % (nb / ms / 1e6)) if nb else "-"))
+t0 = ev[0][2]
+print("first 60 launches (start ms, dur us):")
+for name, nbytes, s0, s1 in ev[:60]:
+    print("  %8.3f %8.1f  %s" % (s0 - t0, (s1 - s0) * 1e3, name))

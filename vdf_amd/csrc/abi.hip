@@ -1127,7 +1127,8 @@ void vdf_shape_free(vdf_shape* shape) {
 
 int vdf_spmv3(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* z, vdf_fe* Az, vdf_fe* Bz, vdf_fe* Cz) {
   return guarded(ctx, [&]() -> Status {
-    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+    // the shape is read-only device data: any context of its device may run over it
+    if (!shape || !shape->ctx || shape->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
     Staging st(ctx);
     const void* dz; void* o[3];
     VDF_TRY(st.in(z, shape->num_cols * 32, &dz));
@@ -1482,10 +1483,15 @@ int vdf_reduce(vdf_ctx* ctx, int field, int kind, const vdf_fe* const tables[], 
 
 int vdf_spmv3_t(vdf_ctx* ctx, const vdf_shape* shape, const vdf_fe* eq, const vdf_fe* rho, vdf_fe* out) {
   return guarded(ctx, [&]() -> Status {
-    if (!shape || shape->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
+    // the shape is read-only device data: any context of its device may run over it
+    if (!shape || !shape->ctx || shape->ctx->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "bad shape handle"};
     if (!rho || ptr_is_device(rho)) return Status{VDF_ERR_BAD_ARG, kHostScalar};
     if (!all_device({eq, out})) return Status{VDF_ERR_BAD_ARG, kDevVec};
     if (!ctx->reduce_scratch) VDF_TRY_HIP(hipMalloc(&ctx->reduce_scratch, vdf::snark_reduce_scratch_bytes()));
+    // algorithmic bytes of M(y) = sum_x eq[x] (A + rho B + rho^2 C)[x, y]: per entry a row index, a packed coefficient index and
+    // the gathered eq value; per column a pointer and the result (SURVEY 8d's SpMV formula, transposed)
+    const double nnz3 = (double)(shape->nnz[0] + shape->nnz[1] + shape->nnz[2]);
+    vdf::KTimer kt(ctx->stream, "k_spmvt(+heavy cols)", nnz3 * (4 + 4 + 32) + (double)shape->num_cols * (4 + 32));
     VDF_TRY(vdf::snark_spmvt(shape->field, shape->d_t_colptr, shape->d_t_row, shape->d_t_cm, shape->d_t_heavy, shape->t_nheavy,
                              shape->t_nbig, shape->d_dict, eq, rho, shape->num_cols, out, ctx->reduce_scratch, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,5 +1,6 @@
 // libvdf_nova.so, part 3: NovaVDFProof::compress and verification of the compressed proof: one Spartan-style argument
 // per side of the curve cycle (SS1 / SS2 of src/nova/proof.rs:32-33), after the last secondary instance is folded.
+#include <thread>
 #include "nova_internal.hpp"
 
 using namespace vdfnova;
@@ -188,7 +189,8 @@ struct IpaJob {
   size_t nj = 0;
   Pt Qp;
   std::unique_ptr<FixedBase> Qtab;
-  Fe cross[2];
+  Fe* cross = nullptr;             // two elements in pinned, device-mapped memory: the reduction writes them in place and they are
+                                   // read after the round's one synchronisation (behind the MSM), not after one of their own
 };
 
 // Several inner-product arguments in lockstep (the test oracle's ipa_prove_many): statements and values are absorbed job
@@ -222,7 +224,7 @@ int ipa_prove_many(const Side& sd, Transcript& tr, IpaJob* jobs, int njobs, vdf_
     for (int q = 0; q < na; ++q) {
       IpaJob& jb = *act[q];
       const vdf_fe* ab[2] = {(const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_b};
-      HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));
+      HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));      // pinned: no wait here
       HIPCALL(ctx, vdf_ipa_scalars(ctx, sd.field, (const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_s, jb.n, jb.nj, (vdf_fe*)jb.d_sL,
                                    (vdf_fe*)jb.d_sR));
       sc[2 * q] = (const vdf_fe*)jb.d_sL; sc[2 * q + 1] = (const vdf_fe*)jb.d_sR;
@@ -382,9 +384,10 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
   for (void** p : {&d_mvec, &d_zpad}) { int rc = bufs.zeros(L.Z, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   for (void** p : {&d_w, &d_s, &d_sL, &d_sR}) { int rc = bufs.zeros(L.NW, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   { int rc = bufs.zeros(pp->ncols, &d_cols); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
-  vdf_jac* h_lr = nullptr;
-  HIPCALL(ctx, vdf_host_alloc(ctx, 4 * sizeof(vdf_jac), (void**)&h_lr));
+  vdf_jac* h_lr = nullptr;                        // pinned: four result points of a round's batched MSM, then 2 x 2 cross terms
+  HIPCALL(ctx, vdf_host_alloc(ctx, 4 * sizeof(vdf_jac) + 4 * sizeof(Fe), (void**)&h_lr));
   struct HostFree { vdf_ctx* c; void* p; ~HostFree() { vdf_host_free(c, p); } } hf{ctx, h_lr};
+  Fe* h_cross = reinterpret_cast<Fe*>(h_lr + 4);
 
   Transcript tr("compress");
   instance_bytes(tr, sd, cW, cE, u, X);
@@ -465,6 +468,7 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
   jobs[0].d_sR = d_sR; jobs[0].v = out->w_eval; jobs[0].P = cW; jobs[0].out = &out->ipaW;
   jobs[1].label = "ipaE"; jobs[1].n = L.M; jobs[1].d_a = d_e; jobs[1].d_b = d_eq_rx; jobs[1].d_s = d_sE; jobs[1].d_sL = d_sLE;
   jobs[1].d_sR = d_sRE; jobs[1].v = out->claims[3]; jobs[1].P = cE; jobs[1].out = &out->ipaE;
+  jobs[0].cross = h_cross; jobs[1].cross = h_cross + 2;
   return ipa_prove_many(sd, tr, jobs, 2, h_lr);
 }
 
@@ -569,7 +573,7 @@ void fold_challenge(const vdf_pp* pp, const Inst& U2, const Inst& l2, const Aff&
   const Field& F2 = *pp->s[SECONDARY].F;
   uint64_t ux[2][4];
   for (int k = 0; k < 2; ++k) fe_to_int(l2.X[k], F2, ux[k]);
-  hash_challenge(pp->s[PRIMARY].field, pp->params[PRIMARY], to_relaxed(U2, F2), l2.comm_W, ux, T2, r);
+  hash_challenge(pp->s[PRIMARY].field, pp->params[PRIMARY], to_relaxed(U2, F2), l2.comm_W, ux, T2, r, pp->ro);
 }
 
 size_t spartan_flat_size(const Spartan& p) {
@@ -633,10 +637,33 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
     const Fe rf = int_to_fe(r, *S2.F);
     HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_z, (const vdf_fe*)&rf, (const vdf_fe*)p->d_l2z, S2.ncols, (vdf_fe*)d_fz));
     HIPCALL(ctx, vdf_axpy(ctx, S2.field, (const vdf_fe*)s2.d_E, (const vdf_fe*)&rf, (const vdf_fe*)s2.d_T, S2.num_cons, (vdf_fe*)d_fE));
-    int rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]);
+    // The two arguments are independent (a transcript each): the secondary side's runs on a second queue of the device, driven
+    // by a second host thread, beside the primary's -- its small latency-bound MSMs and its host work (transcript, point
+    // arithmetic between rounds) disappear under the primary side's 2^19-generator MSMs.  (nova-snark's CompressedSNARK::prove
+    // runs the two provers in parallel as well.)
+    if (!pp->aux_ctx) {
+      const int dev = vdf_ctx_device(ctx);
+      if (vdf_ctx_create(&dev, 1, &pp->aux_ctx) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: second context: ") + vdf_last_error(nullptr));
+    }
+    vdf_ctx* cb = pp->aux_ctx;
+    HIPCALL(cb, vdf_ctx_set_async(cb, 1));
+    HIPCALL(cb, vdf_ctx_wait(cb, ctx));                                // the folded secondary witness was made on the first queue
+    Side S2b = S2;
+    S2b.ctx = cb;
+    int rc2 = VDF_OK;
+    std::string err2;
+    std::thread side2([&] {
+      try { rc2 = spartan_prove(S2b, f2.comm_W, f2.comm_E, f2.u, f2.X, d_fz, d_fE, &s->sp[1]); }
+      catch (const std::exception& ex) { rc2 = VDF_ERR_DEVICE; err2 = ex.what(); }
+      if (rc2 != VDF_OK && err2.empty()) err2 = vdf_nova_last_error();  // (the message is per thread: carried over by hand)
+      (void)vdf_ctx_sync(cb);
+    });
+    int rc = VDF_OK;
+    try { rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]); }
+    catch (...) { side2.join(); throw; }
+    side2.join();
     if (rc != VDF_OK) return rc;
-    rc = spartan_prove(S2, f2.comm_W, f2.comm_E, f2.u, f2.X, d_fz, d_fE, &s->sp[1]);
-    if (rc != VDF_OK) return rc;
+    if (rc2 != VDF_OK) return fail(rc2, "compress, secondary side: " + err2);
     *out = s.release();
     return VDF_OK;
   });
@@ -659,9 +686,9 @@ int vdf_nova_verify_compressed(const vdf_snark* s, vdf_pp* pp, size_t num_steps,
     if (s->zi1.size() != pp->arity) return VDF_OK;
     const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero()), zi1 = s->zi1, zi2(s->zi2, s->zi2 + 1);
     uint64_t hv[4];
-    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv);
+    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, zi1, to_relaxed(s->r_U2, F2), hv, pp->ro);
     if (int_to_fe(hv, F2) != s->l_u2.X[0]) return VDF_OK;
-    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, zi2, to_relaxed(s->r_U1, F1), hv);
+    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, zi2, to_relaxed(s->r_U1, F1), hv, pp->ro);
     if (int_to_fe(hv, F2) != s->l_u2.X[1]) return VDF_OK;
     uint64_t r[4];
     fold_challenge(pp, s->r_U2, s->l_u2, s->T2, r);

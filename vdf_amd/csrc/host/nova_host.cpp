@@ -120,17 +120,19 @@ AugInputs blank_inputs(size_t arity) {
 struct HostShape { Coo m[3]; size_t num_cons = 0, num_vars = 0, step_begin = 0, step_end = 0; };
 
 // both augmented circuits in shape mode (PublicParams::setup, src/nova/proof.rs:236)
-int build_shapes(uint64_t t, int circuit_kind, HostShape out[2], const vdf_step_circuit* custom = nullptr) {
+int build_shapes(uint64_t t, int circuit_kind, HostShape out[2], const vdf_step_circuit* custom = nullptr, const RoInstance* ro = nullptr) {
   vdf_pp tmp;
   tmp.t = t;
   tmp.circuit_kind = circuit_kind;
   for (int side = 0; side < 2; ++side) {
-    CS cs(side_field(side), true);
+    CS cs(side_field(side), true, ro);
     std::unique_ptr<StepCircuit> step;
     if (side == PRIMARY) step = custom ? make_custom_circuit(custom) : make_primary_circuit(&tmp, nullptr, false);
     else step.reset(new TrivialTestCircuit());
     // the step circuit's variables are one contiguous run: find it by synthesising the wrapper once around an empty step
-    synthesize_augmented(cs, side, blank_inputs(step->arity()), *step);
+    AugInputs blank = blank_inputs(step->arity());
+    blank.ro = ro;
+    synthesize_augmented(cs, side, blank, *step);
     if (side == PRIMARY && custom && static_cast<const CustomStepCircuit*>(step.get())->rc != 0)
       return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed while its shape was recorded");
     cs.finish(out[side].m);
@@ -143,10 +145,11 @@ int build_shapes(uint64_t t, int circuit_kind, HostShape out[2], const vdf_step_
 }
 
 // oracle/nova.py digest_shapes
-void digest_shapes(uint64_t t, int gens_family, const HostShape sh[2], uint8_t out[32]) {
+void digest_shapes(uint64_t t, int gens_family, const HostShape sh[2], uint8_t out[32], const RoInstance* ro = nullptr) {
   Shake256 h;
   h.absorb("vdf-nova-ivc-v1", 15);
-  h.absorb("vdf-poseidon2-v1", 16);
+  if (!ro) ro = ro_default();
+  h.absorb(ro->label.data(), ro->label.size());      // the random oracle's parameter block ("vdf-poseidon2-v1" for the default)
   const uint64_t hdr[3] = {t, GENS_SEED, (uint64_t)gens_family};
   h.absorb(hdr, sizeof(hdr));
   for (int side = 0; side < 2; ++side) {
@@ -302,22 +305,64 @@ extern "C" {
 const char* vdf_nova_last_error(void) { return vdfnova::g_err.c_str(); }
 
 
+// ---- the random oracle's parameter block ------------------------------------------------------------------------
+// null -> the default; a block this build does not support -> nullptr with *bad set
+static const RoInstance* ro_from_abi(const vdf_nova_ro_params* r, bool* bad) {
+  *bad = false;
+  if (!r) return ro_default();
+  if (r->struct_size != sizeof(vdf_nova_ro_params)) { *bad = true; return nullptr; }
+  RoSpec sp;
+  sp.family = r->family; sp.width = r->width; sp.full_rounds = r->full_rounds; sp.partial_rounds = r->partial_rounds;
+  sp.alpha = r->alpha; sp.challenge_bits = r->challenge_bits; sp.hash_bits = r->hash_bits;
+  const RoInstance* ro = ro_instance(sp);
+  if (!ro) *bad = true;
+  return ro;
+}
+static void ro_to_abi(const RoInstance* ro, vdf_nova_ro_params* out) {
+  const RoSpec& sp = (ro ? ro : ro_default())->spec;
+  out->struct_size = (uint32_t)sizeof(vdf_nova_ro_params);
+  out->family = sp.family; out->width = sp.width; out->full_rounds = sp.full_rounds; out->partial_rounds = sp.partial_rounds;
+  out->alpha = sp.alpha; out->challenge_bits = sp.challenge_bits; out->hash_bits = sp.hash_bits;
+}
+int vdf_nova_ro_preset(int which, vdf_nova_ro_params* out) {
+  if (!out || (which != 0 && which != 1)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+  RoInstance tmp;
+  if (which == 1) { tmp.spec.family = VDF_RO_POSEIDON; tmp.spec.width = 25; tmp.spec.full_rounds = 8; tmp.spec.partial_rounds = 57; }
+  ro_to_abi(&tmp, out);
+  return VDF_OK;
+}
+int vdf_nova_pp_ro(const vdf_pp* pp, vdf_nova_ro_params* out) {
+  if (!pp || !out) return fail(VDF_ERR_BAD_ARG, "null argument");
+  ro_to_abi(pp->ro, out);
+  return VDF_OK;
+}
+
 // ---- host-only entry points ------------------------------------------------------------------------------------
-int vdf_nova_ro_hash(int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) {
+int vdf_nova_ro_hash_ro(const vdf_nova_ro_params* rop, int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) {
   return nova_guard([&]() -> int {
+    bool bad;
+    const RoInstance* ro = ro_from_abi(rop, &bad);
+    if (bad) return fail(VDF_ERR_BAD_ARG, "unsupported RO parameter block");
     if (!valid_field(f) || (!xs && n) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
-    const Fe r = ro_hash(f, tag, (const Fe*)xs, n);
+    const Fe r = ro_hash(f, tag, (const Fe*)xs, n, ro);
     memcpy(out, &r, 32);
     return VDF_OK;
   });
 }
+int vdf_nova_ro_hash(int f, uint64_t tag, const vdf_fe* xs, size_t n, vdf_fe* out) { return vdf_nova_ro_hash_ro(nullptr, f, tag, xs, n, out); }
 
 int vdf_nova_shape_digest(uint64_t t, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
+  return vdf_nova_shape_digest_ro(nullptr, t, circuit_kind, gens_family, out, sizes);
+}
+int vdf_nova_shape_digest_ro(const vdf_nova_ro_params* rop, uint64_t t, int circuit_kind, int gens_family, uint8_t out[32], uint64_t sizes[2][3]) {
   return nova_guard([&]() -> int {
+    bool bad;
+    const RoInstance* ro = ro_from_abi(rop, &bad);
+    if (bad) return fail(VDF_ERR_BAD_ARG, "unsupported RO parameter block");
     if (t == 0 || t > (1ull << 24) || !out) return fail(VDF_ERR_BAD_ARG, "bad argument");
     HostShape sh[2];
-    build_shapes(t, circuit_kind, sh);
-    digest_shapes(t, gens_family, sh, out);
+    build_shapes(t, circuit_kind, sh, nullptr, ro);
+    digest_shapes(t, gens_family, sh, out, ro);
     if (sizes)
       for (int s = 0; s < 2; ++s) {
         sizes[s][0] = sh[s].num_cons; sizes[s][1] = sh[s].num_vars;
@@ -389,7 +434,15 @@ static AugInputs aug_from_abi(int side, const vdf_nova_aug_inputs* a) {
 int vdf_nova_aug_synthesize(int side, uint64_t t, int circuit_kind, const vdf_nova_aug_inputs* a, const vdf_state* result,
                             const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars, size_t* num_cons, vdf_fe X[2],
                             vdf_fe z_next[3]) {
+  return vdf_nova_aug_synthesize_ro(nullptr, side, t, circuit_kind, a, result, input, W, w_cap, num_vars, num_cons, X, z_next);
+}
+int vdf_nova_aug_synthesize_ro(const vdf_nova_ro_params* rop, int side, uint64_t t, int circuit_kind, const vdf_nova_aug_inputs* a,
+                               const vdf_state* result, const vdf_state* input, vdf_fe* W, size_t w_cap, size_t* num_vars, size_t* num_cons,
+                               vdf_fe X[2], vdf_fe z_next[3]) {
   return nova_guard([&]() -> int {
+    bool bad;
+    const RoInstance* ro = ro_from_abi(rop, &bad);
+    if (bad) return fail(VDF_ERR_BAD_ARG, "unsupported RO parameter block");
     if ((side != PRIMARY && side != SECONDARY) || !a || t == 0) return fail(VDF_ERR_BAD_ARG, "bad argument");
     vdf_pp tmp;
     tmp.t = t;
@@ -401,8 +454,10 @@ int vdf_nova_aug_synthesize(int side, uint64_t t, int circuit_kind, const vdf_no
       c.result = load_state(result); c.input = load_state(input); c.t = t;
       step = make_primary_circuit(&tmp, &c, false);
     } else step.reset(new TrivialTestCircuit());
-    CS cs(side_field(side), false);
-    const std::vector<Fe> zn = synthesize_augmented(cs, side, aug_from_abi(side, a), *step);
+    CS cs(side_field(side), false, ro);
+    AugInputs ain = aug_from_abi(side, a);
+    ain.ro = ro;
+    const std::vector<Fe> zn = synthesize_augmented(cs, side, ain, *step);
     if (num_vars) *num_vars = cs.W.size();
     if (num_cons) *num_cons = cs.rows;
     if (W) {
@@ -482,7 +537,7 @@ int vdf_nova_public_params(vdf_ctx* ctx, uint64_t t, vdf_pp** out) {
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family,
-                              const vdf_nova_tuning& tune, vdf_pp** out);
+                              const vdf_nova_tuning& tune, vdf_pp** out, const RoInstance* ro = nullptr);
 
 int vdf_nova_public_params_tuned(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, const vdf_nova_tuning* tuning, vdf_pp** out) {
   return nova_guard([&]() -> int {
@@ -491,6 +546,19 @@ int vdf_nova_public_params_tuned(vdf_ctx* ctx, uint64_t t, int circuit_kind, int
       return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
     if (tuning && (tuning->struct_size != sizeof(vdf_nova_tuning) || !tuning_valid(*tuning))) return fail(VDF_ERR_BAD_ARG, "tuning: a field is out of range");
     return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, tuning ? *tuning : default_tuning(), out);
+  });
+}
+int vdf_nova_public_params_ro(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, const vdf_nova_ro_params* rop,
+                              const vdf_nova_tuning* tuning, vdf_pp** out) {
+  return nova_guard([&]() -> int {
+    bool bad;
+    const RoInstance* ro = ro_from_abi(rop, &bad);
+    if (bad) return fail(VDF_ERR_BAD_ARG, "unsupported RO parameter block (vdf_nova.h: alpha 5, 128 / 250 bits, family 1 widths 2..25)");
+    if (!ctx || !out || t == 0 || t > (1ull << 24)) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (circuit_kind != VDF_CIRCUIT_MINROOT_BOUND && circuit_kind != VDF_CIRCUIT_MINROOT_REFERENCE)
+      return fail(VDF_ERR_BAD_ARG, "unknown step circuit");
+    if (tuning && (tuning->struct_size != sizeof(vdf_nova_tuning) || !tuning_valid(*tuning))) return fail(VDF_ERR_BAD_ARG, "tuning: a field is out of range");
+    return public_params_impl(ctx, t, circuit_kind, nullptr, gens_family, tuning ? *tuning : default_tuning(), out, ro);
   });
 }
 int vdf_nova_public_params_flags(vdf_ctx* ctx, uint64_t t, int circuit_kind, int gens_family, uint32_t flags, vdf_pp** out) {
@@ -613,7 +681,7 @@ static bool minroot_stencil_matches(const HostShape& h, const Field& F, uint64_t
 }
 
 static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const vdf_step_circuit* custom, int gens_family,
-                              const vdf_nova_tuning& tune, vdf_pp** out) {
+                              const vdf_nova_tuning& tune, vdf_pp** out, const RoInstance* ro) {
   if (gens_family != VDF_GENS_TRY_AND_INCREMENT && gens_family != VDF_GENS_KNOWN_DLOG && gens_family != VDF_GENS_LABEL_SHAKE)
     return fail(VDF_ERR_BAD_ARG, "unknown generator family");
   *out = nullptr;
@@ -632,12 +700,13 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
   pp->gens_family = gens_family;
   pp->arity = custom ? custom->arity : 3;
   pp->tune = tune;
+  pp->ro = ro ? ro : ro_default();
   double* ms = pp->setup_ms;                       // [0] shapes + digest, [1] shapes to the device, [2] generators, [3] tables, [4] digit tables
   double mark = t_start;
   auto lap = [&](int k) -> int { HIPCALL(ctx, vdf_ctx_sync(ctx)); const double now = now_ms(); ms[k] += now - mark; mark = now; return VDF_OK; };
   HostShape sh[2];
-  { int rc = build_shapes(t, circuit_kind, sh, custom); if (rc != VDF_OK) return rc; }
-  digest_shapes(t, gens_family, sh, pp->digest);
+  { int rc = build_shapes(t, circuit_kind, sh, custom, pp->ro); if (rc != VDF_OK) return rc; }
+  digest_shapes(t, gens_family, sh, pp->digest, pp->ro);
   // only the MinRoot rounds are made on the device; a custom circuit's variables all come from the host
   pp->seg_begin = custom ? 0 : sh[PRIMARY].step_begin;
   pp->seg_len = custom ? 0 : sh[PRIMARY].step_end - sh[PRIMARY].step_begin;
@@ -769,6 +838,7 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
 }
 void vdf_nova_pp_free(vdf_pp* pp) {
   if (!pp) return;
+  if (pp->aux_ctx) vdf_ctx_destroy(pp->aux_ctx);
   if (pp->seg_gens) vdf_bases_free(pp->seg_gens);
   for (Side& sd : pp->s) {
     if (sd.d_zero) vdf_dev_free(pp->ctx, sd.d_zero);
@@ -1110,6 +1180,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
 
   // the primary circuit's inputs but for the two commitments of (a); its step circuit
   AugInputs in1;
+  in1.ro = pp->ro;
   in1.params = pp->params[PRIMARY];
   in1.i = i_fe1;
   in1.z0 = p->z0[PRIMARY];
@@ -1124,6 +1195,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   }
   const std::unique_ptr<StepCircuit> c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
   AugInputs in2;
+  in2.ro = pp->ro;
   const TrivialTestCircuit c2;
   AugEarlyPtr early1(nullptr, aug_early_free), early2(nullptr, aug_early_free);
   auto make_early1 = [&] { return synthesize_augmented_early(PRIMARY, in1, *c1); };
@@ -1171,7 +1243,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
   {
     AugInputs& in = in1;
     if (!first) { in.u_W = p->l2.comm_W; in.T = comm_T2; }
-    CS cs(S1.field, false);
+    CS cs(S1.field, false, pp->ro);
     Fe unew[9];
     const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2, early1.get());
     early1.reset();
@@ -1288,7 +1360,7 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     AugInputs& in = in2;
     in.u_W = l1.comm_W;
     in.T = comm_T1;
-    CS cs(S2.field, false);
+    CS cs(S2.field, false, pp->ro);
     Fe unew[9];
     const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
     early2.reset();
@@ -1514,9 +1586,9 @@ int vdf_nova_verify_custom(const vdf_proof* p, vdf_pp* pp, size_t num_steps, con
     // (1) the two output hashes the last secondary instance carries
     const std::vector<Fe> z0p((const Fe*)z0, (const Fe*)z0 + pp->arity), z0s(1, zero());
     uint64_t hv[4];
-    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv);
+    hash_state(S1.field, pp->params[PRIMARY], from_u64(num_steps, F1), z0p, p->zi[PRIMARY], to_relaxed(p->r[SECONDARY].inst, F2), hv, pp->ro);
     if (int_to_fe(hv, F2) != p->l2.X[0]) return VDF_OK;
-    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, p->zi[SECONDARY], to_relaxed(p->r[PRIMARY].inst, F1), hv);
+    hash_state(S2.field, pp->params[SECONDARY], from_u64(num_steps, F2), z0s, p->zi[SECONDARY], to_relaxed(p->r[PRIMARY].inst, F1), hv, pp->ro);
     if (int_to_fe(hv, F2) != p->l2.X[1]) return VDF_OK;
     // (2) three satisfiability claims
     vdf_ctx* ctx = pp->ctx;

@@ -96,6 +96,9 @@ struct vdf_pp {
   // the reference's step circuit only: generators of the packed commitment to the MinRoot rounds (3t + 4 points derived from
   // the 4t + 1 of the segment: vdf_hip.h vdf_minroot_step_segment_packed), with a fixed-base table of their own
   vdf_bases* seg_gens = nullptr;
+  const vdfnova::RoInstance* ro = nullptr;  // the random oracle's parameter block (covered by the digest); never null once the set is made
+  vdf_ctx* aux_ctx = nullptr;              // a second queue of the same device for compress (the secondary side's argument runs beside the
+                                           // primary's, as nova-snark's CompressedSNARK::prove does); created on first use
   vdf_nova_tuning tune;                    // the tuning this set was made with, and that its prover runs with
   double setup_ms[7] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t digit_table_bytes[2] = {0, 0};  // HBM held by each side's digit table (vdf_nova_pp_memory)

@@ -44,7 +44,7 @@ void witness_buffer_give(std::vector<Fe>&& v) {
   if (p.free_.size() < POOL_KEEP) p.free_.push_back(std::move(v));
 }
 
-CS::CS(int f, bool shape_mode) : field_id(f), F(field(f)), shape(shape_mode) { if (!shape) W = witness_buffer_take(); }
+CS::CS(int f, bool shape_mode, const RoInstance* r) : ro(r ? r : ro_default()), field_id(f), F(field(f)), shape(shape_mode) { if (!shape) W = witness_buffer_take(); }
 CS::~CS() { if (!shape) witness_buffer_give(std::move(W)); }
 
 Num CS::constant(const Fe& k) const {
@@ -221,6 +221,76 @@ const RoConstants& ro_constants(int f) {
   return f == VDF_FIELD_FP ? fp : fq;
 }
 
+// ---- the parameter block: instances ---------------------------------------------------------------------------
+// family 1 [UPSTREAM-RECALL, the Poseidon paper's generate_parameters_grain; oracle/poseidon.py classic_constants is the
+// restatement this is tested against]: round constants from an 80-bit Grain LFSR seeded with the instance's own numbers,
+// Cauchy MDS matrix 1 / (i + t + j).
+static void make_classic(RoInstance& R, int f) {
+  const Field& F = field(f);
+  const int t = R.spec.width, rf = R.spec.full_rounds, rp = R.spec.partial_rounds, n = 255;
+  uint8_t st[80];
+  int k = 0;
+  auto put = [&](unsigned v, int w) { for (int b = w - 1; b >= 0; --b) st[k++] = (uint8_t)((v >> b) & 1u); };
+  put(1, 2); put(0, 4); put((unsigned)n, 12); put((unsigned)t, 12); put((unsigned)rf, 10); put((unsigned)rp, 10);
+  while (k < 80) st[k++] = 1;
+  int head = 0;                                        // st[(head + i) % 80] = b_i of the paper
+  auto step = [&]() -> unsigned {
+    auto at = [&](int i) { return st[(head + i) % 80]; };
+    const uint8_t b = at(62) ^ at(51) ^ at(38) ^ at(23) ^ at(13) ^ at(0);
+    st[head] = b;
+    head = (head + 1) % 80;
+    return b;
+  };
+  for (int i = 0; i < 160; ++i) step();
+  auto next_bit = [&]() -> unsigned { for (;;) { const unsigned a = step(), b = step(); if (a) return b; } };
+  auto next_fe = [&]() -> Fe {
+    for (;;) {
+      uint64_t v[4] = {0, 0, 0, 0};
+      for (int i = 0; i < n; ++i) {                    // most significant bit first
+        v[3] = (v[3] << 1) | (v[2] >> 63); v[2] = (v[2] << 1) | (v[1] >> 63); v[1] = (v[1] << 1) | (v[0] >> 63);
+        v[0] = (v[0] << 1) | next_bit();
+      }
+      if (!geq(v, F.m)) { Fe c; memcpy(c.l, v, 32); return to_mont(c, F); }
+    }
+  };
+  R.rc[f].resize((size_t)(rf + rp) * t);
+  for (Fe& c : R.rc[f]) c = next_fe();
+  R.mds[f].resize((size_t)t * t);
+  for (int i = 0; i < t; ++i)
+    for (int j = 0; j < t; ++j) R.mds[f][(size_t)i * t + j] = inverse(from_u64((uint64_t)(i + t + j), F), F);
+}
+const RoInstance* ro_default() {
+  static const RoInstance d = [] {
+    RoInstance r;
+    r.rate = 3; r.is_default = true;
+    const char* l = "vdf-poseidon2-v1";
+    r.label.assign(l, l + 16);
+    return r;
+  }();
+  return &d;
+}
+const RoInstance* ro_instance(const RoSpec& sp) {
+  if (sp == RoSpec()) return ro_default();
+  // what this build supports: x^5, the protocol's 128 / 250-bit truncations; family 0 is the default block only
+  if (sp.alpha != 5 || sp.challenge_bits != CHAL_BITS || sp.hash_bits != HASH_BITS || sp.family != 1) return nullptr;
+  if (sp.width < 2 || sp.width > RO_MAX_T || sp.full_rounds < 2 || sp.full_rounds > 16 || (sp.full_rounds & 1) || sp.partial_rounds < 0 ||
+      sp.partial_rounds > 128)
+    return nullptr;
+  static std::mutex mu;
+  static std::vector<std::unique_ptr<RoInstance>> made;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& r : made) if (r->spec == sp) return r.get();
+  std::unique_ptr<RoInstance> r(new RoInstance());
+  r->spec = sp; r->rate = sp.width - 1; r->is_default = false;
+  const char* l = "vdf-ro-block-v1:";
+  r->label.assign(l, l + 16);
+  for (int v : {sp.family, sp.width, sp.full_rounds, sp.partial_rounds, sp.alpha, sp.challenge_bits, sp.hash_bits}) r->label.push_back((uint8_t)v);
+  make_classic(*r, VDF_FIELD_FP);
+  make_classic(*r, VDF_FIELD_FQ);
+  made.push_back(std::move(r));
+  return made.back().get();
+}
+
 static inline Fe dbl(const Fe& a, const Field& F) { return vdfhost::add(a, a, F); }
 // M4 s with 14 additions (the factorisation of the Poseidon2 paper, section 5.1)
 static inline void ext_layer(Fe s[4], const Field& F) {
@@ -241,7 +311,28 @@ static inline void int_layer(Fe s[4], const Field& F) {
 }
 static inline Fe pow5(const Fe& x, const Field& F) { const Fe x2 = sqr(x, F); return vdfhost::mul(sqr(x2, F), x, F); }
 
-void ro_permute(Fe s[RO_T], int f) {
+// the original Poseidon permutation (family 1): add constants, x^5 on all lanes / on lane 0, dense matrix
+static void classic_permute(Fe* s, int f, const RoInstance& R) {
+  const Field& F = field(f);
+  const int t = R.spec.width, half = R.spec.full_rounds / 2, rounds = R.spec.full_rounds + R.spec.partial_rounds;
+  const Fe* rc = R.rc[f].data();
+  const Fe* M = R.mds[f].data();
+  Fe tmp[RO_MAX_T];
+  for (int r = 0; r < rounds; ++r) {
+    for (int i = 0; i < t; ++i) s[i] = vdfhost::add(s[i], rc[(size_t)r * t + i], F);
+    if (r < half || r >= half + R.spec.partial_rounds) for (int i = 0; i < t; ++i) s[i] = pow5(s[i], F);
+    else s[0] = pow5(s[0], F);
+    for (int i = 0; i < t; ++i) {
+      Fe acc = vdfhost::mul(M[(size_t)i * t], s[0], F);
+      for (int j = 1; j < t; ++j) acc = vdfhost::add(acc, vdfhost::mul(M[(size_t)i * t + j], s[j], F), F);
+      tmp[i] = acc;
+    }
+    for (int i = 0; i < t; ++i) s[i] = tmp[i];
+  }
+}
+
+void ro_permute(Fe* s, int f, const RoInstance* ro) {
+  if (ro && !ro->is_default) { classic_permute(s, f, *ro); return; }
   const Field& F = field(f);
   const RoConstants& rc = ro_constants(f);
   ext_layer(s, F);
@@ -257,12 +348,16 @@ void ro_permute(Fe s[RO_T], int f) {
   }
 }
 
-Fe ro_hash(int f, uint64_t tag, const Fe* xs, size_t n) {
+Fe ro_hash(int f, uint64_t tag, const Fe* xs, size_t n, const RoInstance* ro) {
   const Field& F = field(f);
-  Fe s[4] = {from_u64(tag + ((uint64_t)n << 32), F), vdfhost::zero(), vdfhost::zero(), vdfhost::zero()};
-  for (size_t k = 0; k < n; k += RO_RATE) {
-    for (size_t j = 0; j < RO_RATE && k + j < n; ++j) s[1 + j] = vdfhost::add(s[1 + j], xs[k + j], F);
-    ro_permute(s, f);
+  if (!ro) ro = ro_default();
+  const size_t rate = (size_t)ro->rate;
+  Fe s[RO_MAX_T];
+  s[0] = from_u64(tag + ((uint64_t)n << 32), F);
+  for (int i = 1; i < RO_MAX_T; ++i) s[i] = vdfhost::zero();
+  for (size_t k = 0; k < n; k += rate) {
+    for (size_t j = 0; j < rate && k + j < n; ++j) s[1 + j] = vdfhost::add(s[1 + j], xs[k + j], F);
+    ro_permute(s, f, ro);
   }
   return s[1];
 }
@@ -405,15 +500,34 @@ static Num sbox(CS& cs, const Num& x) {
   return cs.mul(x4, x);
 }
 // witness mode: the permutation on bare field elements; an S-box leaves x^2, x^4, x^5 in W (three constraints)
-static void poseidon_permute_witness(CS& cs, Fe s[4]) {
+static void poseidon_permute_witness(CS& cs, Fe* s) {
   const Field& F = cs.F;
-  const RoConstants& rc = ro_constants(cs.field_id);
   auto sbox_w = [&](const Fe& x) {
     const Fe x2 = sqr(x, F), x4 = sqr(x2, F), x5 = vdfhost::mul(x4, x, F);
     cs.W.push_back(x2); cs.W.push_back(x4); cs.W.push_back(x5);
     cs.rows += 3;
     return x5;
   };
+  if (!cs.ro->is_default) {                           // the original Poseidon permutation (family 1), as classic_permute
+    const RoInstance& R = *cs.ro;
+    const int t = R.spec.width, half = R.spec.full_rounds / 2, rounds = R.spec.full_rounds + R.spec.partial_rounds;
+    const Fe* rcc = R.rc[cs.field_id].data();
+    const Fe* M = R.mds[cs.field_id].data();
+    Fe tmp[RO_MAX_T];
+    for (int r = 0; r < rounds; ++r) {
+      for (int i = 0; i < t; ++i) s[i] = vdfhost::add(s[i], rcc[(size_t)r * t + i], F);
+      if (r < half || r >= half + R.spec.partial_rounds) for (int i = 0; i < t; ++i) s[i] = sbox_w(s[i]);
+      else s[0] = sbox_w(s[0]);
+      for (int i = 0; i < t; ++i) {
+        Fe acc = vdfhost::mul(M[(size_t)i * t], s[0], F);
+        for (int j = 1; j < t; ++j) acc = vdfhost::add(acc, vdfhost::mul(M[(size_t)i * t + j], s[j], F), F);
+        tmp[i] = acc;
+      }
+      for (int i = 0; i < t; ++i) s[i] = tmp[i];
+    }
+    return;
+  }
+  const RoConstants& rc = ro_constants(cs.field_id);
   ext_layer(s, F);
   for (int r = 0; r < RO_RF + RO_RP; ++r) {
     if (r < RO_RF / 2 || r >= RO_RF / 2 + RO_RP) {
@@ -427,6 +541,25 @@ static void poseidon_permute_witness(CS& cs, Fe s[4]) {
   }
 }
 static void poseidon_permute(CS& cs, std::vector<Num>& s) {
+  if (!cs.ro->is_default) {                           // family 1 in R1CS: the matrix as linear combinations (oracle/nova.py poseidon_permute_classic)
+    const RoInstance& R = *cs.ro;
+    const int t = R.spec.width, half = R.spec.full_rounds / 2, rounds = R.spec.full_rounds + R.spec.partial_rounds;
+    const Fe* rcc = R.rc[cs.field_id].data();
+    const Fe* M = R.mds[cs.field_id].data();
+    for (int r = 0; r < rounds; ++r) {
+      for (int i = 0; i < t; ++i) s[i] = cs.add(s[i], cs.constant(rcc[(size_t)r * t + i]));
+      if (r < half || r >= half + R.spec.partial_rounds) for (int i = 0; i < t; ++i) s[i] = sbox(cs, s[i]);
+      else s[0] = sbox(cs, s[0]);
+      std::vector<Num> o(t);
+      for (int i = 0; i < t; ++i) {
+        Num acc = cs.zero_num();                       // the oracle's lin(): from zero, term by term
+        for (int j = 0; j < t; ++j) acc = cs.add(acc, cs.scale(s[j], M[(size_t)i * t + j]));
+        o[i] = std::move(acc);
+      }
+      s.swap(o);
+    }
+    return;
+  }
   const RoConstants& rc = ro_constants(cs.field_id);
   ext_layer_num(cs, s);
   for (int r = 0; r < RO_RF + RO_RP; ++r) {
@@ -442,22 +575,25 @@ static void poseidon_permute(CS& cs, std::vector<Num>& s) {
   }
 }
 Num poseidon_hash(CS& cs, uint64_t tag, const std::vector<Num>& xs) {
+  const size_t rate = (size_t)cs.ro->rate, width = (size_t)cs.ro->spec.width;
   if (!cs.shape) {
     const Field& F = cs.F;
-    Fe st[4] = {from_u64(tag + ((uint64_t)xs.size() << 32), F), vdfhost::zero(), vdfhost::zero(), vdfhost::zero()};
-    for (size_t k = 0; k < xs.size(); k += RO_RATE) {
-      for (size_t j = 0; j < RO_RATE && k + j < xs.size(); ++j) st[1 + j] = vdfhost::add(st[1 + j], xs[k + j].v, F);
+    Fe st[RO_MAX_T];
+    st[0] = from_u64(tag + ((uint64_t)xs.size() << 32), F);
+    for (size_t i = 1; i < width; ++i) st[i] = vdfhost::zero();
+    for (size_t k = 0; k < xs.size(); k += rate) {
+      for (size_t j = 0; j < rate && k + j < xs.size(); ++j) st[1 + j] = vdfhost::add(st[1 + j], xs[k + j].v, F);
       poseidon_permute_witness(cs, st);
     }
     Num out;
     out.v = st[1];
     return out;
   }
-  std::vector<Num> s(4);
+  std::vector<Num> s(width);
   s[0] = cs.constant_u64(tag + ((uint64_t)xs.size() << 32));
-  s[1] = s[2] = s[3] = cs.zero_num();
-  for (size_t k = 0; k < xs.size(); k += RO_RATE) {
-    for (size_t j = 0; j < RO_RATE && k + j < xs.size(); ++j) s[1 + j] = cs.add(s[1 + j], xs[k + j]);
+  for (size_t i = 1; i < width; ++i) s[i] = cs.zero_num();
+  for (size_t k = 0; k < xs.size(); k += rate) {
+    for (size_t j = 0; j < rate && k + j < xs.size(); ++j) s[1 + j] = cs.add(s[1 + j], xs[k + j]);
     poseidon_permute(cs, s);
   }
   return s[1];
@@ -940,7 +1076,7 @@ void relaxed_elements(const RelaxedInst& U, const Field& F, Fe out[9]) {
 }
 
 Fe hash_state(int f, const Fe& params, const Fe& i, const std::vector<Fe>& z0, const std::vector<Fe>& zi, const RelaxedInst& U,
-              uint64_t out_int[4]) {
+              uint64_t out_int[4], const RoInstance* ro) {
   const Field& F = field(f);
   std::vector<Fe> xs = {params, i};
   xs.insert(xs.end(), z0.begin(), z0.end());
@@ -949,13 +1085,13 @@ Fe hash_state(int f, const Fe& params, const Fe& i, const std::vector<Fe>& z0, c
   relaxed_elements(U, F, ue);
   xs.insert(xs.end(), ue, ue + 9);
   uint64_t h[4];
-  fe_to_int(ro_hash(f, TAG_STATE, xs.data(), xs.size()), F, h);
+  fe_to_int(ro_hash(f, TAG_STATE, xs.data(), xs.size(), ro), F, h);
   low_bits(h, HASH_BITS, out_int);
   return int_to_fe(out_int, F);
 }
 
 void hash_challenge(int f, const Fe& params, const RelaxedInst& U, const Aff& u_W, const uint64_t u_X[2][4], const Aff& T,
-                    uint64_t r_out[4]) {
+                    uint64_t r_out[4], const RoInstance* ro) {
   const Field& F = field(f);
   Fe xs[16];
   xs[0] = params;
@@ -964,7 +1100,7 @@ void hash_challenge(int f, const Fe& params, const RelaxedInst& U, const Aff& u_
   xs[12] = int_to_fe(u_X[0], F); xs[13] = int_to_fe(u_X[1], F);
   xs[14] = T.x; xs[15] = T.y;
   uint64_t h[4];
-  fe_to_int(ro_hash(f, TAG_CHAL, xs, 16), F, h);
+  fe_to_int(ro_hash(f, TAG_CHAL, xs, 16, ro), F, h);
   low_bits(h, CHAL_BITS, r_out);
 }
 
@@ -987,16 +1123,16 @@ inline void take(Blk& b, CS& t) { t.resolve(); b.W = std::move(t.W); t.W = std::
 // poseidon_hash (above) in witness mode, element by element
 namespace {
 struct WSponge {
-  Fe st[4];
+  Fe st[RO_MAX_T];
   size_t fill = 0;
   void init(uint64_t tag, size_t len, const Field& F) {
     st[0] = from_u64(tag + ((uint64_t)len << 32), F);
-    st[1] = st[2] = st[3] = vdfhost::zero();
+    for (int i = 1; i < RO_MAX_T; ++i) st[i] = vdfhost::zero();
     fill = 0;
   }
   void absorb(CS& cs, const Fe& x) {
     st[1 + fill] = vdfhost::add(st[1 + fill], x, cs.F);
-    if (++fill == RO_RATE) { poseidon_permute_witness(cs, st); fill = 0; }
+    if (++fill == (size_t)cs.ro->rate) { poseidon_permute_witness(cs, st); fill = 0; }
   }
   Fe finish(CS& cs) {
     if (fill) { poseidon_permute_witness(cs, st); fill = 0; }
@@ -1038,7 +1174,7 @@ AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const Step
   // ---- block 1 (helper 0): the hash this step must have been handed
   AugEarly* p = e.get();
   auto run_b1 = [p] {
-    CS t(p->fid, false);
+    CS t(p->fid, false, p->in.ro);
     WSponge sp;
     sp.init(TAG_STATE, 2 + 2 * p->a + 9, t.F);
     sp.absorb(t, p->in.params); sp.absorb(t, p->in.i);
@@ -1052,12 +1188,12 @@ AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const Step
   e->helped = e->helpers != nullptr;
   if (e->helped) { e->helpers->start(0, run_b1); e->pending0 = true; } else run_b1();
   // ---- block 2, first half: the challenge hash over what is known (params and the running instance)
-  e->chal.reset(new CS(fid, false));
+  e->chal.reset(new CS(fid, false, in.ro));
   e->chal_sp.init(TAG_CHAL, 16, F);
   e->chal_sp.absorb(*e->chal, in.params);
   for (int k = 0; k < 9; ++k) e->chal_sp.absorb(*e->chal, e->ue[k]);
   // ---- block 5, first half: the bits of u.X
-  e->foreign.reset(new CS(fid, false));
+  e->foreign.reset(new CS(fid, false, in.ro));
   for (int k = 0; k < 2; ++k) e->xb[k] = alloc_bits(*e->foreign, in.u_X[k], HASH_BITS);
   e->foreign->rows += 2;                              // the two packings equal u.X[k]
   // ---- the output hash up to z_out, when the step circuit can tell it
@@ -1067,7 +1203,7 @@ AugEarlyPtr synthesize_augmented_early(int side, const AugInputs& in, const Step
     for (size_t k = 0; k < a; ++k) z_in[k] = is_base ? in.z0[k] : in.zi[k];
     e->z_out.resize(a);
     step.output(z_in.data(), e->z_out.data());
-    e->outh.reset(new CS(fid, false));
+    e->outh.reset(new CS(fid, false, in.ro));
     e->out_sp.init(TAG_STATE, 2 + 2 * a + 9, F);
     e->out_sp.absorb(*e->outh, in.params);
     e->out_sp.absorb(*e->outh, vdfhost::add(in.i, one(F), F));
@@ -1094,7 +1230,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   AugEarlyPtr own(nullptr, aug_early_free);
   if (!early) { own = synthesize_augmented_early(side, in, step); early = own.get(); }
   AugEarly& e = *early;
-  if (e.side != side || e.a != a || e.in.params != in.params || e.in.i != in.i || e.in.z0 != in.z0 || e.in.zi != in.zi ||
+  if (e.side != side || e.a != a || e.in.ro != in.ro || e.in.params != in.params || e.in.i != in.i || e.in.z0 != in.z0 || e.in.zi != in.zi ||
       memcmp(&e.in.U, &in.U, sizeof(RelaxedInst)) != 0 || memcmp(e.in.u_X, in.u_X, sizeof(in.u_X)) != 0)
     throw std::runtime_error("synthesize_augmented: the early half was made for other inputs");
   const Fe* ue = e.ue;
@@ -1106,7 +1242,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
   std::atomic<bool> r_ready{false};
   struct alignas(64) FoldOut { Fe x, y; size_t queued = 0, misses = 0; double done = 0, tr[4] = {0, 0, 0, 0}; } fo_w, fo_e;
   auto run_fold = [&](const Aff& Upt, const Aff& P, Blk* b, FoldOut* o) {
-    CS t(fid, false);
+    CS t(fid, false, in.ro);
     static thread_local FoldPre pre;                  // a helper thread keeps its scratch: no allocation, no page fault per step
     ec_fold_prepare(F, P, CHAL_BITS, &pre);
     o->tr[0] = us();
@@ -1211,7 +1347,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
     if (e.have_out)
       for (size_t k = 0; k < a; ++k) if (e.z_out[k] != z_out[k].v) e.have_out = false;
     if (!e.have_out) {
-      e.outh.reset(new CS(fid, false));
+      e.outh.reset(new CS(fid, false, in.ro));
       e.out_sp.init(TAG_STATE, 2 + 2 * a + 9, F);
       e.out_sp.absorb(*e.outh, in.params);
       e.out_sp.absorb(*e.outh, i_new_v);
@@ -1243,6 +1379,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
 std::vector<Fe> synthesize_augmented(CS& cs, int side, const AugInputs& in, const StepCircuit& step, Fe* unew_out, uint64_t* r_out,
                                      AugEarly* early) {
   static const bool sequential = [] { const char* e = env_override("VDF_NOVA_SEQ_SYNTH"); return e && e[0] == '1'; }();
+  if (cs.ro != (in.ro ? in.ro : ro_default())) throw std::runtime_error("synthesize_augmented: the constraint system and the inputs name different RO parameter blocks");
   if (!cs.shape && !sequential) return synthesize_augmented_blocks(cs, side, in, step, unew_out, r_out, early);
   const Field& F = cs.F;
   const Field& PF = field(side_field(1 - side));

@@ -35,9 +35,34 @@ struct Coo { std::vector<uint32_t> rows, cols; std::vector<Fe> vals; };
 std::vector<Fe> witness_buffer_take();
 void witness_buffer_give(std::vector<Fe>&& v);
 
+// ---- the random oracle as a parameter block (include/vdf_nova.h vdf_nova_ro_params; oracle/poseidon.py RoSpec) -----
+// family 0: this build's Poseidon2-style permutation (width 4, 8 + 56 rounds, SHAKE256 constants: the fast path below);
+// family 1: the original Poseidon permutation [UPSTREAM-RECALL: neptune's shape] -- dense Cauchy MDS, Grain-LFSR constants,
+// any width up to 25, a sponge of rate width - 1.  The block is covered by the parameters' digest (digest_shapes absorbs
+// its label, and the shapes change with it); the two truncations are recorded in it and checked against what this build
+// supports (128 / 250).
+constexpr int RO_MAX_T = 25;
+struct RoSpec {
+  int family = 0, width = 4, full_rounds = 8, partial_rounds = 56, alpha = 5, challenge_bits = 128, hash_bits = 250;
+  bool operator==(const RoSpec& o) const {
+    return family == o.family && width == o.width && full_rounds == o.full_rounds && partial_rounds == o.partial_rounds &&
+           alpha == o.alpha && challenge_bits == o.challenge_bits && hash_bits == o.hash_bits;
+  }
+};
+struct RoInstance {
+  RoSpec spec;
+  int rate = 3;
+  std::vector<Fe> rc[2], mds[2];         // family 1, per field id: (RF + RP) x width round constants, width x width matrix
+  std::vector<uint8_t> label;            // what the parameters' digest absorbs for the RO
+  bool is_default = true;
+};
+const RoInstance* ro_default();
+const RoInstance* ro_instance(const RoSpec& s);      // null: a block this build does not support; instances live for the process
+
 class CS {
  public:
-  CS(int field_id, bool shape_mode);
+  CS(int field_id, bool shape_mode, const RoInstance* ro = nullptr);      // ro = null: the default block
+  const RoInstance* const ro;
   ~CS();
   CS(const CS&) = delete;
   CS& operator=(const CS&) = delete;
@@ -93,8 +118,8 @@ class CS {
 constexpr int RO_T = 4, RO_RATE = 3, RO_RF = 8, RO_RP = 56;
 struct RoConstants { Fe ext[RO_RF][RO_T]; Fe in[RO_RP]; unsigned mu_minus_1[RO_T]; };
 const RoConstants& ro_constants(int field_id);
-void ro_permute(Fe s[RO_T], int field_id);
-Fe ro_hash(int field_id, uint64_t tag, const Fe* xs, size_t n);       // full field element (lane 1)
+void ro_permute(Fe* s, int field_id, const RoInstance* ro = nullptr);      // s: ro->spec.width elements (4 for the default)
+Fe ro_hash(int field_id, uint64_t tag, const Fe* xs, size_t n, const RoInstance* ro = nullptr);       // full field element (lane 1)
 
 // ---- gadgets (allocation and constraint order as in oracle/nova.py) -------------------------------------------------
 Num is_zero(CS& cs, const Num& a);
@@ -173,12 +198,13 @@ struct AugInputs {
   Aff u_W;
   uint64_t u_X[2][4];                    // canonical integers (250-bit hashes)
   Aff T;
+  const RoInstance* ro = nullptr;        // the random oracle's parameter block (null: the default)
 };
 void relaxed_elements(const RelaxedInst& U, const Field& F, Fe out[9]);       // what a running instance is hashed as
 Fe hash_state(int field_id, const Fe& params, const Fe& i, const std::vector<Fe>& z0, const std::vector<Fe>& zi,
-              const RelaxedInst& U, uint64_t out_int[4]);
+              const RelaxedInst& U, uint64_t out_int[4], const RoInstance* ro = nullptr);
 void hash_challenge(int field_id, const Fe& params, const RelaxedInst& U, const Aff& u_W, const uint64_t u_X[2][4], const Aff& T,
-                    uint64_t r_out[4]);
+                    uint64_t r_out[4], const RoInstance* ro = nullptr);
 // side 0 = primary (circuit over Fq, folds Vesta instances), side 1 = secondary; returns z_{i+1}
 // unew (optional): the nine elements of the running instance the circuit hands on (the folded one, or the base case's);
 // r (optional): the fold challenge it derived, a 128-bit integer

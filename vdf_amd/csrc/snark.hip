@@ -63,6 +63,7 @@ Status snark_pair_table(int field, const vdf_fe* lo, const vdf_fe* hi, int k, vo
   a.k = k;
   for (int j = 0; j < k; ++j) { a.lo[j] = to_arg(&lo[j]); a.hi[j] = to_arg(&hi[j]); }
   const size_t n = (size_t)1 << k;
+  KTimer kt(s, "k_eq_table", 32.0 * n);                          // one element written per index; the factors are kernel arguments
   SNARK_DISPATCH(field, k_eq_table, grid_for(n), dim3(256), 0, s, a, n, reinterpret_cast<char*>(out));
   return Status{};
 }
@@ -94,6 +95,7 @@ Status snark_pair_table_pattern(int field, const vdf_fe* lo, const vdf_fe* hi, i
   pa.log_m = log_m;
   for (int j = 0; j < (1 << log_m); ++j) pa.p[j] = to_arg(&pattern[j]);
   const size_t n = (size_t)1 << (k + log_m);
+  KTimer kt(s, "k_eq_table_pattern", 32.0 * n);
   SNARK_DISPATCH(field, k_eq_table_pattern, grid_for(n), dim3(256), 0, s, a, pa, n, reinterpret_cast<char*>(out));
   return Status{};
 }
@@ -121,6 +123,7 @@ Status snark_fold_halves(int field, int k, void* const v[], const vdf_fe c_lo[],
   for (int t = 0; t < k; ++t) { a.v[t] = reinterpret_cast<char*>(v[t]); a.c_lo[t] = to_arg(&c_lo[t]); a.c_hi[t] = to_arg(&c_hi[t]); }
   const size_t h = n / 2;
   dim3 grid((unsigned)((h + 255) / 256), (unsigned)k);
+  KTimer kt(s, "k_fold_halves", 96.0 * h * k);                   // two halves read, the lower one written, per vector
   SNARK_DISPATCH(field, k_fold_halves, grid, dim3(256), 0, s, a, h);
   return Status{};
 }
@@ -232,6 +235,9 @@ Status snark_reduce(int field, int kind, const void* const tables[], const vdf_f
   for (int k = 0; k < ntab; ++k) a.t[k] = reinterpret_cast<const char*>(tables[k]);
   if (u) a.u = to_arg(u);
   a.n = n;
+  // bytes read: kind 0 two vectors of n; kind 1 / 3 two vectors of n (both halves); kind 2 five tables of n
+  KTimer kt(s, kind == 0 ? "k_reduce(dot)" : kind == 1 ? "k_reduce(quad round)" : kind == 2 ? "k_reduce(cubic round)" : "k_reduce(ipa cross)",
+            32.0 * n * ntab);
 #define RL(P, K) reduce_launch<P, K>(a, scratch, out, s)
   if (field == VDF_FIELD_FP) return kind == 0 ? RL(FpParams, 0) : kind == 1 ? RL(FpParams, 1) : kind == 2 ? RL(FpParams, 2) : RL(FpParams, 3);
   if (field == VDF_FIELD_FQ) return kind == 0 ? RL(FqParams, 0) : kind == 1 ? RL(FqParams, 1) : kind == 2 ? RL(FqParams, 2) : RL(FqParams, 3);
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(256) void k_scale_pattern(char* __restrict__ sv, si
 
 Status snark_ipa_scalars(int field, const void* a, const void* sv, size_t n, size_t nj, void* sL, void* sR, hipStream_t s) {
   if (n == 0 || (n & (n - 1)) || nj < 2 || (nj & (nj - 1)) || nj > n) return Status{VDF_ERR_BAD_LENGTH, "lengths must be powers of two, 2 <= n_j <= n"};
+  KTimer kt(s, "k_ipa_scalars", 96.0 * n + 32.0 * nj);           // s read, sL and sR written, a read once
   SNARK_DISPATCH(field, k_ipa_scalars, grid_for(n), dim3(256), 0, s, reinterpret_cast<const char*>(a),
                  reinterpret_cast<const char*>(sv), n, nj, reinterpret_cast<char*>(sL), reinterpret_cast<char*>(sR));
   return Status{};
@@ -395,6 +402,7 @@ Status snark_ipa_scalars(int field, const void* a, const void* sv, size_t n, siz
 
 Status snark_scale_pattern(int field, void* sv, size_t n, size_t nj, const vdf_fe* x_lo, const vdf_fe* x_hi, hipStream_t s) {
   if (n == 0 || (n & (n - 1)) || nj < 2 || (nj & (nj - 1)) || nj > n) return Status{VDF_ERR_BAD_LENGTH, "lengths must be powers of two, 2 <= n_j <= n"};
+  KTimer kt(s, "k_scale_pattern", 64.0 * n);
   SNARK_DISPATCH(field, k_scale_pattern, grid_for(n), dim3(256), 0, s, reinterpret_cast<char*>(sv), n, nj, to_arg(x_lo), to_arg(x_hi));
   return Status{};
 }

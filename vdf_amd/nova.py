@@ -20,6 +20,12 @@ for _name, _res, _args in [
     ("vdf_nova_public_params_flags", _i, [_vp, _u64, _i, _i, C.c_uint, C.POINTER(_vp)]),
     ("vdf_nova_public_params_tuned", _i, [_vp, _u64, _i, _i, _vp, C.POINTER(_vp)]),
     ("vdf_nova_tuning_default", None, [_vp]),
+    ("vdf_nova_ro_preset", _i, [_i, _vp]),
+    ("vdf_nova_public_params_ro", _i, [_vp, _u64, _i, _i, _vp, _vp, C.POINTER(_vp)]),
+    ("vdf_nova_pp_ro", _i, [_vp, _vp]),
+    ("vdf_nova_ro_hash_ro", _i, [_vp, _i, _u64, _vp, _sz, _vp]),
+    ("vdf_nova_shape_digest_ro", _i, [_vp, _u64, _i, _i, _vp, _vp]),
+    ("vdf_nova_aug_synthesize_ro", _i, [_vp, _i, _u64, _i, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), C.POINTER(_sz), _vp, _vp]),
     ("vdf_nova_pp_tuning", _i, [_vp, _vp]),
     ("vdf_nova_pp_setup_ms", _i, [_vp, C.POINTER(C.c_double * 7)]),
     ("vdf_nova_pp_memory", _i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint)]),
@@ -103,6 +109,34 @@ class NovaTuning(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class RoParams(C.Structure):
+    """vdf_nova_ro_params (include/vdf_nova.h): the random oracle as a parameter block covered by the parameters' digest."""
+    _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in (
+        "family", "width", "full_rounds", "partial_rounds", "alpha", "challenge_bits", "hash_bits")]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}
+
+
+RO_DEFAULT, RO_NEPTUNE_SHAPED = 0, 1
+
+
+def ro_preset(which: int = RO_DEFAULT, **fields) -> RoParams:
+    """0: this build's default block (Poseidon2-style, width 4); 1: the neptune-shaped block (original Poseidon, width 25,
+    8 + 57 rounds; [UPSTREAM-RECALL], unpinned).  Keyword fields replace members (e.g. width=9 for a smaller instance)."""
+    r = RoParams()
+    _check(nova_lib.vdf_nova_ro_preset(which, C.byref(r)))
+    for k, v in fields.items():
+        if k not in dict(RoParams._fields_):
+            raise KeyError(k)
+        setattr(r, k, int(v))
+    return r
+
+
+def _ro_ptr(ro):
+    return C.byref(ro) if ro is not None else None
+
+
 def tuning_default(**fields) -> NovaTuning:
     """The library's defaults (environment overrides applied once per process), with the named fields replaced."""
     t = NovaTuning()
@@ -135,19 +169,19 @@ def point_decompress(data: bytes, curve: int = 0) -> np.ndarray:
     return out
 
 
-def ro_hash(field: int, tag: int, xs: np.ndarray) -> np.ndarray:
-    """The random oracle's sponge (host only): lane 1 after absorbing xs (Montgomery limbs in and out)."""
+def ro_hash(field: int, tag: int, xs: np.ndarray, ro: "RoParams | None" = None) -> np.ndarray:
+    """The random oracle's sponge (host only): lane 1 after absorbing xs (Montgomery limbs in and out); `ro`: another block."""
     xs = np.ascontiguousarray(xs, dtype="<u8").reshape(-1, 4)
     out = np.zeros(4, dtype="<u8")
-    _check(nova_lib.vdf_nova_ro_hash(field, tag, xs.ctypes.data, xs.shape[0], out.ctypes.data))
+    _check(nova_lib.vdf_nova_ro_hash_ro(_ro_ptr(ro), field, tag, xs.ctypes.data, xs.shape[0], out.ctypes.data))
     return out
 
 
-def shape_digest(t: int, circuit_kind: int = 1, gens_family: int = 1):
+def shape_digest(t: int, circuit_kind: int = 1, gens_family: int = 1, ro: "RoParams | None" = None):
     """(digest as an integer, sizes[side] = (num_cons, num_vars, nnz)) of the parameters public_params(t) would make."""
     d = (C.c_uint8 * 32)()
     sizes = np.zeros((2, 3), dtype="<u8")
-    _check(nova_lib.vdf_nova_shape_digest(t, circuit_kind, gens_family, d, sizes.ctypes.data))
+    _check(nova_lib.vdf_nova_shape_digest_ro(_ro_ptr(ro), t, circuit_kind, gens_family, d, sizes.ctypes.data))
     return int.from_bytes(bytes(d), "little"), sizes.tolist()
 
 
@@ -284,16 +318,16 @@ class AugInputs(C.Structure):     # vdf_nova_aug_inputs
                 ("u_comm_W", _Fe * 2), ("u_X", _Fe * 2), ("T", _Fe * 2)]
 
 
-def aug_synthesize(side: int, t: int, circuit_kind: int, inputs: AugInputs, result=None, inp=None, cap: int = 1 << 16):
+def aug_synthesize(side: int, t: int, circuit_kind: int, inputs: AugInputs, result=None, inp=None, cap: int = 1 << 16, ro=None):
     """One augmented circuit synthesised on the host: (W, X, z_next, num_cons)."""
     W = np.zeros((cap, 4), dtype="<u8")
     X, zn = np.zeros((2, 4), dtype="<u8"), np.zeros((3, 4), dtype="<u8")
     nv, nc = C.c_size_t(), C.c_size_t()
     r = C.byref(result._c()) if result is not None else None
     i = C.byref(inp._c()) if inp is not None else None
-    _check(nova_lib.vdf_nova_aug_synthesize(side, t, circuit_kind, C.addressof(inputs), C.cast(r, _vp) if r else None,
-                                            C.cast(i, _vp) if i else None, W.ctypes.data, cap, C.byref(nv), C.byref(nc),
-                                            X.ctypes.data, zn.ctypes.data))
+    _check(nova_lib.vdf_nova_aug_synthesize_ro(_ro_ptr(ro), side, t, circuit_kind, C.addressof(inputs), C.cast(r, _vp) if r else None,
+                                               C.cast(i, _vp) if i else None, W.ctypes.data, cap, C.byref(nv), C.byref(nc),
+                                               X.ctypes.data, zn.ctypes.data))
     return W[:nv.value].copy(), X, zn[:3 if side == 0 else 1].copy(), nc.value
 
 
@@ -333,6 +367,12 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
         """4 / 3: the early rows run as the MinRoot stencil (reference / bound rounds), 0: through the sparse kernel."""
         return int(nova_lib.vdf_nova_pp_stencil(self.handle))
 
+    def ro(self) -> dict:
+        """The random oracle's parameter block this set was made under (vdf_nova_pp_ro)."""
+        r = RoParams()
+        _check(nova_lib.vdf_nova_pp_ro(self.handle, C.byref(r)))
+        return r.as_dict()
+
     def tuning(self) -> dict:
         t = NovaTuning()
         _check(nova_lib.vdf_nova_pp_tuning(self.handle, C.byref(t)))
@@ -368,10 +408,19 @@ class NovaVDFPublicParams:        # src/nova/proof.rs:38-43
 
 def public_params(ctx: Context, num_iters_per_step: int, circuit_kind: int = CIRCUIT_MINROOT_REFERENCE,
                   gens_family: int = GENS_TRY_AND_INCREMENT, flags: int = 0, tuning: "NovaTuning | None" = None,
-                  **tune) -> NovaVDFPublicParams:      # :232-237
-    """`tuning` / keyword fields of vdf_nova_tuning (e.g. digit_window=12, early_rows=0): vdf_nova_public_params_tuned."""
+                  ro: "RoParams | None" = None, **tune) -> NovaVDFPublicParams:      # :232-237
+    """`tuning` / keyword fields of vdf_nova_tuning (e.g. digit_window=12, early_rows=0): vdf_nova_public_params_tuned;
+    `ro`: the random oracle's parameter block (ro_preset): vdf_nova_public_params_ro."""
     h = C.c_void_p()
-    if tuning is not None or tune:
+    if ro is not None:
+        t = tuning if tuning is not None else tuning_default()
+        for k, v in tune.items():
+            if k not in dict(NovaTuning._fields_):
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        t.flags |= flags
+        _check(nova_lib.vdf_nova_public_params_ro(ctx.handle, num_iters_per_step, circuit_kind, gens_family, C.byref(ro), C.byref(t), C.byref(h)))
+    elif tuning is not None or tune:
         t = tuning if tuning is not None else tuning_default()
         for k, v in tune.items():
             if k not in dict(NovaTuning._fields_):
