@@ -569,7 +569,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     ctx.set_async(True)
     first_timed = 2 if nsteps > 2 else 1
     nsteady = max(nsteps - first_timed, 1)
-    rates, stages, base_case, first_fold, proof = [], [], 0.0, 0.0, None
+    rates, stages, base_case, first_fold, proof, outliers = [], [], 0.0, 0.0, None, []
     fp_before = box_fingerprint(ctx, "before the timed repeats")
     # Settle (untimed): one whole pass over the chain -- base case + every fold -- before the first timed repeat: the device
     # reaches the clock it then holds, every workspace has its final size, the helper threads are awake (the
@@ -581,9 +581,15 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         proof.instance(INST_FRESH_SECONDARY)
         ctx.sync()
         settle_steps = nsteps
+    import gc
     for rep in range(max(1, repeats)):
         if proof is not None:
             proof.free()
+        # the interpreter's cyclic collector runs when it pleases: one full collection of this process's objects (torch is
+        # imported) is ~45 ms -- fifty steps' worth -- inside whichever repeat it lands in (r4: per_repeat_slowest_call showed one
+        # such call per run).  It is the harness's, not the prover's: collected here, switched off for the timed steps.
+        gc.collect()
+        gc.disable()
         a = time.perf_counter()
         proof = NovaVDFProof.prove_step(pp, None, circuits, 0, z0)
         ctx.sync()
@@ -596,14 +602,22 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
             if rep == 0:
                 first_fold = time.perf_counter() - a
         a = time.perf_counter()
+        prev, worst = a, (0.0, -1)
         for k in range(first_timed, nsteps):
             proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
             stages.append(proof.last_step_ms())
+            now = time.perf_counter()
+            if now - prev > worst[0]:
+                worst = (now - prev, k)
+            prev = now
             if os.environ.get("VDF_BENCH_TRACE"):
                 print("step %d" % k, {a_: round(b_, 3) for a_, b_ in stages[-1].items()}, file=sys.stderr)
         proof.instance(INST_FRESH_SECONDARY)     # the last secondary commitment (it rides in the NEXT step's batch otherwise)
         ctx.sync()
-        rates.append((time.perf_counter() - a) / nsteady)
+        end = time.perf_counter()
+        gc.enable()
+        rates.append((end - a) / nsteady)
+        outliers.append({"slowest_call_ms": round(worst[0] * 1e3, 3), "at_step": worst[1], "closing_sync_ms": round((end - prev) * 1e3, 3)})
     fp_after = box_fingerprint(ctx, "after the timed repeats")
     ok = proof.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
     avg = median(rates) if nsteps > 1 else base_case          # the MEDIAN repeat: one cold or disturbed repeat does not move it
@@ -617,7 +631,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
            "ms_per_step_by_repeat": {"min": srt[0] * 1e3, "median": median(rates) * 1e3, "max": srt[-1] * 1e3,
                                      "mean": sum(rates) / len(rates) * 1e3, "in_order": [round(x * 1e3, 4) for x in rates]},
            "value_is": "1 / median over the repeats of (wall time of the timed folds / their number); every repeat a fresh proof",
-           "settle_steps_untimed": settle_steps, "box": [fp_before, fp_after],
+           "settle_steps_untimed": settle_steps, "box": [fp_before, fp_after], "per_repeat_slowest_call": outliers,
            "base_case_ms": base_case * 1e3, "first_fold_ms_untimed_warmup": first_fold * 1e3,
            "steady_state_steps": nsteady if nsteps > 1 else 0,
            "stage_ms": stage_avg, "verified": bool(ok), "shape": sizes, "public_params_s": pp_s,
@@ -755,12 +769,15 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         rates2 = []
         for rep in range(4):                          # repeat 0 is the settle pass of this leg: run, not rated
             proofs = warm()
+            gc.collect()
+            gc.disable()
             spans = [None] * chains
             ths = [threading.Thread(target=run, args=(i, i * avg / chains)) for i in range(chains)]
             for th in ths:
                 th.start()
             for th in ths:
                 th.join()
+            gc.enable()
             # aggregate over the window in which ALL chains were proving (the stagger leaves a chain alone at either end)
             a_, b_ = max(sp[0] for sp in spans), min(sp[1] for sp in spans)
             done = sum((nsteps - 2) * (b_ - a_) / (sp[1] - sp[0]) for sp in spans)
@@ -1041,12 +1058,16 @@ def main():
     # +-3 %); ms_per_step x steps is the duration of that one region.
     fp_msm = [box_fingerprint(ctx, "before the MSM regions")]
     region_s = []
+    import gc
+    gc.collect()
+    gc.disable()                            # (the harness's collector stays out of the timed regions; see prove_step_leg)
     for _ in range(max(1, args.regions)):
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
         fence()
         region_s.append(time.perf_counter() - t0)
+    gc.enable()
     fp_msm.append(box_fingerprint(ctx, "after the MSM regions"))
     elapsed = median(region_s)
     sort_ms = acc_ms = tail_ms = total_ms = 0.0
@@ -1224,6 +1245,10 @@ def main():
                                                             "reference's circuit in the same process on parameters of its own")
             if not args.no_reference_cases:
                 line["prove_step"]["reference_bench_cases"] = reference_bench_cases_leg(ctx)
+            if "hbm" in line["box"]:
+                # the same probe after the proving legs' allocations (65 GB of digit tables made and freed several times): a
+                # drop in the gather rate or a jump in the allocation time is this process's own fragmentation of the pool
+                line["box"]["hbm_after_prove_legs"] = hbm_fingerprint(ctx)
         failures = []
         if world == 1 and not args.no_cpu:
             ctx.set_async(False)

@@ -3,7 +3,7 @@
 # VALU count (separate --pmc passes, kernel trace only, as MI355X_MICROARCH.md prescribes), and the raw micro-benchmark
 # logs the issue-rate model rests on.  Every bench.py under rocprofv3 runs with --no-cpu: nothing is spawned under the
 # profiler (the cpu_baseline leg may rebuild the C restatement) and no CPU MSM sits inside a profiled run.
-TAG=${1:-r03}
+TAG=${1:-r04}
 COMMIT=${2:-unknown}      # the commit of the code being profiled (the GPU box has no .git): stamped into the JSON files
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -14,12 +14,12 @@ for t in op_rates clock_probe; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I $R/vdf_amd/csrc $R/tools/ubench/$t.hip -o $OUT/$t || exit 1
   timeout -k 10 120 $OUT/$t > $OUT/$t.txt 2>&1 || exit 1
 done
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_under_rocprof.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-prove --no-cpu > $OUT/bench_msm_under_rocprof.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm_depth1 -o bench -- python $R/bench.py --depth 1 --steps 20 --warmup 3 --no-prove --no-cpu > $OUT/bench_msm_depth1_under_rocprof.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu > $OUT/fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu > $OUT/write.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/valu -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu > $OUT/valu.log 2>&1 || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-sizes > $OUT/bench_under_rocprof.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-prove --no-cpu --no-sizes > $OUT/bench_msm_under_rocprof.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_msm_depth1 -o bench -- python $R/bench.py --depth 1 --steps 20 --warmup 3 --no-prove --no-cpu --no-sizes > $OUT/bench_msm_depth1_under_rocprof.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu --no-sizes > $OUT/fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu --no-sizes > $OUT/write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/valu -o p -- python $R/bench.py --depth 1 --steps 3 --warmup 1 --no-prove --no-cpu --no-sizes > $OUT/valu.log 2>&1 || exit 1
 # one steady-state prove_step: timeline and VALU per kernel
 timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/prove -o p -- python $R/tools/gpu_prove_time.py 16 10 ref > $OUT/prove.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/prove_valu -o p -- python $R/tools/gpu_prove_time.py 16 8 ref > $OUT/prove_valu.log 2>&1 || exit 1
