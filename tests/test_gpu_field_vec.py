@@ -279,6 +279,20 @@ def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
     assert np.array_equal(_host(eT)[:nr], expT[:nr]) and not _host(eT)[nr:].any()
     for got, e in zip(e2, abc2):
         assert np.array_equal(_host(got)[:nr], e[:nr]) and not _host(got)[nr:].any()
+    # the constant's column holding ONE (every fresh instance): the kernel's small-integer path, no product for (j + 1) * one --
+    # against the sparse kernel on the same z2
+    z2u = z2.copy()
+    z2u[sh.num_vars] = limbs([o.to_mont(1, m)])[0]
+    g2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    gT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term(shape, _dev(z2u), *d1, u1, *g2, gT)
+    e2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+    eT = _dev(np.zeros((nc, 4), dtype="<u8"))
+    ctx.nifs_cross_term_minroot(field, 4, t, 3, sh.num_vars, 0, _dev(z2u), *d1, u1, *e2, eT)
+    ctx.sync()
+    assert np.array_equal(_host(eT)[:nr], _host(gT)[:nr])
+    for got, want in zip(e2, g2):
+        assert np.array_equal(_host(got)[:nr], _host(want)[:nr])
     with pytest.raises(Exception):
         ctx.nifs_cross_term_minroot(field, 5, t, 3, sh.num_vars, 0, _dev(z2), *d1, u1, *e2, eT)      # 3 or 4 variables per round
     with pytest.raises(Exception):

@@ -509,6 +509,51 @@ template <class P> VDF_HD Fe<P> fe_from_u64(uint64_t x) {     // Montgomery form
   return fe_to_mont(r);
 }
 
+// Montgomery form of a SMALL integer without a Montgomery product: k * (2^256 mod m) is below 2^288, and with
+// m = 2^254 + c (c < 2^126: limbs 0..3 of the modulus) the quotient is its bits from 254 up (below 2^34... 2^32 for k < 2^30):
+// r = (x mod 2^254) - q c, plus m if that went negative -- about 50 instructions instead of the ~270 of fe_to_mont.
+// Used where a kernel needs the constant j + 1 of round j (vecops.hip k_nifs_cross_minroot).  k < 2^30.
+template <class P> VDF_HD Fe<P> fe_from_small(uint32_t k) {
+  uint32_t x[9];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    carry += (uint64_t)k * P::ONE[i];
+    x[i] = (uint32_t)carry;
+    carry >>= 32;
+  }
+  x[8] = (uint32_t)carry;                                         // k < 2^30: x < 2^286, x[8] < 2^30
+  const uint32_t q = (x[8] << 2) | (x[7] >> 30);                  // floor(x / 2^254)
+  x[7] &= 0x3FFFFFFFu;
+  uint32_t qc[5];
+  carry = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    carry += (uint64_t)q * P::MOD[i];
+    qc[i] = (uint32_t)carry;
+    carry >>= 32;
+  }
+  qc[4] = (uint32_t)carry;
+  Fe<P> r;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t d = (uint64_t)x[i] - (i < 5 ? qc[i] : 0u) - borrow;
+    r.v[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  if (borrow) {                                                   // negative: add m (the result is then within 2^158 of m, below it)
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t sum = (uint64_t)r.v[i] + P::MOD[i] + c;
+      r.v[i] = (uint32_t)sum;
+      c = (uint32_t)(sum >> 32);
+    }
+  }
+  return r;
+}
+
 // 16-byte vectorised load/store of one 32-byte element (two dwordx4 per lane).
 template <class P> VDF_HD Fe<P> fe_load(const void* p) {
   Fe<P> r;

@@ -1006,58 +1006,85 @@ static int upload_fresh(vdf_ctx* ctx, const Side& sd, const CS& cs, Fe* stage, v
   return VDF_OK;
 }
 
-static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_step_circuit* custom,
-                           const vdf_fe* z0, vdf_proof** fresh) {
-  if (!pp || !proof || (!circuits && !custom) || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
-  static const Circuit no_circuit{};
-  if (!custom && k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
-  const Circuit& c = custom ? no_circuit : circuits->v[k];
-  if (!custom && c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
-  const size_t arity = pp->arity;
-  vdf_ctx* ctx = pp->ctx;
-  const Side& S1 = pp->s[PRIMARY];
-  const Side& S2 = pp->s[SECONDARY];
-  const Field& F1 = *S1.F;
-  const Field& F2 = *S2.F;
-  vdf_proof* p = *proof;
-  const bool first = (p == nullptr);
-  if (first) {
-    p = new vdf_proof();
-    *fresh = p;
-    p->pp = pp;
-    p->z0[PRIMARY].assign((const Fe*)z0, (const Fe*)z0 + arity);
-    p->z0[SECONDARY].assign(1, zero());                              // z0_secondary = [0], :310, :389-391
-    p->zi[PRIMARY] = p->z0[PRIMARY];
-    p->zi[SECONDARY] = p->z0[SECONDARY];
-    int rc = alloc_proof_buffers(p);
-    if (rc != VDF_OK) return rc;
-  } else if (memcmp(p->z0[PRIMARY].data(), z0, 32 * arity) != 0) {
-    return fail(VDF_ERR_BAD_ARG, "z0 differs from the one this proof was started with");
-  }
-  // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
-  if (!custom && memcmp(p->zi[PRIMARY].data(), &c.result, 96) != 0)
-    return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
-  const double t0 = now_ms();
-  int was_async = 0;
-  HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
-  HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
-  struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
-  constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
-  // marks on a lookahead context: segment written / its commitment landed / early rows of T committed; MARK_STEP on the
-  // caller's context (one of the slots include/vdf_hip.h keeps for this library): the step's last uploads and folds
-  enum { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6, MARK_ZIN = 7 };
+// ---- prove_step ----------------------------------------------------------------------------------------------
+// One IVC step drives THREE device queues and the host between them (StepRun below: one method per phase, grouped by the
+// queue it feeds).  The programmes, and the marks (vdf_ctx_mark slots) through which they meet:
+//
+//   CHAIN       the caller's context (pp->ctx) and the calling thread: NIFS of the secondary side (a), synthesis of the
+//               primary circuit (b), NIFS of the primary side (c), synthesis of the secondary circuit and the folds (d) --
+//               a step's critical path.
+//   LOOKAHEAD   p->ctx2[j % DEPTH]: the MinRoot rounds of step k + 1 from the forward trace, and their commitment.
+//   EARLY ROWS  p->ctx3: the rows of the primary cross term T that read only those rounds, and their commitment.
+//
+//   MARK_Z        set on LOOKAHEAD   the rounds of a ring slot are written            EARLY ROWS start behind it; a step ends behind it
+//   MARK_W        set on LOOKAHEAD   their commitment has landed in h_pts[slot]       CHAIN (c) waits for it before it sums comm_W
+//   MARK_T        set on EARLY ROWS  the early rows' commitment has landed in hb[4]   CHAIN (c) waits for it before it sums comm_T
+//   MARK_STEP     set on CHAIN       the step's uploads have left the staging buffers  the call returns behind it
+//   MARK_PRIMARY  set on CHAIN       the primary side's direct sums are enqueued      the LOOKAHEAD's bucket accumulation is gated on it
+//   MARK_FOLD     set on the fold's queue (EARLY ROWS, or CHAIN)                      the next step's EARLY ROWS start behind it; CHAIN waits for it at the end
+//   MARK_ZIN      set on CHAIN       the next step's z_in is in its ring slot         the fold on the EARLY ROWS queue waits for it
+// (slots 4..7 are the ones include/vdf_hip.h keeps for this library on the caller's context)
+namespace {
+enum StepMark { MARK_Z = 0, MARK_W = 1, MARK_T = 2, MARK_STEP = 4, MARK_PRIMARY = 5, MARK_FOLD = 6, MARK_ZIN = 7 };
+
+struct StepRun {
+  static constexpr int D = vdf_proof::DEPTH, R = vdf_proof::RING;
+  // ---- what the step works on
+  vdf_pp* const pp;
+  vdf_proof* const p;
+  const vdf_circuits* const circuits;
+  const size_t k;
+  const vdf_step_circuit* const custom;
+  const Circuit& c;
+  const bool first;
+  const size_t arity;
+  vdf_ctx* const ctx;                  // CHAIN
+  vdf_ctx* const ct;                   // EARLY ROWS
+  const Side& S1;
+  const Side& S2;
+  const Field& F1;
+  const Field& F2;
+  const size_t seg_b, seg_n, seg_e;    // the primary witness's run of round variables
+  const int per;
+  const bool t_ahead;                  // this step has early rows
+  const size_t ta_b, ta_n, ta_e;
+  const int t_parts;                   // (tuning.early_row_parts = 2 or 3: the early rows as an MSM job of that many parts (vdf_msm_job_*): a later part's
+                                       // rows and sort run under an earlier part's bucket accumulation, one shared bucket reduction.  r3: 1.10 ms per step against 0.95 as ONE MSM, the default)
+  const bool fold_on_rows;             // (tuning.fold_on_rows = 0: the primary fold on the main queue, the early rows waiting for its mark)
+  vdf_jac* const hb;                   // four result slots of the batched commitments, then the early rows' parts
+  // ---- state of this step
+  double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+  bool hit = false;                    // the rounds of this step were made by the previous step's lookahead
+  int slot = 0;                        // ring slot of this step's fresh primary witness
+  vdf_ctx* cq = nullptr;               // LOOKAHEAD queue that made this step's rounds
+  void* d_z2 = nullptr;
   int zin_slot = -1;                   // ring slot whose z_in this step has already uploaded (for the next step's early rows)
-  // (tuning.fold_on_rows = 0: the primary fold on the main queue, the early rows waiting for its mark)
-  const bool fold_on_rows = pp->tune.fold_on_rows != 0;
-  bool fold_elsewhere = false;        // the primary fold ran on the early rows' queue: the main queue waits for it before the step ends
-  std::function<int()> rows_deferred;  // the launches of the next step's early rows: set up behind the fold, issued after the NIFS's
-  int rows_deferred_slot = -1;
-  bool gate_next_segment = false;     // the next enqueue_segment holds its bucket accumulation behind MARK_PRIMARY
+  bool fold_elsewhere = false;         // the primary fold ran on the early rows' queue: the main queue waits for it before the step ends
+  struct { bool pending = false; void* d_next = nullptr; vdf_ctx* cq_next = nullptr; vdf_ctx* fq = nullptr; int slot = -1; } deferred;   // the next step's early rows
+  bool gate_next_segment = false;      // the next lookahead_enqueue holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
-  const size_t seg_b = pp->seg_begin, seg_n = pp->seg_len, seg_e = seg_b + seg_n;
-  const int per = pp->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4;
+  bool looked = false, waited_w = false;
+  Aff comm_T2, comm_T1;
+  uint64_t r2[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+  AugInputs in1, in2;
+  std::unique_ptr<StepCircuit> c1;
+  const TrivialTestCircuit c2;
+  AugEarlyPtr early1, early2;
+  Inst l1;
+
+  StepRun(vdf_pp* pp_, vdf_proof* p_, const vdf_circuits* circuits_, size_t k_, const vdf_step_circuit* custom_, const Circuit& c_, bool first_)
+      : pp(pp_), p(p_), circuits(circuits_), k(k_), custom(custom_), c(c_), first(first_), arity(pp_->arity), ctx(pp_->ctx), ct(p_->ctx3),
+        S1(pp_->s[PRIMARY]), S2(pp_->s[SECONDARY]), F1(*pp_->s[PRIMARY].F), F2(*pp_->s[SECONDARY].F), seg_b(pp_->seg_begin), seg_n(pp_->seg_len),
+        seg_e(pp_->seg_begin + pp_->seg_len), per(pp_->circuit_kind == VDF_CIRCUIT_MINROOT_BOUND ? 3 : 4),
+        t_ahead(!first_ && !custom_ && pp_->ahead_rows != 0), ta_b(pp_->ahead_row), ta_n(pp_->ahead_rows), ta_e(pp_->ahead_row + pp_->ahead_rows),
+        t_parts(pp_->tune.early_row_parts), fold_on_rows(pp_->tune.fold_on_rows != 0), hb(&p_->h_pts[R]), early1(nullptr, aug_early_free),
+        early2(nullptr, aug_early_free) {
+    memset(&comm_T2, 0, sizeof(Aff)); memset(&comm_T1, 0, sizeof(Aff));
+  }
+
+  // ================================ LOOKAHEAD queue ==================================================================
   // the MinRoot rounds of step j into ring slot s on that step's lookahead context, and their share of the commitment
-  auto enqueue_segment = [&](size_t j, int s, bool cold) -> int {
+  int lookahead_enqueue(size_t j, int s, bool cold) {
     const Circuit& cc = circuits->v[j];
     vdf_ctx* q = p->ctx2[j % D];
     if (cold) HIPCALL(q, vdf_ctx_wait(q, ctx));   // outside the steady state the ring slot may still be read by a fold
@@ -1085,27 +1112,32 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     a.result = cc.result; a.input = cc.input; a.slot = s;
     p->ahead.push_back(a);
     return VDF_OK;
-  };
-  const bool hit = !custom && !p->ahead.empty() && p->ahead_circuits == circuits && p->ahead_k == k &&
-                   memcmp(&p->ahead[0].result, &c.result, sizeof(St)) == 0 && memcmp(&p->ahead[0].input, &c.input, sizeof(St)) == 0;
-  if (custom) {
-    // every variable comes from the host: no rounds to make ahead of time, the ring just rotates
-    vdf_proof::Ahead a;
-    a.slot = first ? 0 : (p->slot + 1) % R;
-    p->ahead.assign(1, a);
-  } else if (!hit) {
-    if (!p->ahead.empty()) for (vdf_ctx* q : p->ctx2) HIPCALL(q, vdf_ctx_sync(q));       // lookaheads nobody came for
-    p->ahead.clear();
-    p->ahead_circuits = circuits;
-    p->ahead_k = k;
-    int rc = enqueue_segment(k, first ? 0 : (p->slot + 1) % R, !first);
-    if (rc != VDF_OK) return rc;
   }
-  const int slot = p->ahead[0].slot;
-  vdf_ctx* cq = p->ctx2[k % D];
-  p->slot = slot;
-  void* d_z2 = p->d_z2s[slot];
-  auto look_ahead = [&]() -> int {
+  // which ring slot holds this step's rounds: the previous step's lookahead (a hit), or made now
+  int lookahead_select() {
+    hit = !custom && !p->ahead.empty() && p->ahead_circuits == circuits && p->ahead_k == k &&
+          memcmp(&p->ahead[0].result, &c.result, sizeof(St)) == 0 && memcmp(&p->ahead[0].input, &c.input, sizeof(St)) == 0;
+    if (custom) {
+      // every variable comes from the host: no rounds to make ahead of time, the ring just rotates
+      vdf_proof::Ahead a;
+      a.slot = first ? 0 : (p->slot + 1) % R;
+      p->ahead.assign(1, a);
+    } else if (!hit) {
+      if (!p->ahead.empty()) for (vdf_ctx* q : p->ctx2) HIPCALL(q, vdf_ctx_sync(q));       // lookaheads nobody came for
+      p->ahead.clear();
+      p->ahead_circuits = circuits;
+      p->ahead_k = k;
+      int rc = lookahead_enqueue(k, first ? 0 : (p->slot + 1) % R, !first);
+      if (rc != VDF_OK) return rc;
+    }
+    slot = p->ahead[0].slot;
+    cq = p->ctx2[k % D];
+    p->slot = slot;
+    d_z2 = p->d_z2s[slot];
+    return VDF_OK;
+  }
+  // this step's entry leaves the list; the rounds of the steps that follow are enqueued
+  int lookahead_advance() {
     p->ahead.erase(p->ahead.begin());
     if (custom) return VDF_OK;
     p->ahead_k = k + 1;
@@ -1113,23 +1145,19 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       const size_t j = p->ahead_k + p->ahead.size();
       if (j >= circuits->v.size() || circuits->v[j].t != pp->t) break;
       const int last = p->ahead.empty() ? slot : p->ahead.back().slot;
-      int rc = enqueue_segment(j, (last + 1) % R, !hit);
+      int rc = lookahead_enqueue(j, (last + 1) % R, !hit);
       if (rc != VDF_OK) return rc;
     }
     return VDF_OK;
-  };
-  vdf_jac* hb = &p->h_pts[R];                     // four result slots of the batched commitments
-  // The constraints of the MinRoot rounds read nothing of this step's witness but the rounds themselves, which are on
-  // the device already, and the running instance they are crossed with is final since the last step: their rows of T,
-  // and that part of comm_T, start NOW on the lookahead context, beside the secondary side's NIFS and the host's
-  // synthesis of the primary circuit, and leave ~10^4 rows instead of 2 x 10^5 on the critical path.
-  const bool t_ahead = !first && !custom && pp->ahead_rows != 0;
-  const size_t ta_b = pp->ahead_row, ta_n = pp->ahead_rows, ta_e = ta_b + ta_n;
-  vdf_ctx* ct = p->ctx3;
-  // (tuning.early_row_parts = 2 or 3: the early rows as an MSM job of that many parts (vdf_msm_job_*): a later part's rows and sort
-  // run under an earlier part's bucket accumulation, one shared bucket reduction.  Measured r3: 1.10 ms per step against 0.95 as ONE MSM, the default)
-  const int t_parts = pp->tune.early_row_parts;
-  auto early_rows = [&](void* d_z2, vdf_ctx* cq, bool zin_in_place) -> int {            // for the step whose fresh witness lives in d_z2
+  }
+
+  // ================================ EARLY ROWS queue =================================================================
+  // The constraints of the MinRoot rounds read nothing of a step's witness but the rounds themselves, which are on the
+  // device already, and the running instance they are crossed with is final since the previous fold: their rows of T, and
+  // that part of comm_T, run on a queue of their own beside the secondary side's NIFS and the host's synthesis of the
+  // primary circuit, and leave ~10^4 rows instead of 2 x 10^5 on the critical path.  For the step whose fresh witness
+  // lives in d_z2 (this step's, or -- launched on the way out -- the next one's).
+  int early_rows_launch(void* d_z2, vdf_ctx* cq, bool zin_in_place) {
     SideState& s1 = p->r[PRIMARY];
     HIPCALL(ct, vdf_ctx_wait_mark(ct, cq, MARK_Z));                 // the rounds are in place (written a step ago, normally)
     // z_in = z_i past the base step (the circuit's selection); the same values arrive again with the host's variables
@@ -1170,37 +1198,29 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     }
     HIPCALL(ct, vdf_ctx_mark(ct, MARK_T));
     return VDF_OK;
-  };
-  double t1 = t0, t2 = t0, t3 = t0, t4 = t0, t5 = t0, t6 = t0;
-  bool looked = false, waited_w = false;
-  Aff comm_T2, comm_T1;
-  memset(&comm_T2, 0, sizeof(Aff)); memset(&comm_T1, 0, sizeof(Aff));
-  uint64_t r2[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
-  const Fe i_fe1 = from_u64((uint64_t)p->i, F1), i_fe2 = from_u64((uint64_t)p->i, F2);
-
-  // the primary circuit's inputs but for the two commitments of (a); its step circuit
-  AugInputs in1;
-  in1.ro = pp->ro;
-  in1.params = pp->params[PRIMARY];
-  in1.i = i_fe1;
-  in1.z0 = p->z0[PRIMARY];
-  in1.zi = p->zi[PRIMARY];
-  if (first) {
-    const AugInputs b = blank_inputs(arity);
-    in1.U = b.U; in1.u_W = b.u_W; memcpy(in1.u_X, b.u_X, sizeof(in1.u_X)); in1.T = b.T;
-  } else {
-    in1.U = to_relaxed(p->r[SECONDARY].inst, F2);
-    memset(&in1.u_W, 0, sizeof(Aff)); memset(&in1.T, 0, sizeof(Aff));
-    for (int j = 0; j < 2; ++j) fe_to_int(p->l2.X[j], F2, in1.u_X[j]);
   }
-  const std::unique_ptr<StepCircuit> c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
-  AugInputs in2;
-  in2.ro = pp->ro;
-  const TrivialTestCircuit c2;
-  AugEarlyPtr early1(nullptr, aug_early_free), early2(nullptr, aug_early_free);
-  auto make_early1 = [&] { return synthesize_augmented_early(PRIMARY, in1, *c1); };
-  // ---- (a) NIFS on the secondary side: cross term of (running, l2), commitments of l2's witness and of T ----------
-  auto launch_nifs2 = [&]() -> int {               // cross term of (running secondary, l2), commit(w2) unless known, commit(T2)
+
+  // ================================ CHAIN: the caller's queue and the calling thread ================================
+  // the two circuits' inputs but for the commitments the device is still making; the primary step circuit
+  void chain_prepare_inputs() {
+    in1.ro = pp->ro;
+    in1.params = pp->params[PRIMARY];
+    in1.i = from_u64((uint64_t)p->i, F1);
+    in1.z0 = p->z0[PRIMARY];
+    in1.zi = p->zi[PRIMARY];
+    if (first) {
+      const AugInputs b = blank_inputs(arity);
+      in1.U = b.U; in1.u_W = b.u_W; memcpy(in1.u_X, b.u_X, sizeof(in1.u_X)); in1.T = b.T;
+    } else {
+      in1.U = to_relaxed(p->r[SECONDARY].inst, F2);
+      memset(&in1.u_W, 0, sizeof(Aff)); memset(&in1.T, 0, sizeof(Aff));
+      for (int j = 0; j < 2; ++j) fe_to_int(p->l2.X[j], F2, in1.u_X[j]);
+    }
+    c1 = custom ? make_custom_circuit(custom) : make_primary_circuit(pp, &c, true);
+    in2.ro = pp->ro;
+  }
+  // cross term of (running secondary, l2), commit(w2) unless known, commit(T2)
+  int chain_launch_nifs2() {
     SideState& s2 = p->r[SECONDARY];
     HIPCALL(ctx, vdf_nifs_cross_term(ctx, S2.shape, (const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_abc[0], (const vdf_fe*)s2.d_abc[1],
                                      (const vdf_fe*)s2.d_abc[2], (const vdf_fe*)&s2.inst.u, (vdf_fe*)s2.d_abc2[0], (vdf_fe*)s2.d_abc2[1],
@@ -1213,238 +1233,295 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
       HIPCALL(ctx, vdf_msm_batch(ctx, S2.gens, 2, off, sc, len, 1, hb));
     }
     return VDF_OK;
-  };
-  if (!first) {
-    if (p->nifs2 == vdf_proof::NIFS2_NONE) {       // normally in flight since the previous step's last lines
-      int rc = launch_nifs2();
+  }
+  // ---- (a) NIFS on the secondary side: cross term of (running, l2), commitments of l2's witness and of T ----------
+  int chain_secondary_nifs() {
+    if (!first) {
+      if (p->nifs2 == vdf_proof::NIFS2_NONE) {       // normally in flight since the previous step's last lines
+        int rc = chain_launch_nifs2();
+        if (rc != VDF_OK) return rc;
+        p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
+      }
+      // launched while the host waits for this side's commitments, on a queue of their own: their 0.6 ms must be over when
+      // the primary side's own commitments are (0.65 ms into the step), and this side's direct sum, one prioritised
+      // wavefront per SIMD for 0.1 ms, loses little to a bucket accumulation beside it
+      const bool rows_inflight = t_ahead && hit && p->tahead_valid && p->tahead_slot == slot && p->tahead_k == k &&
+                                 p->tahead_circuits == circuits;       // launched by the previous step on its way out
+      if (t_ahead && !rows_inflight) {
+        if (pp->ahead_mode == 1) HIPCALL(ct, vdf_ctx_wait(ct, ctx));
+        else if (p->tahead_valid) HIPCALL(ct, vdf_ctx_sync(ct));       // rows made for a step that did not come: let them finish
+        int rc = early_rows_launch(d_z2, cq, false);
+        if (rc != VDF_OK) return rc;
+      }
+      p->tahead_valid = false;
+      early1 = synthesize_augmented_early(PRIMARY, in1, *c1);      // the host's share of the wait: what the circuit can do without T
+      { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }      // waits, collects comm_W2 and comm_T2
+      comm_T2 = p->nifs2_T;
+      p->nifs2 = vdf_proof::NIFS2_NONE;               // consumed: the fold below uses the scratch vectors up
+    }
+    t1 = now_ms();
+    return VDF_OK;
+  }
+  // ---- (b) the primary augmented circuit -----------------------------------------------------------------------
+  int chain_primary_circuit() {
+    {
+      AugInputs& in = in1;
+      if (!first) { in.u_W = p->l2.comm_W; in.T = comm_T2; }
+      CS cs(S1.field, false, pp->ro);
+      Fe unew[9];
+      const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2, early1.get());
+      early1.reset();
+      if (custom && static_cast<const CustomStepCircuit*>(c1.get())->rc != 0) return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed");
+      if (cs.dev_len != seg_n || (seg_n && cs.dev_begin != seg_b)) return fail(VDF_ERR_DEVICE, "device segment moved");
+      t2 = now_ms();
+      p->r[SECONDARY].inst = inst_from_elements(unew, F1, F2);       // base step: the default instance
+      // the host-made variables go next to the rounds the lookahead context has written (vdf_ctx_wait at their launch)
+      int rc = upload_fresh(ctx, S1, cs, p->h_stage[PRIMARY], d_z2);
+      if (rc != VDF_OK) return rc;
+      if (!first && !custom && pp->ahead_rows != 0 && seg_n) {
+        // the NEXT step's z_in = this step's output, known now: into its place in the next ring slot's fresh witness, half a
+        // step before the early rows of that step read it
+        zin_slot = (slot + 1) % R;
+        memcpy(p->h_zin + arity, z_next.data(), arity * 32);          // the second pinned slot (the first may still feed this step's early rows)
+        HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[zin_slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
+        HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
+      }
+      l1.X[0] = cs.X[0]; l1.X[1] = cs.X[1];
+      l1.u = one(F1);
+      memset(&l1.comm_E, 0, sizeof(Aff));
+      p->zi[PRIMARY] = z_next;
+    }
+    return VDF_OK;
+  }
+  // ---- (c) NIFS on the primary side ----------------------------------------------------------------------------
+  int chain_primary_nifs() {
+    {
+      SideState& s1 = p->r[PRIMARY];
+      // host-made variables before and after the device's run (one group when there is no such run), then T -- all of it,
+      // or the rows before and after the ones committed early
+      size_t off[4], len[4];
+      const vdf_fe* sc[4];
+      int ng = 0, first_T = 0;
+      auto group = [&](const void* base, size_t begin, size_t n) {
+        if (n == 0) return;
+        off[ng] = begin; len[ng] = n; sc[ng] = (const vdf_fe*)((const char*)base + begin * 32); ++ng;
+      };
+      if (seg_n) { group(d_z2, 0, seg_b); group(d_z2, seg_e, S1.num_vars - seg_e); }
+      else group(d_z2, 0, S1.num_vars);
+      first_T = ng;
+      if (!first) {
+        if (t_ahead) {
+          group(s1.d_T, 0, ta_b); group(s1.d_T, ta_e, S1.num_cons - ta_e);
+          HIPCALL(ctx, vdf_nifs_cross_term_rows(ctx, S1.shape, ta_b, ta_n, VDF_ROWS_OUTSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
+                                                (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
+                                                (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+        } else {
+          group(s1.d_T, 0, S1.num_cons);
+          HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
+                                           (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
+                                           (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+        }
+      }
+      HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
+      // the lookahead launched under this wait sorts beside these commitments but holds its bucket accumulation -- every SIMD
+      // for 0.25 ms -- until they are done: it then runs while the host synthesises the secondary circuit (tuning.gate_accumulate = 0: no hold)
+      const bool gate = pp->tune.gate_accumulate != 0;
+      if (gate && !first && !custom) { HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_PRIMARY)); gate_next_segment = true; }
+      if (!first) {
+        // behind the primary side's launches (it does not depend on them, they do not wait for it): the fold of the secondary
+        // witness on the device (z, E, A z, B z, C z += r2 * fresh); the instance came from the circuit
+        SideState& s2 = p->r[SECONDARY];
+        const Fe rr = int_to_fe(r2, F2);
+        vdf_fe* acc[5] = {(vdf_fe*)s2.d_z, (vdf_fe*)s2.d_E, (vdf_fe*)s2.d_abc[0], (vdf_fe*)s2.d_abc[1], (vdf_fe*)s2.d_abc[2]};
+        const vdf_fe* addv[5] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T, (const vdf_fe*)s2.d_abc2[0], (const vdf_fe*)s2.d_abc2[1],
+                                 (const vdf_fe*)s2.d_abc2[2]};
+        const size_t len[5] = {S2.ncols, S2.num_cons, S2.num_cons, S2.num_cons, S2.num_cons};
+        HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+      }
+      t3 = now_ms();
+      // The next step's MinRoot rounds and their commitment go to the second queue NOW, under this wait: their dozen launches
+      // cost the chain nothing here, and their 0.65 ms are over that much sooner (they are the next step's primary
+      // commitment; back to back the device is the co-bottleneck).  This step's own rounds were committed a step ago; their
+      // mark is waited for first, because the launch reuses it.  (tuning.lookahead_early = 0: launched after the wait.)
+      const bool la_early = pp->tune.lookahead_early != 0;
+      if (la_early && !first && !custom) {
+        if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+        waited_w = true;
+        int rc = lookahead_advance();
+        if (rc != VDF_OK) return rc;
+        looked = true;
+      }
+      // the host's share of this wait: the secondary circuit's inputs but for comm_W and comm_T, and what it can do with them
+      in2.params = pp->params[SECONDARY];
+      in2.i = from_u64((uint64_t)p->i, F2);
+      in2.z0 = p->z0[SECONDARY];
+      in2.zi = p->zi[SECONDARY];
+      if (first) { const AugInputs b = blank_inputs(1); in2.U = b.U; }
+      else in2.U = to_relaxed(p->r[PRIMARY].inst, F1);
+      memset(&in2.u_W, 0, sizeof(Aff)); memset(&in2.T, 0, sizeof(Aff));
+      for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in2.u_X[j]);
+      early2 = synthesize_augmented_early(SECONDARY, in2, c2);
+      if (seg_n && !waited_w) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
+      if (t_ahead) HIPCALL(ct, vdf_ctx_sync_mark(ct, MARK_T));
+      HIPCALL(ctx, vdf_ctx_sync(ctx));
+      const Field& Fb = *S1.Fb;
+      // partial commitments leave the device as Jacobian points: summed as they are, one inversion for W and T together
+      auto sum = [&](Pt acc, int from, int to) { for (int g = from; g < to; ++g) acc = pt_add(acc, pt_from_jac(hb[g], Fb), Fb); return acc; };
+      const Pt w_sum = seg_n ? sum(pt_from_jac(p->h_pts[slot], Fb), 0, first_T) : pt_from_jac(hb[0], Fb);
+      if (first) l1.comm_W = pt_to_aff(w_sum, Fb);
+      else pt_to_aff2(w_sum, t_ahead ? sum(pt_add(pt_add(pt_from_jac(hb[4], Fb), pt_from_jac(hb[5], Fb), Fb), pt_from_jac(hb[6], Fb), Fb), first_T, ng)
+                                     : pt_from_jac(hb[first_T], Fb), Fb, &l1.comm_W, &comm_T1);
+      if (first) {
+        // running primary := the fresh instance, relaxed; its A z, B z, C z once, folded from then on
+        HIPCALL(ctx, vdf_dev_memcpy(ctx, s1.d_z, d_z2, S1.ncols * 32));
+        HIPCALL(ctx, vdf_spmv3(ctx, S1.shape, (const vdf_fe*)s1.d_z, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]));
+      }
+    }
+    t4 = now_ms();
+    if (!looked) {                                  // (the base step, a custom circuit, or the switch above)
+      int rc = lookahead_advance();
+      if (rc != VDF_OK) return rc;
+    }
+    return VDF_OK;
+  }
+  // ---- (d) the secondary augmented circuit, the primary fold, the next step's early rows set up ---------------------
+  int chain_secondary_circuit() {
+    {
+      AugInputs& in = in2;
+      in.u_W = l1.comm_W;
+      in.T = comm_T1;
+      CS cs(S2.field, false, pp->ro);
+      Fe unew[9];
+      const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
+      early2.reset();
+      t5 = now_ms();
+      const bool ahead_rows = pp->tune.nifs_ahead != 0;
+      const bool rows_next = ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
+      if (rows_next && p->ahead[0].slot != zin_slot) {
+        // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
+        memcpy(p->h_zin + arity, p->zi[PRIMARY].data(), arity * 32);   // (this thread has waited for the primary side's launches: the slot's last copy is over)
+        HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
+        HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
+      }
+      // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
+      // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
+      // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
+      // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
+      vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
+      if (!first) {
+        SideState& s1 = p->r[PRIMARY];
+        const Fe rr = int_to_fe(r1, F1);
+        vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
+        const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
+                                 (const vdf_fe*)s1.d_abc2[2]};
+        const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
+        if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
+        HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+      }
+      p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
+      // (the folded instance is in place: the launches below read its u)
+      // The early rows of the NEXT step's cross term, as soon as this fold is on its queue: from the fold to their commitment
+      // they are a step's longest dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms).  Its rounds are
+      // in their ring slot (the lookahead), its input z_in is this step's output (uploaded above, in front of the fold), the running
+      // instance is final once the fold is done: they wait for MARK_FOLD, not for the uploads and the NIFS that follow.  Their
+      // dozen launches are issued after the NIFS's (below); a helper thread issuing them at once was measured and bought
+      // nothing (0.882-0.888 ms per step either way).
+      if (rows_next) {
+        void* d_next = p->d_z2s[p->ahead[0].slot];
+        vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
+        HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
+        fold_elsewhere = fq != ctx;
+        deferred.pending = true; deferred.d_next = d_next; deferred.cq_next = cq_next; deferred.fq = fq;
+        deferred.slot = p->ahead[0].slot;                              // (tahead_* are set once the rows are really on their queue)
+      }
+      int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
+      if (rc != VDF_OK) return rc;
+      p->l2.X[0] = cs.X[0]; p->l2.X[1] = cs.X[1];
+      p->l2.u = one(F2);
+      memset(&p->l2.comm_E, 0, sizeof(Aff));
+      memset(&p->l2.comm_W, 0, sizeof(Aff));
+      p->l2_committed = false;
+      p->zi[SECONDARY] = z_next;
+    }
+    t6 = now_ms();
+    return VDF_OK;
+  }
+  // ---- the way out: marks, and the next step's first device phases ---------------------------------------------------
+  int chain_finish() {
+    // the staging buffers are rewritten by the next call: their copies must have left (a mark), and nothing in flight may
+    // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
+    // needs nothing of the next step: the NIFS of the secondary instance just made (tuning.nifs_ahead = 0: left to the next call)
+    const bool ahead = pp->tune.nifs_ahead != 0;
+    HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_STEP));
+    if (ahead) {
+      int rc = chain_launch_nifs2();
       if (rc != VDF_OK) return rc;
       p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
     }
-    // launched while the host waits for this side's commitments, on a queue of their own: their 0.6 ms must be over when
-    // the primary side's own commitments are (0.65 ms into the step), and this side's direct sum, one prioritised
-    // wavefront per SIMD for 0.1 ms, loses little to a bucket accumulation beside it
-    const bool rows_inflight = t_ahead && hit && p->tahead_valid && p->tahead_slot == slot && p->tahead_k == k &&
-                               p->tahead_circuits == circuits;       // launched by the previous step on its way out
-    if (t_ahead && !rows_inflight) {
-      if (pp->ahead_mode == 1) HIPCALL(ct, vdf_ctx_wait(ct, ctx));
-      else if (p->tahead_valid) HIPCALL(ct, vdf_ctx_sync(ct));       // rows made for a step that did not come: let them finish
-      int rc = early_rows(d_z2, cq, false);
-      if (rc != VDF_OK) return rc;
+    if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
+    if (deferred.pending) {                         // EARLY ROWS of the next step, behind the fold's mark
+      if (deferred.fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, deferred.fq, MARK_FOLD));
+      int rc = early_rows_launch(deferred.d_next, deferred.cq_next, true);
+      if (rc != VDF_OK) return rc;                  // tahead_valid stays false: a retried step launches its rows itself
+      p->tahead_valid = true; p->tahead_slot = deferred.slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
     }
-    p->tahead_valid = false;
-    early1 = make_early1();                         // the host's share of the wait: what the circuit can do without T
-    { int rc = finalize_l2(p); if (rc != VDF_OK) return rc; }      // waits, collects comm_W2 and comm_T2
-    comm_T2 = p->nifs2_T;
-    p->nifs2 = vdf_proof::NIFS2_NONE;               // consumed: the fold below uses the scratch vectors up
+    HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
+    for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
+    p->i += 1;
+    memcpy(&p->last.comm_W1, &l1.comm_W, sizeof(vdf_affine));
+    memcpy(p->last.X1, l1.X, 64);
+    memcpy(&p->last.comm_T1, &comm_T1, 64);
+    memcpy(&p->last.comm_T2, &comm_T2, 64);
+    memcpy(p->last.r1, r1, 32); memcpy(p->last.r2, r2, 32);
+    return VDF_OK;
   }
-  t1 = now_ms();
-  // ---- (b) the primary augmented circuit -----------------------------------------------------------------------
-  Inst l1;
-  {
-    AugInputs& in = in1;
-    if (!first) { in.u_W = p->l2.comm_W; in.T = comm_T2; }
-    CS cs(S1.field, false, pp->ro);
-    Fe unew[9];
-    const std::vector<Fe> z_next = synthesize_augmented(cs, PRIMARY, in, *c1, unew, r2, early1.get());
-    early1.reset();
-    if (custom && static_cast<const CustomStepCircuit*>(c1.get())->rc != 0) return fail(VDF_ERR_BAD_ARG, "the step circuit's synthesize failed");
-    if (cs.dev_len != seg_n || (seg_n && cs.dev_begin != seg_b)) return fail(VDF_ERR_DEVICE, "device segment moved");
-    t2 = now_ms();
-    p->r[SECONDARY].inst = inst_from_elements(unew, F1, F2);       // base step: the default instance
-    // the host-made variables go next to the rounds the lookahead context has written (vdf_ctx_wait at their launch)
-    int rc = upload_fresh(ctx, S1, cs, p->h_stage[PRIMARY], d_z2);
+};
+}  // namespace
+
+static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* circuits, size_t k, const vdf_step_circuit* custom,
+                           const vdf_fe* z0, vdf_proof** fresh) {
+  if (!pp || !proof || (!circuits && !custom) || !z0) return fail(VDF_ERR_BAD_ARG, "null argument");
+  static const Circuit no_circuit{};
+  if (!custom && k >= circuits->v.size()) return fail(VDF_ERR_BAD_LENGTH, "circuit index out of range");
+  const Circuit& c = custom ? no_circuit : circuits->v[k];
+  if (!custom && c.t != pp->t) return fail(VDF_ERR_BAD_LENGTH, "circuit t differs from the public parameters");
+  const size_t arity = pp->arity;
+  vdf_ctx* ctx = pp->ctx;
+  vdf_proof* p = *proof;
+  const bool first = (p == nullptr);
+  if (first) {
+    p = new vdf_proof();
+    *fresh = p;
+    p->pp = pp;
+    p->z0[PRIMARY].assign((const Fe*)z0, (const Fe*)z0 + arity);
+    p->z0[SECONDARY].assign(1, zero());                              // z0_secondary = [0], :310, :389-391
+    p->zi[PRIMARY] = p->z0[PRIMARY];
+    p->zi[SECONDARY] = p->z0[SECONDARY];
+    int rc = alloc_proof_buffers(p);
     if (rc != VDF_OK) return rc;
-    if (!first && !custom && pp->ahead_rows != 0 && seg_n) {
-      // the NEXT step's z_in = this step's output, known now: into its place in the next ring slot's fresh witness, half a
-      // step before the early rows of that step read it
-      zin_slot = (slot + 1) % R;
-      memcpy(p->h_zin + arity, z_next.data(), arity * 32);          // the second pinned slot (the first may still feed this step's early rows)
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[zin_slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
-      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
-    }
-    l1.X[0] = cs.X[0]; l1.X[1] = cs.X[1];
-    l1.u = one(F1);
-    memset(&l1.comm_E, 0, sizeof(Aff));
-    p->zi[PRIMARY] = z_next;
+  } else if (memcmp(p->z0[PRIMARY].data(), z0, 32 * arity) != 0) {
+    return fail(VDF_ERR_BAD_ARG, "z0 differs from the one this proof was started with");
   }
-  // ---- (c) NIFS on the primary side ----------------------------------------------------------------------------
-  {
-    SideState& s1 = p->r[PRIMARY];
-    // host-made variables before and after the device's run (one group when there is no such run), then T -- all of it,
-    // or the rows before and after the ones committed early
-    size_t off[4], len[4];
-    const vdf_fe* sc[4];
-    int ng = 0, first_T = 0;
-    auto group = [&](const void* base, size_t begin, size_t n) {
-      if (n == 0) return;
-      off[ng] = begin; len[ng] = n; sc[ng] = (const vdf_fe*)((const char*)base + begin * 32); ++ng;
-    };
-    if (seg_n) { group(d_z2, 0, seg_b); group(d_z2, seg_e, S1.num_vars - seg_e); }
-    else group(d_z2, 0, S1.num_vars);
-    first_T = ng;
-    if (!first) {
-      if (t_ahead) {
-        group(s1.d_T, 0, ta_b); group(s1.d_T, ta_e, S1.num_cons - ta_e);
-        HIPCALL(ctx, vdf_nifs_cross_term_rows(ctx, S1.shape, ta_b, ta_n, VDF_ROWS_OUTSIDE, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0],
-                                              (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u,
-                                              (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
-      } else {
-        group(s1.d_T, 0, S1.num_cons);
-        HIPCALL(ctx, vdf_nifs_cross_term(ctx, S1.shape, (const vdf_fe*)d_z2, (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1],
-                                         (const vdf_fe*)s1.d_abc[2], (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0], (vdf_fe*)s1.d_abc2[1],
-                                         (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
-      }
-    }
-    HIPCALL(ctx, vdf_msm_batch(ctx, S1.gens, ng, off, sc, len, 1, hb));
-    // the lookahead launched under this wait sorts beside these commitments but holds its bucket accumulation -- every SIMD
-    // for 0.25 ms -- until they are done: it then runs while the host synthesises the secondary circuit (tuning.gate_accumulate = 0: no hold)
-    const bool gate = pp->tune.gate_accumulate != 0;
-    if (gate && !first && !custom) { HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_PRIMARY)); gate_next_segment = true; }
-    if (!first) {
-      // behind the primary side's launches (it does not depend on them, they do not wait for it): the fold of the secondary
-      // witness on the device (z, E, A z, B z, C z += r2 * fresh); the instance came from the circuit
-      SideState& s2 = p->r[SECONDARY];
-      const Fe rr = int_to_fe(r2, F2);
-      vdf_fe* acc[5] = {(vdf_fe*)s2.d_z, (vdf_fe*)s2.d_E, (vdf_fe*)s2.d_abc[0], (vdf_fe*)s2.d_abc[1], (vdf_fe*)s2.d_abc[2]};
-      const vdf_fe* addv[5] = {(const vdf_fe*)p->d_l2z, (const vdf_fe*)s2.d_T, (const vdf_fe*)s2.d_abc2[0], (const vdf_fe*)s2.d_abc2[1],
-                               (const vdf_fe*)s2.d_abc2[2]};
-      const size_t len[5] = {S2.ncols, S2.num_cons, S2.num_cons, S2.num_cons, S2.num_cons};
-      HIPCALL(ctx, vdf_fold_many(ctx, S2.field, (const vdf_fe*)&rr, 5, acc, addv, len));
-    }
-    t3 = now_ms();
-    // The next step's MinRoot rounds and their commitment go to the second queue NOW, under this wait: their dozen launches
-    // cost the chain nothing here, and their 0.65 ms are over that much sooner (they are the next step's primary
-    // commitment; back to back the device is the co-bottleneck).  This step's own rounds were committed a step ago; their
-    // mark is waited for first, because the launch reuses it.  (tuning.lookahead_early = 0: launched after the wait.)
-    const bool la_early = pp->tune.lookahead_early != 0;
-    if (la_early && !first && !custom) {
-      if (seg_n) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
-      waited_w = true;
-      int rc = look_ahead();
-      if (rc != VDF_OK) return rc;
-      looked = true;
-    }
-    // the host's share of this wait: the secondary circuit's inputs but for comm_W and comm_T, and what it can do with them
-    in2.params = pp->params[SECONDARY];
-    in2.i = i_fe2;
-    in2.z0 = p->z0[SECONDARY];
-    in2.zi = p->zi[SECONDARY];
-    if (first) { const AugInputs b = blank_inputs(1); in2.U = b.U; }
-    else in2.U = to_relaxed(p->r[PRIMARY].inst, F1);
-    memset(&in2.u_W, 0, sizeof(Aff)); memset(&in2.T, 0, sizeof(Aff));
-    for (int j = 0; j < 2; ++j) fe_to_int(l1.X[j], F1, in2.u_X[j]);
-    early2 = synthesize_augmented_early(SECONDARY, in2, c2);
-    if (seg_n && !waited_w) HIPCALL(cq, vdf_ctx_sync_mark(cq, MARK_W));
-    if (t_ahead) HIPCALL(ct, vdf_ctx_sync_mark(ct, MARK_T));
-    HIPCALL(ctx, vdf_ctx_sync(ctx));
-    const Field& Fb = *S1.Fb;
-    // partial commitments leave the device as Jacobian points: summed as they are, one inversion for W and T together
-    auto sum = [&](Pt acc, int from, int to) { for (int g = from; g < to; ++g) acc = pt_add(acc, pt_from_jac(hb[g], Fb), Fb); return acc; };
-    const Pt w_sum = seg_n ? sum(pt_from_jac(p->h_pts[slot], Fb), 0, first_T) : pt_from_jac(hb[0], Fb);
-    if (first) l1.comm_W = pt_to_aff(w_sum, Fb);
-    else pt_to_aff2(w_sum, t_ahead ? sum(pt_add(pt_add(pt_from_jac(hb[4], Fb), pt_from_jac(hb[5], Fb), Fb), pt_from_jac(hb[6], Fb), Fb), first_T, ng)
-                                   : pt_from_jac(hb[first_T], Fb), Fb, &l1.comm_W, &comm_T1);
-    if (first) {
-      // running primary := the fresh instance, relaxed; its A z, B z, C z once, folded from then on
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, s1.d_z, d_z2, S1.ncols * 32));
-      HIPCALL(ctx, vdf_spmv3(ctx, S1.shape, (const vdf_fe*)s1.d_z, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]));
-    }
-  }
-  t4 = now_ms();
-  if (!looked) {                                  // (the base step, a custom circuit, or the switch above)
-    int rc = look_ahead();
-    if (rc != VDF_OK) return rc;
-  }
-  // ---- (d) the secondary augmented circuit -----------------------------------------------------------------------
-  {
-    AugInputs& in = in2;
-    in.u_W = l1.comm_W;
-    in.T = comm_T1;
-    CS cs(S2.field, false, pp->ro);
-    Fe unew[9];
-    const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
-    early2.reset();
-    t5 = now_ms();
-    const bool ahead_rows = pp->tune.nifs_ahead != 0;
-    const bool rows_next = ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
-    if (rows_next && p->ahead[0].slot != zin_slot) {
-      // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
-      memcpy(p->h_zin + arity, p->zi[PRIMARY].data(), arity * 32);   // (this thread has waited for the primary side's launches: the slot's last copy is over)
-      HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
-      HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
-    }
-    // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
-    // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
-    // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
-    // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
-    vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
-    if (!first) {
-      SideState& s1 = p->r[PRIMARY];
-      const Fe rr = int_to_fe(r1, F1);
-      vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
-      const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
-                               (const vdf_fe*)s1.d_abc2[2]};
-      const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
-      if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
-      HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
-    }
-    p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
-    // (the folded instance is in place: the launches below read its u)
-    // The early rows of the NEXT step's cross term, as soon as this fold is on its queue: from the fold to their commitment
-    // they are a step's longest dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms).  Its rounds are
-    // in their ring slot (the lookahead), its input z_in is this step's output (uploaded above, in front of the fold), the running
-    // instance is final once the fold is done: they wait for MARK_FOLD, not for the uploads and the NIFS that follow.  Their
-    // dozen launches are issued after the NIFS's (below); a helper thread issuing them at once was measured and bought
-    // nothing (0.882-0.888 ms per step either way).
-    if (rows_next) {
-      void* d_next = p->d_z2s[p->ahead[0].slot];
-      vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
-      HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
-      auto launch_rows = [&, d_next, cq_next, fq]() -> int {
-        if (fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, fq, MARK_FOLD));
-        return early_rows(d_next, cq_next, true);
-      };
-      fold_elsewhere = fq != ctx;
-      rows_deferred_slot = p->ahead[0].slot;                         // (tahead_* are set once the rows are really on their queue)
-      rows_deferred = launch_rows;
-    }
-    int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
-    if (rc != VDF_OK) return rc;
-    p->l2.X[0] = cs.X[0]; p->l2.X[1] = cs.X[1];
-    p->l2.u = one(F2);
-    memset(&p->l2.comm_E, 0, sizeof(Aff));
-    memset(&p->l2.comm_W, 0, sizeof(Aff));
-    p->l2_committed = false;
-    p->zi[SECONDARY] = z_next;
-  }
-  t6 = now_ms();
-  // the staging buffers are rewritten by the next call: their copies must have left (a mark), and nothing in flight may
-  // read the circuits' memory once this call returns.  Behind that mark goes the next step's first device phase, which
-  // needs nothing of the next step: the NIFS of the secondary instance just made (tuning.nifs_ahead = 0: left to the next call)
-  const bool ahead = pp->tune.nifs_ahead != 0;
-  HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_STEP));
-  if (ahead) {
-    int rc = launch_nifs2();
-    if (rc != VDF_OK) return rc;
-    p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
-  }
-  if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
-  if (rows_deferred) {
-    int rc = rows_deferred();
-    if (rc != VDF_OK) return rc;                  // tahead_valid stays false: a retried step launches its rows itself
-    p->tahead_valid = true; p->tahead_slot = rows_deferred_slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
-  }
-  HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
-  for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
-  p->i += 1;
-  memcpy(&p->last.comm_W1, &l1.comm_W, sizeof(vdf_affine));
-  memcpy(p->last.X1, l1.X, 64);
-  memcpy(&p->last.comm_T1, &comm_T1, 64);
-  memcpy(&p->last.comm_T2, &comm_T2, 64);
-  memcpy(p->last.r1, r1, 32); memcpy(p->last.r2, r2, 32);
+  // StepCircuit::output's debug assertion: z_i must be the circuit's result (src/nova/proof.rs:147-149)
+  if (!custom && memcmp(p->zi[PRIMARY].data(), &c.result, 96) != 0)
+    return fail(VDF_ERR_BAD_ARG, "z_i does not match the circuit's result state");
+  const double t0 = now_ms();
+  int was_async = 0;
+  HIPCALL(ctx, vdf_ctx_get_async(ctx, &was_async));
+  HIPCALL(ctx, vdf_ctx_set_async(ctx, 1));
+  struct Restore { vdf_ctx* c; int a; ~Restore() { if (!a) { vdf_ctx_sync(c); vdf_ctx_set_async(c, 0); } } } restore{ctx, was_async};
+  StepRun run(pp, p, circuits, k, custom, c, first);
+  run.t0 = run.t1 = run.t2 = run.t3 = run.t4 = run.t5 = run.t6 = t0;
+  { int rc = run.lookahead_select(); if (rc != VDF_OK) return rc; }
+  run.chain_prepare_inputs();
+  { int rc = run.chain_secondary_nifs(); if (rc != VDF_OK) return rc; }
+  { int rc = run.chain_primary_circuit(); if (rc != VDF_OK) return rc; }
+  { int rc = run.chain_primary_nifs(); if (rc != VDF_OK) return rc; }
+  { int rc = run.chain_secondary_circuit(); if (rc != VDF_OK) return rc; }
+  { int rc = run.chain_finish(); if (rc != VDF_OK) return rc; }
   const double t7 = now_ms();
-  p->ms[0] = t1 - t0; p->ms[1] = t2 - t1; p->ms[2] = t3 - t2; p->ms[3] = t4 - t3;
-  p->ms[4] = t5 - t4; p->ms[5] = t6 - t5; p->ms[6] = t7 - t6; p->ms[7] = t7 - t0;
+  p->ms[0] = run.t1 - t0; p->ms[1] = run.t2 - run.t1; p->ms[2] = run.t3 - run.t2; p->ms[3] = run.t4 - run.t3;
+  p->ms[4] = run.t5 - run.t4; p->ms[5] = run.t6 - run.t5; p->ms[6] = t7 - run.t6; p->ms[7] = t7 - t0;
   *proof = p;
   *fresh = nullptr;
   return VDF_OK;

@@ -369,11 +369,18 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
   const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
   const Fe<P> onev = fe_load<P>(z2 + one_col * 32);
   const Fe<P> i_in = fe_load<P>(z2 + (S - 1) * 32);
+  // k * z2[one]: the constant's value is ONE in every fresh instance (the same for all lanes: a uniform branch), and then
+  // the small-integer conversion is all it takes -- no Montgomery product (fe.cuh fe_from_small: ~50 instructions)
+  const bool unit = fe_eq(onev, fe_one<P>());
+  auto times_one = [&](uint64_t k) -> Fe<P> {
+    const Fe<P> km = k < (1u << 30) ? fe_from_small<P>((uint32_t)k) : fe_from_u64<P>(k);
+    return unit ? km : fe_mul(km, onev);
+  };
   Fe<P> a2, b2, c2;
   if (i == 3 * t) {
     a2 = fe_load<P>(z2 + (S + (size_t)PER * t) * 32);
     b2 = onev;
-    c2 = fe_sub(i_in, fe_mul(fe_from_u64<P>(t), onev));
+    c2 = fe_sub(i_in, times_one(t));
   } else {
     const uint64_t j = i / 3;
     const uint32_t role = (uint32_t)(i - 3 * j);
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
       else if (j == 0) x = fe_load<P>(z2 + (S - 3) * 32);
       else {                                                        // y_(j-1) - i + j * one
         const Fe<P> yprev = fe_load<P>(j > 1 ? rd - (size_t)PER * 32 - 32 : z2 + (S - 2) * 32);
-        x = fe_add(fe_sub(yprev, i_in), fe_mul(fe_from_u64<P>(j), onev));
+        x = fe_add(fe_sub(yprev, i_in), times_one(j));
       }
     }
     if (role == 0) { a2 = x; b2 = x; c2 = fe_load<P>(t1p); }
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
     else {
       a2 = fe_load<P>(t1p + 32); b2 = x;
       const Fe<P> ny = fe_load<P>(t1p + 64), y = fe_load<P>(yp);
-      c2 = fe_add(fe_sub(fe_add(ny, y), i_in), fe_mul(fe_from_u64<P>(j + 1), onev));
+      c2 = fe_add(fe_sub(fe_add(ny, y), i_in), times_one(j + 1));
     }
   }
   fe_store<P>(az2 + r * 32, a2);
