@@ -685,55 +685,6 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         proof.free()
         pp.free()
         return out
-    # compress (src/nova/proof.rs:360-368) and verification of the compressed proof, once, outside `value`
-    if proof.num_steps() != nsteps:
-        proof.free()
-        proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
-    # the first compression of a parameter set creates its second queue and grows two MSM workspaces: timed apart, the figure
-    # reported is the second call's (as every other timed region here follows its own warm-up)
-    a = time.perf_counter()
-    snark = proof.compress(pp)
-    compress_first_ms = (time.perf_counter() - a) * 1e3
-    snark.free()
-    a = time.perf_counter()
-    snark = proof.compress(pp)
-    compress_ms = (time.perf_counter() - a) * 1e3
-    a = time.perf_counter()
-    ok_c = snark.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
-    verify_c_ms = (time.perf_counter() - a) * 1e3
-    # the same compression once more with HIP events around every launch (a pass of its own, not the figure above): where
-    # the time goes, pass by pass, each priced by its own bytes against the 8 TB/s roof (SURVEY 8f-1: the sum-check passes are
-    # the genuinely HBM-bound work of this library)
-    ctx.sync()
-    ctx.set_kernel_timing(True); ctx.kernel_events()
-    a = time.perf_counter()
-    snark2 = proof.compress(pp)
-    ctx.sync()
-    timed_ms = (time.perf_counter() - a) * 1e3
-    cev = ctx.kernel_events()
-    ctx.set_kernel_timing(False)
-    snark2.free()
-    agg = {}
-    for name, nbytes, s0, s1 in cev:
-        e = agg.setdefault(name, {"kernel": name, "calls": 0, "ms": 0.0, "bytes": 0.0})
-        e["calls"] += 1; e["ms"] += s1 - s0; e["bytes"] += nbytes
-    crow = []
-    for e in sorted(agg.values(), key=lambda e: -e["ms"]):
-        gbs = e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["bytes"] and e["ms"] else None
-        crow.append({"kernel": e["kernel"], "calls": e["calls"], "ms": round(e["ms"], 3), "avg_us": round(e["ms"] / e["calls"] * 1e3, 1),
-                     "MB": round(e["bytes"] / 1e6, 1), "GB_per_s": gbs and round(gbs, 1), "frac_of_8TBs": gbs and round(gbs / 8000.0, 4)})
-    dev_ms = sum(e["ms"] for e in agg.values())
-    msm_ms = sum(e["ms"] for e in agg.values() if e["kernel"].startswith(("msm_", "k_accumulate", "k_direct")))
-    out["compress"] = {"compress_ms": compress_ms, "verify_compressed_ms": verify_c_ms, "verified": bool(ok_c),
-                       "per_kernel": crow, "per_kernel_pass_ms": round(timed_ms, 2), "device_ms_sum_of_launches": round(dev_ms, 2),
-                       "msm_share_of_device_time": round(msm_ms / dev_ms, 3) if dev_ms else None,
-                       "host_and_idle_ms": round(timed_ms - dev_ms, 2), "compress_first_call_ms": compress_first_ms,
-                       "per_kernel_covers": "the caller's queue: the fold of the last secondary instance and the PRIMARY side's argument; the "
-                                            "secondary side's argument runs beside it on a second queue (its launches are not in this table)",
-                       "argument_bytes": len(snark.to_bytes()),
-                       "wire_bytes": len(snark.serialize()),
-                       "what": "one Spartan-style argument with inner-product-argument openings per side of the cycle (vdf_nova.h)"}
-    snark.free()
     proof.free()
     # Aggregate rate of TWO independent chains proven concurrently on this GPU (two host threads, two contexts):
     # one chain's bucket reduction and host transcript run under the other's accumulation.  The headline `value`
@@ -807,6 +758,56 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
         for cx, p_, cs, z_ in work[1:]:
             p_.free(); cs.free(); cx.close()
         ctx.set_async(was_async)
+    # compress (src/nova/proof.rs:360-368) and verification of the compressed proof, once, outside `value`
+    # (after the two-chain leg: a compression opens a second queue on this parameter set, and with two provers' six queues
+    # beside the MSM leg's the process would go past the hardware queues the runtime maps streams onto)
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    # the first compression of a parameter set creates its second queue and grows two MSM workspaces: timed apart, the figure
+    # reported is the second call's (as every other timed region here follows its own warm-up)
+    a = time.perf_counter()
+    snark = proof.compress(pp)
+    compress_first_ms = (time.perf_counter() - a) * 1e3
+    snark.free()
+    a = time.perf_counter()
+    snark = proof.compress(pp)
+    compress_ms = (time.perf_counter() - a) * 1e3
+    a = time.perf_counter()
+    ok_c = snark.verify(pp, nsteps, z0, [initial.x, initial.y, initial.i])
+    verify_c_ms = (time.perf_counter() - a) * 1e3
+    # the same compression once more with HIP events around every launch (a pass of its own, not the figure above): where
+    # the time goes, pass by pass, each priced by its own bytes against the 8 TB/s roof (SURVEY 8f-1: the sum-check passes are
+    # the genuinely HBM-bound work of this library)
+    ctx.sync()
+    ctx.set_kernel_timing(True); ctx.kernel_events()
+    a = time.perf_counter()
+    snark2 = proof.compress(pp)
+    ctx.sync()
+    timed_ms = (time.perf_counter() - a) * 1e3
+    cev = ctx.kernel_events()
+    ctx.set_kernel_timing(False)
+    snark2.free()
+    agg = {}
+    for name, nbytes, s0, s1 in cev:
+        e = agg.setdefault(name, {"kernel": name, "calls": 0, "ms": 0.0, "bytes": 0.0})
+        e["calls"] += 1; e["ms"] += s1 - s0; e["bytes"] += nbytes
+    crow = []
+    for e in sorted(agg.values(), key=lambda e: -e["ms"]):
+        gbs = e["bytes"] / (e["ms"] * 1e-3) / 1e9 if e["bytes"] and e["ms"] else None
+        crow.append({"kernel": e["kernel"], "calls": e["calls"], "ms": round(e["ms"], 3), "avg_us": round(e["ms"] / e["calls"] * 1e3, 1),
+                     "MB": round(e["bytes"] / 1e6, 1), "GB_per_s": gbs and round(gbs, 1), "frac_of_8TBs": gbs and round(gbs / 8000.0, 4)})
+    dev_ms = sum(e["ms"] for e in agg.values())
+    msm_ms = sum(e["ms"] for e in agg.values() if e["kernel"].startswith(("msm_", "k_accumulate", "k_direct")))
+    out["compress"] = {"compress_ms": compress_ms, "verify_compressed_ms": verify_c_ms, "verified": bool(ok_c),
+                       "per_kernel": crow, "per_kernel_pass_ms": round(timed_ms, 2), "device_ms_sum_of_launches": round(dev_ms, 2),
+                       "msm_share_of_device_time": round(msm_ms / dev_ms, 3) if dev_ms else None,
+                       "host_and_idle_ms": round(timed_ms - dev_ms, 2), "compress_first_call_ms": compress_first_ms,
+                       "per_kernel_covers": "the caller's queue: the fold of the last secondary instance and the PRIMARY side's argument; the "
+                                            "secondary side's argument runs beside it on a second queue (its launches are not in this table)",
+                       "argument_bytes": len(snark.to_bytes()),
+                       "wire_bytes": len(snark.serialize()),
+                       "what": "one Spartan-style argument with inner-product-argument openings per side of the cycle (vdf_nova.h)"}
+    snark.free()
+    proof.free()
     pp.free()
     return out
 
@@ -1053,6 +1054,11 @@ def main():
     # Setup, before the W warm-up steps the contract asks for: bring the device to its sustained clock and grow every
     # workspace (a GPU that has idled through the generator set-up runs its first ~30 ms below the clock it then holds:
     # 20 timed steps after 3 warm-up steps measured 0.79 GPoints/s, the same 20 steps after this 0.86)
+    import gc
+    gc.collect()
+    gc.disable()                            # (the harness's collector stays out of the timed regions -- and out of the gap between the
+                                            # settle steps and them: a collection is ~50 ms of idle device; see prove_step_leg)
+    fp_msm = [box_fingerprint(ctx, "before the settle steps of the MSM leg")]
     for i in range(args.settle):
         step(i)
     fence()
@@ -1065,11 +1071,7 @@ def main():
     # The contract's timed region -- EXACTLY `steps` steps between two fences -- is run `regions` times back to back and the
     # MEDIAN region is reported (at the driver's --steps 20 one region is 25 ms: a single one cannot be read finer than
     # +-3 %); ms_per_step x steps is the duration of that one region.
-    fp_msm = [box_fingerprint(ctx, "before the MSM regions")]
     region_s = []
-    import gc
-    gc.collect()
-    gc.disable()                            # (the harness's collector stays out of the timed regions; see prove_step_leg)
     for _ in range(max(1, args.regions)):
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -1209,6 +1211,8 @@ def main():
                 c.set_async(True)
         if world == 1 and not args.no_prove and not args.rehearse_collective:
             ctx.set_async(False)
+            for c in ctxs[1:]:                    # the MSM leg's other queues are done: a prover needs the hardware queues (three per chain)
+                c.close()
             # one forward evaluation serves both forms of the step circuit (the circuits hold states and traces, not shapes);
             # the second chain of the two-chain leg is evaluated on another host thread meanwhile (ctypes releases the GIL)
             import threading
