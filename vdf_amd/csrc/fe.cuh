@@ -322,22 +322,25 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul_lazy(const Fe<P>& a, 
   return o;
 }
 
-// a - b (+ 2m on borrow) for a, b in [0, 2m + eps)
+// a - b (+ 2m on borrow) for a, b in [0, 2m + eps).  Three-operand form: the difference goes to registers of its own
+// (early-clobber outputs), so an operand that stays live afterwards -- X1, Y1, Q in the bucket addition -- is not copied first
+// (the in-place form cost eight v_mov per live operand: 42 moves per addition in round 4's first version of the loop).
 template <class P> __device__ __forceinline__ Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) {
-  Fe<P> r = a;
+  Fe<P> r;
   uint32_t mask;
-  asm("v_sub_co_u32_e32 %0, vcc, %0, %9\n\t"
-      "v_subb_co_u32_e32 %1, vcc, %1, %10, vcc\n\t"
-      "v_subb_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"
-      "v_subb_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"
-      "v_subb_co_u32_e32 %4, vcc, %4, %13, vcc\n\t"
-      "v_subb_co_u32_e32 %5, vcc, %5, %14, vcc\n\t"
-      "v_subb_co_u32_e32 %6, vcc, %6, %15, vcc\n\t"
-      "v_subb_co_u32_e32 %7, vcc, %7, %16, vcc\n\t"
+  asm("v_sub_co_u32_e32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, %16, %24, vcc\n\t"
       "v_cndmask_b32_e64 %8, 0, -1, vcc"
-      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]),
         "=&v"(mask)
-      : "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+        "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
       : "vcc");
   // 2m = {2, 2*m1 (33 bits: low word + carry into limb 2), ...}: computed limb-wise at compile time
   constexpr uint64_t D1 = 2ull * P::MOD[1], D2 = 2ull * P::MOD[2] + (D1 >> 32), D3 = 2ull * P::MOD[3] + (D2 >> 32);
@@ -413,6 +416,25 @@ template <class P> __device__ __forceinline__ Fe<P> fe_neg_lazy(const Fe<P>& a) 
   return r;
 }
 
+// m - a for a canonical, NON-ZERO a (the y of a curve point: neither curve has a point with y = 0): eight instructions, where
+// fe_neg pays a zero test and a masked correction (~45) -- the bucket loops negate a point per addition
+template <class P> __device__ __forceinline__ Fe<P> fe_neg_nz(const Fe<P>& a) {
+  Fe<P> r;
+  asm("v_sub_co_u32_e32 %0, vcc, 1, %8\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %16, %9, vcc\n\t"
+      "v_subb_co_u32_e32 %2, vcc, %17, %10, vcc\n\t"
+      "v_subb_co_u32_e32 %3, vcc, %18, %11, vcc\n\t"
+      "v_subb_co_u32_e32 %4, vcc, 0, %12, vcc\n\t"
+      "v_subb_co_u32_e32 %5, vcc, 0, %13, vcc\n\t"
+      "v_subb_co_u32_e32 %6, vcc, 0, %14, vcc\n\t"
+      "v_subb_co_u32_e32 %7, vcc, 2.0, %15, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+        "v"(P::MOD[1]), "v"(P::MOD[2]), "v"(P::MOD[3])
+      : "vcc");
+  return r;
+}
+
 // [0, 2m + eps) -> [0, m)
 template <class P> __device__ __forceinline__ Fe<P> fe_canon(Fe<P> a) {
   fe_cond_sub<P>(a.v);
@@ -429,6 +451,7 @@ template <class P> VDF_HD Fe<P> fe_mul2_lazy(const Fe<P>& a, const Fe<P>& b, con
   return fe_add(fe_mul_generic(a, b), fe_mul_generic(c, d));
 }
 template <class P> VDF_HD Fe<P> fe_neg_lazy(const Fe<P>& a) { return fe_neg(a); }
+template <class P> VDF_HD Fe<P> fe_neg_nz(const Fe<P>& a) { return fe_neg(a); }
 #endif
 
 // Out-of-line multiply (by-value arguments travel in VGPRs): one copy per field per TU.

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const uint32_t* __restrict__
       next = bstart[g + 1];
     }
     if (!affine_is_identity(pt)) {
-      if (((e & SIGN_BIT) != 0) != (have && flip)) pt.y = fe_neg(pt.y);      // digit sign XOR the accumulator's pending sign
+      if (((e & SIGN_BIT) != 0) != (have && flip)) pt.y = fe_neg_nz(pt.y);   // digit sign XOR the accumulator's pending sign (y != 0 on these curves)
       xyzz_madd_lazy<P>(acc, have, flip, pt);
     }
     e = en;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_direct_sum(DirectArgs a, int is_mont, i
       Affine<P> ptn;
       if (ptrn) ptn = affine_load<P>(ptrn);
       if (ptr) {
-        if (neg != (have && flip)) pt.y = fe_neg(pt.y);
+        if (neg != (have && flip)) pt.y = fe_neg_nz(pt.y);
         xyzz_madd_lazy<P>(acc, have, flip, pt);
       }
       e += L; ptr = ptrn; neg = negn; pt = ptn; k1 = k2;
