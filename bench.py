@@ -1116,6 +1116,9 @@ def main():
     replicas = None
     if (world > 1 or args.rehearse_collective) and not args.no_prove:
         ctx.set_async(False)
+        for k in range(1, depth):                 # the MSM legs are done: the prover needs the hardware queues (three per chain)
+            shs[k] = None
+            ctxs[k].close()
         mine = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=1, chains=1, with_compress=False,
                               with_roofline=False, seed_offset=rank, digit_budget_gib=args.digit_budget_gib)
         r = torch.tensor([mine["value"], -mine["value"], mine["value"], 1.0 if mine["verified"] else 0.0],
@@ -1320,6 +1323,12 @@ def main():
                 "shader_mhz": [b_.get("shader_mhz") for b_ in ps.get("box", [])]})
             line["prove_step_per_s"] = ps["value"]
             line["prove_step_ms_median"] = ps["ms_per_step"]
+        if replicas is not None:                  # N > 1: one independent chain per GPU; the whole-job rate is their sum
+            summary.update({"prove_step_per_s": replicas["value"], "prove_step_per_gpu_min": replicas["per_gpu_min"],
+                            "prove_step_per_gpu_max": replicas["per_gpu_max"], "prove_step_what": "sum over one chain per GPU (replicas)"})
+            line["prove_step_per_s"] = replicas["value"]
+        if strong is not None:
+            summary["msm_sharded_2_%d_gpoints_per_s" % args.strong_log2n] = strong["value"]
         summary["cpu_msm_gpoints_per_s"] = (line.get("cpu_baseline") or {}).get("value")
         summary["parity"] = "unpinned against nova-snark (no reference-held vector exists); bit-exact against oracle/ in this run: %s" % (not failures)
         line["summary"] = summary

@@ -408,6 +408,8 @@ typedef struct vdf_hip_tuning {
   int32_t giant_span;          /* ... and more than this to several wavefronts; 0 = 64 */
   int32_t nifs_lanes;          /* lanes per row of the fused cross term: 1, 4, 8; 0 = 8 up to 2^15 rows, else 1 */
   int32_t shim_cache;          /* generator arrays the mult_pippenger shims keep resident, 0..64 (0; vdf_shim_set_cache) */
+  int32_t nifs_fused;          /* 1: rows of more than 8 entries are summed inside the cross term's launch (k_nifs_cross_f) when it
+                                  runs eight lanes per row; 0: by a launch of their own before it (1) */
 } vdf_hip_tuning;
 int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
 int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */

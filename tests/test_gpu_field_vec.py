@@ -424,8 +424,8 @@ def test_ctx_marks(ctx):
 @pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
 def test_spmv_and_fused_cross_term_on_skewed_rows(ctx, cref, field):
     """Rows of 0 .. 300 entries with arbitrary coefficients, as an augmented circuit has them (bit packings of 255 terms,
-    Poseidon states of ~60): rows beyond VDF_LONG_ROW = 8 entries are summed by a wavefront each (k_spmv_long) ahead of
-    the lane-per-row kernels.  Against the C restatement, for vdf_spmv3 and for vdf_nifs_cross_term."""
+    Poseidon states of ~60): rows beyond VDF_LONG_ROW = 8 entries are summed by a wavefront each (k_spmv_long ahead of
+    the lane-per-row kernels, or inside the cross term's launch: k_nifs_cross_f).  Against the C restatement, for vdf_spmv3 and for vdf_nifs_cross_term."""
     m = o.modulus(field)
     rng = np.random.default_rng(77 + field)
     lens = [0, 1, 2, 7, 8, 9, 10, 33, 63, 64, 65, 127, 128, 129, 255, 300] * 9 + [1] * 500 + [60] * 200
@@ -455,13 +455,21 @@ def test_spmv_and_fused_cross_term_on_skewed_rows(ctx, cref, field):
     u1 = rand_limbs(rng, 1)
     expT = cref.fe_array(nc)
     cref.lib().ref_cross_term(field, *(cref.p(x) for x in abc1 + exp), cref.p(u1), nc, cref.p(expT))
-    d2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
-    dT = _dev(np.zeros((nc, 4), dtype="<u8"))
-    ctx.nifs_cross_term(shape, _dev(z), *[_dev(x) for x in abc1], u1, *d2, dT)
-    ctx.sync()
-    for got, e in zip(d2, exp):
-        assert np.array_equal(_host(got), e)
-    assert np.array_equal(_host(dT), expT)
+    # the long rows inside the cross term's own launch (k_nifs_cross_f, the default) and by k_spmv_long ahead of it
+    from vdf_amd import hip as _hip
+    was = _hip.tuning_get().nifs_fused
+    try:
+        for fused in (1, 0):
+            _hip.tuning_set(nifs_fused=fused)
+            d2 = [_dev(np.zeros((nc, 4), dtype="<u8")) for _ in range(3)]
+            dT = _dev(np.zeros((nc, 4), dtype="<u8"))
+            ctx.nifs_cross_term(shape, _dev(z), *[_dev(x) for x in abc1], u1, *d2, dT)
+            ctx.sync()
+            for got, e in zip(d2, exp):
+                assert np.array_equal(_host(got), e), fused
+            assert np.array_equal(_host(dT), expT), fused
+    finally:
+        _hip.tuning_set(nifs_fused=was)
     # a row range must not hold a long row (they are the OUTSIDE call's work); a range of short rows is fine
     long_rows = [r for r in range(nc) if any(np.roll(lens, 17 * k)[r] > 8 for k in range(3))]
     with pytest.raises(Exception):

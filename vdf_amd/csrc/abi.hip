@@ -116,7 +116,7 @@ vdf_hip_tuning tuning_defaults() {
   t.struct_size = (uint32_t)sizeof(vdf_hip_tuning);
   t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
   t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
-  t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0;
+  t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0; t.nifs_fused = 1;
   return t;
 }
 bool tuning_valid(const vdf_hip_tuning& t) {
@@ -125,7 +125,7 @@ bool tuning_valid(const vdf_hip_tuning& t) {
          in(t.accumulate_fill, 1, 3) && in(t.accumulate_lds, 0, 65536) && in(t.slice_len, 0, 65536) && in(t.part_bits, -1, 19) &&
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
-         (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64);
+         (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) && in(t.nifs_fused, 0, 1);
 }
 // the environment overrides of earlier rounds, read once: the only place this library looks at the environment for tuning
 void tuning_from_env() {
@@ -135,7 +135,7 @@ void tuning_from_env() {
       {"VDF_MSM_LIGHT_PRIO", &g_tune.light_priority}, {"VDF_MSM_ACC_WG", &g_tune.accumulate_fill}, {"VDF_MSM_ACC_LDS", &g_tune.accumulate_lds},
       {"VDF_MSM_L", &g_tune.slice_len}, {"VDF_MSM_PB", &g_tune.part_bits}, {"VDF_MSM_RED", &g_tune.reduction},
       {"VDF_MSM_RED_QUADS", &g_tune.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &g_tune.heavy_min}, {"VDF_MSM_GIANT_SPAN", &g_tune.giant_span},
-      {"VDF_NIFS_LANES", &g_tune.nifs_lanes}, {"VDF_SHIM_CACHE", &g_tune.shim_cache}};
+      {"VDF_NIFS_LANES", &g_tune.nifs_lanes}, {"VDF_SHIM_CACHE", &g_tune.shim_cache}, {"VDF_NIFS_FUSED", &g_tune.nifs_fused}};
   for (const auto& v : vars) {
     const char* e = std::getenv(v.name);
     if (!e || !*e) continue;
@@ -1042,6 +1042,7 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
       (void)hipFree(s->d_dict);
       (void)hipFree(s->d_t_colptr); (void)hipFree(s->d_t_row); (void)hipFree(s->d_t_cm); (void)hipFree(s->d_t_heavy);
       (void)hipFree(s->d_long);
+      (void)hipFree(s->d_long_rowlist);
       delete s;
     };
     hipError_t e = hipMalloc(&s->d_dict, dict.size() * 32);
@@ -1104,6 +1105,12 @@ int vdf_shape_create(vdf_ctx* ctx, int field, size_t num_cons, size_t num_cols, 
       std::sort(s->h_long_rows.begin(), s->h_long_rows.end());
       if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_long), (lng.size() + 1) * 4);
       if (e == hipSuccess && !lng.empty()) e = hipMemcpy(s->d_long, lng.data(), lng.size() * 4, hipMemcpyHostToDevice);
+      std::vector<uint32_t> distinct(s->h_long_rows);
+      distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+      s->n_long_rowlist = distinct.size();
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_long_rowlist), (distinct.size() + 1) * 4);
+      if (e == hipSuccess && !distinct.empty())
+        e = hipMemcpy(s->d_long_rowlist, distinct.data(), distinct.size() * 4, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { cleanup(); return vdf::hip_status(e, "vdf_shape_create upload"); }
     *out = s;
@@ -1121,6 +1128,7 @@ void vdf_shape_free(vdf_shape* shape) {
     (void)hipFree(shape->d_dict);
     (void)hipFree(shape->d_t_colptr); (void)hipFree(shape->d_t_row); (void)hipFree(shape->d_t_cm); (void)hipFree(shape->d_t_heavy);
     (void)hipFree(shape->d_long);
+    (void)hipFree(shape->d_long_rowlist);
   }
   delete shape;
 }
@@ -1276,7 +1284,11 @@ static Status nifs_cross_impl(vdf_ctx* ctx, const vdf_shape* shape, size_t row_b
   size_t rows = shape->num_cons, skip_begin = shape->num_cons, skip_len = 0;
   if (part == VDF_ROWS_INSIDE) { rows = row_count; skip_begin = 0; skip_len = row_begin; }
   if (part == VDF_ROWS_OUTSIDE) { rows = shape->num_cons - row_count; skip_begin = row_begin; skip_len = row_count; }
-  if (part != VDF_ROWS_INSIDE) {
+  // the rows of more than VDF_LONG_ROW entries: summed inside the cross term's own launch when it runs eight lanes per row
+  // (an augmented circuit, ~10^4 rows: one launch to wait for instead of two), else by a launch of their own before it
+  const bool long_inside = part != VDF_ROWS_INSIDE && shape->n_long_rowlist > 0 && vdf::tuning().nifs_fused &&
+                           vdf::nifs_cross_lanes(rows) == 8;
+  if (part != VDF_ROWS_INSIDE && !long_inside) {
     void* const outs[3] = {Az2, Bz2, Cz2};
     VDF_TRY(vdf::vec_spmv_long(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, shape->d_long,
                                shape->n_long, outs, ctx->stream));
@@ -1293,7 +1305,8 @@ static Status nifs_cross_impl(vdf_ctx* ctx, const vdf_shape* shape, size_t row_b
     alg_bytes = nnz_run * 8.0 + (double)rows * (3 * 36.0 + 7 * 32.0);
   }
   VDF_TRY(vdf::vec_nifs_cross(shape->field, shape->d_rowptr, shape->d_col, shape->d_coef, shape->d_dict, z2, Az1, Bz1, Cz1,
-                              u1, rows, skip_begin, skip_len, Az2, Bz2, Cz2, T, alg_bytes, ctx->stream));
+                              u1, rows, skip_begin, skip_len, long_inside ? shape->d_long_rowlist : nullptr,
+                              long_inside ? shape->n_long_rowlist : 0, Az2, Bz2, Cz2, T, alg_bytes, ctx->stream));
   if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
   return Status{};
 }

@@ -113,6 +113,9 @@ struct vdf_shape {
   // rows with more than VDF_LONG_ROW entries, as row | matrix << 30: one wavefront each (vec_spmv_long) instead of one lane
   uint32_t* d_long = nullptr;
   size_t n_long = 0;
+  // the distinct rows among them, ascending: one wavefront each in the fused cross term (k_nifs_cross_f)
+  uint32_t* d_long_rowlist = nullptr;
+  size_t n_long_rowlist = 0;
   std::vector<uint64_t> h_nnz_prefix;                     // entries of A + B + C in the rows above r (pricing of a row range)
   std::vector<uint32_t> h_long_rows;                      // ... their row numbers, ascending (vdf_nifs_cross_term_rows)
 };
@@ -226,8 +229,10 @@ Status vec_step_z(int field, const void* trace_xy, uint64_t t, const vdf_fe z_in
                   const vdf_fe X[6], void* z, void* packed, hipStream_t s);
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
-                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
-                      void* bz2, void* cz2, void* T, double alg_bytes, hipStream_t s);
+                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len,
+                      const uint32_t* long_rowlist, size_t n_long_rows, void* az2, void* bz2, void* cz2, void* T,
+                      double alg_bytes, hipStream_t s);
+int nifs_cross_lanes(size_t rows);                       // lanes per row vec_nifs_cross picks for a launch over `rows` rows
 Status vec_nifs_cross_minroot(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
                               const void* az1, const void* bz1, const void* cz1, const vdf_fe* u1, void* az2, void* bz2, void* cz2,
                               void* T, hipStream_t s);

@@ -282,23 +282,26 @@ __global__ __launch_bounds__(256) void k_nifs_cross(Csr3 m, const char* __restri
 // What it buys is LATENCY: the ~10^4 rows of an augmented circuit that a step waits for take 12 us instead of 26-48 (a lane
 // that walks 8 entries of 3 matrices in turn pays 24 round trips); for the 2 x 10^5 uniform rows of the MinRoot rounds
 // (1 + 1 + 4 entries) four lanes per row issue the four gathers of C together.
-template <class P, int LPR>
-__global__ __launch_bounds__(256) void k_nifs_cross_w(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
-                                                      const char* __restrict__ az1, const char* __restrict__ bz1,
-                                                      const char* __restrict__ cz1, FeVal u1, size_t rows,
-                                                      size_t skip_begin, size_t skip_len,
-                                                      char* __restrict__ az2, char* __restrict__ bz2,
-                                                      char* __restrict__ cz2, char* __restrict__ T) {
-  __builtin_amdgcn_s_setprio(3);
+// (LEAVE_LONG: a row with a matrix of more than VDF_LONG_ROW entries is left to the wavefront k_nifs_cross_f gives it)
+template <class P, int LPR, bool LEAVE_LONG>
+__device__ __forceinline__ void nifs_cross_group(const Csr3& m, const char* __restrict__ dict, const char* __restrict__ z2,
+                                                 const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                 const char* __restrict__ cz1, const FeVal& u1, size_t rows, size_t skip_begin,
+                                                 size_t skip_len, char* __restrict__ az2, char* __restrict__ bz2,
+                                                 char* __restrict__ cz2, char* __restrict__ T, uint32_t block) {
   constexpr uint32_t RPB = 256 / LPR;                                // rows per workgroup
   const uint32_t l = threadIdx.x & (LPR - 1);
-  size_t r = (size_t)blockIdx.x * RPB + threadIdx.x / LPR;
-  const bool live = r < rows;
+  size_t r = (size_t)block * RPB + threadIdx.x / LPR;
+  bool live = r < rows;
   if (!live) r = rows ? rows - 1 : 0;                                // keeps the group's lanes together for the butterfly
   if (r >= skip_begin) r += skip_len;
   uint32_t lo[3], hi[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
+  if (LEAVE_LONG && (hi[0] - lo[0] > VDF_LONG_ROW || hi[1] - lo[1] > VDF_LONG_ROW || hi[2] - lo[2] > VDF_LONG_ROW)) {
+    live = false;                                                    // (all lanes of the group agree: the row is theirs)
+    hi[0] = lo[0]; hi[1] = lo[1]; hi[2] = lo[2];
+  }
   Fe<P> a1, b1, c1;
   if (l == 0) { a1 = fe_load<P>(az1 + r * 32); b1 = fe_load<P>(bz1 + r * 32); c1 = fe_load<P>(cz1 + r * 32); }
   char* const outs[3] = {az2, bz2, cz2};
@@ -343,6 +346,100 @@ __global__ __launch_bounds__(256) void k_nifs_cross_w(Csr3 m, const char* __rest
   fe_store<P>(T + r * 32, t);
 }
 
+template <class P, int LPR>
+__global__ __launch_bounds__(256) void k_nifs_cross_w(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
+                                                      const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                      const char* __restrict__ cz1, FeVal u1, size_t rows,
+                                                      size_t skip_begin, size_t skip_len,
+                                                      char* __restrict__ az2, char* __restrict__ bz2,
+                                                      char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);
+  nifs_cross_group<P, LPR, false>(m, dict, z2, az1, bz1, cz1, u1, rows, skip_begin, skip_len, az2, bz2, cz2, T, blockIdx.x);
+}
+
+// The cross term of an augmented circuit in ONE launch instead of k_spmv_long followed by k_nifs_cross_w: the first
+// `long_wgs` workgroups give every row that has a matrix of more than VDF_LONG_ROW entries (the S-box rows of the
+// circuit's hash: sums of a few hundred terms) a wavefront of its own, the others run the eight-lane groups over all rows
+// and leave those rows alone.  A step waits for this kernel with the device otherwise idle on its queue, so what counts is
+// its depth in dependent memory round trips, not its work: a long row is the list entry, the six row pointers, then per
+// pass of 128 entries the column / coefficient indices of all three matrices, then their z and dictionary values -- every
+// load of a pass is in flight before the first product (two passes cover the longest rows of the built-in circuits).
+template <class P>
+__global__ __launch_bounds__(256) void k_nifs_cross_f(Csr3 m, const char* __restrict__ dict, const char* __restrict__ z2,
+                                                      const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                      const char* __restrict__ cz1, FeVal u1, size_t rows,
+                                                      size_t skip_begin, size_t skip_len,
+                                                      const uint32_t* __restrict__ long_rowlist, size_t n_long_rows,
+                                                      uint32_t long_wgs, char* __restrict__ az2, char* __restrict__ bz2,
+                                                      char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);
+  if (blockIdx.x >= long_wgs) {
+    nifs_cross_group<P, 8, true>(m, dict, z2, az1, bz1, cz1, u1, rows, skip_begin, skip_len, az2, bz2, cz2, T,
+                                 blockIdx.x - long_wgs);
+    return;
+  }
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_long_rows) return;                                     // whole wavefronts leave together
+  const uint32_t lane = threadIdx.x & 63;
+  const size_t r = long_rowlist[w];
+  uint32_t lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { lo[k] = m.rowptr[k][r]; hi[k] = m.rowptr[k][r + 1]; }
+  Fe<P> a1, b1, c1;
+  if (lane == 0) { a1 = fe_load<P>(az1 + r * 32); b1 = fe_load<P>(bz1 + r * 32); c1 = fe_load<P>(cz1 + r * 32); }
+  uint32_t longest = hi[0] - lo[0];
+  if (hi[1] - lo[1] > longest) longest = hi[1] - lo[1];
+  if (hi[2] - lo[2] > longest) longest = hi[2] - lo[2];
+  Fe<P> acc[3] = {fe_zero<P>(), fe_zero<P>(), fe_zero<P>()};
+  for (uint32_t base = 0; base < longest; base += 128) {            // (the same trip count for every lane of the wavefront)
+    uint32_t cc[3][2], kk[3][2];
+    bool has[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t e = lo[k] + base + lane + 64 * j;
+        has[k][j] = e < hi[k];
+        cc[k][j] = m.col[k][has[k][j] ? e : lo[k]];                   // (arrays are nnz + 1 long: lo is always readable)
+        kk[k][j] = m.coef[k][has[k][j] ? e : lo[k]];
+      }
+    Fe<P> v[3][2], d[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        v[k][j] = fe_load<P>(z2 + (size_t)(has[k][j] ? cc[k][j] : 0u) * 32);
+        d[k][j] = fe_load<P>(dict + (size_t)(has[k][j] ? kk[k][j] : 0u) * 32);
+      }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!has[k][j]) continue;
+        const Fe<P> term = kk[k][j] == 0 ? v[k][j] : (kk[k][j] == 1 ? fe_neg(v[k][j]) : fe_mul(v[k][j], d[k][j]));
+        acc[k] = fe_add(acc[k], term);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      Fe<P> o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.v[i] = __shfl_xor(acc[k].v[i], off, 64);
+      acc[k] = fe_add(acc[k], o);
+    }
+  }
+  if (lane != 0) return;
+  fe_store<P>(az2 + r * 32, acc[0]);
+  fe_store<P>(bz2 + r * 32, acc[1]);
+  fe_store<P>(cz2 + r * 32, acc[2]);
+  Fe<P> t = fe_add(fe_mul(a1, acc[1]), fe_mul(acc[0], b1));
+  t = fe_sub(t, fe_mul(fe_from_val<P>(u1), acc[2]));
+  t = fe_sub(t, c1);
+  fe_store<P>(T + r * 32, t);
+}
+
 // The cross term over the rows of the built-in MinRoot step circuits WITHOUT the sparse matrices: the 3t + 1 constraints
 // InverseMinRootCircuit::synthesize records (src/nova/proof.rs:107-133, :219-227) are a fixed stencil over the round's own
 // variables, so A z2, B z2, C z2 of a row are copies of witness values (and one four-term sum): no row pointers, no
@@ -376,35 +473,29 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
     const Fe<P> km = k < (1u << 30) ? fe_from_small<P>((uint32_t)k) : fe_from_u64<P>(k);
     return unit ? km : fe_mul(km, onev);
   };
-  Fe<P> a2, b2, c2;
-  if (i == 3 * t) {
-    a2 = fe_load<P>(z2 + (S + (size_t)PER * t) * 32);
-    b2 = onev;
-    c2 = fe_sub(i_in, times_one(t));
-  } else {
-    const uint64_t j = i / 3;
-    const uint32_t role = (uint32_t)(i - 3 * j);
-    const char* rd = z2 + (S + (size_t)PER * j) * 32;              // this round's variables
-    const char* t1p = rd + (PER - 3) * 32;                          // tmp1, tmp2, new_y
-    // y_j and (PER = 3) the value below x_j: new_y of earlier rounds, or z_in
-    const char* yp = j ? rd - 32 : z2 + (S - 2) * 32;               // y_j = new_y_(j-1): the element right before this round
-    Fe<P> x;
-    if (role != 1) {
-      if (PER == 4) x = fe_load<P>(j ? rd - (size_t)PER * 32 : z2 + (S - 3) * 32);      // new_x_(j-1)
-      else if (j == 0) x = fe_load<P>(z2 + (S - 3) * 32);
-      else {                                                        // y_(j-1) - i + j * one
-        const Fe<P> yprev = fe_load<P>(j > 1 ? rd - (size_t)PER * 32 - 32 : z2 + (S - 2) * 32);
-        x = fe_add(fe_sub(yprev, i_in), times_one(j));
-      }
-    }
-    if (role == 0) { a2 = x; b2 = x; c2 = fe_load<P>(t1p); }
-    else if (role == 1) { a2 = fe_load<P>(t1p); b2 = a2; c2 = fe_load<P>(t1p + 32); }
-    else {
-      a2 = fe_load<P>(t1p + 32); b2 = x;
-      const Fe<P> ny = fe_load<P>(t1p + 64), y = fe_load<P>(yp);
-      c2 = fe_add(fe_sub(fe_add(ny, y), i_in), times_one(j + 1));
-    }
+  // The three kinds of row differ in WHERE their values sit, not in what is done with them: the addresses are selected
+  // first and every load of the row is issued before the first use (a wavefront holds all three kinds: as branches they
+  // would be three serial rounds of loads).  pa / pb / pc = the sources of A z2, B z2 and the first term of C z2.
+  const bool last = i == 3 * t;
+  const uint64_t j = last ? t - 1 : i / 3;
+  const uint32_t role = last ? 3u : (uint32_t)(i - 3 * j);
+  const char* rd = z2 + (S + (size_t)PER * j) * 32;                // this round's variables
+  const char* t1p = rd + (PER - 3) * 32;                            // tmp1, tmp2, new_y
+  const char* yp = j ? rd - 32 : z2 + (S - 2) * 32;                 // y_j = new_y_(j-1): the element right before this round
+  // x_j: a variable (PER = 4: new_x_(j-1), or z_in.x), or y_(j-1) - i + j * one (PER = 3, j > 0; y_(-1) does not exist)
+  const char* px = PER == 4 ? (j ? rd - (size_t)PER * 32 : z2 + (S - 3) * 32)
+                            : (j == 0 ? z2 + (S - 3) * 32 : (j > 1 ? rd - (size_t)PER * 32 - 32 : z2 + (S - 2) * 32));
+  const char* pa = role == 0 ? px : (role == 1 ? t1p : (role == 2 ? t1p + 32 : z2 + (S + (size_t)PER * t) * 32));
+  const char* pb = role == 1 ? t1p : (role == 3 ? z2 + one_col * 32 : px);
+  const char* pc = role == 3 ? z2 + (S - 1) * 32 : t1p + role * 32;
+  Fe<P> a2 = fe_load<P>(pa), b2 = fe_load<P>(pb), c2 = fe_load<P>(pc);
+  const Fe<P> y = fe_load<P>(yp);
+  if (PER == 3 && j > 0) {                                          // the loaded value is y_(j-1): turn it into x_j
+    const Fe<P> xa = fe_add(fe_sub(role == 0 ? a2 : b2, i_in), times_one(j));
+    if (role == 0) { a2 = xa; b2 = xa; } else if (role == 2) b2 = xa;
   }
+  if (role == 2) c2 = fe_add(fe_sub(fe_add(c2, y), i_in), times_one(j + 1));
+  if (role == 3) c2 = fe_sub(c2, times_one(t));
   fe_store<P>(az2 + r * 32, a2);
   fe_store<P>(bz2 + r * 32, b2);
   fe_store<P>(cz2 + r * 32, c2);
@@ -547,17 +638,33 @@ Status vec_step_segment(int field, const void* trace_xy, uint64_t t, const vdf_f
   return Status{};
 }
 
+// lanes per row: 8 for the ~10^4 rows a step waits for (latency), 4 for long runs of short rows (the MinRoot rounds: all
+// gathers of a row at once), 1 = the lane-per-row kernel.  vdf_hip_tuning.nifs_lanes = 1 | 4 | 8 forces one (tuning / A-B measurements).
+int nifs_cross_lanes(size_t rows) {
+  const int forced = tuning().nifs_lanes;
+  return forced == 1 || forced == 4 || forced == 8 ? forced : (rows <= (1u << 15) ? 8 : 1);
+}
+
+// With `long_rowlist` (the distinct rows that have a matrix of more than VDF_LONG_ROW entries) the launch sums those rows
+// itself (k_nifs_cross_f; the caller checked nifs_cross_lanes(rows) == 8); without, vec_spmv_long ran before it.
 Status vec_nifs_cross(int field, const uint32_t* const rowptr[3], const uint32_t* const col[3],
                       const uint32_t* const coef[3], const void* dict, const void* z2, const void* az1, const void* bz1,
-                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len, void* az2,
-                      void* bz2, void* cz2, void* T, double alg_bytes, hipStream_t s) {
+                      const void* cz1, const vdf_fe* u1, size_t rows, size_t skip_begin, size_t skip_len,
+                      const uint32_t* long_rowlist, size_t n_long_rows, void* az2, void* bz2, void* cz2, void* T,
+                      double alg_bytes, hipStream_t s) {
   if (rows == 0) return Status{};
   Csr3 m;
   for (int k = 0; k < 3; ++k) { m.rowptr[k] = rowptr[k]; m.col[k] = col[k]; m.coef[k] = coef[k]; }
-  // lanes per row: 8 for the ~10^4 rows a step waits for (latency), 4 for long runs of short rows (the MinRoot rounds: all
-  // gathers of a row at once), 1 = the lane-per-row kernel.  vdf_hip_tuning.nifs_lanes = 1 | 4 | 8 forces one (tuning / A-B measurements).
-  const int forced = tuning().nifs_lanes;
-  const int lpr = forced == 1 || forced == 4 || forced == 8 ? forced : (rows <= (1u << 15) ? 8 : 1);
+  const int lpr = nifs_cross_lanes(rows);
+  if (long_rowlist && n_long_rows) {
+    if (lpr != 8) return Status{VDF_ERR_BAD_ARG, "the fused cross term runs eight lanes per row"};
+    KTimer kt(s, "k_nifs_cross_f", alg_bytes);
+    const uint32_t long_wgs = (uint32_t)((n_long_rows + 3) / 4);
+    const dim3 grid((unsigned)((rows + 31) / 32) + long_wgs);
+    FIELD_DISPATCH(field, k_nifs_cross_f, grid, dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1), to_val(u1), rows,
+                   skip_begin, skip_len, long_rowlist, n_long_rows, long_wgs, M(az2), M(bz2), M(cz2), M(T));
+    return Status{};
+  }
   KTimer kt(s, lpr == 1 ? "k_nifs_cross" : (lpr == 4 ? "k_nifs_cross_w4" : "k_nifs_cross_w8"), alg_bytes);
   if (lpr == 1) {
     FIELD_DISPATCH(field, k_nifs_cross, grid_for(rows), dim3(256), 0, s, m, C(dict), C(z2), C(az1), C(bz1), C(cz1),
