@@ -388,8 +388,9 @@ int  vdf_fe_from_mont(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, vdf_fe
 int  vdf_fe_mul_chain(vdf_ctx* ctx, int field, const vdf_fe* a, size_t n, int iters, vdf_fe* out);
 /* Process-wide tuning of the kernels (every field has a measured default; DESIGN.md says what each was worth).  The
  * environment variables of earlier rounds (VDF_MSM_*, VDF_NIFS_LANES, VDF_SHIM_CACHE) are read ONCE, the first time the
- * library needs a value, as overrides of these defaults; a host sets them here instead.  Set before the first MSM of the
- * process (values are read at launch time; changing them between calls is allowed, not while a call is in flight). */
+ * library needs a value, as overrides of these defaults; a host sets them here instead.  Values are read at launch time.
+ * Thread-safe: a set publishes a new immutable snapshot; a call running on another thread meanwhile sees the old values or
+ * the new ones at each of its launches, never a mixture within one read (set before a call for a defined outcome). */
 typedef struct vdf_hip_tuning {
   uint32_t struct_size;        /* sizeof(vdf_hip_tuning) as the caller compiled it */
   int32_t msm_direct;          /* 1: MSMs inside a digit table's ranges are direct sums (msm_direct.hip); 0: bucket method only */

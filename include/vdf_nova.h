@@ -20,6 +20,16 @@
  * generator derivation) are not in /root/reference and pinned by none of its tests:
  * proofs are self-consistent and bit-exact against oracle/nova.py, not interchangeable with
  * nova-snark's -- parity unpinned.
+ *
+ * Threading.  The evaluator functions and vdf_nova_ro_hash / shape_digest / aug_synthesize are pure (any thread, any time).
+ * A parameter set (vdf_pp) owns the device queue its proofs enqueue on: ONE call at a time per parameter set and per
+ * handle made under it (prove_step, verify, compress, the wire functions that touch the device); calls under different
+ * parameter sets are independent and may run on different threads at once (two chains = two sets: bench.py's
+ * aggregate_over_concurrent_chains).  Concurrent vdf_nova_compress calls under one set are serialised by the library at the
+ * point where they share its second queue; nothing else is.  The library has threads of its own: up to a few sets of three
+ * detached synthesis helpers, made when a prover first wants them and parked between calls (they never touch a handle
+ * outside the call that handed them work), and one thread per vdf_nova_compress for the secondary side's argument, joined
+ * before the call returns.
  */
 #ifndef VDF_NOVA_H
 #define VDF_NOVA_H

@@ -32,3 +32,12 @@ t0 = ev[0][2]
 print("first 60 launches (start ms, dur us):")
 for name, nbytes, s0, s1 in ev[:60]:
     print("  %8.3f %8.1f  %s" % (s0 - t0, (s1 - s0) * 1e3, name))
+# three rounds of the inner-product arguments from the middle of the pass: the gaps are the host between the launches
+mid = [i for i, e in enumerate(ev) if e[0] == "k_accumulate"]
+if len(mid) >= 8:
+    lo, hi = mid[5], mid[8]
+    print("rounds 6-8 of the primary side's arguments (start ms, dur us, gap to the previous launch's end us):")
+    prev = ev[lo - 1][3] if lo else ev[0][2]
+    for name, nbytes, s0, s1 in ev[lo - 4:hi + 1]:
+        print("  %8.3f %8.1f %8.1f  %s" % (s0 - t0, (s1 - s0) * 1e3, (s0 - prev) * 1e3, name))
+        prev = s1

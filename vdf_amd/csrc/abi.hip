@@ -9,6 +9,8 @@
 #include <array>
 #include <new>
 #include <memory>
+#include <atomic>
+#include <deque>
 #include <mutex>
 #include <initializer_list>
 #include <utility>
@@ -108,9 +110,13 @@ int fail(vdf_ctx* ctx, const Status& s) {
 
 
 // ---- process-wide tuning (include/vdf_hip.h vdf_hip_tuning) ---------------------------------------------------------
+// Readers (every launch, on any thread) take the current snapshot through one atomic pointer; a set publishes a NEW immutable
+// snapshot and never touches an old one (they are kept: a few dozen bytes per call), so a launch racing with
+// vdf_hip_tuning_set sees either the old values or the new ones, never a mixture, and holds no lock.
 std::once_flag g_tune_once;
-std::mutex g_tune_mu;
-vdf_hip_tuning g_tune;
+std::mutex g_tune_mu;                                   // writers only
+std::deque<vdf_hip_tuning> g_tune_snapshots;            // (a deque: push_back moves no element)
+std::atomic<const vdf_hip_tuning*> g_tune{nullptr};
 vdf_hip_tuning tuning_defaults() {
   vdf_hip_tuning t{};
   t.struct_size = (uint32_t)sizeof(vdf_hip_tuning);
@@ -125,46 +131,51 @@ bool tuning_valid(const vdf_hip_tuning& t) {
          in(t.accumulate_fill, 1, 3) && in(t.accumulate_lds, 0, 65536) && in(t.slice_len, 0, 65536) && in(t.part_bits, -1, 19) &&
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
-         (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) && in(t.nifs_fused, 0, 1);
+         (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) &&
+         in(t.nifs_fused, 0, 1);
+}
+void tuning_publish(const vdf_hip_tuning& t) {           // caller holds g_tune_mu (or is the once-initialiser)
+  g_tune_snapshots.push_back(t);
+  g_tune_snapshots.back().struct_size = (uint32_t)sizeof(vdf_hip_tuning);
+  g_tune.store(&g_tune_snapshots.back(), std::memory_order_release);
 }
 // the environment overrides of earlier rounds, read once: the only place this library looks at the environment for tuning
 void tuning_from_env() {
-  g_tune = tuning_defaults();
+  vdf_hip_tuning t = tuning_defaults();
   const struct { const char* name; int32_t* field; } vars[] = {
-      {"VDF_MSM_DIRECT", &g_tune.msm_direct}, {"VDF_MSM_DIRECT_PRIO", &g_tune.direct_priority}, {"VDF_MSM_DIRECT_FUSED", &g_tune.direct_fused},
-      {"VDF_MSM_LIGHT_PRIO", &g_tune.light_priority}, {"VDF_MSM_ACC_WG", &g_tune.accumulate_fill}, {"VDF_MSM_ACC_LDS", &g_tune.accumulate_lds},
-      {"VDF_MSM_L", &g_tune.slice_len}, {"VDF_MSM_PB", &g_tune.part_bits}, {"VDF_MSM_RED", &g_tune.reduction},
-      {"VDF_MSM_RED_QUADS", &g_tune.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &g_tune.heavy_min}, {"VDF_MSM_GIANT_SPAN", &g_tune.giant_span},
-      {"VDF_NIFS_LANES", &g_tune.nifs_lanes}, {"VDF_SHIM_CACHE", &g_tune.shim_cache}, {"VDF_NIFS_FUSED", &g_tune.nifs_fused}};
+      {"VDF_MSM_DIRECT", &t.msm_direct}, {"VDF_MSM_DIRECT_PRIO", &t.direct_priority}, {"VDF_MSM_DIRECT_FUSED", &t.direct_fused},
+      {"VDF_MSM_LIGHT_PRIO", &t.light_priority}, {"VDF_MSM_ACC_WG", &t.accumulate_fill}, {"VDF_MSM_ACC_LDS", &t.accumulate_lds},
+      {"VDF_MSM_L", &t.slice_len}, {"VDF_MSM_PB", &t.part_bits}, {"VDF_MSM_RED", &t.reduction},
+      {"VDF_MSM_RED_QUADS", &t.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &t.heavy_min}, {"VDF_MSM_GIANT_SPAN", &t.giant_span},
+      {"VDF_NIFS_LANES", &t.nifs_lanes}, {"VDF_SHIM_CACHE", &t.shim_cache}, {"VDF_NIFS_FUSED", &t.nifs_fused}};
   for (const auto& v : vars) {
     const char* e = std::getenv(v.name);
     if (!e || !*e) continue;
     const int32_t old = *v.field;
     *v.field = (int32_t)std::atol(e);
-    if (!tuning_valid(g_tune)) *v.field = old;          // an out-of-range override is ignored, as before
+    if (!tuning_valid(t)) *v.field = old;               // an out-of-range override is ignored, as before
   }
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  tuning_publish(t);
 }
 }  // namespace
 namespace vdf {
 thread_local KSink* tl_ksink = nullptr;
 const vdf_hip_tuning& tuning() {
   std::call_once(g_tune_once, tuning_from_env);
-  return g_tune;
+  return *g_tune.load(std::memory_order_acquire);
 }
 }  // namespace vdf
 extern "C" int vdf_hip_tuning_get(vdf_hip_tuning* out) {
   if (!out) return VDF_ERR_BAD_ARG;
-  (void)vdf::tuning();
-  std::lock_guard<std::mutex> lock(g_tune_mu);
-  *out = g_tune;
-  out->struct_size = (uint32_t)sizeof(vdf_hip_tuning);
+  *out = vdf::tuning();
   return VDF_OK;
 }
 extern "C" int vdf_hip_tuning_set(const vdf_hip_tuning* in) {
   if (!in || in->struct_size != sizeof(vdf_hip_tuning) || !tuning_valid(*in)) return VDF_ERR_BAD_ARG;
   (void)vdf::tuning();
   std::lock_guard<std::mutex> lock(g_tune_mu);
-  g_tune = *in;
+  tuning_publish(*in);
   return VDF_OK;
 }
 namespace {

@@ -641,6 +641,7 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
     // by a second host thread, beside the primary's -- its small latency-bound MSMs and its host work (transcript, point
     // arithmetic between rounds) disappear under the primary side's 2^19-generator MSMs.  (nova-snark's CompressedSNARK::prove
     // runs the two provers in parallel as well.)
+    std::lock_guard<std::mutex> aux_lock(pp->aux_mu);
     if (!pp->aux_ctx) {
       const int dev = vdf_ctx_device(ctx);
       if (vdf_ctx_create(&dev, 1, &pp->aux_ctx) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: second context: ") + vdf_last_error(nullptr));

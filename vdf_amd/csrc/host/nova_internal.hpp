@@ -11,6 +11,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <vector>
 #include "../../../include/vdf_nova.h"
 #include "host_math.hpp"
@@ -99,6 +100,8 @@ struct vdf_pp {
   const vdfnova::RoInstance* ro = nullptr;  // the random oracle's parameter block (covered by the digest); never null once the set is made
   vdf_ctx* aux_ctx = nullptr;              // a second queue of the same device for compress (the secondary side's argument runs beside the
                                            // primary's, as nova-snark's CompressedSNARK::prove does); created on first use
+  std::mutex aux_mu;                       // ... one compression at a time uses it: concurrent vdf_nova_compress calls under ONE parameter
+                                           // set take turns at the arguments (calls under different sets do not meet)
   vdf_nova_tuning tune;                    // the tuning this set was made with, and that its prover runs with
   double setup_ms[7] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t digit_table_bytes[2] = {0, 0};  // HBM held by each side's digit table (vdf_nova_pp_memory)
