@@ -146,6 +146,8 @@ typedef struct vdf_nova_tuning {
   int32_t  lookahead_priority;   /* wave priority of the lookahead's sort and bucket reduction, 0..3 (1) */
   int32_t  side_accumulate_fill; /* accumulation workgroups per CU the two side queues' MSMs fill, 1..3 (3) */
   int32_t  verbose;              /* 1 = decisions (skipped tables, the window chosen) on stderr */
+  int32_t  compress_queues;      /* 1: vdf_nova_compress runs the primary side's two openings on two queues half a round apart (one
+                                    opening's sort and bucket reduction under the other's accumulation); 0: in lockstep on one (1) */
 } vdf_nova_tuning;
 void vdf_nova_tuning_default(vdf_nova_tuning* out);
 /* public_params with the tuning given (NULL = the defaults); VDF_ERR_BAD_ARG for a field out of range */

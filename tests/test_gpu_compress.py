@@ -55,6 +55,26 @@ def test_compressed_arguments_equal_the_oracles(ctx, t, n, kind):
     assert proof.compress(pp).serialize() == snark.serialize()
 
 
+def test_two_queue_openings_change_no_byte(ctx):
+    """vdf_nova_tuning.compress_queues: the primary side's two openings on two queues half a round apart (the default) and in
+    lockstep on one produce the same proof -- only launches move, the transcript sees the same sequence -- at a size where
+    the two openings have different numbers of rounds (t = 1024: 2^13 / 2^12 entries)."""
+    from vdf_amd.nova import public_params, GENS_TRY_AND_INCREMENT
+    t, n = 1024, 2
+    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
+    assert pp.tuning()["compress_queues"] == 1
+    proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
+    a = proof.compress(pp)
+    pp0 = public_params(ctx, t, CIRCUIT_MINROOT_REFERENCE, GENS_TRY_AND_INCREMENT, compress_queues=0)
+    assert pp0.tuning()["compress_queues"] == 0 and pp0.digest() == pp.digest()
+    proof0 = NovaVDFProof.prove_recursively(pp0, circuits, t, z0)
+    b = proof0.compress(pp0)
+    assert a.serialize() == b.serialize()
+    assert a.verify(pp, n, z0, _zi(init_ints)) and b.verify(pp0, n, z0, _zi(init_ints))
+    # again on the same parameter set: the queues made by the first call are reused
+    assert proof.compress(pp).serialize() == a.serialize()
+
+
 def test_nova_proof_compress_leg(ctx):
     """test_nova_proof_aux(5, 3), src/nova/proof.rs:446-450: compress succeeds and the compressed proof verifies."""
     t, n = 5, 3

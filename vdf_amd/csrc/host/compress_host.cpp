@@ -193,6 +193,80 @@ struct IpaJob {
                                    // read after the round's one synchronisation (behind the MSM), not after one of their own
 };
 
+// The same two openings, same transcript, on TWO queues half a round apart.  A round's batched MSM is sort (0.26 ms at
+// 2^19 + 2^18 generators), bucket accumulation (0.91), fix-up and bucket reduction (0.26): only the middle one fills the
+// device, and in lockstep the device idles through the other two and through the host's turn, 15 times.  Here opening W
+// runs on the side's queue and opening E on a second one, E's accumulation gated behind W's whole MSM
+// (vdf_ctx_gate_accumulate): E's sort runs under W's accumulation, E's accumulation under W's host turn and W's next sort,
+// E's reduction under W's next accumulation.  The transcript sees what it saw before -- round by round W's L, R and
+// challenge, then E's -- because only LAUNCHES move: W's next round is enqueued as soon as W's challenge is drawn, before
+// E's points of this round are read.  The bytes of the proof do not change (tests/test_gpu_compress.py compares them with
+// the oracle's lockstep prover).
+constexpr int IPA_MARK = 3;                  // (a mark slot prove_step does not use: nova_host.cpp StepMark)
+static int ipa_prove_two_queues(const Side& sd, Transcript& tr, IpaJob* jobs, vdf_jac* h_lr) {
+  const Side* pp = &sd;
+  vdf_ctx* cq[2] = {sd.ctx, sd.ctx_b};
+  const Field& F = *sd.F;
+  const Field& Fb = *sd.Fb;
+  uint64_t raw[4];
+  HIPCALL(cq[1], vdf_ctx_set_async(cq[1], 1));
+  HIPCALL(cq[1], vdf_ctx_wait(cq[1], cq[0]));                          // the E opening's vectors were made on the first queue
+  bool w_marked = false;
+  auto enqueue = [&](int q) -> int {                                   // this round's L and R of opening q, on its queue
+    IpaJob& jb = jobs[q];
+    vdf_ctx* ctx = cq[q];
+    const vdf_fe* ab[2] = {(const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_b};
+    HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_IPA_CROSS, ab, nullptr, jb.nj, (vdf_fe*)jb.cross));        // pinned: no wait here
+    HIPCALL(ctx, vdf_ipa_scalars(ctx, sd.field, (const vdf_fe*)jb.d_a, (const vdf_fe*)jb.d_s, jb.n, jb.nj, (vdf_fe*)jb.d_sL,
+                                 (vdf_fe*)jb.d_sR));
+    if (q == 1 && w_marked) HIPCALL(ctx, vdf_ctx_gate_accumulate(ctx, cq[0], IPA_MARK));
+    const size_t off[2] = {0, 0}, len[2] = {jb.n, jb.n};
+    const vdf_fe* sc[2] = {(const vdf_fe*)jb.d_sL, (const vdf_fe*)jb.d_sR};
+    HIPCALL(ctx, vdf_msm_batch(ctx, pp->gens, 2, off, sc, len, 1, h_lr + 2 * q));
+    if (q == 0) { HIPCALL(ctx, vdf_ctx_mark(ctx, IPA_MARK)); w_marked = true; }
+    return VDF_OK;
+  };
+  auto finish = [&](int q) -> int {                                    // the round's points, challenge and fold of opening q
+    IpaJob& jb = jobs[q];
+    vdf_ctx* ctx = cq[q];
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    Aff l0, r0;
+    jac_to_aff2(h_lr[2 * q], h_lr[2 * q + 1], Fb, &l0, &r0);
+    const Aff Lp = pt_to_aff(pt_add(pt_from_aff(l0, Fb), jb.Qtab->mul(jb.cross[0], F), Fb), Fb);
+    const Aff Rp = pt_to_aff(pt_add(pt_from_aff(r0, Fb), jb.Qtab->mul(jb.cross[1], F), Fb), Fb);
+    const Aff lr[2] = {Lp, Rp};
+    tr.absorb_pt(jb.label, lr, 2, Fb);
+    const Fe x = tr.challenge(jb.label, F, raw);
+    const Fe xi = inverse(x, F);
+    vdf_fe* vecs[2] = {(vdf_fe*)jb.d_a, (vdf_fe*)jb.d_b};
+    const Fe c_lo[2] = {x, xi}, c_hi[2] = {xi, x};
+    HIPCALL(ctx, vdf_fold_halves(ctx, sd.field, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, jb.nj));
+    HIPCALL(ctx, vdf_scale_pattern(ctx, sd.field, (vdf_fe*)jb.d_s, jb.n, jb.nj, (const vdf_fe*)&xi, (const vdf_fe*)&x));
+    jb.out->L.push_back(Lp); jb.out->R.push_back(Rp);
+    jb.nj >>= 1;
+    return VDF_OK;
+  };
+  for (int q = 0; q < 2; ++q)
+    if (jobs[q].nj > IPA_STOP) { int rc = enqueue(q); if (rc != VDF_OK) return rc; }
+  for (;;) {
+    const bool active[2] = {jobs[0].nj > IPA_STOP, jobs[1].nj > IPA_STOP};       // in THIS round (the lockstep loop's `act`)
+    if (!active[0] && !active[1]) break;
+    w_marked = false;
+    for (int q = 0; q < 2; ++q) {
+      if (!active[q]) continue;
+      { int rc = finish(q); if (rc != VDF_OK) return rc; }
+      if (jobs[q].nj > IPA_STOP) { int rc = enqueue(q); if (rc != VDF_OK) return rc; }
+    }
+  }
+  for (int q = 0; q < 2; ++q) {
+    HIPCALL(cq[q], vdf_ctx_sync(cq[q]));
+    jobs[q].out->a.resize(jobs[q].nj);
+    HIPCALL(cq[q], vdf_dev_memcpy(cq[q], jobs[q].out->a.data(), jobs[q].d_a, jobs[q].nj * 32));
+  }
+  HIPCALL(cq[1], vdf_ctx_sync(cq[1]));
+  return VDF_OK;
+}
+
 // Several inner-product arguments in lockstep (the test oracle's ipa_prove_many): statements and values are absorbed job
 // by job; then every round ALL still-active jobs put their L and R into ONE batched MSM (up to four groups: one sort, one
 // accumulate grid, one bucket reduction) before any challenge of the round is drawn, and job by job absorb them, draw
@@ -214,6 +288,7 @@ int ipa_prove_many(const Side& sd, Transcript& tr, IpaJob* jobs, int njobs, vdf_
     jb.nj = jb.n;
     jb.out->L.clear(); jb.out->R.clear();
   }
+  if (njobs == 2 && sd.ctx_b) return ipa_prove_two_queues(sd, tr, jobs, h_lr);
   for (;;) {
     IpaJob* act[2];
     int na = 0;
@@ -646,6 +721,10 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
       const int dev = vdf_ctx_device(ctx);
       if (vdf_ctx_create(&dev, 1, &pp->aux_ctx) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: second context: ") + vdf_last_error(nullptr));
     }
+    if (!pp->aux_ctx2 && pp->tune.compress_queues) {
+      const int dev = vdf_ctx_device(ctx);
+      if (vdf_ctx_create(&dev, 1, &pp->aux_ctx2) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: third context: ") + vdf_last_error(nullptr));
+    }
     vdf_ctx* cb = pp->aux_ctx;
     HIPCALL(cb, vdf_ctx_set_async(cb, 1));
     HIPCALL(cb, vdf_ctx_wait(cb, ctx));                                // the folded secondary witness was made on the first queue
@@ -660,7 +739,9 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
       (void)vdf_ctx_sync(cb);
     });
     int rc = VDF_OK;
-    try { rc = spartan_prove(S1, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]); }
+    Side S1b = S1;
+    S1b.ctx_b = pp->tune.compress_queues ? pp->aux_ctx2 : nullptr;   // the primary side's second opening on a queue of its own
+    try { rc = spartan_prove(S1b, s->r_U1.comm_W, s->r_U1.comm_E, s->r_U1.u, s->r_U1.X, p->r[PRIMARY].d_z, p->r[PRIMARY].d_E, &s->sp[0]); }
     catch (...) { side2.join(); throw; }
     side2.join();
     if (rc != VDF_OK) return rc;

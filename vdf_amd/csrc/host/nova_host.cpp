@@ -485,7 +485,7 @@ bool tuning_valid(const vdf_nova_tuning& t) {
          (t.digit_window == -1 || t.digit_window == 0 || in(t.digit_window, 6, 12)) && in(t.early_rows, 0, 2) && in(t.stencil, 0, 1) &&
          in(t.small_window, 6, 16) && in(t.big_window, 12, 20) && in(t.packed_commit, 0, 1) && in(t.lookahead_early, 0, 1) &&
          in(t.gate_accumulate, 0, 1) && in(t.fold_on_rows, 0, 1) && in(t.nifs_ahead, 0, 1) && in(t.early_row_parts, 1, 3) &&
-         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1);
+         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1) && in(t.compress_queues, 0, 1);
 }
 const vdf_nova_tuning& default_tuning() {
   static const vdf_nova_tuning d = [] {
@@ -493,14 +493,14 @@ const vdf_nova_tuning& default_tuning() {
     t.struct_size = (uint32_t)sizeof(vdf_nova_tuning);
     t.flags = 0; t.digit_budget_bytes = (uint64_t)20 << 30; t.digit_window = 0; t.early_rows = 2; t.stencil = 1; t.small_window = 15;
     t.big_window = 16; t.packed_commit = 1; t.lookahead_early = 1; t.gate_accumulate = 1; t.fold_on_rows = 1; t.nifs_ahead = 1;
-    t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0;
+    t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0; t.compress_queues = 1;
     // the environment overrides of earlier rounds, read once: the only place the prover looks at the environment for tuning
     const struct { const char* name; int32_t* field; } vars[] = {
         {"VDF_NOVA_DIGIT_WINDOW", &t.digit_window}, {"VDF_NOVA_T_AHEAD", &t.early_rows}, {"VDF_NOVA_STENCIL", &t.stencil},
         {"VDF_NOVA_SMALL_WINDOW", &t.small_window}, {"VDF_NOVA_BIG_WINDOW", &t.big_window}, {"VDF_NOVA_PACKED_COMMIT", &t.packed_commit},
         {"VDF_NOVA_LOOKAHEAD_EARLY", &t.lookahead_early}, {"VDF_NOVA_GATE", &t.gate_accumulate}, {"VDF_NOVA_FOLD_ON_ROWS", &t.fold_on_rows},
         {"VDF_NOVA_NIFS_AHEAD", &t.nifs_ahead}, {"VDF_NOVA_T_PARTS", &t.early_row_parts}, {"VDF_NOVA_LOOKAHEAD_PRIO", &t.lookahead_priority},
-        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}};
+        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}, {"VDF_NOVA_COMPRESS_QUEUES", &t.compress_queues}};
     for (const auto& v : vars) {
       const char* e = env_override(v.name);
       if (!e || !*e) continue;
@@ -839,6 +839,7 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
 void vdf_nova_pp_free(vdf_pp* pp) {
   if (!pp) return;
   if (pp->aux_ctx) vdf_ctx_destroy(pp->aux_ctx);
+  if (pp->aux_ctx2) vdf_ctx_destroy(pp->aux_ctx2);
   if (pp->seg_gens) vdf_bases_free(pp->seg_gens);
   for (Side& sd : pp->s) {
     if (sd.d_zero) vdf_dev_free(pp->ctx, sd.d_zero);

@@ -59,6 +59,7 @@ struct Side {
   const Field* F = nullptr;                // scalars of this side's instances (= the circuit's field)
   const Field* Fb = nullptr;               // coordinates of this side's commitments
   vdf_ctx* ctx = nullptr;
+  vdf_ctx* ctx_b = nullptr;                // compress only (a copy of the side made for one call): a second queue for the E opening
   size_t num_cons = 0, num_vars = 0, ncols = 0, nnz3 = 0, num_gens = 0;
   vdf_shape* shape = nullptr;
   vdf_bases* gens = nullptr;
@@ -100,6 +101,7 @@ struct vdf_pp {
   const vdfnova::RoInstance* ro = nullptr;  // the random oracle's parameter block (covered by the digest); never null once the set is made
   vdf_ctx* aux_ctx = nullptr;              // a second queue of the same device for compress (the secondary side's argument runs beside the
                                            // primary's, as nova-snark's CompressedSNARK::prove does); created on first use
+  vdf_ctx* aux_ctx2 = nullptr;             // ... and a third for the primary side's second opening (compress_host.cpp ipa_prove_two_queues)
   std::mutex aux_mu;                       // ... one compression at a time uses it: concurrent vdf_nova_compress calls under ONE parameter
                                            // set take turns at the arguments (calls under different sets do not meet)
   vdf_nova_tuning tune;                    // the tuning this set was made with, and that its prover runs with
