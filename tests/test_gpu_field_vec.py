@@ -3,6 +3,7 @@ the C ABI, bit-exact against the golden vectors and the C restatement."""
 import numpy as np
 import pytest
 
+import vdf_amd
 from oracle import pasta as o
 from util import limbs, ints, mont, unmont, hexes, rand_limbs
 
@@ -348,7 +349,6 @@ def test_fold_many_equals_axpy_per_vector(ctx, cref, field):
 
 def test_ctx_wait_orders_two_contexts(ctx):
     """vdf_ctx_wait: work on the second context sees the results of the first without a host sync."""
-    import vdf_amd
     n = 1 << 16
     rng = np.random.default_rng(9)
     a, b = rand_limbs(rng, n), rand_limbs(rng, n)
@@ -380,8 +380,10 @@ def test_ctx_marks(ctx):
     was = ctx.get_async()
     ctx.set_async(True)
     try:
+        fresh = vdf_amd.Context(0)                    # (the session's context has had its marks set by earlier proofs)
         with pytest.raises(Exception):
-            ctx.sync_mark(3)                          # never set
+            fresh.sync_mark(3)                        # never set
+        fresh.close()
         for bad in (-1, 8):
             with pytest.raises(Exception):
                 ctx.mark(bad)
@@ -398,7 +400,6 @@ def test_ctx_marks(ctx):
         ctx.fe_mul(o.FIELD_FQ, a, b, n, exp1)
         assert np.array_equal(got1, exp1)
         # a second context waits for a mark of the first, not for the long work behind it
-        import vdf_amd
         other = vdf_amd.Context(0)
         other.set_async(True)
         ctx.set_async(True)
@@ -415,8 +416,8 @@ def test_ctx_marks(ctx):
         ctx.fe_mul(o.FIELD_FQ, exp1, b, n, exp4)
         assert np.array_equal(_host(d4), exp4)
         with pytest.raises(Exception):
-            other.wait_mark(ctx, 3)                    # never set
-        other.close() if hasattr(other, "close") else None
+            ctx.wait_mark(other, 3)                    # never set (on `other`: the session's context has had its marks set by earlier proofs)
+        other.close()
     finally:
         ctx.set_async(was)
 
@@ -559,7 +560,6 @@ def test_kernel_events_and_the_accumulate_gate(ctx, cref):
     """vdf_ctx_set_kernel_timing / vdf_ctx_kernel_events: every launch of a bucket-method MSM shows up once, in order, with the
     pipeline's algorithmic bytes on its accumulation kernel; vdf_ctx_gate_accumulate holds that kernel of the NEXT MSM of a
     context behind another context's mark (results unchanged), one-shot."""
-    import vdf_amd
     n = 1 << 14
     rng = np.random.default_rng(3)
     sc = rand_limbs(rng, n)
