@@ -801,8 +801,9 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
                        "per_kernel": crow, "per_kernel_pass_ms": round(timed_ms, 2), "device_ms_sum_of_launches": round(dev_ms, 2),
                        "msm_share_of_device_time": round(msm_ms / dev_ms, 3) if dev_ms else None,
                        "host_and_idle_ms": round(timed_ms - dev_ms, 2), "compress_first_call_ms": compress_first_ms,
-                       "per_kernel_covers": "the caller's queue: the fold of the last secondary instance and the PRIMARY side's argument; the "
-                                            "secondary side's argument runs beside it on a second queue (its launches are not in this table)",
+                       "per_kernel_covers": "the caller's queue: the fold of the last secondary instance, the PRIMARY side's sum-checks and its W "
+                                            "opening; the primary side's E opening runs half a round behind on a third queue and the secondary "
+                                            "side's argument on a second (their launches are not in this table)",
                        "argument_bytes": len(snark.to_bytes()),
                        "wire_bytes": len(snark.serialize()),
                        "what": "one Spartan-style argument with inner-product-argument openings per side of the cycle (vdf_nova.h)"}
