@@ -162,7 +162,8 @@ int  vdf_nova_public_params_ro(vdf_ctx* ctx, uint64_t num_iters_per_step, int ci
 int  vdf_nova_pp_setup_ms(const vdf_pp* pp, double ms[7]);
 /* bytes of HBM held per side: generators, their fixed-base table, the digit table (0 = none; *skipped bit s set when
  * side s wanted one and it did not fit).  The primary side's figures include the derived generators of the packed
- * commitment and their table. */
+ * commitment and their table.  (Not in these figures: after the first vdf_nova_compress / vdf_nova_verify_compressed a set also
+ * keeps that call's scratch vectors, 0.18 GB for the reference's circuit at t = 2^16, until it is freed.) */
 int  vdf_nova_pp_memory(const vdf_pp* pp, uint64_t gens_bytes[2], uint64_t table_bytes[2], uint64_t digit_bytes[2], uint32_t* skipped);
 void vdf_nova_pp_free(vdf_pp* pp);
 int  vdf_nova_pp_sizes(const vdf_pp* pp, int side, uint64_t* num_cons, uint64_t* num_vars, uint64_t* num_io, uint64_t* nnz3,

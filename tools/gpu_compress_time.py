@@ -41,3 +41,12 @@ if len(mid) >= 8:
     for name, nbytes, s0, s1 in ev[lo - 4:hi + 1]:
         print("  %8.3f %8.1f %8.1f  %s" % (s0 - t0, (s1 - s0) * 1e3, (s0 - prev) * 1e3, name))
         prev = s1
+# every gap of more than 40 us on the caller's queue (host turns, synchronisations, the other queues' work it waits for)
+print("gaps over 40 us on the caller's queue (at ms, gap us, after -> before):")
+tot = 0.0
+for (n0, _, _, e0), (n1, _, s1, _) in zip(ev, ev[1:]):
+    g = (s1 - e0) * 1e3
+    if g > 40:
+        tot += g
+        print("  %8.3f %8.1f  %s -> %s" % (e0 - t0, g, n0, n1))
+print("  total %.2f ms" % (tot / 1e3))

@@ -88,10 +88,26 @@ Layout layout_of(const Side& pp_) {
 // device buffers released on scope exit
 struct DevBufs {
   vdf_ctx* ctx;
+  Arena* arena;                    // the side's block (kept by the parameter set), or none: every vector its own allocation
+  size_t reserved = 0, used = 0;
   std::vector<void*> v;
-  explicit DevBufs(vdf_ctx* c) : ctx(c) {}
+  explicit DevBufs(vdf_ctx* c, Arena* a = nullptr) : ctx(c), arena(a) {}
   ~DevBufs() { for (void* p : v) vdf_dev_free(ctx, p); }
+  // all vectors of a call at once: one allocation the first time (or when a larger call comes), one memset every time
+  int reserve(size_t elems) {
+    if (!arena) return VDF_OK;
+    const size_t bytes = elems * 32;
+    if (arena->cap < bytes) {
+      if (arena->p) { vdf_ctx_sync(ctx); vdf_dev_free(ctx, arena->p); arena->p = nullptr; arena->cap = 0; }
+      int rc = vdf_dev_alloc(ctx, bytes, &arena->p);
+      if (rc != VDF_OK) return rc;
+      arena->cap = bytes;
+    }
+    reserved = bytes; used = 0;
+    return vdf_dev_memset(ctx, arena->p, 0, bytes);
+  }
   int zeros(size_t elems, void** out) {
+    if (arena && used + elems * 32 <= reserved) { *out = static_cast<char*>(arena->p) + used; used += elems * 32; return VDF_OK; }
     int rc = vdf_dev_alloc(ctx, elems * 32, out);
     if (rc != VDF_OK) return rc;
     v.push_back(*out);
@@ -187,8 +203,14 @@ struct IpaJob {
   Ipa* out;
   // state
   size_t nj = 0;
+  uint64_t q_raw[4];               // the 128-bit challenge Q = q_raw * gen_u comes from
   Pt Qp;
   std::unique_ptr<FixedBase> Qtab;
+  // Q and its table of 960 multiples (~0.15 ms of host work): wanted when the first round's points come back, not before
+  void make_q(const Aff& gen_u, const Field& Fb) {
+    Qp = pt_mul(pt_from_aff(gen_u, Fb), q_raw, 128, Fb);
+    Qtab.reset(new FixedBase(Qp, Fb));
+  }
   Fe* cross = nullptr;             // two elements in pinned, device-mapped memory: the reduction writes them in place and they are
                                    // read after the round's one synchronisation (behind the MSM), not after one of their own
 };
@@ -248,6 +270,7 @@ static int ipa_prove_two_queues(const Side& sd, Transcript& tr, IpaJob* jobs, vd
   };
   for (int q = 0; q < 2; ++q)
     if (jobs[q].nj > IPA_STOP) { int rc = enqueue(q); if (rc != VDF_OK) return rc; }
+  for (int q = 0; q < 2; ++q) jobs[q].make_q(pp->gen_u, Fb);             // under the first round's MSMs
   for (;;) {
     const bool active[2] = {jobs[0].nj > IPA_STOP, jobs[1].nj > IPA_STOP};       // in THIS round (the lockstep loop's `act`)
     if (!active[0] && !active[1]) break;
@@ -282,13 +305,12 @@ int ipa_prove_many(const Side& sd, Transcript& tr, IpaJob* jobs, int njobs, vdf_
     IpaJob& jb = jobs[q];
     tr.absorb_pt(jb.label, &jb.P, 1, Fb);
     tr.absorb_fe(jb.label, &jb.v, 1, F);
-    tr.challenge(jb.label, F, raw);
-    jb.Qp = pt_mul(pt_from_aff(pp->gen_u, Fb), raw, 128, Fb);
-    jb.Qtab.reset(new FixedBase(jb.Qp, Fb));
+    tr.challenge(jb.label, F, jb.q_raw);
     jb.nj = jb.n;
     jb.out->L.clear(); jb.out->R.clear();
   }
   if (njobs == 2 && sd.ctx_b) return ipa_prove_two_queues(sd, tr, jobs, h_lr);
+  for (int q = 0; q < njobs; ++q) jobs[q].make_q(pp->gen_u, Fb);
   for (;;) {
     IpaJob* act[2];
     int na = 0;
@@ -453,7 +475,8 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
   if (L.l1 > 24 || L.s > 24) return fail(VDF_ERR_BAD_LENGTH, "shape too large for the compression SNARK (2^24 entries)");
   if (L.NW > pp->num_gens) return fail(VDF_ERR_BAD_LENGTH, "not enough generators");
   const size_t nv = pp->num_vars, nc = pp->num_cons;
-  DevBufs bufs(ctx);
+  DevBufs bufs(ctx, sd.arena);
+  { int rc = bufs.reserve(5 * L.M + 2 * L.Z + 4 * L.NW + pp->ncols); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   void *d_eq, *d_az, *d_bz, *d_cz, *d_e, *d_cols, *d_mvec, *d_zpad, *d_w, *d_s, *d_sL, *d_sR;
   for (void** p : {&d_eq, &d_az, &d_bz, &d_cz, &d_e}) { int rc = bufs.zeros(L.M, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   for (void** p : {&d_mvec, &d_zpad}) { int rc = bufs.zeros(L.Z, p); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
@@ -585,7 +608,8 @@ int spartan_verify(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, co
     ry.push_back(r);
   }
   // M(r_y) on the device: eq(r_x, .) -> transposed product -> dot with eq(r_y, .)
-  DevBufs bufs(ctx);
+  DevBufs bufs(ctx, sd.arena);
+  { int rc = bufs.reserve(L.M + pp->ncols + 2 * L.Z + L.NW); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   void *d_eq_rx, *d_cols, *d_mvec, *d_eq_ry, *d_s;
   { int rc = bufs.zeros(L.M, &d_eq_rx); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }
   { int rc = bufs.zeros(pp->ncols, &d_cols); if (rc != VDF_OK) return fail(rc, vdf_last_error(ctx)); }

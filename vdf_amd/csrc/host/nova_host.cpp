@@ -733,6 +733,7 @@ static int public_params_impl(vdf_ctx* ctx, uint64_t t, int circuit_kind, const 
     sd.F = &field(sd.field);
     sd.Fb = &field(s == PRIMARY ? VDF_FIELD_FP : VDF_FIELD_FQ);
     sd.ctx = ctx;
+    sd.arena = &pp->arena[s];
     sd.num_cons = sh[s].num_cons; sd.num_vars = sh[s].num_vars;
     sd.ncols = sd.num_vars + 1 + NUM_IO;
     memcpy(sd.digest, pp->digest, 32);
@@ -840,6 +841,7 @@ void vdf_nova_pp_free(vdf_pp* pp) {
   if (!pp) return;
   if (pp->aux_ctx) vdf_ctx_destroy(pp->aux_ctx);
   if (pp->aux_ctx2) vdf_ctx_destroy(pp->aux_ctx2);
+  for (auto& a : pp->arena) if (a.p) vdf_dev_free(pp->ctx, a.p);
   if (pp->seg_gens) vdf_bases_free(pp->seg_gens);
   for (Side& sd : pp->s) {
     if (sd.d_zero) vdf_dev_free(pp->ctx, sd.d_zero);
