@@ -62,11 +62,13 @@ def parse():
                     help="also report the aggregate rate of this many independent chains proven concurrently (1 = skip)")
     ap.add_argument("--prove-steps", type=int, default=26, help="1 base case + 1 warm-up fold + timed steady-state folds")
     ap.add_argument("--prove-repeats", type=int, default=5, help="the steady state is timed this many times (a fresh proof each): 5 x 24 = 120 timed steps")
-    ap.add_argument("--digit-budget-gib", type=int, default=40,
-                    help="HBM the prove_step leg lets the digit tables of a parameter set take (vdf_nova_tuning.digit_budget_bytes): 40 GiB "
-                         "buys the 11-bit tables (35 GB at t = 2^16; 72 GiB would buy the 12-bit ones, 65 GB, for nothing more: r4 A/B) -- an "
-                         "opt-in of a host with 288 GB; the library's own default, 20 GiB (10-bit tables, 19 GB), is measured beside it as "
-                         "prove_step.library_default_budget")
+    ap.add_argument("--digit-budget-gib", type=int, default=20,
+                    help="HBM the prove_step leg lets the digit tables of a parameter set take (vdf_nova_tuning.digit_budget_bytes).  The "
+                         "default is the LIBRARY's default, 20 GiB (10-bit tables, 19 GB at t = 2^16): the headline is what a host gets "
+                         "without asking.  40 GiB buys the 11-bit tables (35 GB) for ~1 % (r4: 1,130-1,145 against 1,123 prove_step/s), 72 GiB "
+                         "the 12-bit ones (65 GB) for nothing more; with another value the library's default is measured beside it as "
+                         "prove_step.library_default_budget (a leg that follows the main one in the same process runs ~10 % below its own "
+                         "process's rate: DESIGN.md 4.3.4)")
     ap.add_argument("--no-bound-form", action="store_true", help="skip the bound-form sub-record of the prove_step leg")
     ap.add_argument("--no-reference-cases", action="store_true", help="skip the reference's own bench cases (benches/nova.rs:62-66)")
     return ap.parse_args()
@@ -542,7 +544,7 @@ def kernel_report(events, nsteps):
 
 
 def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compress=True, with_roofline=True, seed_offset=0,
-                   circuits_in=None, chain2=None, digit_budget_gib=40):
+                   circuits_in=None, chain2=None, digit_budget_gib=20):
     """BASELINE config 3: Nova prove_step for MinRoot at 2^16 iterations per step on one GPU -- a full IVC step on the
     Pallas / Vesta cycle (both augmented circuits, in-circuit NIFS verifier, see include/vdf_nova.h) over the step circuit
     `kind`.  Forward evaluation and public parameters are outside the timed region (benches/nova.rs:28-59); step 0 (base
@@ -1247,8 +1249,9 @@ def main():
                                                 chains=args.prove_chains, circuits_in=shared, chain2=chain2 if th2 else None,
                                                 digit_budget_gib=args.digit_budget_gib)
             line["prove_step"]["config"] = {"digit_budget_gib": args.digit_budget_gib,
-                                            "note": "digit tables opted in beyond the library's 20 GiB default (vdf_nova.h); "
-                                                    "library_default_budget is the same leg on the default"}
+                                            "note": ("the library's default budget (vdf_nova.h)" if args.digit_budget_gib == 20 else
+                                                     "digit tables opted in beyond the library's 20 GiB default (vdf_nova.h); "
+                                                     "library_default_budget is the same leg on the default")}
             if args.digit_budget_gib != 20:
                 dflt = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=3, chains=1, with_compress=False,
                                       with_roofline=False, circuits_in=shared, digit_budget_gib=20)
