@@ -231,6 +231,8 @@ static int ipa_prove_two_queues(const Side& sd, Transcript& tr, IpaJob* jobs, vd
   const Field& F = *sd.F;
   const Field& Fb = *sd.Fb;
   uint64_t raw[4];
+  // whatever way this function is left, nothing of it is still on either queue: the caller frees the pinned result slots
+  struct Drain { vdf_ctx* a; vdf_ctx* b; ~Drain() { (void)vdf_ctx_sync(a); (void)vdf_ctx_sync(b); } } drain{cq[0], cq[1]};
   HIPCALL(cq[1], vdf_ctx_set_async(cq[1], 1));
   HIPCALL(cq[1], vdf_ctx_wait(cq[1], cq[0]));                          // the E opening's vectors were made on the first queue
   bool w_marked = false;
@@ -286,7 +288,6 @@ static int ipa_prove_two_queues(const Side& sd, Transcript& tr, IpaJob* jobs, vd
     jobs[q].out->a.resize(jobs[q].nj);
     HIPCALL(cq[q], vdf_dev_memcpy(cq[q], jobs[q].out->a.data(), jobs[q].d_a, jobs[q].nj * 32));
   }
-  HIPCALL(cq[1], vdf_ctx_sync(cq[1]));
   return VDF_OK;
 }
 
