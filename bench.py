@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--prove-chains", type=int, default=2,
                     help="also report the aggregate rate of this many independent chains proven concurrently (1 = skip)")
     ap.add_argument("--prove-steps", type=int, default=26, help="1 base case + 1 warm-up fold + timed steady-state folds")
-    ap.add_argument("--prove-repeats", type=int, default=5, help="the steady state is timed this many times (a fresh proof each): 5 x 24 = 120 timed steps")
+    ap.add_argument("--prove-repeats", type=int, default=7, help="the steady state is timed this many times (a fresh proof each): 7 x 24 = 168 timed steps; the median repeat is reported (a host stall of a few ms -- other tenants of the node -- lands in one or two)")
     ap.add_argument("--digit-budget-gib", type=int, default=20,
                     help="HBM the prove_step leg lets the digit tables of a parameter set take (vdf_nova_tuning.digit_budget_bytes).  The "
                          "default is the LIBRARY's default, 20 GiB (10-bit tables, 19 GB at t = 2^16): the headline is what a host gets "
