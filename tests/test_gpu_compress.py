@@ -61,7 +61,8 @@ def test_two_queue_openings_change_no_byte(ctx):
     the two openings have different numbers of rounds (t = 1024: 2^13 / 2^12 entries)."""
     from vdf_amd.nova import public_params, GENS_TRY_AND_INCREMENT
     t, n = 1024, 2
-    pp, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
+    _, z0, circuits, initial, init_ints = make(ctx, t, n, seed=77)
+    pp = public_params(ctx, t, CIRCUIT_MINROOT_REFERENCE, GENS_TRY_AND_INCREMENT, compress_queues=1)   # (explicit: the environment may override the default)
     assert pp.tuning()["compress_queues"] == 1
     proof = NovaVDFProof.prove_recursively(pp, circuits, t, z0)
     a = proof.compress(pp)
