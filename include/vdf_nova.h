@@ -148,6 +148,8 @@ typedef struct vdf_nova_tuning {
   int32_t  verbose;              /* 1 = decisions (skipped tables, the window chosen) on stderr */
   int32_t  compress_queues;      /* 1: vdf_nova_compress runs the primary side's two openings on two queues half a round apart (one
                                     opening's sort and bucket reduction under the other's accumulation); 0: in lockstep on one (1) */
+  int32_t  rows_at_challenge;    /* 1: the primary fold and the next step's early rows are launched the moment the secondary circuit's
+                                    synthesis has derived the fold challenge (a call-back from inside it); 0: after the synthesis (1) */
 } vdf_nova_tuning;
 void vdf_nova_tuning_default(vdf_nova_tuning* out);
 /* public_params with the tuning given (NULL = the defaults); VDF_ERR_BAD_ARG for a field out of range */

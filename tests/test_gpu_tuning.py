@@ -42,7 +42,7 @@ def proof_bytes(pp, circuits, t, n, z0, zi):
 NOVA_VARIANTS = [dict(early_rows=0), dict(early_rows=1), dict(stencil=0), dict(digit_window=-1), dict(digit_window=8), dict(digit_window=12),
                  dict(packed_commit=0), dict(lookahead_early=0), dict(gate_accumulate=0), dict(fold_on_rows=0), dict(nifs_ahead=0),
                  dict(early_row_parts=2), dict(lookahead_priority=3), dict(side_accumulate_fill=2), dict(small_window=12, big_window=14),
-                 dict(digit_budget_bytes=1 << 20)]
+                 dict(digit_budget_bytes=1 << 20), dict(rows_at_challenge=0), dict(compress_queues=0)]
 
 
 @pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])

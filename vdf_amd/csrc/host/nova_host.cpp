@@ -485,7 +485,7 @@ bool tuning_valid(const vdf_nova_tuning& t) {
          (t.digit_window == -1 || t.digit_window == 0 || in(t.digit_window, 6, 12)) && in(t.early_rows, 0, 2) && in(t.stencil, 0, 1) &&
          in(t.small_window, 6, 16) && in(t.big_window, 12, 20) && in(t.packed_commit, 0, 1) && in(t.lookahead_early, 0, 1) &&
          in(t.gate_accumulate, 0, 1) && in(t.fold_on_rows, 0, 1) && in(t.nifs_ahead, 0, 1) && in(t.early_row_parts, 1, 3) &&
-         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1) && in(t.compress_queues, 0, 1);
+         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1) && in(t.compress_queues, 0, 1) && in(t.rows_at_challenge, 0, 1);
 }
 const vdf_nova_tuning& default_tuning() {
   static const vdf_nova_tuning d = [] {
@@ -493,14 +493,14 @@ const vdf_nova_tuning& default_tuning() {
     t.struct_size = (uint32_t)sizeof(vdf_nova_tuning);
     t.flags = 0; t.digit_budget_bytes = (uint64_t)20 << 30; t.digit_window = 0; t.early_rows = 2; t.stencil = 1; t.small_window = 15;
     t.big_window = 16; t.packed_commit = 1; t.lookahead_early = 1; t.gate_accumulate = 1; t.fold_on_rows = 1; t.nifs_ahead = 1;
-    t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0; t.compress_queues = 1;
+    t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0; t.compress_queues = 1; t.rows_at_challenge = 1;
     // the environment overrides of earlier rounds, read once: the only place the prover looks at the environment for tuning
     const struct { const char* name; int32_t* field; } vars[] = {
         {"VDF_NOVA_DIGIT_WINDOW", &t.digit_window}, {"VDF_NOVA_T_AHEAD", &t.early_rows}, {"VDF_NOVA_STENCIL", &t.stencil},
         {"VDF_NOVA_SMALL_WINDOW", &t.small_window}, {"VDF_NOVA_BIG_WINDOW", &t.big_window}, {"VDF_NOVA_PACKED_COMMIT", &t.packed_commit},
         {"VDF_NOVA_LOOKAHEAD_EARLY", &t.lookahead_early}, {"VDF_NOVA_GATE", &t.gate_accumulate}, {"VDF_NOVA_FOLD_ON_ROWS", &t.fold_on_rows},
         {"VDF_NOVA_NIFS_AHEAD", &t.nifs_ahead}, {"VDF_NOVA_T_PARTS", &t.early_row_parts}, {"VDF_NOVA_LOOKAHEAD_PRIO", &t.lookahead_priority},
-        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}, {"VDF_NOVA_COMPRESS_QUEUES", &t.compress_queues}};
+        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}, {"VDF_NOVA_COMPRESS_QUEUES", &t.compress_queues}, {"VDF_NOVA_ROWS_AT_CHALLENGE", &t.rows_at_challenge}};
     for (const auto& v : vars) {
       const char* e = env_override(v.name);
       if (!e || !*e) continue;
@@ -1395,48 +1395,76 @@ struct StepRun {
       in.T = comm_T1;
       CS cs(S2.field, false, pp->ro);
       Fe unew[9];
-      const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
-      early2.reset();
-      t5 = now_ms();
       const bool ahead_rows = pp->tune.nifs_ahead != 0;
       const bool rows_next = ahead_rows && !first && !custom && pp->ahead_rows != 0 && pp->ahead_mode != 1 && !p->ahead.empty();
-      if (rows_next && p->ahead[0].slot != zin_slot) {
-        // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
-        memcpy(p->h_zin + arity, p->zi[PRIMARY].data(), arity * 32);   // (this thread has waited for the primary side's launches: the slot's last copy is over)
-        HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
-        HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
-      }
-      // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
-      // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
-      // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
-      // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
-      vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
-      if (!first) {
-        SideState& s1 = p->r[PRIMARY];
-        const Fe rr = int_to_fe(r1, F1);
-        vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
-        const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
-                                 (const vdf_fe*)s1.d_abc2[2]};
-        const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
-        if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
-        HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
-      }
+      // The fold of the primary side and, behind it, the early rows of the NEXT step's cross term need nothing of this circuit
+      // but its fold challenge r1 -- and from the fold to their commitment those rows are a step's longest dependent path
+      // (fold, rows, sort, bucket accumulation, bucket reduction: ~0.7 ms; the chain waits for MARK_T half a step later).  The
+      // synthesis derives r1 a few tens of microseconds into its late half and calls back (AugInputs::on_challenge): fold and
+      // rows go out from THERE, under the rest of the synthesis (~0.1 ms of host work the device used to idle through on that
+      // path), instead of after it.  `fold_and_rows(.., false)` after the synthesis is the same launches for the cases without
+      // a call-back (base step, sequential synthesis, tuning.rows_at_challenge = 0).
+      Fe u_folded = p->r[PRIMARY].inst.u;
+      bool folded = false, rows_launched = false;
+      auto fold_and_rows = [&](const uint64_t rch[4], bool launch_rows_now) -> int {
+        folded = true;
+        if (rows_next && p->ahead[0].slot != zin_slot) {
+          // (not the slot the primary phase wrote z_in to: cannot happen with a lookahead of one step; copied again if it does)
+          memcpy(p->h_zin + arity, p->zi[PRIMARY].data(), arity * 32);   // (this thread has waited for the primary side's launches: the slot's last copy is over)
+          HIPCALL(ctx, vdf_dev_memcpy(ctx, (char*)p->d_z2s[p->ahead[0].slot] + (seg_b - arity) * 32, p->h_zin + arity, arity * 32));
+          HIPCALL(ctx, vdf_ctx_mark(ctx, MARK_ZIN));
+        }
+        // The fold of the primary side goes to the queue of the early rows when they follow (they are what waits for it: the
+        // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
+        // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
+        // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
+        vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
+        if (!first) {
+          SideState& s1 = p->r[PRIMARY];
+          const Fe rr = int_to_fe(rch, F1);
+          vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
+          const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
+                                   (const vdf_fe*)s1.d_abc2[2]};
+          const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
+          if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
+          HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+          u_folded = add(p->r[PRIMARY].inst.u, rr, F1);                   // u' = u + r: what the next step's rows are crossed with
+        }
+        // The early rows of the NEXT step's cross term: its rounds are in their ring slot (the lookahead), its input z_in is
+        // this step's output (uploaded above, in front of the fold), the running instance is final once the fold is done: they
+        // wait for MARK_FOLD, not for the uploads and the NIFS that follow.
+        if (rows_next) {
+          void* d_next = p->d_z2s[p->ahead[0].slot];
+          vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
+          HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
+          fold_elsewhere = fq != ctx;
+          if (launch_rows_now) {
+            if (fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, fq, MARK_FOLD));
+            p->r[PRIMARY].inst.u = u_folded;                             // (the launch reads it; the circuit's own value follows below)
+            int rc = early_rows_launch(d_next, cq_next, true);
+            if (rc != VDF_OK) return rc;                                 // tahead_valid stays false: a retried step launches its rows itself
+            p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
+            rows_launched = true;
+          } else {
+            deferred.pending = true; deferred.d_next = d_next; deferred.cq_next = cq_next; deferred.fq = fq;
+            deferred.slot = p->ahead[0].slot;                            // (tahead_* are set once the rows are really on their queue)
+          }
+        }
+        return VDF_OK;
+      };
+      int hook_rc = VDF_OK;
+      if (!first && rows_next && pp->tune.rows_at_challenge)
+        in.on_challenge = [&](const uint64_t rch[4]) { hook_rc = fold_and_rows(rch, true); };
+      const std::vector<Fe> z_next = synthesize_augmented(cs, SECONDARY, in, c2, unew, r1, early2.get());
+      in.on_challenge = nullptr;
+      early2.reset();
+      t5 = now_ms();
+      if (hook_rc != VDF_OK) return hook_rc;
+      if (!folded) { int rc = fold_and_rows(r1, false); if (rc != VDF_OK) return rc; }
       p->r[PRIMARY].inst = inst_from_elements(unew, F2, F1);           // base step: the first primary instance, relaxed
       // (the folded instance is in place: the launches below read its u)
-      // The early rows of the NEXT step's cross term, as soon as this fold is on its queue: from the fold to their commitment
-      // they are a step's longest dependent path (rows, sort, bucket accumulation, bucket reduction: ~0.7 ms).  Its rounds are
-      // in their ring slot (the lookahead), its input z_in is this step's output (uploaded above, in front of the fold), the running
-      // instance is final once the fold is done: they wait for MARK_FOLD, not for the uploads and the NIFS that follow.  Their
-      // dozen launches are issued after the NIFS's (below); a helper thread issuing them at once was measured and bought
-      // nothing (0.882-0.888 ms per step either way).
-      if (rows_next) {
-        void* d_next = p->d_z2s[p->ahead[0].slot];
-        vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
-        HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
-        fold_elsewhere = fq != ctx;
-        deferred.pending = true; deferred.d_next = d_next; deferred.cq_next = cq_next; deferred.fq = fq;
-        deferred.slot = p->ahead[0].slot;                              // (tahead_* are set once the rows are really on their queue)
-      }
+      if (rows_launched && memcmp(&p->r[PRIMARY].inst.u, &u_folded, sizeof(Fe)) != 0)
+        return fail(VDF_ERR_DEVICE, "prove_step: the circuit's folded u differs from the one the early rows were launched with");
       int rc = upload_fresh(ctx, S2, cs, p->h_stage[SECONDARY], p->d_l2z);
       if (rc != VDF_OK) return rc;
       p->l2.X[0] = cs.X[0]; p->l2.X[1] = cs.X[1];

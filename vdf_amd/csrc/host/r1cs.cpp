@@ -1281,6 +1281,7 @@ static std::vector<Fe> synthesize_augmented_blocks(CS& cs, int side, const AugIn
     r_ready.store(true, std::memory_order_release);
     take(b2, t);
   }
+  if (in.on_challenge) in.on_challenge(rv);          // (the helpers' folds run meanwhile; this thread has the slack: it joins them below)
   tr[1] = us();
   // ---- block 5, second half (this thread, while the folds run): X' = X + r x in the other field
   Fe f_lo[2], f_hi[2], x_lo[2], x_hi[2];

@@ -199,6 +199,10 @@ struct AugInputs {
   uint64_t u_X[2][4];                    // canonical integers (250-bit hashes)
   Aff T;
   const RoInstance* ro = nullptr;        // the random oracle's parameter block (null: the default)
+  // witness mode, the block-wise synthesis only: called on the calling thread the moment the fold challenge r is derived
+  // (a few tens of microseconds into the late half, long before the witness is assembled) -- a prover launches what needs
+  // nothing but r from here.  Not called by the sequential synthesis or in shape mode: a caller checks whether it ran.
+  std::function<void(const uint64_t r[4])> on_challenge;
 };
 void relaxed_elements(const RelaxedInst& U, const Field& F, Fe out[9]);       // what a running instance is hashed as
 Fe hash_state(int field_id, const Fe& params, const Fe& i, const std::vector<Fe>& z0, const std::vector<Fe>& zi,
