@@ -411,6 +411,8 @@ typedef struct vdf_hip_tuning {
   int32_t shim_cache;          /* generator arrays the mult_pippenger shims keep resident, 0..64 (0; vdf_shim_set_cache) */
   int32_t nifs_fused;          /* 1: rows of more than 8 entries are summed inside the cross term's launch (k_nifs_cross_f) when it
                                   runs eight lanes per row; 0: by a launch of their own before it (1) */
+  int32_t fold_u128;           /* 1: vdf_fold_many with a scalar below 2^128 (every NIFS fold challenge) multiplies by its plain value
+                                  without a Montgomery reduction (fe_mul_u128); 0: the general multiplication (1) */
 } vdf_hip_tuning;
 int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
 int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */

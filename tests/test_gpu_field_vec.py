@@ -347,6 +347,42 @@ def test_fold_many_equals_axpy_per_vector(ctx, cref, field):
         ctx.fold_many(field, r, dacc * 2, dadd * 2, sizes * 2)      # more than 8 vectors
 
 
+@pytest.mark.parametrize("field", [o.FIELD_FP, o.FIELD_FQ])
+def test_fold_many_with_challenges_below_2_128(ctx, cref, field):
+    """A fold challenge is a 128-bit integer (CHAL_BITS): vdf_fold_many then multiplies by its PLAIN value without a Montgomery
+    reduction (fe_mul_u128: y r = Ph 2^254 + Pl = Pl - c Ph mod m).  Edge scalars (0, 1, 2^128 - 1, 2^127, the first value that
+    takes the general path again: 2^128) and edge elements (0, 1, m - 1, 2^254, c, values whose product lands on Ph = 2^128),
+    against the C restatement; and the same inputs with the fast path switched off."""
+    from vdf_amd import hip as _hip
+    m = o.modulus(field)
+    rng = np.random.default_rng(128 + field)
+    n = 4099
+    edge = [0, 1, m - 1, m - 2, 1 << 254, (1 << 254) - 1, m - (1 << 254), (m - 1) // 2, 3, (1 << 128) - 1]
+    vals = edge + [int(rng.integers(0, 1 << 62)) * int(rng.integers(0, 1 << 62)) * int(rng.integers(1, 1 << 62)) *
+                   int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 8)) % m for _ in range(n - len(edge))]
+    add = mont(vals, m)
+    add[:len(edge)] = limbs(edge)                  # the edge patterns as STORED limbs too (the kernel multiplies those)
+    add[len(edge):2 * len(edge)] = mont(edge, m)
+    acc0 = rand_limbs(rng, n)
+    acc0[:3] = limbs([0, m - 1, 1])
+    scalars = [0, 1, (1 << 128) - 1, 1 << 127, (1 << 128) - 0x1234567, 1 << 128, int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)),
+               int(rng.integers(1, 1 << 62)) << 66 | 5]
+    was = _hip.tuning_get().fold_u128
+    try:
+        for fast in (1, 0):
+            _hip.tuning_set(fold_u128=fast)
+            for rint in scalars:
+                r = mont([rint % m], m)
+                e = np.zeros_like(acc0)
+                cref.lib().ref_axpy(field, cref.p(acc0), cref.p(r), cref.p(add), n, cref.p(e))
+                d = _dev(acc0.copy())
+                ctx.fold_many(field, r, [d], [_dev(add)], [n])
+                ctx.sync()
+                assert np.array_equal(_host(d), e), (fast, hex(rint))
+    finally:
+        _hip.tuning_set(fold_u128=was)
+
+
 def test_ctx_wait_orders_two_contexts(ctx):
     """vdf_ctx_wait: work on the second context sees the results of the first without a host sync."""
     n = 1 << 16

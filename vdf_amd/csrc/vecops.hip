@@ -505,6 +505,55 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
   fe_store<P>(T + r * 32, tt);
 }
 
+// y * r for a scalar r below 2^128 given as a PLAIN integer (four limbs), y and the result in Montgomery form: the fold
+// challenges of NIFS are 128-bit (CHAL_BITS), so  y R * r  is a 383-bit integer whose residue is the Montgomery form of y r
+// -- no Montgomery reduction at all.  With m = 2^254 + c (c = the low four limbs of the modulus, below 2^126):
+//   P = y r = Ph 2^254 + Pl,  Pl < 2^254,  Ph <= 2^128   (y < m, r < 2^128),   P = Pl - c Ph  (mod m),   c Ph < 2^254 < m:
+// both terms are canonical, one fe_sub finishes.  32 + 16 limb products instead of the 96 of a Montgomery multiplication.
+template <class P>
+__device__ __forceinline__ Fe<P> fe_mul_u128(const Fe<P>& y, const uint32_t r[4]) {
+  uint32_t p[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) p[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t t = (uint64_t)y.v[j] * r[i] + p[i + j] + carry;        // <= 2^64 - 1: no overflow
+      p[i + j] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+    p[i + 8] = carry;
+  }
+  uint32_t ph[5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ph[k] = (p[7 + k] >> 30) | (p[8 + k] << 2);
+  ph[4] = p[11] >> 30;                                                       // 0 or 1 (Ph <= 2^128)
+  Fe<P> lo;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) lo.v[i] = p[i];
+  lo.v[7] = p[7] & 0x3FFFFFFFu;
+  uint32_t d[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                              // c = MOD[0..3]
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint64_t t = (uint64_t)ph[j] * P::MOD[i] + d[i + j] + carry;
+      d[i + j] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+    d[i + 5] = carry;
+  }
+  Fe<P> hi;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hi.v[i] = d[i];                               // (d[8] = 0: c Ph < 2^254)
+  return fe_sub(lo, hi);
+}
+
 // acc_k <- acc_k + r * add_k for up to 8 vectors in one launch (the witness fold W, E and the running Az, Bz, Cz)
 struct FoldArgs { char* acc[8]; const char* add[8]; uint32_t blk_end[8]; uint64_t n[8]; int k; };
 template <class P>
@@ -519,6 +568,20 @@ __global__ __launch_bounds__(256) void k_fold_many(FoldArgs a, FeVal rv) {
   const Fe<P> x = fe_load<P>(a.acc[seg] + i * 32);
   const Fe<P> y = fe_load<P>(a.add[seg] + i * 32);
   fe_store<P>(a.acc[seg] + i * 32, fe_add(x, fe_mul(r, y)));
+}
+// the same with r below 2^128, as a plain integer in rv.v[0..3] (every fold challenge: fe_mul_u128)
+template <class P>
+__global__ __launch_bounds__(256) void k_fold_many_u128(FoldArgs a, FeVal rv) {
+  __builtin_amdgcn_s_setprio(3);
+  int seg = 0;
+  while (seg < a.k - 1 && blockIdx.x >= a.blk_end[seg]) ++seg;
+  const uint32_t blk0 = seg ? a.blk_end[seg - 1] : 0u;
+  const size_t i = (size_t)(blockIdx.x - blk0) * 256 + threadIdx.x;
+  if (i >= a.n[seg]) return;
+  const uint32_t r[4] = {rv.v[0], rv.v[1], rv.v[2], rv.v[3]};
+  const Fe<P> x = fe_load<P>(a.acc[seg] + i * 32);
+  const Fe<P> y = fe_load<P>(a.add[seg] + i * 32);
+  fe_store<P>(a.acc[seg] + i * 32, fe_add(x, fe_mul_u128<P>(y, r)));
 }
 
 template <class P>
@@ -726,6 +789,19 @@ Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const
   double elems = 0;
   for (int i = 0; i < k; ++i) elems += (double)n[i];
   KTimer kt(s, "k_fold_many", 96.0 * elems);
+  // a challenge below 2^128 (every NIFS fold): its plain value travels instead, and the product needs no Montgomery reduction
+  if (tuning().fold_u128) {
+    FeVal plain{};
+    bool small = false;
+    if (field == VDF_FIELD_FP) { Fe<FpParams> t; memcpy(t.v, r, 32); t = fe_from_mont(t); memcpy(plain.v, t.v, 32); }
+    else if (field == VDF_FIELD_FQ) { Fe<FqParams> t; memcpy(t.v, r, 32); t = fe_from_mont(t); memcpy(plain.v, t.v, 32); }
+    else return Status{VDF_ERR_BAD_ARG, "unknown field"};
+    small = (plain.v[4] | plain.v[5] | plain.v[6] | plain.v[7]) == 0;
+    if (small) {
+      FIELD_DISPATCH(field, k_fold_many_u128, dim3((unsigned)blocks), dim3(256), 0, s, a, plain);
+      return Status{};
+    }
+  }
   FIELD_DISPATCH(field, k_fold_many, dim3((unsigned)blocks), dim3(256), 0, s, a, to_val(r));
   return Status{};
 }
