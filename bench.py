@@ -35,6 +35,127 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+MAX_LINE_BYTES = 6144        # the driver keeps the last 8 KB of stdout; the line stays well inside that
+
+
+def _r(x, nd=4):
+    """Round a float to `nd` significant-enough decimals for the line (None and non-floats pass through)."""
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def flat_summary(line, failures=()):
+    """The two halves of BASELINE's metric and what qualifies them as flat scalars: the LAST key of the line."""
+    ps = line.get("prove_step") or {}
+    rl = line.get("roofline") or {}
+    s = {"msm_gpoints_per_s": _r(line.get("value")), "msm_ms_per_step": _r(line.get("ms_per_step")),
+         "msm_single_gpoints_per_s": _r((line.get("single_msm") or {}).get("value")), "msm_roofline_frac": _r(rl.get("frac"), 5),
+         "msm_valu_issue_frac": _r((rl.get("valu") or {}).get("valu_issue_frac"))}
+    for k_, v_ in (line.get("msm_sizes") or {}).items():
+        if isinstance(v_, dict):
+            s["msm_" + k_ + "_gpoints_per_s"] = _r(v_.get("GPoints_per_s"))
+    if ps:
+        s.update({"prove_step_per_s": _r(ps.get("value"), 2), "prove_step_ms_median": _r(ps.get("ms_per_step")),
+                  "prove_roofline_frac": _r((ps.get("roofline") or {}).get("frac"), 5),
+                  "prove_step_bound_form_per_s": _r((ps.get("bound_form") or {}).get("value"), 2),
+                  "prove_step_two_chains_per_s": _r((ps.get("aggregate_over_concurrent_chains") or {}).get("value"), 2),
+                  "compress_ms": _r((ps.get("compress") or {}).get("compress_ms"), 2),
+                  "cpu_prove_step_per_s": _r((ps.get("cpu_baseline") or {}).get("value")),
+                  "public_params_s": _r(ps.get("public_params_s"), 3),
+                  "digit_table_GB": round(sum((ps.get("hbm") or {}).get("digit_table_bytes", [0])) / 1e9, 1)})
+    rep = line.get("prove_step_replicas")
+    if rep:                                       # N > 1: one independent chain per GPU; the whole-job rate is their sum
+        s.update({"prove_step_per_s": _r(rep["value"], 2), "prove_step_per_gpu_min": _r(rep["per_gpu_min"], 2),
+                  "prove_step_per_gpu_max": _r(rep["per_gpu_max"], 2), "prove_step_what": "sum over one chain per GPU (replicas)"})
+    for k_, v_ in line.items():
+        if k_.startswith("strong_2_") and isinstance(v_, dict):
+            s["msm_sharded_" + k_[7:] + "_gpoints_per_s"] = _r(v_.get("value"))
+    s["cpu_msm_gpoints_per_s"] = _r((line.get("cpu_baseline") or {}).get("value"), 6)
+    s["parity"] = "bit-exact vs oracle/ in this run: %s; unpinned vs nova-snark" % (not failures)
+    return s
+
+
+def contract_line(full):
+    """The ONE stdout line: the contract's keys, `roofline` and `cpu_baseline` as numbers (no prose), a prove_step of under
+    1 KB, msm_sizes as four numbers, `summary` last.  Everything else lives in bench_detail.json.  Pure function of the full
+    record so that tests/test_bench_contract.py can hold its size and key set without a GPU."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: _r(full.get(k), 6) for k in keep}
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:240]}
+    for k in ("points_per_gpu", "window_bits", "bucket_sets", "steps_in_flight"):
+        if k in cfg:
+            out["config"][k] = cfg[k]
+    if full.get("invalid"):
+        out["invalid"] = [str(x)[:120] for x in full["invalid"]][:6]
+    rl = full.get("roofline") or {}
+    out["roofline"] = {"bound": rl.get("bound"), "achieved": _r(rl.get("achieved"), 3), "peak": rl.get("peak"), "unit": rl.get("unit"),
+                       "frac": _r(rl.get("frac"), 6), "traffic": rl.get("traffic"), "kernel": rl.get("kernel"),
+                       "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"),
+                       "avg_launch_ms": _r(rl.get("avg_launch_ms"), 5),
+                       "valu_issue_frac": _r((rl.get("valu") or {}).get("valu_issue_frac"))}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb.get("value"), 7), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": str(cb.get("sample", ""))[:160], "parity_bit_exact": cb.get("parity_bit_exact")}
+    if full.get("self_check"):
+        out["self_check"] = {"ok": full["self_check"].get("ok"), "points": full["self_check"].get("points")}
+    ps = full.get("prove_step")
+    if ps:
+        pr = ps.get("roofline") or {}
+        pc = ps.get("cpu_baseline") or {}
+        p = {"metric": ps.get("metric"), "value": _r(ps.get("value"), 2), "unit": ps.get("unit"), "ms_per_step": _r(ps.get("ms_per_step")),
+             "ms_by_repeat": (ps.get("ms_per_step_by_repeat") or {}).get("in_order"), "timed_steps": ps.get("timed_steps"),
+             "circuit": "reference (src/nova/proof.rs:155-230)" if str(ps.get("circuit", "")).startswith("reference") else "bound",
+             "verified": ps.get("verified"),
+             "roofline": {"bound": pr.get("bound"), "achieved": _r(pr.get("achieved"), 2), "peak": pr.get("peak"), "unit": pr.get("unit"),
+                          "frac": _r(pr.get("frac"), 5), "algorithmic_bytes_per_step": pr.get("algorithmic_bytes_per_step"),
+                          "device_busy_frac": _r(pr.get("device_busy_frac"))},
+             "cpu_baseline": {"value": _r(pc.get("value")), "unit": pc.get("unit"), "cores": pc.get("cores"), "kind": pc.get("kind"),
+                              "parity_bit_exact": pc.get("parity_bit_exact")},
+             "parity": pc.get("parity"),
+             "two_chains_per_s": _r((ps.get("aggregate_over_concurrent_chains") or {}).get("value"), 2),
+             "bound_form_per_s": _r((ps.get("bound_form") or {}).get("value"), 2),
+             "compress_ms": _r((ps.get("compress") or {}).get("compress_ms"), 2),
+             "compress_verified": (ps.get("compress") or {}).get("verified"),
+             "cpu_config1_per_s": _r((ps.get("cpu_baseline_config1") or {}).get("value"))}
+        out["prove_step"] = {k: v for k, v in p.items() if v is not None}
+    ms = full.get("msm_sizes")
+    if ms:
+        out["msm_sizes"] = {k: _r(v.get("GPoints_per_s")) for k, v in ms.items() if isinstance(v, dict)}
+        out["msm_sizes"]["exact"] = all(v.get("exact", False) for v in ms.values() if isinstance(v, dict))
+    for k, v in full.items():
+        if k.startswith("strong_2_") and isinstance(v, dict):
+            out[k] = {kk: _r(v.get(kk)) for kk in ("value", "unit", "n_gpus", "scaling", "total_points", "points_per_gpu", "ms_per_msm",
+                                                   "steps", "exact", "path")}
+    rep = full.get("prove_step_replicas")
+    if rep:
+        out["prove_step_replicas"] = {kk: _r(rep.get(kk), 2) for kk in ("value", "unit", "n_gpus", "per_gpu_min", "per_gpu_max", "verified",
+                                                                        "scaling")}
+    out["detail"] = "bench_detail.json (beside bench.py) and stderr"
+    out["summary"] = full.get("summary") or flat_summary(full, full.get("invalid") or ())
+
+    def clamp(o, depth=0):
+        """No prose and no tables on the line, whatever the legs put in their records: strings to 200 characters, lists to 12
+        items, dictionaries to 24 keys, nothing deeper than three levels."""
+        if isinstance(o, str):
+            return o[:200]
+        if isinstance(o, dict):
+            return {str(k)[:48]: clamp(v, depth + 1) for k, v in list(o.items())[:24]} if depth < 3 else None
+        if isinstance(o, (list, tuple)):
+            return [clamp(v, depth + 1) for v in list(o)[:12]] if depth < 3 else None
+        return o
+    out = clamp(out)
+    # the size is a contract too: shed the optional sub-records, least important first, rather than ever exceed it
+    for drop in ("msm_sizes", "prove_step_replicas", "self_check", "detail"):
+        if len(json.dumps(out, separators=(",", ":"))) <= MAX_LINE_BYTES:
+            break
+        out.pop(drop, None)
+    if len(json.dumps(out, separators=(",", ":"))) > MAX_LINE_BYTES:
+        out["summary"] = {k: v for k, v in out["summary"].items() if k in ("msm_gpoints_per_s", "prove_step_per_s", "msm_roofline_frac")}
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1175,11 +1296,12 @@ def main():
             "metric": "MSM GPoints/s at 2^20 (Pallas, Pedersen-commitment MSM of Nova prove_step); prove_step/s in `prove_step`",
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (255-bit Montgomery, v_mad_u64_u32)", "data": "synthetic",
-            "config": {"workload": f"Pippenger MSM, 2^{args.log2n} Pallas points per GPU ({'seeded try-and-increment' if args.bases == 'tai' else '[k_i]G'} "
-                                   f"generators, seed 7), uniform 254-bit scalars (torch Philox, seed 1234+rank) resident in HBM, "
-                                   f"fixed-base table c={window} sets={args.sets}; {depth} independent steps in flight on {depth} streams; "
-                                   f"N>1: point-chunk shards + all-gather of 96-B partials",
+            "dtype": "u32", "dtype_note": "255-bit Montgomery residues in 8 x 32-bit limbs, v_mad_u64_u32; exact integer arithmetic",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: Pippenger MSM, 2^{args.log2n} Pallas points per GPU, uniform 254-bit scalars resident in HBM, "
+                                   f"fixed-base table c={window}, {depth} MSMs in flight; N>1: point-chunk shards + all-gather of 96-B partials",
+                       "workload_detail": f"{'seeded try-and-increment' if args.bases == 'tai' else '[k_i]G'} generators (seed 7), scalars from torch Philox "
+                                          f"(seed 1234+rank), bucket sets {args.sets}, {depth} independent steps in flight on {depth} streams",
                        "points_per_gpu": n, "window_bits": window, "bucket_sets": args.sets, "steps_in_flight": depth},
             # the two ways to run the same MSM, side by side: `value` is the pipelined throughput
             "single_msm": {"latency_ms": iso["pipeline"] if iso else total_ms / max(calls, 1),
@@ -1303,40 +1425,22 @@ def main():
         if failures:
             line["value"] = None
             line["invalid"] = failures
-        # The two halves of BASELINE's metric, and what qualifies them, once more as flat scalars and as the LAST key of the
-        # line (a reader that keeps the tail of stdout, or only top-level keys, still sees the prove_step half)
-        ps = line.get("prove_step") or {}
-        summary = {"msm_gpoints_per_s": line["value"], "msm_ms_per_step_median_region": ms_per_step,
-                   "msm_single_gpoints_per_s": line["single_msm"]["value"], "msm_roofline_frac": line["roofline"]["frac"],
-                   "msm_valu_issue_frac": (valu or {}).get("valu_issue_frac")}
-        for k_, v_ in (line.get("msm_sizes") or {}).items():
-            if isinstance(v_, dict):
-                summary["msm_" + k_ + "_gpoints_per_s"] = round(v_["GPoints_per_s"], 4)
-        if ps:
-            summary.update({
-                "prove_step_per_s": ps["value"], "prove_step_ms_median": ps["ms_per_step"],
-                "prove_step_ms_by_repeat": ps["ms_per_step_by_repeat"]["in_order"], "circuit": "reference (src/nova/proof.rs:155-230)",
-                "prove_roofline_frac": (ps.get("roofline") or {}).get("frac"),
-                "prove_step_bound_form_per_s": (ps.get("bound_form") or {}).get("value"),
-                "prove_step_two_chains_per_s": (ps.get("aggregate_over_concurrent_chains") or {}).get("value"),
-                "compress_ms": (ps.get("compress") or {}).get("compress_ms"),
-                "cpu_prove_step_per_s": (ps.get("cpu_baseline") or {}).get("value"),
-                "public_params_s": ps.get("public_params_s"),
-                "prove_step_library_default_budget_per_s": (ps.get("library_default_budget") or {}).get("value"),
-                "digit_table_GB": round(sum((ps.get("hbm") or {}).get("digit_table_bytes", [0])) / 1e9, 1),
-                "shader_mhz": [b_.get("shader_mhz") for b_ in ps.get("box", [])]})
-            line["prove_step_per_s"] = ps["value"]
-            line["prove_step_ms_median"] = ps["ms_per_step"]
-        if replicas is not None:                  # N > 1: one independent chain per GPU; the whole-job rate is their sum
-            summary.update({"prove_step_per_s": replicas["value"], "prove_step_per_gpu_min": replicas["per_gpu_min"],
-                            "prove_step_per_gpu_max": replicas["per_gpu_max"], "prove_step_what": "sum over one chain per GPU (replicas)"})
-            line["prove_step_per_s"] = replicas["value"]
-        if strong is not None:
-            summary["msm_sharded_2_%d_gpoints_per_s" % args.strong_log2n] = strong["value"]
-        summary["cpu_msm_gpoints_per_s"] = (line.get("cpu_baseline") or {}).get("value")
-        summary["parity"] = "unpinned against nova-snark (no reference-held vector exists); bit-exact against oracle/ in this run: %s" % (not failures)
-        line["summary"] = summary
-        json_out.write(json.dumps(line) + "\n")
+        line["summary"] = flat_summary(line, failures)
+        if "prove_step" in line:
+            line["prove_step_per_s"] = line["summary"].get("prove_step_per_s")
+            line["prove_step_ms_median"] = line["summary"].get("prove_step_ms_median")
+        # The WHOLE record (per-kernel tables, the compress table, tunings, box fingerprints, notes) goes to bench_detail.json
+        # beside this script and to stderr; stdout carries ONE line of at most MAX_LINE_BYTES built from it (the
+        # driver keeps the last 8 KB of stdout, and a 24 KB line left its record unparsed)
+        detail = json.dumps(line)
+        try:
+            with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+                f.write(detail + "\n")
+        except OSError as ex:
+            print("bench.py: bench_detail.json not written: %s" % ex, file=sys.stderr)
+        print("bench_detail " + detail, file=sys.stderr)
+        sys.stderr.flush()
+        json_out.write(json.dumps(contract_line(line), separators=(",", ":")) + "\n")
         json_out.flush()
         if failures:
             raise SystemExit("bench.py: " + "; ".join(failures))

@@ -8,7 +8,11 @@
  *
  * The flow of the reference's own test (/root/reference/src/nova/proof.rs:403-451).
  * Build:  cc -O2 examples/prove_chain.c -Iinclude -Lvdf_amd -lvdf_nova -lvdf_hip -Wl,-rpath,'$ORIGIN/../vdf_amd' -o examples/prove_chain
- * Run:    examples/prove_chain [log2 iterations per step = 10] [steps = 3]
+ * Run:    examples/prove_chain [log2 iterations per step = 10] [steps = 3] [x0 = 123 | 64 hex digits] [i0 = 0] [file]
+ *         x0: a small integer, or a field element as the 32 bytes of a vdf_fe in hex (Montgomery form, as the ABI passes it);
+ *         file: where the compressed proof's wire bytes go.  It prints the parameters' digest and an FNV-1a-64 of those bytes,
+ *         so a caller can compare the run with another client's (tests/test_gpu_c_client.py does, against vdf_amd.nova and
+ *         against the committed vector tests/golden/vectors.json "wire_ivc_t2_reference").
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,6 +37,9 @@ int main(int argc, char** argv) {
   const size_t steps = argc > 2 ? (size_t)atoi(argv[2]) : 3;
   if (log2t < 1 || log2t > 20 || steps < 1 || steps > 1000) { fprintf(stderr, "usage: prove_chain [log2 t] [steps]\n"); return 2; }
   const uint64_t t = 1ull << log2t;
+  const char* x0_arg = argc > 3 ? argv[3] : "123";
+  const uint64_t i0 = argc > 4 ? strtoull(argv[4], NULL, 10) : 0;
+  const char* wire_path = argc > 5 ? argv[5] : NULL;
 
   int device = 0;
   vdf_ctx* ctx = NULL;
@@ -40,14 +47,29 @@ int main(int argc, char** argv) {
 
   /* initial state x = 123, y = 0, i = 0 (benches/nova.rs:24-26), as Montgomery field elements */
   vdf_state initial;
-  CHECK(vdf_minroot_element(VDF_FIELD_FQ, 123, &initial.x), "element");
+  if (strlen(x0_arg) == 64) {
+    uint8_t raw[32];
+    for (int k = 0; k < 32; ++k) {
+      unsigned byte = 0;
+      if (sscanf(x0_arg + 2 * k, "%2x", &byte) != 1) { fprintf(stderr, "x0: not hex\n"); return 2; }
+      raw[k] = (uint8_t)byte;
+    }
+    memcpy(&initial.x, raw, 32);
+  } else {
+    CHECK(vdf_minroot_element(VDF_FIELD_FQ, strtoull(x0_arg, NULL, 10), &initial.x), "element");
+  }
   CHECK(vdf_minroot_element(VDF_FIELD_FQ, 0, &initial.y), "element");
-  CHECK(vdf_minroot_element(VDF_FIELD_FQ, 0, &initial.i), "element");
+  CHECK(vdf_minroot_element(VDF_FIELD_FQ, i0, &initial.i), "element");
 
   double a = now_ms();
   vdf_pp* pp = NULL;
   CHECK(vdf_nova_public_params(ctx, t, &pp), "public_params");
   printf("public_params(2^%d): %.0f ms\n", log2t, now_ms() - a);
+  uint8_t digest[32];
+  CHECK(vdf_nova_pp_digest(pp, digest), "pp_digest");
+  printf("digest: ");
+  for (int k = 31; k >= 0; --k) printf("%02x", digest[k]);       /* (little-endian bytes, printed as the number) */
+  printf("\n");
 
   a = now_ms();
   vdf_fe z0[3];
@@ -86,6 +108,14 @@ int main(int argc, char** argv) {
   CHECK(vdf_nova_verify_compressed(received, pp, steps, z0, zi, &ok), "verify_compressed (decoded)");
   printf("compressed proof on the wire: %zu bytes; decoded and verified: %s\n", wire_len, ok ? "true" : "FALSE");
   all_ok = all_ok && ok;
+  uint64_t fnv = 0xcbf29ce484222325ull;
+  for (size_t k = 0; k < wire_len; ++k) { fnv ^= wire[k]; fnv *= 0x100000001b3ull; }
+  printf("wire fnv1a64: %016llx\n", (unsigned long long)fnv);
+  if (wire_path) {
+    FILE* f = fopen(wire_path, "wb");
+    if (!f || fwrite(wire, 1, wire_len, f) != wire_len) { fprintf(stderr, "cannot write %s\n", wire_path); return 1; }
+    fclose(f);
+  }
   free(wire);
   vdf_nova_snark_free(received);
 

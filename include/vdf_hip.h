@@ -321,10 +321,12 @@ int  vdf_fold_many(vdf_ctx* ctx, int field, const vdf_fe* r, int k, vdf_fe* cons
 /* Stream order across contexts of one device: work enqueued on `ctx` after this call starts only after
  * everything enqueued on `other` so far has finished (an event; the host does not wait). */
 int  vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other);
-/* Marks: vdf_ctx_mark remembers the current end of the context's queue under `slot` (0..3 for the caller; 4..7 are
- * used by libvdf_nova.so on the contexts it is given); vdf_ctx_sync_mark
+/* Marks: vdf_ctx_mark remembers the current end of the context's queue under `slot` (0 .. VDF_MARK_SLOTS-1: 0..3 are the
+ * caller's on ANY context; 4..15 are used by libvdf_nova.so on the contexts it is given -- prove_step 4..7, compress 8 --
+ * and never 0..3 there); vdf_ctx_sync_mark
  * blocks the host until everything enqueued before that mark has finished, while later work keeps running.  A
  * prover that looks one step ahead waits for this step's commitment without waiting for the next step's. */
+#define VDF_MARK_SLOTS 16
 int  vdf_ctx_mark(vdf_ctx* ctx, int slot);
 int  vdf_ctx_sync_mark(vdf_ctx* ctx, int slot);
 /* ... and vdf_ctx_wait_mark makes work enqueued on `ctx` from now on start only after `other`'s mark `slot` has been

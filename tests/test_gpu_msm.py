@@ -1,5 +1,6 @@
 """GPU parity: Pippenger MSM through the C ABI against the golden vectors, the C restatement
 and (at full BASELINE sizes) the discrete-log identity of the synthetic generators."""
+import os
 import numpy as np
 import pytest
 
@@ -278,6 +279,13 @@ def test_pippenger_shim_generator_cache(cref):
 
     assert lib.vdf_shim_set_cache(65) != 0 and lib.vdf_shim_set_cache(-1) != 0
     assert lib.vdf_shim_set_cache(2) == 0
+    # ONE knob: the call is reflected by vdf_hip_tuning_get, and vdf_hip_tuning_set(shim_cache = ...) is in force
+    # on the next shim call -- nothing is latched at first use
+    from vdf_amd.hip import tuning_get, tuning_set
+    assert tuning_get().shim_cache == 2
+    tuning_set(shim_cache=3)
+    assert tuning_get().shim_cache == 3
+    assert lib.vdf_shim_set_cache(2) == 0 and tuning_get().shim_cache == 2
     try:
         times = []
         for call in range(4):                      # upload, cached + table build, cached table, cached table
@@ -804,3 +812,17 @@ def test_digit_table_msm_at_witness_size_dlog_identity(ctx):
     for vec, res in ((w, got[0]), (t, got[1])):
         assert jac_to_affine(res, curve) == o.msm_by_dlog_limbs(vec, curve, 0x4E6F7661)
     bases.free()
+
+
+def test_lazy_addition_chains_stay_inside_their_bound():
+    """ec.cuh xyzz_madd_lazy (the bucket loops' sign-tracked mixed addition): fe_mul2_lazy / fe_neg_lazy against the canonical
+    operations, short chains step by step, and 10,240-long chains per lane -- with cancellations to the identity every 997
+    additions and further additions behind them -- in which every stored coordinate must stay below 2m + 2^130 (the proven
+    bound is 2m + 9 eps, eps ~ 2^125) and the resolved sum must equal the canonical one.  tools/ubench/madd_check.hip, run as
+    a child process (built by vdf_amd/csrc/Makefile)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "madd_check")
+    assert os.path.exists(exe), "make -C vdf_amd/csrc"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "coordinates above 2m + 2^130: 0, mismatches 0" in r.stdout, r.stdout

@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdf_hip.so")
+# VDF_HIP_LIB=/path/to/other.so loads ANOTHER build of the same ABI (A/B runs of kernels: tools/ab_*.sh) without touching the
+# shipped binary; libvdf_nova.so then binds to it too (same SONAME, loaded first with RTLD_GLOBAL).  Unset = the product.
+LIB_PATH = os.environ.get("VDF_HIP_LIB") or os.path.join(_HERE, "libvdf_hip.so")
+IS_OVERRIDE = bool(os.environ.get("VDF_HIP_LIB"))
 
 VDF_OK, VDF_ERR_BAD_ARG, VDF_ERR_BAD_LENGTH, VDF_ERR_NONCANONICAL, VDF_ERR_DEVICE, VDF_ERR_OOM, VDF_ERR_NO_DEVICE = range(7)
 CURVE_PALLAS, CURVE_VESTA = 0, 1
@@ -114,6 +117,9 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). vdf_amd has no CPU fallback.")
+    if IS_OVERRIDE:
+        import sys
+        print("vdf_amd: VDF_HIP_LIB override in force: loading %s (not the shipped library)" % LIB_PATH, file=sys.stderr)
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted from the header

@@ -338,7 +338,6 @@ vdf_ctx* default_ctx() {
 struct ShimEntry { int curve; const void* ptr; size_t n; uint64_t fp; vdf_bases* bases; uint64_t last_use; bool table; };
 std::mutex g_shim_mu;
 std::vector<ShimEntry> g_shim;
-int g_shim_cap = -1;                 // -1: not decided yet (environment), 0: off
 uint64_t g_shim_clock = 0;
 
 // Content hash of the WHOLE array (every coordinate word), so a generator rewritten in place anywhere is a different
@@ -372,10 +371,9 @@ uint64_t shim_fingerprint(const vdf_affine* points, size_t n) {
 }
 
 int shim_cache_capacity() {          // caller holds g_shim_mu
-  if (g_shim_cap < 0) {
-    g_shim_cap = vdf::tuning().shim_cache;
-  }
-  return g_shim_cap;
+  // ONE knob: vdf_hip_tuning.shim_cache, read on every call (vdf_hip_tuning_set takes effect on the next call, as the header
+  // says: nothing is latched); vdf_shim_set_cache publishes a tuning snapshot with the new value, so tuning_get reports it
+  return (int)vdf::tuning().shim_cache;
 }
 
 void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf_fe* scalars, bool is_mont) {
@@ -995,8 +993,14 @@ int vdf_msm_timing(vdf_ctx* ctx, float ms[4], int* calls) {
 
 int vdf_shim_set_cache(int entries) {
   if (entries < 0 || entries > 64) return VDF_ERR_BAD_ARG;
+  {
+    (void)vdf::tuning();                               // (environment overrides applied before the first publication)
+    std::lock_guard<std::mutex> tl(g_tune_mu);
+    vdf_hip_tuning t = vdf::tuning();
+    t.shim_cache = entries;
+    tuning_publish(t);
+  }
   std::lock_guard<std::mutex> lock(g_shim_mu);
-  g_shim_cap = entries;
   while ((int)g_shim.size() > entries) { vdf_bases_free(g_shim.back().bases); g_shim.pop_back(); }
   return VDF_OK;
 }
@@ -1382,7 +1386,7 @@ int vdf_ctx_wait(vdf_ctx* ctx, vdf_ctx* other) {
 
 int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
+    if (slot < 0 || slot >= VDF_MARK_SLOTS) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..15"};
     if (!ctx->marks[slot]) VDF_TRY_HIP(hipEventCreateWithFlags(&ctx->marks[slot], hipEventDisableTiming));
     VDF_TRY_HIP(hipEventRecord(ctx->marks[slot], ctx->stream));
     return Status{};
@@ -1392,7 +1396,7 @@ int vdf_ctx_mark(vdf_ctx* ctx, int slot) {
 int vdf_ctx_wait_mark(vdf_ctx* ctx, vdf_ctx* other, int slot) {
   if (!other) return VDF_ERR_BAD_ARG;
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
+    if (slot < 0 || slot >= VDF_MARK_SLOTS) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..15"};
     if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
     if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     if (other == ctx) return Status{};
@@ -1420,7 +1424,7 @@ int vdf_ctx_set_light_priority(vdf_ctx* ctx, int priority) {
 int vdf_ctx_gate_accumulate(vdf_ctx* ctx, vdf_ctx* other, int slot) {
   if (!other) return VDF_ERR_BAD_ARG;
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
+    if (slot < 0 || slot >= VDF_MARK_SLOTS) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..15"};
     if (other->device != ctx->device) return Status{VDF_ERR_BAD_ARG, "contexts live on different devices"};
     if (!other->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     ctx->acc_gate = other == ctx ? nullptr : other->marks[slot];
@@ -1430,7 +1434,7 @@ int vdf_ctx_gate_accumulate(vdf_ctx* ctx, vdf_ctx* other, int slot) {
 
 int vdf_ctx_sync_mark(vdf_ctx* ctx, int slot) {
   return guarded(ctx, [&]() -> Status {
-    if (slot < 0 || slot >= 8) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..7"};
+    if (slot < 0 || slot >= VDF_MARK_SLOTS) return Status{VDF_ERR_BAD_ARG, "mark slot must be 0..15"};
     if (!ctx->marks[slot]) return Status{VDF_ERR_BAD_ARG, "no mark was set in this slot"};
     for (int spin = 0; spin < 4000; ++spin) {                    // poll first, as vdf_ctx_sync does
       hipError_t q = hipEventQuery(ctx->marks[slot]);

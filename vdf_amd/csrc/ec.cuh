@@ -94,9 +94,17 @@ template <class P, bool INL = false> VDF_HD void xyzz_madd(XYZZ<P>& acc, const A
 // Mixed addition in the lazy domain (fe.cuh) for the bucket loops of msm.hip and msm_direct.hip, with the SIGN of the
 // accumulator tracked beside it: the point a lane holds is  sigma * (x/zz, y/zzz),  sigma = -1 when `flip` is set.
 // madd-2008-s needs P = U2 - X1, R = S2 - Y1 and Y3 = R (Q - X3) - Y1 PPP: a difference of two products.  With the
-// operands of both subtractions swapped (P' = -P, R' = -R: free) PPP' = P' PP = -PPP and
-//     X3 = R'^2 + PPP' - 2Q          Y3 = R' (X3 - Q) + Y1 PPP'
+// operands of the FIRST subtraction swapped (P' = X1 - U2 = -P: free) PPP' = P' PP = -PPP and
+//     X3 = R^2 + PPP' - 2Q          Y3 = R (Q - X3) + Y1 PPP'
 // is a SUM of two products -- one column scan, one Montgomery reduction (fe_mul2_lazy) -- while ZZZ1 PPP' = -ZZZ3.
+// Slack (how far above 2m a lazy coordinate may sit, fe.cuh): a difference inherits its MINUEND's slack, a product gives
+// eps + half the sum of its factors' slacks, the product pair 2 eps + half the sum of all four.  R = S2 - Y1 has the
+// minuend S2 = y_b * ZZZ1 with y_b canonical: below 2m, slack 0, whatever Y1 is -- so X3 (minuend R^2) has slack eps,
+// Q - X3 (minuend Q = X1 PP) 1.5 eps + d_x <= 2.5 eps, PPP' 1.5 eps + d_x, and
+//     d_y' <= 2 eps + (0 + 2.5 eps)/2 + (d_y + 2.5 eps)/2 = 4.5 eps + d_y / 2      d_zz' <= 2 eps + d_zz / 2      d_zzz' <= 2.25 eps + d_zzz / 2
+// CONTRACT: every coordinate stays below 2m + 9 eps for a chain of any length (tools/ubench/madd_check.hip runs 10^4-long
+// chains with cancellations and checks the bound at every step).  (With R' = Y1 - S2, as this function first had it, the
+// minuend was Y1 and d_y' <= 3.25 eps + 1.5 d_y + 0.5 d_x: safe only with overwhelming probability, not by construction.)
 // (X3, Y3, ZZ3, -ZZZ3) is the negated sum: instead of negating a coordinate (8+ instructions per addition) the sign
 // moves into `flip`, the NEXT point is negated before it is added (the loops negate by the digit's sign anyway:
 // sigma (A + sigma b) = sigma A + b), and a pending sign is applied once when the accumulator is flushed.
@@ -130,19 +138,19 @@ __device__ __forceinline__ void xyzz_madd_lazy(XYZZ<P>& acc, bool& have, bool& f
 #endif
   const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
   const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
-  const Fe<P> Pn = fe_sub_lazy(acc.x, U2);
-  const Fe<P> Rn = fe_sub_lazy(acc.y, S2);
+  const Fe<P> Pn = fe_sub_lazy(acc.x, U2);         // P' = -P
+  const Fe<P> Rr = fe_sub_lazy(S2, acc.y);         // R itself: the minuend is a product with a canonical factor, below 2m (no slack)
   // P == 0 (mod m) means P in {0, m, 2m}; m == 1 (mod 2^32), so the low limb is 0, 1 or 2: cheap filter
   if (Pn.v[0] <= 2u && fe_is_zero(fe_canon(Pn))) {
-    if (fe_is_zero(fe_canon(Rn))) acc = xyzz_dbl_affine(b);          // same point: double (canonical output), sign unchanged
+    if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);          // same point: double (canonical output), sign unchanged
     else have = false;                                                // opposite points: identity
     return;
   }
   const Fe<P> PP = fe_mul_lazy(Pn, Pn);
   const Fe<P> PPPn = fe_mul_lazy(Pn, PP);
   const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
-  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rn, Rn), Qq), fe_sub_lazy(Qq, PPPn));
-  acc.y = fe_mul2_lazy(Rn, fe_sub_lazy(X3, Qq), acc.y, PPPn);
+  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), Qq), fe_sub_lazy(Qq, PPPn));
+  acc.y = fe_mul2_lazy(Rr, fe_sub_lazy(Qq, X3), acc.y, PPPn);
   acc.x = X3;
   acc.zz = fe_mul_lazy(acc.zz, PP);
   acc.zzz = fe_mul_lazy(acc.zzz, PPPn);

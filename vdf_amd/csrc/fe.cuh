@@ -367,7 +367,9 @@ template <class P> __device__ __forceinline__ Fe<P> fe_sub_lazy(const Fe<P>& a, 
 // column scan ends below 3m + 2eps + 2d < 2^256 (the ninth word is zero).  Back into the lazy domain with the top bit:
 // bit 255 clear -> below 2^255 = 2m - 2c, nothing to do; set -> at least 2^255 > m, subtract m: the result is at least
 // 2^255 - m = m - 2c > 0 and below 2m + 2eps + 2d.  (14 instructions; a compare-and-subtract of 2m would underflow for
-// values in [2^255, 2m).)  In the mixed addition d grows by a few eps per addition, as with the single product.
+// values in [2^255, 2m).)  Exactly: out < 2m + 2 eps + (d_a + d_b + d_c + d_d) / 2 -- each factor's slack is halved, because the
+// OTHER factor is below 2m + d and 2m / 2^256 = 1/2 (+ 2^-130).  The pair alone does not contract (four halves); the mixed
+// addition feeds it one slack-free factor and two bounded ones, which does (ec.cuh xyzz_madd_lazy: d_y' <= 4.5 eps + d_y / 2).
 template <class P> __device__ __forceinline__ Fe<P> fe_mul2_lazy(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
   constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
   const uint32_t* A = a.v;
@@ -398,6 +400,8 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul2_lazy(const Fe<P>& a,
 // -a in the lazy domain: 3m - a, exact for every a below 3m (fe_sub_lazy(0, a) would wrap for a in (2m, 2m + eps));
 // the result lies in (m - eps, 3m], so it goes ONLY where the consumer canonicalises: a bucket accumulator flushed with
 // its sign pending (ec.cuh xyzz_lazy_resolve; the tail kernels load through fe_canon, two conditional subtractions).
+// Precondition a != 0 (mod m) -- a = 0 would give 3m, which fe_canon's two subtractions leave at m, not 0 -- holds for the
+// one caller: the y of a point of a curve of odd prime order is never 0 (y = 0 is a point of order 2).
 template <class P> __device__ __forceinline__ Fe<P> fe_neg_lazy(const Fe<P>& a) {
   constexpr uint64_t D1 = 3ull * P::MOD[1], D2 = 3ull * P::MOD[2] + (D1 >> 32), D3 = 3ull * P::MOD[3] + (D2 >> 32);
   constexpr uint32_t T1 = (uint32_t)D1, T2 = (uint32_t)D2, T3 = (uint32_t)D3, T4 = (uint32_t)(D3 >> 32), T7 = 0xC0000000u;   // limb 0 = 3, limbs 5, 6 = 0

@@ -224,7 +224,7 @@ struct IpaJob {
 // challenge, then E's -- because only LAUNCHES move: W's next round is enqueued as soon as W's challenge is drawn, before
 // E's points of this round are read.  The bytes of the proof do not change (tests/test_gpu_compress.py compares them with
 // the oracle's lockstep prover).
-constexpr int IPA_MARK = 3;                  // (a mark slot prove_step does not use: nova_host.cpp StepMark)
+constexpr int IPA_MARK = 8;                  // (a library slot, vdf_hip.h: 0..3 on the caller's context are the caller's; prove_step holds 4..7)
 static int ipa_prove_two_queues(const Side& sd, Transcript& tr, IpaJob* jobs, vdf_jac* h_lr) {
   const Side* pp = &sd;
   vdf_ctx* cq[2] = {sd.ctx, sd.ctx_b};

@@ -66,7 +66,7 @@ struct vdf_ctx {
   std::vector<TimedCall> timed;      // events of calls not yet queried
   std::vector<hipEvent_t> ev_pool;   // recycled events
   hipEvent_t wait_ev = nullptr;      // vdf_ctx_wait
-  hipEvent_t marks[8] = {};                                       // vdf_ctx_mark (0..3 the caller's, 4..7 libvdf_nova.so's)
+  hipEvent_t marks[VDF_MARK_SLOTS] = {};                          // vdf_ctx_mark (0..3 the caller's, 4..15 libvdf_nova.so's)
   // MSM jobs (vdf_msm_job_*): one side stream and two events per vector, created on first use
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t side_go[4] = {nullptr, nullptr, nullptr, nullptr}, side_done[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -1222,6 +1222,7 @@ Status msm_run(int curve, const MsmPlan& plan, const void* d_points, const void*
                void* d_out, hipStream_t stream, hipEvent_t* ev, void* ext_bucket_acc, hipEvent_t acc_gate, int prio) {
   // Pallas: coordinates in Fp, scalars in Fq.  Vesta: coordinates in Fq, scalars in Fp.
   char* ext = reinterpret_cast<char*>(ext_bucket_acc);
+  prio = std::min(prio, (int)tuning().light_priority);     // the process-wide ceiling holds on EVERY path that gets here (jobs too)
   if (curve == VDF_CURVE_PALLAS)
     return msm_run_t<FpParams, FqParams>(plan, d_points, d_scalars, is_mont, ws, d_out, stream, ev, ext, acc_gate, prio);
   if (curve == VDF_CURVE_VESTA)
@@ -1242,6 +1243,7 @@ size_t msm_tail_ws_bytes(int groups, int sets, uint32_t nbk) {
 }
 Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail_ws, void* d_out, hipStream_t stream, int prio) {
   const size_t gsets = (size_t)groups * sets;
+  prio = std::min(prio, (int)tuning().light_priority);
   char* bucket_acc = reinterpret_cast<char*>(tail_ws);
   char* partials = bucket_acc + align_up(gsets * nbk * 128, 256);
   char* wsum = partials + tail_scratch_bytes(gsets, nbk);
@@ -1252,8 +1254,8 @@ Status msm_tail(int curve, int c, int sets, int groups, uint32_t nbk, void* tail
 
 // sum of n Jacobian points: one wavefront = 16 quads striding over the inputs, butterfly reduce
 template <class P>
-__global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, uint32_t n, char* __restrict__ out) {
-  raise_wave_priority();
+__global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, uint32_t n, char* __restrict__ out, int wave_prio) {
+  raise_wave_priority(wave_prio);
   const uint32_t quad = threadIdx.x >> 2;
   QPoint<P> acc = qpoint_identity<P>();
   for (uint32_t i = quad; i < n; i += 16) {
@@ -1273,12 +1275,13 @@ __global__ __launch_bounds__(64) void k_point_sum(const char* __restrict__ pts, 
 }
 
 Status point_sum(int curve, const void* d_jac, size_t n, void* d_out, hipStream_t stream) {
+  const int prio = std::min(3, (int)tuning().light_priority);
   if (curve == VDF_CURVE_PALLAS)
     hipLaunchKernelGGL((k_point_sum<FpParams>), dim3(1), dim3(64), 0, stream, reinterpret_cast<const char*>(d_jac),
-                       (uint32_t)n, reinterpret_cast<char*>(d_out));
+                       (uint32_t)n, reinterpret_cast<char*>(d_out), prio);
   else if (curve == VDF_CURVE_VESTA)
     hipLaunchKernelGGL((k_point_sum<FqParams>), dim3(1), dim3(64), 0, stream, reinterpret_cast<const char*>(d_jac),
-                       (uint32_t)n, reinterpret_cast<char*>(d_out));
+                       (uint32_t)n, reinterpret_cast<char*>(d_out), prio);
   else
     return Status{VDF_ERR_BAD_ARG, "unknown curve"};
   VDF_TRY_HIP(hipGetLastError());
