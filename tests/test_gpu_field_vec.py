@@ -420,7 +420,7 @@ def test_ctx_marks(ctx):
         with pytest.raises(Exception):
             fresh.sync_mark(3)                        # never set
         fresh.close()
-        for bad in (-1, 8):
+        for bad in (-1, 16):
             with pytest.raises(Exception):
                 ctx.mark(bad)
         da, db = _dev(a), _dev(b)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round 5, first GPU call: the GPU suite, the driver's bench command (line + detail kept), the lazy-addition A/B.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r5
+mkdir -p $OUT
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.txt
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_stderr.txt; echo "bench rc=$?"
+cp bench_detail.json $OUT/bench_detail.json 2>/dev/null
+wc -c $OUT/bench_line.json; cat $OUT/bench_line.json
+bash tools/ab_madd.sh 2 > $OUT/ab_madd_r4_vs_r5.txt 2>&1; cat $OUT/ab_madd_r4_vs_r5.txt

@@ -139,7 +139,11 @@ __device__ __forceinline__ void xyzz_madd_lazy(XYZZ<P>& acc, bool& have, bool& f
   const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
   const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
   const Fe<P> Pn = fe_sub_lazy(acc.x, U2);         // P' = -P
+#ifdef VDF_MADD_R4     // A/B build only: round 4's operand order (R' = Y1 - S2; same instruction count, no slack contraction)
+  const Fe<P> Rr = fe_sub_lazy(acc.y, S2);
+#else
   const Fe<P> Rr = fe_sub_lazy(S2, acc.y);         // R itself: the minuend is a product with a canonical factor, below 2m (no slack)
+#endif
   // P == 0 (mod m) means P in {0, m, 2m}; m == 1 (mod 2^32), so the low limb is 0, 1 or 2: cheap filter
   if (Pn.v[0] <= 2u && fe_is_zero(fe_canon(Pn))) {
     if (fe_is_zero(fe_canon(Rr))) acc = xyzz_dbl_affine(b);          // same point: double (canonical output), sign unchanged
@@ -150,7 +154,11 @@ __device__ __forceinline__ void xyzz_madd_lazy(XYZZ<P>& acc, bool& have, bool& f
   const Fe<P> PPPn = fe_mul_lazy(Pn, PP);
   const Fe<P> Qq = fe_mul_lazy(acc.x, PP);
   const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), Qq), fe_sub_lazy(Qq, PPPn));
+#ifdef VDF_MADD_R4
+  acc.y = fe_mul2_lazy(Rr, fe_sub_lazy(X3, Qq), acc.y, PPPn);
+#else
   acc.y = fe_mul2_lazy(Rr, fe_sub_lazy(Qq, X3), acc.y, PPPn);
+#endif
   acc.x = X3;
   acc.zz = fe_mul_lazy(acc.zz, PP);
   acc.zzz = fe_mul_lazy(acc.zzz, PPPn);
