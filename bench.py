@@ -53,6 +53,8 @@ def flat_summary(line, failures=()):
     for k_, v_ in (line.get("msm_sizes") or {}).items():
         if isinstance(v_, dict):
             s["msm_" + k_ + "_gpoints_per_s"] = _r(v_.get("GPoints_per_s"))
+            if v_.get("two_in_flight_GPoints_per_s"):
+                s["msm_" + k_ + "_two_in_flight_gpoints_per_s"] = _r(v_["two_in_flight_GPoints_per_s"])
     if ps:
         s.update({"prove_step_per_s": _r(ps.get("value"), 2), "prove_step_ms_median": _r(ps.get("ms_per_step")),
                   "prove_roofline_frac": _r((ps.get("roofline") or {}).get("frac"), 5),
@@ -123,6 +125,8 @@ def contract_line(full):
     ms = full.get("msm_sizes")
     if ms:
         out["msm_sizes"] = {k: _r(v.get("GPoints_per_s")) for k, v in ms.items() if isinstance(v, dict)}
+        out["msm_sizes"].update({k + "_two_in_flight": _r(v["two_in_flight_GPoints_per_s"]) for k, v in ms.items()
+                                 if isinstance(v, dict) and v.get("two_in_flight_GPoints_per_s")})
         out["msm_sizes"]["exact"] = all(v.get("exact", False) for v in ms.values() if isinstance(v, dict))
     for k, v in full.items():
         if k.startswith("strong_2_") and isinstance(v, dict):
@@ -290,6 +294,7 @@ def msm_sizes_leg(ctx, curve, sizes=(20, 22, 24), reps=5):
     import vdf_amd
     bm, sm = (_P, _Q) if curve == vdf_amd.CURVE_PALLAS else (_Q, _P)
     out = {}
+    ctx2 = vdf_amd.Context(ctx.device)
 
     def timed(bases, sc, n, res):
         ctx.set_async(True)
@@ -341,7 +346,23 @@ def msm_sizes_leg(ctx, curve, sizes=(20, 22, 24), reps=5):
             want = _scalar_mul_generator(_sum_s_k(sc.cpu().numpy().view("<u8"), _dlogs(11, 0, n)) % sm, bm)
         ok = _jac_to_affine_ints(res.cpu().numpy().view("<u8").tobytes(), bm) == want
         acc = st["accumulate"]
-        rec = {"ms": median(per), "ms_by_rep": [round(x, 4) for x in per], "ms_back_to_back": b2b,
+        # two MSMs in flight on two contexts over the one table (what `value` measures at 2^20), for the sizes north_star names
+        two = None
+        if lg >= 22:
+            ctx2.set_async(True); ctx.set_async(True)
+            res2 = torch.zeros(12, dtype=torch.int64, device="cuda")
+            for _ in range(2):
+                ctx.msm(bases, sc, n=n, out=res); ctx2.msm(bases, sc, n=n, out=res2)
+            ctx.sync(); ctx2.sync()
+            a2 = time.perf_counter()
+            for _ in range(reps):
+                ctx.msm(bases, sc, n=n, out=res); ctx2.msm(bases, sc, n=n, out=res2)
+            ctx.sync(); ctx2.sync()
+            two = 2 * reps * n / (time.perf_counter() - a2) / 1e9
+            # (the two results are the same POINT; their Jacobian representatives differ with the order the sort's atomics took)
+            ok = ok and _jac_to_affine_ints(res2.cpu().numpy().view("<u8").tobytes(), bm) == want
+            ctx2.set_async(False); ctx.set_async(False)
+        rec = {"ms": median(per), "ms_by_rep": [round(x, 4) for x in per], "ms_back_to_back": b2b, "two_in_flight_GPoints_per_s": two,
                "GPoints_per_s": n / b2b / 1e6, "window_bits": bases.window, "table_GiB": round(((255 + bases.window - 1) // bases.window) * n * 64 / 2**30, 2),
                "stage_ms": st, "k_accumulate_GB_per_s": 96.0 * n / (acc * 1e-3) / 1e9 if acc else None,
                "k_accumulate_frac": 96.0 * n / (acc * 1e-3) / 8e12 if acc else None, "exact": bool(ok),
@@ -350,6 +371,7 @@ def msm_sizes_leg(ctx, curve, sizes=(20, 22, 24), reps=5):
         bases.free()
         del sc
         torch.cuda.empty_cache()
+    ctx2.close()
     out["what"] = ("one MSM at a time on one stream (ms = median latency of %d stream-synchronised calls; GPoints_per_s from the "
                    "same calls back to back), [k_i]G generators, exact = the result equals [sum s_i k_i mod q] G; `value` of this "
                    "line is the 2^20 case with two independent MSMs in flight (pipelined)" % reps)

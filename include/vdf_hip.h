@@ -65,6 +65,22 @@ enum { VDF_FIELD_FP = 0, VDF_FIELD_FQ = 1 };          /* S2 = Fp, S1 = Fq, src/n
  * reference is CPU-only); this is the handle the FFI shim would keep in a OnceCell. */
 int  vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out);
 void vdf_ctx_destroy(vdf_ctx* ctx);
+/* The budget of hardware queues.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (this
+ * library asks for 8 when it makes the process's first HIP call); with more streams than queues, kernels of one stream wait
+ * behind another's (two provers and a compression -- 11 streams -- ran slower than one prover).  A context made HERE takes
+ * its stream from a per-device pool instead of opening one: a new stream while the device's streams known to this library
+ * (vdf_ctx_create contexts + pooled ones) number less than the budget minus one (left to the host's own streams: torch's,
+ * a caller's copies), otherwise it SHARES the least used pooled stream of its role -- VDF_QUEUE_SIDE contexts (work with a
+ * step's slack: a prover's look-ahead, a compression's second and third queue) with each other before they share with a
+ * VDF_QUEUE_CRITICAL one (a prover's early rows).  Sharing serialises the sharers' work and nothing else: results do not
+ * change.  libvdf_nova.so makes all of its internal contexts this way, so a host may run any number of provers and
+ * compressions in one process; contexts from vdf_ctx_create always own their stream (the host decides how many it opens). */
+#define VDF_QUEUE_CRITICAL 1
+#define VDF_QUEUE_SIDE 2
+int  vdf_ctx_create_pooled(const int* device_ids, int n_devices, int role, vdf_ctx** out);
+/* *pooled = 1 for a pooled context, *sharers = contexts on its stream (1 = its own), *device_streams = streams this library
+ * holds on the context's device.  Any output may be NULL. */
+int  vdf_ctx_queue_info(vdf_ctx* ctx, int* pooled, int* sharers, int* device_streams);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int  vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream);
 void* vdf_ctx_get_stream(vdf_ctx* ctx);
@@ -313,6 +329,17 @@ int  vdf_nifs_cross_term_rows(vdf_ctx* ctx, const vdf_shape* shape, size_t row_b
 int  vdf_nifs_cross_term_minroot(vdf_ctx* ctx, int field, int vars_per_round, uint64_t t, size_t seg_begin, size_t one_col, size_t row_begin,
                                  const vdf_fe* z2, const vdf_fe* Az1, const vdf_fe* Bz1, const vdf_fe* Cz1, const vdf_fe* u1, vdf_fe* Az2,
                                  vdf_fe* Bz2, vdf_fe* Cz2, vdf_fe* T);
+/* The same rows with the PREVIOUS fold of those rows applied on the way.  A prover that keeps A z, B z, C z of the running
+ * instance folds them after every step (X1 <- X1 + r X2); for the stencil rows the fresh vectors X2 of the previous step are
+ * exactly what this call is about to overwrite in Az2 / Bz2 / Cz2.  So, per row: Az1 += r Az2, Bz1 += r Bz2, Cz1 += r Cz2
+ * (and E1 += r T_prev when E1 is not NULL; T_prev may be T itself) with the vectors' CURRENT contents, stored in place; then
+ * Az2, Bz2, Cz2 and T of z2 as vdf_nifs_cross_term_minroot computes them, crossed with the FOLDED running rows and u1 (the
+ * caller passes the folded u).  One pass over the rows instead of a fold over whole vectors in front of it; the caller folds
+ * z, and every vector outside [row_begin, row_begin + 3t + 1), with vdf_fold_many.  r, u1: host memory. */
+int  vdf_nifs_cross_term_minroot_fold(vdf_ctx* ctx, int field, int vars_per_round, uint64_t t, size_t seg_begin, size_t one_col,
+                                      size_t row_begin, const vdf_fe* z2, const vdf_fe* r, vdf_fe* Az1, vdf_fe* Bz1, vdf_fe* Cz1,
+                                      vdf_fe* E1, const vdf_fe* T_prev, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2,
+                                      vdf_fe* T);
 /* acc[i] <- acc[i] + r * add[i], i < k <= 8, n[i] elements each: k vdf_axpy calls with a common r (host
  * memory).  The fold of a relaxed witness is k = 2 (W, E); a prover that keeps A z, B z, C z of the running
  * instance folds them too (they are linear in z), k = 5, instead of recomputing three sparse products. */
@@ -415,6 +442,8 @@ typedef struct vdf_hip_tuning {
                                   runs eight lanes per row; 0: by a launch of their own before it (1) */
   int32_t fold_u128;           /* 1: vdf_fold_many with a scalar below 2^128 (every NIFS fold challenge) multiplies by its plain value
                                   without a Montgomery reduction (fe_mul_u128); 0: the general multiplication (1) */
+  int32_t fixup_serial;        /* 1: the slice heads of a bucket are added by ONE lane (k_fixup_serial: 2.4 x fewer instructions per
+                                  addition, a longer dependent chain; 1); 0: by a quad of lanes (k_fixup) */
 } vdf_hip_tuning;
 int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
 int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */

@@ -150,6 +150,9 @@ typedef struct vdf_nova_tuning {
                                     opening's sort and bucket reduction under the other's accumulation); 0: in lockstep on one (1) */
   int32_t  rows_at_challenge;    /* 1: the primary fold and the next step's early rows are launched the moment the secondary circuit's
                                     synthesis has derived the fold challenge (a call-back from inside it); 0: after the synthesis (1) */
+  int32_t  fold_fused;           /* 1: the stencil kernel of the next step's early rows applies the primary fold to ITS rows of A z, B z,
+                                    C z and E on the way (vdf_nifs_cross_term_minroot_fold) and only z and the other rows are folded by a
+                                    launch of their own, beside it; 0: one fold over whole vectors in front of the rows (0: measured; needs stencil) */
 } vdf_nova_tuning;
 void vdf_nova_tuning_default(vdf_nova_tuning* out);
 /* public_params with the tuning given (NULL = the defaults); VDF_ERR_BAD_ARG for a field out of range */

@@ -229,6 +229,56 @@ def test_step_z_packed_is_the_witness_without_new_x(ctx, cref, field, t):
         ctx.minroot_step_z_packed(field, _dev(tr), t, z_in, i0, u, X, z, np.zeros((3 * t + 4, 4), dtype="<u8"))   # host buffer
 
 
+@pytest.mark.parametrize("per", [4, 3])
+@pytest.mark.parametrize("t", [5, 64, 4096])
+def test_stencil_with_the_fold_on_the_way(ctx, cref, t, per):
+    """vdf_nifs_cross_term_minroot_fold = the fold of the stencil rows (ref_axpy of the C restatement, row by row: X1 += r X2prev,
+    E1 += r Tprev) followed by vdf_nifs_cross_term_minroot over the folded rows -- every vector byte-identical, the rows behind
+    the stencil untouched, for a 128-bit challenge (the plain-integer product) and a full-width one, with and without E."""
+    field, m = o.FIELD_FQ, o.Q
+    L = cref.lib()
+    S = 3 + 11                                                     # some variables in front of z_in, as an augmented circuit has
+    nvars = S + per * t + 1 + 9
+    ncols, nc, row0 = nvars + 3, 3 * t + 1 + 13, 6
+    nr = 3 * t + 1
+    rng = np.random.default_rng(1000 * per + t)
+    z2 = rand_limbs(rng, ncols)
+    z2[nvars] = limbs([o.to_mont(1, m)])[0]                        # a fresh instance: the constant is one
+    u1 = rand_limbs(rng, 1)
+    for bits in (128, 254):
+        r_int = int(rng.integers(1, 2**63)) ** 4 % (1 << bits) | 1
+        r = limbs([o.to_mont(r_int % m, m)])
+        for with_e in (True, False):
+            run = [rand_limbs(rng, nc) for _ in range(4)]           # A z1, B z1, C z1, E1
+            prev = [rand_limbs(rng, nc) for _ in range(4)]          # A z2, B z2, C z2, T of the previous step
+            # expected: fold of rows [row0, row0 + nr) on the host's C restatement, then the plain stencil on the device
+            want_run = [x.copy() for x in run]
+            for k in range(4 if with_e else 3):
+                a, b = np.ascontiguousarray(run[k][row0:row0 + nr]), np.ascontiguousarray(prev[k][row0:row0 + nr])
+                out = cref.fe_array(nr)
+                L.ref_axpy(field, cref.p(a), cref.p(r), cref.p(b), nr, cref.p(out))
+                want_run[k][row0:row0 + nr] = out
+            w2 = [_dev(x) for x in prev[:3]]
+            wT = _dev(prev[3])
+            ctx.nifs_cross_term_minroot(field, per, t, S, nvars, row0, _dev(z2), *[_dev(x) for x in want_run[:3]], u1, *w2, wT)
+            d_run = [_dev(x) for x in run]
+            d_prev = [_dev(x) for x in prev]
+            ctx.nifs_cross_term_minroot_fold(field, per, t, S, nvars, row0, _dev(z2), r, d_run[0], d_run[1], d_run[2],
+                                             d_run[3] if with_e else None, d_prev[3] if with_e else None, u1, d_prev[0], d_prev[1],
+                                             d_prev[2], d_prev[3])
+            ctx.sync()
+            for k in range(4):
+                assert np.array_equal(_host(d_run[k]), want_run[k]), (bits, with_e, k)
+            for k in range(3):
+                assert np.array_equal(_host(d_prev[k]), _host(w2[k])), (bits, with_e, k)
+            assert np.array_equal(_host(d_prev[3]), _host(wT)), (bits, with_e)
+            assert np.array_equal(_host(d_prev[3])[:row0], prev[3][:row0]) and np.array_equal(_host(d_prev[3])[row0 + nr:], prev[3][row0 + nr:])
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_minroot_fold(field, per, t, S, nvars, row0, _dev(z2), _dev(r), *d_run[:3], None, None, u1, *d_prev)   # r on the device
+    with pytest.raises(Exception):
+        ctx.nifs_cross_term_minroot_fold(field, per, t, S, nvars, row0, _dev(z2), r, *d_run[:3], d_run[3], None, u1, *d_prev)      # E without T_prev
+
+
 @pytest.mark.parametrize("t", [5, 64, 4096])
 def test_nifs_cross_term_equals_spmv_then_cross(ctx, cref, t):
     field, m = o.FIELD_FQ, o.Q

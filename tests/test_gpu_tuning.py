@@ -42,7 +42,8 @@ def proof_bytes(pp, circuits, t, n, z0, zi):
 NOVA_VARIANTS = [dict(early_rows=0), dict(early_rows=1), dict(stencil=0), dict(digit_window=-1), dict(digit_window=8), dict(digit_window=12),
                  dict(packed_commit=0), dict(lookahead_early=0), dict(gate_accumulate=0), dict(fold_on_rows=0), dict(nifs_ahead=0),
                  dict(early_row_parts=2), dict(lookahead_priority=3), dict(side_accumulate_fill=2), dict(small_window=12, big_window=14),
-                 dict(digit_budget_bytes=1 << 20), dict(rows_at_challenge=0), dict(compress_queues=0)]
+                 dict(digit_budget_bytes=1 << 20), dict(rows_at_challenge=0), dict(compress_queues=0), dict(fold_fused=1),
+                 dict(fold_fused=1, fold_on_rows=0), dict(fold_fused=1, rows_at_challenge=0)]
 
 
 @pytest.mark.parametrize("kind", [CIRCUIT_MINROOT_REFERENCE, CIRCUIT_MINROOT_BOUND], ids=["reference", "bound"])
@@ -104,7 +105,8 @@ def test_out_of_range_tuning_is_refused(ctx):
 
 HIP_VARIANTS = [dict(msm_direct=0), dict(direct_fused=0), dict(direct_priority=0), dict(light_priority=1), dict(accumulate_fill=3),
                 dict(accumulate_fill=1), dict(accumulate_lds=55296), dict(slice_len=16), dict(reduction=0), dict(nifs_lanes=1),
-                dict(nifs_lanes=4), dict(nifs_fused=0), dict(fold_u128=0), dict(heavy_min=2, giant_span=16)]
+                dict(nifs_lanes=4), dict(nifs_fused=0), dict(fold_u128=0), dict(heavy_min=2, giant_span=16), dict(fixup_serial=0),
+                dict(fixup_serial=0, heavy_min=2, giant_span=16)]
 
 
 def test_hip_tuning_changes_scheduling_only(ctx):

@@ -25,6 +25,8 @@ _vp, _sz, _i, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
 PROTOTYPES = {
     "vdf_ctx_create": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
     "vdf_ctx_destroy": (None, [_vp]),
+    "vdf_ctx_create_pooled": (_i, [C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
+    "vdf_ctx_queue_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "vdf_ctx_set_stream": (_i, [_vp, _vp]),
     "vdf_ctx_get_stream": (_vp, [_vp]),
     "vdf_ctx_set_async": (_i, [_vp, _i]),
@@ -85,6 +87,7 @@ PROTOTYPES = {
     "vdf_nifs_cross_term": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term_rows": (_i, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_nifs_cross_term_minroot": (_i, [_vp, _i, _i, _u64, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vdf_nifs_cross_term_minroot_fold": (_i, [_vp, _i, _i, _u64, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vdf_fold_many": (_i, [_vp, _i, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz)]),
     "vdf_pair_table": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "vdf_pair_table_pattern": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),

@@ -123,6 +123,7 @@ vdf_hip_tuning tuning_defaults() {
   t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
   t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
   t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0; t.nifs_fused = 1; t.fold_u128 = 1;
+  t.fixup_serial = 1;
   return t;
 }
 bool tuning_valid(const vdf_hip_tuning& t) {
@@ -132,7 +133,7 @@ bool tuning_valid(const vdf_hip_tuning& t) {
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
          (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) &&
-         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1);
+         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1) && in(t.fixup_serial, 0, 1);
 }
 void tuning_publish(const vdf_hip_tuning& t) {           // caller holds g_tune_mu (or is the once-initialiser)
   g_tune_snapshots.push_back(t);
@@ -147,7 +148,8 @@ void tuning_from_env() {
       {"VDF_MSM_LIGHT_PRIO", &t.light_priority}, {"VDF_MSM_ACC_WG", &t.accumulate_fill}, {"VDF_MSM_ACC_LDS", &t.accumulate_lds},
       {"VDF_MSM_L", &t.slice_len}, {"VDF_MSM_PB", &t.part_bits}, {"VDF_MSM_RED", &t.reduction},
       {"VDF_MSM_RED_QUADS", &t.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &t.heavy_min}, {"VDF_MSM_GIANT_SPAN", &t.giant_span},
-      {"VDF_NIFS_LANES", &t.nifs_lanes}, {"VDF_SHIM_CACHE", &t.shim_cache}, {"VDF_NIFS_FUSED", &t.nifs_fused}, {"VDF_FOLD_U128", &t.fold_u128}};
+      {"VDF_NIFS_LANES", &t.nifs_lanes}, {"VDF_SHIM_CACHE", &t.shim_cache}, {"VDF_NIFS_FUSED", &t.nifs_fused}, {"VDF_FOLD_U128", &t.fold_u128},
+      {"VDF_MSM_FIXUP_SERIAL", &t.fixup_serial}};
   for (const auto& v : vars) {
     const char* e = std::getenv(v.name);
     if (!e || !*e) continue;
@@ -430,13 +432,92 @@ void build_dict_consts(std::array<uint32_t, 8>& one, std::array<uint32_t, 8>& mi
 
 }  // namespace
 
+// ---- the process's budget of hardware queues (include/vdf_hip.h vdf_ctx_create_pooled) -----------------------------------------
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (8 here); past that, streams share a queue and a kernel
+// waits behind another stream's (two provers + a compression opened 11 streams: the two-chain rate fell below one chain's,
+// profiles/r04_box_spread.txt).  Contexts a library makes for its own queues take their stream from this per-device pool:
+// a new stream while the device's total (pooled + caller-owned contexts) is below the budget, else they SHARE the least used
+// pooled stream of their role (a side queue -- a lookahead, a compression's second opening -- with another side queue, before
+// a latency-critical one).  Sharing only serialises; every cross-context order in this library is an event recorded before it
+// is waited for, so two contexts on one stream cannot deadlock.
+namespace {
+struct PoolStream { hipStream_t s = nullptr; int users = 0; int role = 0; };
+struct DevicePool { std::vector<PoolStream> streams; int owned = 0; };
+std::mutex g_pool_mu;
+std::map<int, DevicePool> g_pool;
+int hw_queue_budget() {
+  static const int b = [] { const char* e = std::getenv("GPU_MAX_HW_QUEUES"); const int v = e ? std::atoi(e) : 4; return v < 2 ? 2 : (v > 64 ? 64 : v); }();
+  return b;
+}
+// a stream for a pooled context of `role` on `device`; *slot = its index in the pool
+hipError_t pool_take(int device, int role, hipStream_t* out, int* slot) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  DevicePool& dp = g_pool[device];
+  int live = dp.owned;
+  for (const PoolStream& ps : dp.streams) if (ps.users) ++live;
+  // one queue is left to the host's own streams (torch's, a caller's copies) while pooled contexts can still share
+  if (live < hw_queue_budget() - 1) {
+    int idx = -1;
+    for (size_t i = 0; i < dp.streams.size(); ++i) if (!dp.streams[i].users) { idx = (int)i; break; }
+    if (idx < 0) { dp.streams.emplace_back(); idx = (int)dp.streams.size() - 1; }
+    PoolStream& ps = dp.streams[idx];
+    if (!ps.s) { const hipError_t e = hipStreamCreateWithFlags(&ps.s, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+    ps.users = 1; ps.role = role;
+    *out = ps.s; *slot = idx;
+    return hipSuccess;
+  }
+  int best = -1;
+  for (int pass = 0; pass < 2 && best < 0; ++pass)                      // same role first (side with side), then any pooled stream
+    for (size_t i = 0; i < dp.streams.size(); ++i) {
+      const PoolStream& ps = dp.streams[i];
+      if (!ps.users || (pass == 0 && ps.role != role)) continue;
+      if (best < 0 || ps.users < dp.streams[best].users) best = (int)i;
+    }
+  if (best < 0) {                                                        // nothing pooled yet (the callers hold the whole budget): one stream over it
+    dp.streams.emplace_back();
+    best = (int)dp.streams.size() - 1;
+    const hipError_t e = hipStreamCreateWithFlags(&dp.streams[best].s, hipStreamNonBlocking);
+    if (e != hipSuccess) { dp.streams.pop_back(); return e; }
+    dp.streams[best].role = role;
+  }
+  dp.streams[best].users += 1;
+  *out = dp.streams[best].s; *slot = best;
+  return hipSuccess;
+}
+void pool_release(int device, int slot) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  DevicePool& dp = g_pool[device];
+  if (slot < 0 || slot >= (int)dp.streams.size() || dp.streams[slot].users <= 0) return;
+  if (--dp.streams[slot].users == 0 && dp.streams[slot].s) { (void)hipStreamDestroy(dp.streams[slot].s); dp.streams[slot].s = nullptr; }
+}
+void pool_count_owned(int device, int delta) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  g_pool[device].owned += delta;
+}
+}  // namespace
+
 extern "C" {
 
 int vdf_ctx_device(vdf_ctx* ctx) { return ctx ? ctx->device : 0; }
 
 const char* vdf_version(void) { return "vdf_hip gfx950 r1 (" __DATE__ ")"; }
 
-int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
+static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_ctx** out);
+int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) { return ctx_create_impl(device_ids, n_devices, 0, out); }
+int vdf_ctx_create_pooled(const int* device_ids, int n_devices, int role, vdf_ctx** out) {
+  if (role != VDF_QUEUE_CRITICAL && role != VDF_QUEUE_SIDE) { g_create_err = "vdf_ctx_create_pooled: unknown role"; return VDF_ERR_BAD_ARG; }
+  return ctx_create_impl(device_ids, n_devices, role, out);
+}
+int vdf_ctx_queue_info(vdf_ctx* ctx, int* pooled, int* sharers, int* device_streams) {
+  if (!ctx) return VDF_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  DevicePool& dp = g_pool[ctx->device];
+  if (pooled) *pooled = ctx->pool_slot >= 0 ? 1 : 0;
+  if (sharers) *sharers = ctx->pool_slot >= 0 ? dp.streams[ctx->pool_slot].users : 1;
+  if (device_streams) { int live = dp.owned; for (const PoolStream& ps : dp.streams) if (ps.users) ++live; *device_streams = live; }
+  return VDF_OK;
+}
+static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_ctx** out) {
   if (!out) { g_create_err = "null out"; return VDF_ERR_BAD_ARG; }
   *out = nullptr;
   if (n_devices != 1 || !device_ids) {
@@ -461,7 +542,10 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   if (!c) { g_create_err = "host allocation failed"; return VDF_ERR_OOM; }
   c->device = device_ids[0];
   e = hipSetDevice(c->device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    if (role == 0) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e == hipSuccess) { c->own_stream = true; pool_count_owned(c->device, +1); } }
+    else e = pool_take(c->device, role, &c->stream, &c->pool_slot);
+  }
   if (e == hipSuccess) e = hipMalloc(&c->d_out, 256);
   if (e == hipSuccess) e = hipMalloc(&c->small_pool, vdf_ctx::SMALL_POOL_BYTES);
   if (e == hipSuccess) {
@@ -477,10 +561,11 @@ int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
   if (e != hipSuccess) {
     g_create_err = std::string("vdf_ctx_create: ") + hipGetErrorString(e);
+    if (c->pool_slot >= 0) pool_release(c->device, c->pool_slot);
+    if (c->own_stream) { if (c->stream) (void)hipStreamDestroy(c->stream); pool_count_owned(c->device, -1); }
     delete c;
     return VDF_ERR_DEVICE;
   }
-  c->own_stream = true;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = c;
   return VDF_OK;
@@ -505,14 +590,16 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
     if (ctx->side_done[g]) (void)hipEventDestroy(ctx->side_done[g]);
     if (ctx->side[g]) { (void)hipStreamSynchronize(ctx->side[g]); (void)hipStreamDestroy(ctx->side[g]); }
   }
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); pool_count_owned(ctx->device, -1); }
+  if (ctx->pool_slot >= 0) pool_release(ctx->device, ctx->pool_slot);
   delete ctx;
 }
 
 int vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream) {
   return guarded(ctx, [&]() -> Status {
     VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); pool_count_owned(ctx->device, -1); }
+    if (ctx->pool_slot >= 0) { pool_release(ctx->device, ctx->pool_slot); ctx->pool_slot = -1; }
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
     return Status{};
@@ -649,7 +736,10 @@ int vdf_bases_generate_label(vdf_ctx* ctx, int curve, const uint8_t* label, size
 int vdf_bases_precompute(vdf_ctx* ctx, vdf_bases* bases, int window_bits, int sets) {
   return guarded(ctx, [&]() -> Status {
     if (!bases || bases->ctx != ctx) return Status{VDF_ERR_BAD_ARG, "bad bases handle"};
-    if (window_bits == 0) window_bits = bases->n >= ((size_t)1 << 19) ? 17 : 16;      // measured: DESIGN.md 4.2
+    // measured (profiles/r05_window_sweep.txt): 16 below 2^19 generators, 17 up to 2^21, 20 from 2^22 on (13 windows
+    // instead of 15: the accumulation's -13 % outweighs a bucket reduction over 2^19 buckets only there; 18 and 19 leave a top
+    // window of 2 / 7 significant bits, i.e. a handful of hot buckets for uniform scalars)
+    if (window_bits == 0) window_bits = bases->n >= ((size_t)1 << 22) ? 20 : (bases->n >= ((size_t)1 << 19) ? 17 : 16);
     if (window_bits < 4 || window_bits > 20) return Status{VDF_ERR_BAD_ARG, "window_bits must be 0 (recommended) or 4..20"};
     const int windows = (256 + window_bits - 1) / window_bits;
     if (sets <= 0) sets = 1;
@@ -1349,6 +1439,27 @@ int vdf_nifs_cross_term_minroot(vdf_ctx* ctx, int field, int vars_per_round, uin
     if (t == 0 || t > (1ull << 26)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
     if (seg_begin < 3 || one_col < seg_begin + (size_t)vars_per_round * t + 1) return Status{VDF_ERR_BAD_ARG, "the constant's column lies behind the rounds"};
     VDF_TRY(vdf::vec_nifs_cross_minroot(field, vars_per_round, t, seg_begin, one_col, row_begin, z2, Az1, Bz1, Cz1, u1, Az2, Bz2, Cz2, T, ctx->stream));
+    if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    return Status{};
+  });
+}
+
+int vdf_nifs_cross_term_minroot_fold(vdf_ctx* ctx, int field, int vars_per_round, uint64_t t, size_t seg_begin, size_t one_col,
+                                     size_t row_begin, const vdf_fe* z2, const vdf_fe* r, vdf_fe* Az1, vdf_fe* Bz1, vdf_fe* Cz1,
+                                     vdf_fe* E1, const vdf_fe* T_prev, const vdf_fe* u1, vdf_fe* Az2, vdf_fe* Bz2, vdf_fe* Cz2,
+                                     vdf_fe* T) {
+  return guarded(ctx, [&]() -> Status {
+    if (!z2 || !r || !Az1 || !Bz1 || !Cz1 || !u1 || !Az2 || !Bz2 || !Cz2 || !T) return Status{VDF_ERR_BAD_ARG, "null argument"};
+    if (E1 && !T_prev) return Status{VDF_ERR_BAD_ARG, "E1 without T_prev"};
+    if (ptr_is_device(u1) || ptr_is_device(r)) return Status{VDF_ERR_BAD_ARG, "scalar operands of fused calls live in host memory"};
+    for (const void* v : {(const void*)z2, (const void*)Az1, (const void*)Bz1, (const void*)Cz1, (const void*)Az2, (const void*)Bz2,
+                          (const void*)Cz2, (const void*)T})
+      if (!ptr_is_device(v)) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    if (E1 && (!ptr_is_device(E1) || !ptr_is_device(T_prev))) return Status{VDF_ERR_BAD_ARG, "vector operands of fused calls live in device memory"};
+    if (t == 0 || t > (1ull << 26)) return Status{VDF_ERR_BAD_LENGTH, "t out of range"};
+    if (seg_begin < 3 || one_col < seg_begin + (size_t)vars_per_round * t + 1) return Status{VDF_ERR_BAD_ARG, "the constant's column lies behind the rounds"};
+    VDF_TRY(vdf::vec_nifs_cross_minroot_fold(field, vars_per_round, t, seg_begin, one_col, row_begin, z2, r, Az1, Bz1, Cz1, E1, E1 ? T_prev : nullptr,
+                                             u1, Az2, Bz2, Cz2, T, ctx->stream));
     if (!ctx->async) VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     return Status{};
   });

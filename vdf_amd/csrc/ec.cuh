@@ -198,6 +198,43 @@ template <class P> VDF_HD void xyzz_add(XYZZ<P>& acc, const XYZZ<P>& b) {
   acc.zzz = fe_mul(fe_mul(acc.zzz, b.zzz), PPP);
 }
 
+#ifdef __HIPCC__
+// acc + b for two XYZZ points by ONE lane in the lazy domain, sign-tracked like xyzz_madd_lazy (the lane-serial fix-up of
+// msm.hip: 12 products + 1 product pair + 6 subtractions, ~3,300 instructions, where the quad-cooperative law spends 4 lanes x
+// ~2,070).  `b`: CANONICAL coordinates, not the identity, already negated by the caller when `flip` is set.  add-2008-s with
+// P' = U1 - U2 = -P:  X3 = R^2 + PPP' - 2Q,  Y3 = R (Q - X3) + S1 PPP' (a SUM: fe_mul2_lazy),  ZZ3 = ZZ1 ZZ2 PP,
+// ZZZ1 ZZZ2 PPP' = -ZZZ3: the negated sum, so `flip` toggles.  Every product has a factor that is canonical or a product with
+// a canonical factor (below 2m: no slack), so the stored coordinates stay below 2m + 4 eps whatever the chain's length.
+template <class P>
+__device__ __forceinline__ void xyzz_add_lazy(XYZZ<P>& acc, bool& have, bool& flip, const XYZZ<P>& b) {
+  if (!have) { acc = b; have = true; flip = false; return; }
+  const Fe<P> U1 = fe_mul_lazy(acc.x, b.zz);
+  const Fe<P> U2 = fe_mul_lazy(b.x, acc.zz);
+  const Fe<P> S1 = fe_mul_lazy(acc.y, b.zzz);
+  const Fe<P> S2 = fe_mul_lazy(b.y, acc.zzz);
+  const Fe<P> Pn = fe_sub_lazy(U1, U2);
+  const Fe<P> Rr = fe_sub_lazy(S2, S1);
+  if (Pn.v[0] <= 2u && fe_is_zero(fe_canon(Pn))) {                     // same x: the canonical law decides (double / identity)
+    XYZZ<P> a = xyzz_lazy_resolve<P>(acc, have, flip);
+    a.x = fe_canon(a.x); a.y = fe_canon(a.y); a.zz = fe_canon(a.zz); a.zzz = fe_canon(a.zzz);
+    XYZZ<P> bb = b;
+    if (flip) bb.y = fe_neg(bb.y);                                     // the caller negated it for the stored sign: undo
+    xyzz_add(a, bb);
+    acc = a; flip = false; have = !xyzz_is_identity(a);
+    return;
+  }
+  const Fe<P> PP = fe_mul_lazy(Pn, Pn);
+  const Fe<P> PPPn = fe_mul_lazy(Pn, PP);
+  const Fe<P> Qq = fe_mul_lazy(U1, PP);
+  const Fe<P> X3 = fe_sub_lazy(fe_sub_lazy(fe_mul_lazy(Rr, Rr), Qq), fe_sub_lazy(Qq, PPPn));
+  acc.y = fe_mul2_lazy(Rr, fe_sub_lazy(Qq, X3), S1, PPPn);
+  acc.x = X3;
+  acc.zz = fe_mul_lazy(fe_mul_lazy(acc.zz, b.zz), PP);
+  acc.zzz = fe_mul_lazy(fe_mul_lazy(acc.zzz, b.zzz), PPPn);
+  flip = !flip;
+}
+#endif
+
 template <class P> VDF_HD Affine<P> affine_neg(const Affine<P>& a) {
   Affine<P> r;
   r.x = a.x;

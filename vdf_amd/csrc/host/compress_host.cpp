@@ -744,11 +744,11 @@ int vdf_nova_compress(const vdf_proof* p, vdf_pp* pp, vdf_snark** out) {
     std::lock_guard<std::mutex> aux_lock(pp->aux_mu);
     if (!pp->aux_ctx) {
       const int dev = vdf_ctx_device(ctx);
-      if (vdf_ctx_create(&dev, 1, &pp->aux_ctx) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: second context: ") + vdf_last_error(nullptr));
+      if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_SIDE, &pp->aux_ctx) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: second context: ") + vdf_last_error(nullptr));
     }
     if (!pp->aux_ctx2 && pp->tune.compress_queues) {
       const int dev = vdf_ctx_device(ctx);
-      if (vdf_ctx_create(&dev, 1, &pp->aux_ctx2) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: third context: ") + vdf_last_error(nullptr));
+      if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_SIDE, &pp->aux_ctx2) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("compress: third context: ") + vdf_last_error(nullptr));
     }
     vdf_ctx* cb = pp->aux_ctx;
     HIPCALL(cb, vdf_ctx_set_async(cb, 1));

@@ -226,7 +226,7 @@ int alloc_proof_buffers(vdf_proof* p) {
   for (int k = 0; k < vdf_proof::DEPTH; ++k) {
     if (pp->seg_gens) HIPCALL(ctx, vdf_dev_alloc(ctx, (3 * pp->t + 4) * 32, &p->d_packed[k]));
     const int dev = vdf_ctx_device(ctx);
-    if (vdf_ctx_create(&dev, 1, &p->ctx2[k]) != VDF_OK)
+    if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_SIDE, &p->ctx2[k]) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
     // the lookahead's commitment is needed a whole step later: its sort and bucket reduction yield to the early rows' (the
@@ -238,7 +238,7 @@ int alloc_proof_buffers(vdf_proof* p) {
   }
   {
     const int dev = vdf_ctx_device(ctx);
-    if (vdf_ctx_create(&dev, 1, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
+    if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_CRITICAL, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx3, vdf_ctx_set_async(p->ctx3, 1));
     HIPCALL(p->ctx3, vdf_ctx_set_accumulate_fill(p->ctx3, pp->tune.side_accumulate_fill));
   }
@@ -253,6 +253,7 @@ int alloc_proof_buffers(vdf_proof* p) {
 // commitment of the last secondary witness (its MSM normally rides in the next step's batch)
 int finalize_l2(const vdf_proof* cp) {
   vdf_proof* p = const_cast<vdf_proof*>(cp);
+  if (p->poisoned) return fail(VDF_ERR_DEVICE, "this proof's running instance is half folded (an earlier prove_step failed on the device)");
   const Side& sd = p->pp->s[SECONDARY];
   vdf_ctx* ctx = sd.ctx;
   if (p->nifs2 == vdf_proof::NIFS2_INFLIGHT) {        // the step launched it on its way out: collect
@@ -485,7 +486,8 @@ bool tuning_valid(const vdf_nova_tuning& t) {
          (t.digit_window == -1 || t.digit_window == 0 || in(t.digit_window, 6, 12)) && in(t.early_rows, 0, 2) && in(t.stencil, 0, 1) &&
          in(t.small_window, 6, 16) && in(t.big_window, 12, 20) && in(t.packed_commit, 0, 1) && in(t.lookahead_early, 0, 1) &&
          in(t.gate_accumulate, 0, 1) && in(t.fold_on_rows, 0, 1) && in(t.nifs_ahead, 0, 1) && in(t.early_row_parts, 1, 3) &&
-         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1) && in(t.compress_queues, 0, 1) && in(t.rows_at_challenge, 0, 1);
+         in(t.lookahead_priority, 0, 3) && in(t.side_accumulate_fill, 1, 3) && in(t.verbose, 0, 1) && in(t.compress_queues, 0, 1) && in(t.rows_at_challenge, 0, 1) &&
+         in(t.fold_fused, 0, 1);
 }
 const vdf_nova_tuning& default_tuning() {
   static const vdf_nova_tuning d = [] {
@@ -494,13 +496,15 @@ const vdf_nova_tuning& default_tuning() {
     t.flags = 0; t.digit_budget_bytes = (uint64_t)20 << 30; t.digit_window = 0; t.early_rows = 2; t.stencil = 1; t.small_window = 15;
     t.big_window = 16; t.packed_commit = 1; t.lookahead_early = 1; t.gate_accumulate = 1; t.fold_on_rows = 1; t.nifs_ahead = 1;
     t.early_row_parts = 1; t.lookahead_priority = 1; t.side_accumulate_fill = 3; t.verbose = 0; t.compress_queues = 1; t.rows_at_challenge = 1;
+    t.fold_fused = 0;      // measured (profiles/r05_ab_fold_fused.txt): the fused fold shortens the rows' path by ~45 us and the step gets no faster
     // the environment overrides of earlier rounds, read once: the only place the prover looks at the environment for tuning
     const struct { const char* name; int32_t* field; } vars[] = {
         {"VDF_NOVA_DIGIT_WINDOW", &t.digit_window}, {"VDF_NOVA_T_AHEAD", &t.early_rows}, {"VDF_NOVA_STENCIL", &t.stencil},
         {"VDF_NOVA_SMALL_WINDOW", &t.small_window}, {"VDF_NOVA_BIG_WINDOW", &t.big_window}, {"VDF_NOVA_PACKED_COMMIT", &t.packed_commit},
         {"VDF_NOVA_LOOKAHEAD_EARLY", &t.lookahead_early}, {"VDF_NOVA_GATE", &t.gate_accumulate}, {"VDF_NOVA_FOLD_ON_ROWS", &t.fold_on_rows},
         {"VDF_NOVA_NIFS_AHEAD", &t.nifs_ahead}, {"VDF_NOVA_T_PARTS", &t.early_row_parts}, {"VDF_NOVA_LOOKAHEAD_PRIO", &t.lookahead_priority},
-        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}, {"VDF_NOVA_COMPRESS_QUEUES", &t.compress_queues}, {"VDF_NOVA_ROWS_AT_CHALLENGE", &t.rows_at_challenge}};
+        {"VDF_NOVA_SIDE_ACC_WG", &t.side_accumulate_fill}, {"VDF_NOVA_VERBOSE", &t.verbose}, {"VDF_NOVA_COMPRESS_QUEUES", &t.compress_queues}, {"VDF_NOVA_ROWS_AT_CHALLENGE", &t.rows_at_challenge},
+        {"VDF_NOVA_FOLD_FUSED", &t.fold_fused}};
     for (const auto& v : vars) {
       const char* e = env_override(v.name);
       if (!e || !*e) continue;
@@ -1063,7 +1067,7 @@ struct StepRun {
   void* d_z2 = nullptr;
   int zin_slot = -1;                   // ring slot whose z_in this step has already uploaded (for the next step's early rows)
   bool fold_elsewhere = false;         // the primary fold ran on the early rows' queue: the main queue waits for it before the step ends
-  struct { bool pending = false; void* d_next = nullptr; vdf_ctx* cq_next = nullptr; vdf_ctx* fq = nullptr; int slot = -1; } deferred;   // the next step's early rows
+  struct { bool pending = false; void* d_next = nullptr; vdf_ctx* cq_next = nullptr; vdf_ctx* fq = nullptr; int slot = -1; bool fused = false; Fe fold_r, u_folded; } deferred;   // the next step's early rows
   bool gate_next_segment = false;      // the next lookahead_enqueue holds its bucket accumulation behind MARK_PRIMARY
   bool touched[D] = {};
   bool looked = false, waited_w = false;
@@ -1160,7 +1164,10 @@ struct StepRun {
   // that part of comm_T, run on a queue of their own beside the secondary side's NIFS and the host's synthesis of the
   // primary circuit, and leave ~10^4 rows instead of 2 x 10^5 on the critical path.  For the step whose fresh witness
   // lives in d_z2 (this step's, or -- launched on the way out -- the next one's).
-  int early_rows_launch(void* d_z2, vdf_ctx* cq, bool zin_in_place) {
+  // fold_r (fused mode, stencil_fold_ok()): the challenge of the fold that has NOT been applied to the early rows of the running
+  // A z, B z, C z and E yet -- the stencil applies it on the way (vdf_nifs_cross_term_minroot_fold) and MARK_FOLD is set behind it
+  bool stencil_fold_ok() const { return pp->tune.fold_fused != 0 && pp->stencil_per != 0 && (t_parts == 1 || ta_n < 4096); }
+  int early_rows_launch(void* d_z2, vdf_ctx* cq, bool zin_in_place, const Fe* fold_r = nullptr) {
     SideState& s1 = p->r[PRIMARY];
     HIPCALL(ct, vdf_ctx_wait_mark(ct, cq, MARK_Z));                 // the rounds are in place (written a step ago, normally)
     // z_in = z_i past the base step (the circuit's selection); the same values arrive again with the host's variables
@@ -1169,6 +1176,15 @@ struct StepRun {
       HIPCALL(ct, vdf_dev_memcpy(ct, (char*)d_z2 + (seg_b - arity) * 32, p->h_zin, arity * 32));
     }
     auto rows = [&](size_t b, size_t n) -> int {
+      if (fold_r) {                                                  // the stencil with the previous fold of its rows on the way
+        if (!(pp->stencil_per && b == ta_b && n == ta_n)) return fail(VDF_ERR_DEVICE, "fused fold without the stencil");
+        HIPCALL(ct, vdf_nifs_cross_term_minroot_fold(ct, S1.field, pp->stencil_per, pp->t, seg_b, S1.num_vars, b, (const vdf_fe*)d_z2,
+                                                     (const vdf_fe*)fold_r, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2],
+                                                     (vdf_fe*)s1.d_E, (const vdf_fe*)s1.d_T, (const vdf_fe*)&s1.inst.u, (vdf_fe*)s1.d_abc2[0],
+                                                     (vdf_fe*)s1.d_abc2[1], (vdf_fe*)s1.d_abc2[2], (vdf_fe*)s1.d_T));
+        HIPCALL(ct, vdf_ctx_mark(ct, MARK_FOLD));                    // the running instance is whole again from here on
+        return VDF_OK;
+      }
       if (pp->stencil_per && b == ta_b && n == ta_n) {               // the MinRoot stencil: streams only (vdf_hip.h)
         HIPCALL(ct, vdf_nifs_cross_term_minroot(ct, S1.field, pp->stencil_per, pp->t, seg_b, S1.num_vars, b, (const vdf_fe*)d_z2,
                                                 (const vdf_fe*)s1.d_abc[0], (const vdf_fe*)s1.d_abc[1], (const vdf_fe*)s1.d_abc[2],
@@ -1418,16 +1434,36 @@ struct StepRun {
         // rows then start right behind the fold's kernel, with no event between two queues, and the main queue goes straight to
         // the secondary side's NIFS); the main queue is made to wait for it at the end of the step, before anything reads the
         // folded instance there.  Everything the fold reads is complete: this thread has waited for the primary side's launches.
-        vdf_ctx* fq = (rows_next && fold_on_rows) ? ct : ctx;
+        // FUSED (tuning.fold_fused, the stencil in use): the early rows of A z, B z, C z and E are folded BY the next step's
+        // stencil kernel on its way (it reads the previous fresh rows it is about to overwrite: one pass, no fold in front of it on
+        // the step's longest dependent path); what is left -- z, and the ~10^4 rows outside the stencil -- is folded here on the
+        // chain's queue, beside it: the two touch disjoint elements.
+        const bool fused = rows_next && !first && stencil_fold_ok();
+        vdf_ctx* fq = fused ? ctx : ((rows_next && fold_on_rows) ? ct : ctx);
+        Fe rr = zero();
         if (!first) {
           SideState& s1 = p->r[PRIMARY];
-          const Fe rr = int_to_fe(rch, F1);
-          vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
-          const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
-                                   (const vdf_fe*)s1.d_abc2[2]};
-          const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
-          if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
-          HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+          rr = int_to_fe(rch, F1);
+          if (fused) {
+            auto cut = [&](void* base, size_t b, size_t n) { return (vdf_fe*)((char*)base + b * 32); };
+            vdf_fe* acc[8]; const vdf_fe* addv[8]; size_t len[8];
+            int ns = 0;
+            auto seg = [&](void* a, const void* b_, size_t begin, size_t n) { if (n) { acc[ns] = cut(a, begin, n); addv[ns] = cut((void*)b_, begin, n); len[ns] = n; ++ns; } };
+            seg(s1.d_z, d_z2, 0, S1.ncols);
+            seg(s1.d_E, s1.d_T, 0, ta_b); seg(s1.d_E, s1.d_T, ta_e, S1.num_cons - ta_e);
+            HIPCALL(ctx, vdf_fold_many(ctx, S1.field, (const vdf_fe*)&rr, ns, acc, addv, (const size_t*)len));
+            ns = 0;
+            for (int m = 0; m < 3; ++m) { seg(s1.d_abc[m], s1.d_abc2[m], 0, ta_b); seg(s1.d_abc[m], s1.d_abc2[m], ta_e, S1.num_cons - ta_e); }
+            if (ns) HIPCALL(ctx, vdf_fold_many(ctx, S1.field, (const vdf_fe*)&rr, ns, acc, addv, (const size_t*)len));
+            p->poisoned = true;                                            // until the stencil that finishes this fold is on its queue
+          } else {
+            vdf_fe* acc[5] = {(vdf_fe*)s1.d_z, (vdf_fe*)s1.d_E, (vdf_fe*)s1.d_abc[0], (vdf_fe*)s1.d_abc[1], (vdf_fe*)s1.d_abc[2]};
+            const vdf_fe* addv[5] = {(const vdf_fe*)d_z2, (const vdf_fe*)s1.d_T, (const vdf_fe*)s1.d_abc2[0], (const vdf_fe*)s1.d_abc2[1],
+                                     (const vdf_fe*)s1.d_abc2[2]};
+            const size_t len[5] = {S1.ncols, S1.num_cons, S1.num_cons, S1.num_cons, S1.num_cons};
+            if (fq != ctx) HIPCALL(fq, vdf_ctx_wait_mark(fq, ctx, MARK_ZIN));         // (reached long ago; and the witness uploads in front of it)
+            HIPCALL(fq, vdf_fold_many(fq, S1.field, (const vdf_fe*)&rr, 5, acc, addv, len));
+          }
           u_folded = add(p->r[PRIMARY].inst.u, rr, F1);                   // u' = u + r: what the next step's rows are crossed with
         }
         // The early rows of the NEXT step's cross term: its rounds are in their ring slot (the lookahead), its input z_in is
@@ -1436,18 +1472,21 @@ struct StepRun {
         if (rows_next) {
           void* d_next = p->d_z2s[p->ahead[0].slot];
           vdf_ctx* cq_next = p->ctx2[(k + 1) % D];
-          HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
-          fold_elsewhere = fq != ctx;
+          if (fused) HIPCALL(ct, vdf_ctx_wait_mark(ct, ctx, MARK_ZIN));    // z_in of the next step is in its slot (set in the primary phase)
+          else HIPCALL(fq, vdf_ctx_mark(fq, MARK_FOLD));
+          fold_elsewhere = fused || fq != ctx;
           if (launch_rows_now) {
-            if (fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, fq, MARK_FOLD));
+            if (!fused && fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, fq, MARK_FOLD));
             p->r[PRIMARY].inst.u = u_folded;                             // (the launch reads it; the circuit's own value follows below)
-            int rc = early_rows_launch(d_next, cq_next, true);
+            int rc = early_rows_launch(d_next, cq_next, true, fused ? &rr : nullptr);
             if (rc != VDF_OK) return rc;                                 // tahead_valid stays false: a retried step launches its rows itself
+            p->poisoned = false;
             p->tahead_valid = true; p->tahead_slot = p->ahead[0].slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
             rows_launched = true;
           } else {
             deferred.pending = true; deferred.d_next = d_next; deferred.cq_next = cq_next; deferred.fq = fq;
             deferred.slot = p->ahead[0].slot;                            // (tahead_* are set once the rows are really on their queue)
+            deferred.fused = fused; deferred.fold_r = rr; deferred.u_folded = u_folded;
           }
         }
         return VDF_OK;
@@ -1489,13 +1528,14 @@ struct StepRun {
       if (rc != VDF_OK) return rc;
       p->nifs2 = vdf_proof::NIFS2_INFLIGHT;
     }
-    if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
     if (deferred.pending) {                         // EARLY ROWS of the next step, behind the fold's mark
-      if (deferred.fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, deferred.fq, MARK_FOLD));
-      int rc = early_rows_launch(deferred.d_next, deferred.cq_next, true);
+      if (!deferred.fused && deferred.fq != ct) HIPCALL(ct, vdf_ctx_wait_mark(ct, deferred.fq, MARK_FOLD));
+      int rc = early_rows_launch(deferred.d_next, deferred.cq_next, true, deferred.fused ? &deferred.fold_r : nullptr);
       if (rc != VDF_OK) return rc;                  // tahead_valid stays false: a retried step launches its rows itself
+      p->poisoned = false;
       p->tahead_valid = true; p->tahead_slot = deferred.slot; p->tahead_k = k + 1; p->tahead_circuits = circuits;
     }
+    if (fold_elsewhere) HIPCALL(ctx, vdf_ctx_wait_mark(ctx, ct, MARK_FOLD));      // whatever reads the folded instance on the main queue comes after
     HIPCALL(ctx, vdf_ctx_sync_mark(ctx, MARK_STEP));
     for (int j = 0; j < D; ++j) if (touched[j]) HIPCALL(p->ctx2[j], vdf_ctx_sync_mark(p->ctx2[j], MARK_Z));
     p->i += 1;
@@ -1530,6 +1570,8 @@ static int prove_step_impl(vdf_pp* pp, vdf_proof** proof, const vdf_circuits* ci
     p->zi[SECONDARY] = p->z0[SECONDARY];
     int rc = alloc_proof_buffers(p);
     if (rc != VDF_OK) return rc;
+  } else if (p->poisoned) {
+    return fail(VDF_ERR_DEVICE, "this proof's running instance is half folded (an earlier prove_step failed on the device)");
   } else if (memcmp(p->z0[PRIMARY].data(), z0, 32 * arity) != 0) {
     return fail(VDF_ERR_BAD_ARG, "z0 differs from the one this proof was started with");
   }
@@ -1616,6 +1658,7 @@ int vdf_nova_proof_instance(const vdf_proof* p, int which, vdf_affine* comm_W, v
 int vdf_nova_proof_witness_ptrs(const vdf_proof* p, int which, const void** d_z, const void** d_E) {
   return nova_guard([&]() -> int {
     if (!p || which < 0 || which > 3) return fail(VDF_ERR_BAD_ARG, "bad argument");
+    if (p->poisoned) return fail(VDF_ERR_DEVICE, "this proof's running instance is half folded (an earlier prove_step failed on the device)");
     HIPCALL(p->pp->ctx, vdf_ctx_sync(p->pp->ctx));      // a step may have returned with its fold still in flight
     if (which == VDF_INST_FRESH_PRIMARY_LAST) { if (d_z) *d_z = p->d_z2s[p->slot]; if (d_E) *d_E = nullptr; }
     else if (which == VDF_INST_FRESH_SECONDARY) { if (d_z) *d_z = p->d_l2z; if (d_E) *d_E = nullptr; }

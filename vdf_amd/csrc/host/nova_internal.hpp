@@ -153,6 +153,8 @@ struct vdf_proof {
   // ... and so do the early rows of the NEXT step's cross term, when that step's rounds are already in their ring slot
   // (the lookahead): launched on the way out of a step too; valid for the step that finds this slot and circuit
   bool tahead_valid = false;
+  bool poisoned = false;         // a fused fold was begun and the stencil that finishes it never reached its queue (a device failure): the running
+                                 // instance is half folded and every later call on this proof is refused
   int tahead_slot = -1;
   size_t tahead_k = 0;
   const vdf_circuits* tahead_circuits = nullptr;

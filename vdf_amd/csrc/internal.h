@@ -44,6 +44,7 @@ struct vdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  int pool_slot = -1;                // >= 0: the stream belongs to the device's pool of hardware queues (vdf_ctx_create_pooled)
   bool async = false;
   int msm_window = 0;          // 0 = automatic
   std::mutex mu;
@@ -236,6 +237,9 @@ int nifs_cross_lanes(size_t rows);                       // lanes per row vec_ni
 Status vec_nifs_cross_minroot(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
                               const void* az1, const void* bz1, const void* cz1, const vdf_fe* u1, void* az2, void* bz2, void* cz2,
                               void* T, hipStream_t s);
+Status vec_nifs_cross_minroot_fold(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
+                                   const vdf_fe* r, void* az1, void* bz1, void* cz1, void* e1, const void* tprev, const vdf_fe* u1,
+                                   void* az2, void* bz2, void* cz2, void* T, hipStream_t s);
 Status vec_fold_many(int field, const vdf_fe* r, int k, void* const acc[], const void* const add[], const size_t n[],
                      hipStream_t s);
 Status vec_mul(int field, const void* a, const void* b, size_t n, void* out, hipStream_t s);

@@ -212,14 +212,20 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.pb = 0;
   while (p.pb < c - 1 && ((uint32_t)p.gsets << p.pb) < (uint32_t)num_cus) ++p.pb;
   if (tuning().part_bits >= 0 && tuning().part_bits <= c - 1) p.pb = tuning().part_bits;      // tuning override
-  while (c - 1 - p.pb > 10) ++p.pb;
+  // windows of 18 bits and more: pass B with more than 2^8 fine buckets per partition collapses (k_fine at 2^22 points: 0.65 ms
+  // at 8 fine bits, 3.0 at 9, 6.0 at 10 with 256 partitions -- 2^9..2^10 four-byte write streams per workgroup defeat the
+  // L2's write combining; profiles/r05_window_sweep.txt), so the partitions take the surplus bits instead (up to 8192 of them:
+  // pass A's cursors are 32 KB of LDS) and its chunks grow so that a (workgroup, partition) run stays a few lines long
+  const int fine_max = c >= 18 && tuning().part_bits < 0 ? 8 : 10;
+  while (c - 1 - p.pb > fine_max) ++p.pb;
   while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) --p.pb;
   p.fb = c - 1 - p.pb;
   p.bins = (uint32_t)p.gsets << p.pb;
   size_t chA = (n + 511) / 512;                       // ~2 pass-A workgroups per CU
   chA = (chA + 255) / 256 * 256;
   if (chA < 256) chA = 256;
-  if (chA > 4096) chA = 4096;
+  const size_t chA_max = p.bins > 512 ? 16384 : 4096;
+  if (chA > chA_max) chA = chA_max;
   p.chA = (uint32_t)chA;
   uint32_t blk = 0;
   for (int g = 0; g < groups; ++g) {
@@ -628,6 +634,51 @@ __global__ __launch_bounds__(256) void k_fixup(const uint32_t* __restrict__ bsta
     acc = qpoint_add<P>(acc, cur);
   }
   qpoint_store<P>(bucket_acc + (size_t)g * 128, acc);
+}
+
+// The same with ONE LANE per bucket (vdf_hip_tuning.fixup_serial): the heads are added by ec.cuh's xyzz_add_lazy, ~3,300
+// instructions per addition where a quad spends 4 x ~2,070 -- on a device whose limit is instruction issue, a bucket's few heads
+// cost 2.4 times less this way; what it gives up is latency (one lane's addition is 14 dependent products, a quad's is 4
+// stages), so buckets spanning more than `serial_span` slices still go to the wavefront queue.
+template <class P>
+__global__ __launch_bounds__(256) void k_fixup_serial(const uint32_t* __restrict__ bstart, uint32_t nkeys, uint32_t slots,
+                                                      uint32_t Lfixed, char* __restrict__ bucket_acc,
+                                                      const char* __restrict__ heads, uint32_t* __restrict__ heavy,
+                                                      uint32_t heavy_min, uint32_t giant_span, int wave_prio) {
+  raise_wave_priority(wave_prio);
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nkeys) return;
+  const uint32_t ne = bstart[nkeys];
+  const uint32_t L = slice_len(ne, slots, Lfixed);
+  const uint32_t s = bstart[g], e = bstart[g + 1];
+  if (e <= s) return;
+  const uint32_t tf = s / L, tl = (e - 1) / L;
+  if (tl == tf) return;
+  uint32_t heavy_span = 2u * ((ne / nkeys + L - 1) / L) + 4u;
+  if (heavy_span < heavy_min) heavy_span = heavy_min;
+  if (tl - tf > heavy_span) {
+    const HeavyLayout q = heavy_layout(heavy, nkeys);
+    bool queued = false;
+    if (tl - tf > giant_span) {
+      const uint32_t idx = atomicAdd(q.giant_count, 1u);
+      if (idx < MAX_GIANTS) { q.giants[idx] = g; queued = true; }
+    }
+    if (!queued) q.items[atomicAdd(q.count, 1u)] = g;
+    return;
+  }
+  XYZZ<P> acc = xyzz_load<P>(bucket_acc + (size_t)g * 128);          // lazy coordinates, identity = all-zero zz
+  bool have = !fe_is_zero(acc.zz), flip = false;
+  if (have) { acc.x = fe_canon(acc.x); acc.y = fe_canon(acc.y); acc.zz = fe_canon(acc.zz); acc.zzz = fe_canon(acc.zzz); }
+  XYZZ<P> nxt = xyzz_load<P>(heads + (size_t)(tf + 1) * 128);
+  for (uint32_t t = tf + 1; t <= tl; ++t) {
+    XYZZ<P> cur = nxt;
+    if (t < tl) nxt = xyzz_load<P>(heads + (size_t)(t + 1) * 128);    // next head in flight during the addition
+    if (fe_is_zero(cur.zz)) continue;                                  // a head whose points cancelled
+    cur.x = fe_canon(cur.x); cur.y = fe_canon(cur.y); cur.zz = fe_canon(cur.zz); cur.zzz = fe_canon(cur.zzz);
+    if (have && flip) cur.y = fe_neg_nz(cur.y);
+    xyzz_add_lazy<P>(acc, have, flip, cur);
+  }
+  xyzz_store<P>(bucket_acc + (size_t)g * 128, xyzz_lazy_resolve<P>(acc, have, flip));
 }
 
 // One wavefront (16 quads) per queued heavy bucket: quads stride over the bucket's heads, then a 4-step butterfly of
@@ -1208,8 +1259,12 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[2], st));
   const FixupTune tune = fixup_tune();
   KTimer kt_tail(st, ext_bucket_acc ? "msm_fixup(2 launches)" : "msm_tail(fixup+reduce)", 0.0);
-  hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
-                     heavy, tune.heavy_min, tune.giant_span, prio);
+  if (tuning().fixup_serial)
+    hipLaunchKernelGGL((k_fixup_serial<P>), dim3((nkeys + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
+                       heavy, tune.heavy_min, tune.giant_span, prio);
+  else
+    hipLaunchKernelGGL((k_fixup<P>), dim3((nkeys * 4 + 255) / 256), dim3(256), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads,
+                       heavy, tune.heavy_min, tune.giant_span, prio);
   hipLaunchKernelGGL((k_fixup_heavy<P>), dim3(16 * GIANT_PARTS), dim3(64), 0, st, bstart, nkeys, p.slots, p.Lfixed, bucket_acc, heads, heavy,
                      base + w.giant, prio);
   if (!ext_bucket_acc) VDF_TRY(msm_tail_t<P>(p.c, p.sets, p.groups, p.nbk, bucket_acc, partials, wsum, d_out, st, prio));

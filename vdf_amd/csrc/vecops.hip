@@ -454,16 +454,10 @@ __global__ __launch_bounds__(256) void k_nifs_cross_f(Csr3 m, const char* __rest
 // the witness values a row needs sit in the 128 (96) bytes of its round and the one before.  Exact for ANY z2: the
 // constant's coefficient is multiplied by z2[one] (1 in a fresh instance).  The host checks the stencil against the
 // shape's triples before it uses this kernel (libvdf_nova.so public_params); other circuits keep k_nifs_cross.
+// A z2, B z2, C z2 of stencil row i (0 .. 3t) from the witness: the part both stencil kernels share
 template <class P, int PER>
-__global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restrict__ z2, size_t S, size_t one_col, uint64_t t,
-                                                            size_t row0, const char* __restrict__ az1, const char* __restrict__ bz1,
-                                                            const char* __restrict__ cz1, FeVal u1, char* __restrict__ az2,
-                                                            char* __restrict__ bz2, char* __restrict__ cz2, char* __restrict__ T) {
-  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i > 3 * t) return;
-  const size_t r = row0 + i;
-  const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+__device__ __forceinline__ void minroot_stencil_row(const char* __restrict__ z2, size_t S, size_t one_col, uint64_t t, uint64_t i,
+                                                    Fe<P>& a2, Fe<P>& b2, Fe<P>& c2) {
   const Fe<P> onev = fe_load<P>(z2 + one_col * 32);
   const Fe<P> i_in = fe_load<P>(z2 + (S - 1) * 32);
   // k * z2[one]: the constant's value is ONE in every fresh instance (the same for all lanes: a uniform branch), and then
@@ -488,7 +482,7 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
   const char* pa = role == 0 ? px : (role == 1 ? t1p : (role == 2 ? t1p + 32 : z2 + (S + (size_t)PER * t) * 32));
   const char* pb = role == 1 ? t1p : (role == 3 ? z2 + one_col * 32 : px);
   const char* pc = role == 3 ? z2 + (S - 1) * 32 : t1p + role * 32;
-  Fe<P> a2 = fe_load<P>(pa), b2 = fe_load<P>(pb), c2 = fe_load<P>(pc);
+  a2 = fe_load<P>(pa); b2 = fe_load<P>(pb); c2 = fe_load<P>(pc);
   const Fe<P> y = fe_load<P>(yp);
   if (PER == 3 && j > 0) {                                          // the loaded value is y_(j-1): turn it into x_j
     const Fe<P> xa = fe_add(fe_sub(role == 0 ? a2 : b2, i_in), times_one(j));
@@ -496,6 +490,20 @@ __global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restri
   }
   if (role == 2) c2 = fe_add(fe_sub(fe_add(c2, y), i_in), times_one(j + 1));
   if (role == 3) c2 = fe_sub(c2, times_one(t));
+}
+
+template <class P, int PER>
+__global__ __launch_bounds__(256) void k_nifs_cross_minroot(const char* __restrict__ z2, size_t S, size_t one_col, uint64_t t,
+                                                            size_t row0, const char* __restrict__ az1, const char* __restrict__ bz1,
+                                                            const char* __restrict__ cz1, FeVal u1, char* __restrict__ az2,
+                                                            char* __restrict__ bz2, char* __restrict__ cz2, char* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);     // light kernel: do not starve behind a co-running k_accumulate
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > 3 * t) return;
+  const size_t r = row0 + i;
+  const Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+  Fe<P> a2, b2, c2;
+  minroot_stencil_row<P, PER>(z2, S, one_col, t, i, a2, b2, c2);
   fe_store<P>(az2 + r * 32, a2);
   fe_store<P>(bz2 + r * 32, b2);
   fe_store<P>(cz2 + r * 32, c2);
@@ -552,6 +560,48 @@ __device__ __forceinline__ Fe<P> fe_mul_u128(const Fe<P>& y, const uint32_t r[4]
 #pragma unroll
   for (int i = 0; i < 8; ++i) hi.v[i] = d[i];                               // (d[8] = 0: c Ph < 2^254)
   return fe_sub(lo, hi);
+}
+
+// The stencil rows WITH the previous step's fold of those rows applied on the way: the rows' cross term needs
+// the running A z, B z, C z folded with the previous fresh ones -- which this very kernel wrote a step ago into az2 / bz2 / cz2
+// and is about to overwrite.  So each lane reads its row of the running vectors AND of the previous fresh ones, folds
+// (X1 <- X1 + r X2prev; E1 <- E1 + r Tprev when e1 is given), stores the folded row, and goes on as k_nifs_cross_minroot does
+// with the folded values.  One pass over the row's 7 (8) streams instead of a 5-vector k_fold_many over ALL rows in front of
+// it on the step's longest dependent path; the fold of z and of the ~10^4 other rows runs elsewhere, off that path.
+// U128: r is a plain integer below 2^128 (every NIFS challenge: fe_mul_u128, no Montgomery reduction), else Montgomery form.
+template <class P, int PER, bool U128>
+__global__ __launch_bounds__(256) void k_nifs_cross_minroot_fold(const char* __restrict__ z2, size_t S, size_t one_col, uint64_t t,
+                                                                 size_t row0, FeVal rv, char* __restrict__ az1, char* __restrict__ bz1,
+                                                                 char* __restrict__ cz1, char* __restrict__ e1, const char* tprev,
+                                                                 FeVal u1, char* az2, char* bz2, char* cz2, char* T) {
+  __builtin_amdgcn_s_setprio(3);
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > 3 * t) return;
+  const size_t r = row0 + i;
+  Fe<P> a1 = fe_load<P>(az1 + r * 32), b1 = fe_load<P>(bz1 + r * 32), c1 = fe_load<P>(cz1 + r * 32);
+  const Fe<P> ap = fe_load<P>(az2 + r * 32), bp = fe_load<P>(bz2 + r * 32), cp = fe_load<P>(cz2 + r * 32);
+  Fe<P> a2, b2, c2;
+  minroot_stencil_row<P, PER>(z2, S, one_col, t, i, a2, b2, c2);
+  const uint32_t rr[4] = {rv.v[0], rv.v[1], rv.v[2], rv.v[3]};
+  const Fe<P> rm = fe_from_val<P>(rv);
+  auto times_r = [&](const Fe<P>& y) -> Fe<P> { return U128 ? fe_mul_u128<P>(y, rr) : fe_mul(rm, y); };
+  if (e1) {
+    const Fe<P> e = fe_load<P>(e1 + r * 32), tp = fe_load<P>(tprev + r * 32);
+    fe_store<P>(e1 + r * 32, fe_add(e, times_r(tp)));
+  }
+  a1 = fe_add(a1, times_r(ap));
+  b1 = fe_add(b1, times_r(bp));
+  c1 = fe_add(c1, times_r(cp));
+  fe_store<P>(az1 + r * 32, a1);
+  fe_store<P>(bz1 + r * 32, b1);
+  fe_store<P>(cz1 + r * 32, c1);
+  fe_store<P>(az2 + r * 32, a2);
+  fe_store<P>(bz2 + r * 32, b2);
+  fe_store<P>(cz2 + r * 32, c2);
+  Fe<P> tt = fe_add(fe_mul(a1, b2), fe_mul(a2, b1));
+  tt = fe_sub(tt, fe_mul(fe_from_val<P>(u1), c2));
+  tt = fe_sub(tt, c1);
+  fe_store<P>(T + r * 32, tt);
 }
 
 // acc_k <- acc_k + r * add_k for up to 8 vectors in one launch (the witness fold W, E and the running Az, Bz, Cz)
@@ -768,6 +818,36 @@ Status vec_nifs_cross_minroot(int field, int per, uint64_t t, size_t seg_begin, 
   else if (field == VDF_FIELD_FQ) { if (per == 4) LAUNCH_MR(FqParams, 4); else LAUNCH_MR(FqParams, 3); }
   else return Status{VDF_ERR_BAD_ARG, "unknown field"};
 #undef LAUNCH_MR
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
+// r: Montgomery form (host); sent as a plain integer when it is below 2^128 and tuning().fold_u128 allows (as vec_fold_many does)
+template <class P> static bool plain_if_u128(const vdf_fe* r, FeVal& out) {
+  Fe<P> t; memcpy(t.v, r, 32); t = fe_from_mont(t); memcpy(out.v, t.v, 32);
+  return (out.v[4] | out.v[5] | out.v[6] | out.v[7]) == 0;
+}
+Status vec_nifs_cross_minroot_fold(int field, int per, uint64_t t, size_t seg_begin, size_t one_col, size_t row0, const void* z2,
+                                   const vdf_fe* r, void* az1, void* bz1, void* cz1, void* e1, const void* tprev, const vdf_fe* u1,
+                                   void* az2, void* bz2, void* cz2, void* T, hipStream_t s) {
+  if (per != 3 && per != 4) return Status{VDF_ERR_BAD_ARG, "variables per round must be 3 or 4"};
+  if (t == 0 || seg_begin < 3) return Status{VDF_ERR_BAD_ARG, "bad segment"};
+  if (field != VDF_FIELD_FP && field != VDF_FIELD_FQ) return Status{VDF_ERR_BAD_ARG, "unknown field"};
+  const size_t rows = 3 * (size_t)t + 1;
+  // algorithmic bytes: the row of 3 running vectors read and written, 3 previous fresh read, 3 fresh + T written (E and the
+  // previous T: read, read, written), and the round's variables once
+  KTimer kt(s, "k_nifs_cross_minroot_fold", (double)rows * (13 + (e1 ? 3 : 0)) * 32 + (double)per * t * 32);
+  const dim3 grid = grid_for(rows);
+  FeVal plain{};
+  const bool small = tuning().fold_u128 && (field == VDF_FIELD_FP ? plain_if_u128<FpParams>(r, plain) : plain_if_u128<FqParams>(r, plain));
+  const FeVal rv = small ? plain : to_val(r);
+#define LAUNCH_MRF(PP, PERV, U) hipLaunchKernelGGL((k_nifs_cross_minroot_fold<PP, PERV, U>), grid, dim3(256), 0, s, C(z2), seg_begin, one_col, t, row0, rv, \
+                                                  M(az1), M(bz1), M(cz1), M(e1), C(tprev), to_val(u1), M(az2), M(bz2), M(cz2), M(T))
+#define LAUNCH_MRF2(PP, PERV) do { if (small) LAUNCH_MRF(PP, PERV, true); else LAUNCH_MRF(PP, PERV, false); } while (0)
+  if (field == VDF_FIELD_FP) { if (per == 4) LAUNCH_MRF2(FpParams, 4); else LAUNCH_MRF2(FpParams, 3); }
+  else { if (per == 4) LAUNCH_MRF2(FqParams, 4); else LAUNCH_MRF2(FqParams, 3); }
+#undef LAUNCH_MRF2
+#undef LAUNCH_MRF
   VDF_TRY_HIP(hipGetLastError());
   return Status{};
 }

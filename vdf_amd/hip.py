@@ -17,7 +17,7 @@ class HipTuning(C.Structure):
     """vdf_hip_tuning (include/vdf_hip.h): process-wide tuning of the kernels."""
     _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in (
         "msm_direct", "direct_priority", "direct_fused", "light_priority", "accumulate_fill", "accumulate_lds", "slice_len", "part_bits",
-        "reduction", "reduction_quads", "heavy_min", "giant_span", "nifs_lanes", "shim_cache", "nifs_fused", "fold_u128")]
+        "reduction", "reduction_quads", "heavy_min", "giant_span", "nifs_lanes", "shim_cache", "nifs_fused", "fold_u128", "fixup_serial")]
 
 
 def tuning_get() -> HipTuning:
@@ -184,13 +184,19 @@ class MsmJob:
         return out
 
 
+QUEUE_CRITICAL, QUEUE_SIDE = 1, 2
+
+
 class Context:
     """One context per GPU (one process per GPU)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, pooled_role: int = 0):
+        """pooled_role: 0 = a context with a stream of its own (vdf_ctx_create); QUEUE_CRITICAL / QUEUE_SIDE = a stream from the
+        device's pool of hardware queues, shared once the budget is spent (vdf_ctx_create_pooled)."""
         h = C.c_void_p()
         dev = C.c_int(device)
-        rc = lib.vdf_ctx_create(C.byref(dev), 1, C.byref(h))
+        rc = (lib.vdf_ctx_create_pooled(C.byref(dev), 1, pooled_role, C.byref(h)) if pooled_role
+              else lib.vdf_ctx_create(C.byref(dev), 1, C.byref(h)))
         if rc != _lib.VDF_OK:
             raise VdfError(rc, (lib.vdf_last_error(None) or b"").decode())
         self.handle = h.value
@@ -213,6 +219,12 @@ class Context:
                 child.free()
             lib.vdf_ctx_destroy(self.handle)
             self.handle = None
+
+    def queue_info(self) -> dict:
+        """{"pooled", "sharers", "device_streams"}: vdf_ctx_queue_info."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib.vdf_ctx_queue_info(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pooled": bool(a.value), "sharers": b.value, "device_streams": c.value}
 
     def set_stream(self, stream_ptr: int) -> None:
         self._check(lib.vdf_ctx_set_stream(self.handle, stream_ptr))
@@ -430,6 +442,13 @@ class Context:
         """The 3t + 1 rows of a built-in MinRoot step circuit from row_begin on, by stencil (vdf_hip.h)."""
         self._check(lib.vdf_nifs_cross_term_minroot(self.handle, field, per, t, seg_begin, one_col, row_begin, _ptr(z2), _ptr(az1),
                                                     _ptr(bz1), _ptr(cz1), _ptr(u1), _ptr(az2), _ptr(bz2), _ptr(cz2), _ptr(T)))
+
+    def nifs_cross_term_minroot_fold(self, field, per, t, seg_begin, one_col, row_begin, z2, r, az1, bz1, cz1, e1, t_prev, u1, az2, bz2, cz2, T) -> None:
+        """The same rows with the previous fold of those rows applied on the way (vdf_hip.h); e1 / t_prev may be None."""
+        self._check(lib.vdf_nifs_cross_term_minroot_fold(self.handle, field, per, t, seg_begin, one_col, row_begin, _ptr(z2), _ptr(r), _ptr(az1),
+                                                         _ptr(bz1), _ptr(cz1), _ptr(e1) if e1 is not None else None,
+                                                         _ptr(t_prev) if t_prev is not None else None, _ptr(u1), _ptr(az2), _ptr(bz2),
+                                                         _ptr(cz2), _ptr(T)))
 
     def fold_many(self, field, r, acc, add, n) -> None:
         k = len(acc)

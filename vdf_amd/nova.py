@@ -103,7 +103,7 @@ class NovaTuning(C.Structure):
     """vdf_nova_tuning (include/vdf_nova.h): everything tunable about a parameter set and the prover over it."""
     _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("digit_budget_bytes", C.c_uint64)] + [(k, C.c_int32) for k in (
         "digit_window", "early_rows", "stencil", "small_window", "big_window", "packed_commit", "lookahead_early", "gate_accumulate",
-        "fold_on_rows", "nifs_ahead", "early_row_parts", "lookahead_priority", "side_accumulate_fill", "verbose", "compress_queues", "rows_at_challenge")]
+        "fold_on_rows", "nifs_ahead", "early_row_parts", "lookahead_priority", "side_accumulate_fill", "verbose", "compress_queues", "rows_at_challenge", "fold_fused")]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
