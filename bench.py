@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 # A prove_step keeps three queues busy at once (the step's chain, the next step's rounds, the early rows of T) beside the
 # two of the MSM leg and torch's own: with the runtime's default of 4 hardware queues they share, and the chain's
 # kernels then wait behind another queue's 0.25 ms bucket accumulation (measured: 1.5 ms per step instead of 1.05).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

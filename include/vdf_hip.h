@@ -66,8 +66,9 @@ enum { VDF_FIELD_FP = 0, VDF_FIELD_FQ = 1 };          /* S2 = Fp, S1 = Fq, src/n
 int  vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out);
 void vdf_ctx_destroy(vdf_ctx* ctx);
 /* The budget of hardware queues.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (this
- * library asks for 8 when it makes the process's first HIP call); with more streams than queues, kernels of one stream wait
- * behind another's (two provers and a compression -- 11 streams -- ran slower than one prover).  A context made HERE takes
+ * library asks for 16 when it makes the process's first HIP call and the variable is unset; the runtime's default is 4); with
+ * more streams than queues, kernels of one stream wait behind another's (measured with 8: two provers and a compression -- 11
+ * streams -- ran slower than one prover; with 16 they run at the two-prover rate).  A context made HERE takes
  * its stream from a per-device pool instead of opening one: a new stream while the device's streams known to this library
  * (vdf_ctx_create contexts + pooled ones) number less than the budget minus one (left to the host's own streams: torch's,
  * a caller's copies), otherwise it SHARES the least used pooled stream of its role -- VDF_QUEUE_SIDE contexts (work with a

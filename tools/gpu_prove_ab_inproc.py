@@ -5,7 +5,7 @@ run and a field of vdf_nova_tuning goes into its own parameter set.
 usage: gpu_prove_ab_inproc.py <rounds> <steps> base fused:fold_fused=1 serial:fixup_serial=1 ..."""
 import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import vdf_amd
 from vdf_amd import hip
 from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode

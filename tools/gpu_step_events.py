@@ -2,7 +2,7 @@
 clock, vdf_nova_proof_kernel_events), for DESIGN.md 4.3.  usage: gpu_step_events.py [log2t] [ref|bound]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from oracle import pasta as o
 import vdf_amd
 from vdf_amd.minroot import PallasVDF, State, FIELD_FQ, EvalMode

@@ -8,7 +8,7 @@ import os as _os
 
 # The prover drives three device queues at once; the HIP runtime multiplexes streams onto 4 hardware queues
 # unless told otherwise, and kernels of one stream then wait behind another's.  Only effective before HIP initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from . import _lib  # noqa: F401,E402  (raises ImportError when libvdf_hip.so is missing)
 from .hip import Context, Bases, Shape, VdfError, ints_to_limbs, limbs_to_ints  # noqa: F401,E402

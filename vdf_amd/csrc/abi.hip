@@ -433,7 +433,7 @@ void build_dict_consts(std::array<uint32_t, 8>& one, std::array<uint32_t, 8>& mi
 }  // namespace
 
 // ---- the process's budget of hardware queues (include/vdf_hip.h vdf_ctx_create_pooled) -----------------------------------------
-// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (8 here); past that, streams share a queue and a kernel
+// The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (16 asked for below; 4 by default); past that, streams share a queue and a kernel
 // waits behind another stream's (two provers + a compression opened 11 streams: the two-chain rate fell below one chain's,
 // profiles/r04_box_spread.txt).  Contexts a library makes for its own queues take their stream from this per-device pool:
 // a new stream while the device's total (pooled + caller-owned contexts) is below the budget, else they SHARE the least used
@@ -529,7 +529,7 @@ static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_c
   // -- and set at most once per process (setenv is not safe against concurrent readers of the environment: a second prover thread making its
   // contexts, the runtime's own threads).  A host that makes its first HIP call elsewhere sets the variable itself.
   static std::once_flag hwq_once;
-  std::call_once(hwq_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+  std::call_once(hwq_once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); });
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
