@@ -79,6 +79,15 @@ void vdf_ctx_destroy(vdf_ctx* ctx);
 #define VDF_QUEUE_CRITICAL 1
 #define VDF_QUEUE_SIDE 2
 int  vdf_ctx_create_pooled(const int* device_ids, int n_devices, int role, vdf_ctx** out);
+/* ... and a queue that works HAND IN HAND with `parent`'s (a prover's look-ahead and early rows beside its chain).  The
+ * hardware takes queues onto its pipes in the order they were created, and which pipes a prover's three queues sit on is worth
+ * 10-14 % of its rate (measured: 1,114-1,125 prove_step/s when they were created back to back, 979-1,034 with one or two
+ * foreign streams opened in between; profiles/r05_single_chain_vs_padding.txt).  vdf_ctx_create therefore opens two more
+ * streams right behind the context's own and keeps them; this call hands them out (VDF_QUEUE_SIDE the first, VDF_QUEUE_CRITICAL
+ * the second), whatever the host has opened since.  When they are taken (a second prover on the same context), or `parent`
+ * runs on a foreign stream (vdf_ctx_set_stream), the context comes from the pool as above.  The streams live as long as any
+ * context that uses them. */
+int  vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out);
 /* *pooled = 1 for a pooled context, *sharers = contexts on its stream (1 = its own), *device_streams = streams this library
  * holds on the context's device.  Any output may be NULL. */
 int  vdf_ctx_queue_info(vdf_ctx* ctx, int* pooled, int* sharers, int* device_streams);

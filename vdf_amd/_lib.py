@@ -26,6 +26,7 @@ PROTOTYPES = {
     "vdf_ctx_create": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
     "vdf_ctx_destroy": (None, [_vp]),
     "vdf_ctx_create_pooled": (_i, [C.POINTER(_i), _i, _i, C.POINTER(_vp)]),
+    "vdf_ctx_create_pooled_near": (_i, [_vp, _i, C.POINTER(_vp)]),
     "vdf_ctx_queue_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "vdf_ctx_set_stream": (_i, [_vp, _vp]),
     "vdf_ctx_get_stream": (_vp, [_vp]),

@@ -495,6 +495,11 @@ void pool_count_owned(int device, int delta) {
   g_pool[device].owned += delta;
 }
 }  // namespace
+vdf_queue_family::~vdf_queue_family() {
+  int n = 0;
+  for (hipStream_t& q : s) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; ++n; }
+  if (n) pool_count_owned(device, -n);
+}
 
 extern "C" {
 
@@ -503,16 +508,34 @@ int vdf_ctx_device(vdf_ctx* ctx) { return ctx ? ctx->device : 0; }
 const char* vdf_version(void) { return "vdf_hip gfx950 r1 (" __DATE__ ")"; }
 
 static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_ctx** out);
+int vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out);
 int vdf_ctx_create(const int* device_ids, int n_devices, vdf_ctx** out) { return ctx_create_impl(device_ids, n_devices, 0, out); }
 int vdf_ctx_create_pooled(const int* device_ids, int n_devices, int role, vdf_ctx** out) {
   if (role != VDF_QUEUE_CRITICAL && role != VDF_QUEUE_SIDE) { g_create_err = "vdf_ctx_create_pooled: unknown role"; return VDF_ERR_BAD_ARG; }
   return ctx_create_impl(device_ids, n_devices, role, out);
 }
+int vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out) {
+  if (!parent || !out) { g_create_err = "vdf_ctx_create_pooled_near: null argument"; return VDF_ERR_BAD_ARG; }
+  if (role != VDF_QUEUE_CRITICAL && role != VDF_QUEUE_SIDE) { g_create_err = "vdf_ctx_create_pooled_near: unknown role"; return VDF_ERR_BAD_ARG; }
+  const int dev = parent->device;
+  std::shared_ptr<vdf_queue_family> fam;
+  int idx = -1;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    const int want = role == VDF_QUEUE_SIDE ? 1 : 2;                  // the neighbour right behind the parent's stream, and the one after it
+    if (parent->family && parent->family->s[want] && !parent->family->used[want]) { fam = parent->family; idx = want; fam->used[idx] = true; }
+  }
+  if (idx < 0) return vdf_ctx_create_pooled(&dev, 1, role, out);    // taken (a second prover on this context) or no family: the pool
+  const int rc = ctx_create_impl(&dev, 1, -1, out);                  // role -1: no stream of its own
+  if (rc != VDF_OK) { std::lock_guard<std::mutex> lock(g_pool_mu); fam->used[idx] = false; return rc; }
+  (*out)->family = fam; (*out)->family_idx = idx; (*out)->stream = fam->s[idx];
+  return VDF_OK;
+}
 int vdf_ctx_queue_info(vdf_ctx* ctx, int* pooled, int* sharers, int* device_streams) {
   if (!ctx) return VDF_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lock(g_pool_mu);
   DevicePool& dp = g_pool[ctx->device];
-  if (pooled) *pooled = ctx->pool_slot >= 0 ? 1 : 0;
+  if (pooled) *pooled = (ctx->pool_slot >= 0 || ctx->family_idx > 0) ? 1 : 0;
   if (sharers) *sharers = ctx->pool_slot >= 0 ? dp.streams[ctx->pool_slot].users : 1;
   if (device_streams) { int live = dp.owned; for (const PoolStream& ps : dp.streams) if (ps.users) ++live; *device_streams = live; }
   return VDF_OK;
@@ -543,8 +566,16 @@ static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_c
   c->device = device_ids[0];
   e = hipSetDevice(c->device);
   if (e == hipSuccess) {
-    if (role == 0) { e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); if (e == hipSuccess) { c->own_stream = true; pool_count_owned(c->device, +1); } }
-    else e = pool_take(c->device, role, &c->stream, &c->pool_slot);
+    if (role == 0) {
+      // the context's stream and two more right behind it: neighbours in the hardware's queue order, kept for the queues a
+      // prover opens beside this one (vdf_ctx_create_pooled_near; profiles/r05_single_chain_vs_padding.txt)
+      auto fam = std::make_shared<vdf_queue_family>();
+      fam->device = c->device;
+      int made = 0;
+      for (int k = 0; k < 3 && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&fam->s[k], hipStreamNonBlocking); if (e == hipSuccess) ++made; }
+      pool_count_owned(c->device, made);
+      if (e == hipSuccess) { fam->used[0] = true; c->family = fam; c->family_idx = 0; c->stream = fam->s[0]; }
+    } else if (role > 0) e = pool_take(c->device, role, &c->stream, &c->pool_slot);
   }
   if (e == hipSuccess) e = hipMalloc(&c->d_out, 256);
   if (e == hipSuccess) e = hipMalloc(&c->small_pool, vdf_ctx::SMALL_POOL_BYTES);
@@ -562,7 +593,7 @@ static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_c
   if (e != hipSuccess) {
     g_create_err = std::string("vdf_ctx_create: ") + hipGetErrorString(e);
     if (c->pool_slot >= 0) pool_release(c->device, c->pool_slot);
-    if (c->own_stream) { if (c->stream) (void)hipStreamDestroy(c->stream); pool_count_owned(c->device, -1); }
+    c->family.reset();
     delete c;
     return VDF_ERR_DEVICE;
   }
@@ -592,6 +623,8 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   }
   if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); pool_count_owned(ctx->device, -1); }
   if (ctx->pool_slot >= 0) pool_release(ctx->device, ctx->pool_slot);
+  if (ctx->family) { std::lock_guard<std::mutex> lock(g_pool_mu); ctx->family->used[ctx->family_idx] = false; }
+  ctx->family.reset();                               // the family's streams go with its last member
   delete ctx;
 }
 
@@ -600,6 +633,7 @@ int vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream) {
     VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); pool_count_owned(ctx->device, -1); }
     if (ctx->pool_slot >= 0) { pool_release(ctx->device, ctx->pool_slot); ctx->pool_slot = -1; }
+    if (ctx->family) { { std::lock_guard<std::mutex> lock(g_pool_mu); ctx->family->used[ctx->family_idx] = false; } ctx->family.reset(); ctx->family_idx = -1; }
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
     return Status{};

@@ -226,7 +226,7 @@ int alloc_proof_buffers(vdf_proof* p) {
   for (int k = 0; k < vdf_proof::DEPTH; ++k) {
     if (pp->seg_gens) HIPCALL(ctx, vdf_dev_alloc(ctx, (3 * pp->t + 4) * 32, &p->d_packed[k]));
     const int dev = vdf_ctx_device(ctx);
-    if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_SIDE, &p->ctx2[k]) != VDF_OK)
+    if ((k == 0 ? vdf_ctx_create_pooled_near(ctx, VDF_QUEUE_SIDE, &p->ctx2[k]) : vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_SIDE, &p->ctx2[k])) != VDF_OK)
       return fail(VDF_ERR_DEVICE, std::string("lookahead context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx2[k], vdf_ctx_set_async(p->ctx2[k], 1));
     // the lookahead's commitment is needed a whole step later: its sort and bucket reduction yield to the early rows' (the
@@ -237,8 +237,7 @@ int alloc_proof_buffers(vdf_proof* p) {
     HIPCALL(p->ctx2[k], vdf_ctx_set_accumulate_fill(p->ctx2[k], pp->tune.side_accumulate_fill));
   }
   {
-    const int dev = vdf_ctx_device(ctx);
-    if (vdf_ctx_create_pooled(&dev, 1, VDF_QUEUE_CRITICAL, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
+    if (vdf_ctx_create_pooled_near(ctx, VDF_QUEUE_CRITICAL, &p->ctx3) != VDF_OK) return fail(VDF_ERR_DEVICE, std::string("early-rows context: ") + vdf_last_error(nullptr));
     HIPCALL(p->ctx3, vdf_ctx_set_async(p->ctx3, 1));
     HIPCALL(p->ctx3, vdf_ctx_set_accumulate_fill(p->ctx3, pp->tune.side_accumulate_fill));
   }

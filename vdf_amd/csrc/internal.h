@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -40,11 +41,22 @@ struct KTimer {
 
 namespace vdf { const vdf_hip_tuning& tuning(); }     // process-wide tuning (abi.hip), environment overrides applied once
 
+// A caller context's stream and the two streams opened right behind it (abi.hip: the hardware maps queues to its pipes in the
+// order they were created, and a prover whose three queues are neighbours runs 10-14 % faster than one whose queues are not)
+struct vdf_queue_family {
+  int device = 0;
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  bool used[3] = {false, false, false};
+  ~vdf_queue_family();
+};
+
 struct vdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int pool_slot = -1;                // >= 0: the stream belongs to the device's pool of hardware queues (vdf_ctx_create_pooled)
+  std::shared_ptr<vdf_queue_family> family;   // the stream is family->s[family_idx] (vdf_ctx_create: 0; vdf_ctx_create_pooled_near: 1, 2)
+  int family_idx = -1;
   bool async = false;
   int msm_window = 0;          // 0 = automatic
   std::mutex mu;
