@@ -1265,6 +1265,8 @@ def main():
         for k in range(1, depth):                 # the MSM legs are done: the prover needs the hardware queues (three per chain)
             shs[k] = None
             ctxs[k].close()
+        ctx.sync()
+        ctx.set_stream(None)                      # the chain on the context's own stream: its neighbours are the prover's side queues
         mine = prove_step_leg(ctx, args.prove_log2t, args.prove_steps, kind=1, repeats=1, chains=1, with_compress=False,
                               with_roofline=False, seed_offset=rank, digit_budget_gib=args.digit_budget_gib)
         r = torch.tensor([mine["value"], -mine["value"], mine["value"], 1.0 if mine["verified"] else 0.0],
@@ -1363,6 +1365,11 @@ def main():
             ctx.set_async(False)
             for c in ctxs[1:]:                    # the MSM leg's other queues are done: a prover needs the hardware queues (three per chain)
                 c.close()
+            # the MSM leg ran the context on a torch stream (its collective is ordered there); the prover's chain runs on the
+            # context's OWN stream again, whose two neighbours in creation order are its look-ahead and early-rows queues
+            # (vdf_hip.h vdf_ctx_create_pooled_near: worth 10 % of the rate, profiles/r05_single_chain_vs_padding.txt)
+            ctx.sync()
+            ctx.set_stream(None)
             # one forward evaluation serves both forms of the step circuit (the circuits hold states and traces, not shapes);
             # the second chain of the two-chain leg is evaluated on another host thread meanwhile (ctypes releases the GIL)
             import threading

@@ -91,7 +91,8 @@ int  vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out);
 /* *pooled = 1 for a pooled context, *sharers = contexts on its stream (1 = its own), *device_streams = streams this library
  * holds on the context's device.  Any output may be NULL. */
 int  vdf_ctx_queue_info(vdf_ctx* ctx, int* pooled, int* sharers, int* device_streams);
-/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own; NULL = back to the context's own
+ * (whose neighbours vdf_ctx_create_pooled_near hands out: a prover on a foreign stream takes its queues from the pool). */
 int  vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream);
 void* vdf_ctx_get_stream(vdf_ctx* ctx);
 /* async != 0: calls whose buffers are all device-resident return after enqueueing. */

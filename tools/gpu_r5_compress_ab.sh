@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r5
+mkdir -p $OUT
+cd $R
+for round in 1 2; do
+for cfg in "X=1" "VDF_MSM_FIXUP_SERIAL=0" "GPU_MAX_HW_QUEUES=8" "VDF_MSM_FIXUP_SERIAL=0 GPU_MAX_HW_QUEUES=8"; do
+  echo "== [$cfg] $(env $cfg timeout -k 10 120 python3 tools/gpu_compress_time.py 16 2>&1 | grep "^compress\|^timed pass" | tr '\n' '|')"
+done; done | tee $OUT/compress_ab.txt
+env timeout -k 10 120 python3 tools/gpu_compress_time.py 16 > $OUT/compress_per_kernel.txt 2>&1

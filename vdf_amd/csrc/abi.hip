@@ -495,6 +495,9 @@ void pool_count_owned(int device, int delta) {
   g_pool[device].owned += delta;
 }
 }  // namespace
+// (experiment knobs, read once: which of the family's streams a role takes, and how many it opens)
+static int family_slot(const char* name, int dflt) { const char* e = std::getenv(name); const int v = e ? std::atoi(e) : dflt; return v >= 1 && v < vdf_queue_family::N ? v : dflt; }
+static int family_size() { const int a = family_slot("VDF_Q_SIDE", 1), b = family_slot("VDF_Q_CRITICAL", 2); return 1 + (a > b ? a : b); }
 vdf_queue_family::~vdf_queue_family() {
   int n = 0;
   for (hipStream_t& q : s) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; ++n; }
@@ -522,8 +525,8 @@ int vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out) {
   int idx = -1;
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    const int want = role == VDF_QUEUE_SIDE ? 1 : 2;                  // the neighbour right behind the parent's stream, and the one after it
-    if (parent->family && parent->family->s[want] && !parent->family->used[want]) { fam = parent->family; idx = want; fam->used[idx] = true; }
+    const int want = role == VDF_QUEUE_SIDE ? family_slot("VDF_Q_SIDE", 1) : family_slot("VDF_Q_CRITICAL", 2);   // the neighbour right behind the parent's stream, and the one after it
+    if (parent->family && !parent->foreign_stream && parent->family->s[want] && !parent->family->used[want]) { fam = parent->family; idx = want; fam->used[idx] = true; }
   }
   if (idx < 0) return vdf_ctx_create_pooled(&dev, 1, role, out);    // taken (a second prover on this context) or no family: the pool
   const int rc = ctx_create_impl(&dev, 1, -1, out);                  // role -1: no stream of its own
@@ -572,7 +575,7 @@ static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_c
       auto fam = std::make_shared<vdf_queue_family>();
       fam->device = c->device;
       int made = 0;
-      for (int k = 0; k < 3 && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&fam->s[k], hipStreamNonBlocking); if (e == hipSuccess) ++made; }
+      for (int k = 0; k < family_size() && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&fam->s[k], hipStreamNonBlocking); if (e == hipSuccess) ++made; }
       pool_count_owned(c->device, made);
       if (e == hipSuccess) { fam->used[0] = true; c->family = fam; c->family_idx = 0; c->stream = fam->s[0]; }
     } else if (role > 0) e = pool_take(c->device, role, &c->stream, &c->pool_slot);
@@ -631,11 +634,17 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
 int vdf_ctx_set_stream(vdf_ctx* ctx, void* hip_stream) {
   return guarded(ctx, [&]() -> Status {
     VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+    if (!hip_stream) {                                   // back to the context's own stream (a foreign one was set before)
+      if (ctx->family && ctx->family_idx >= 0) { ctx->stream = ctx->family->s[ctx->family_idx]; ctx->foreign_stream = false; return Status{}; }
+      if (ctx->foreign_stream) return Status{VDF_ERR_BAD_ARG, "this context has no stream of its own to return to"};
+      return Status{};
+    }
     if (ctx->own_stream && ctx->stream) { (void)hipStreamDestroy(ctx->stream); pool_count_owned(ctx->device, -1); }
     if (ctx->pool_slot >= 0) { pool_release(ctx->device, ctx->pool_slot); ctx->pool_slot = -1; }
-    if (ctx->family) { { std::lock_guard<std::mutex> lock(g_pool_mu); ctx->family->used[ctx->family_idx] = false; } ctx->family.reset(); ctx->family_idx = -1; }
+    // (a family member keeps its place: vdf_ctx_set_stream(ctx, NULL) returns to it; its neighbours are not handed out meanwhile)
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
+    ctx->foreign_stream = true;
     return Status{};
   });
 }

@@ -467,6 +467,9 @@ int ipa_verify_many(const Side& sd, Transcript& tr, IpaCheck* jobs, int njobs, v
   return VDF_OK;
 }
 
+// tables of this many entries and fewer finish their sum-check on the host (a power of two; at least 2)
+constexpr size_t SUMCHECK_HOST_TAIL = 512;
+
 int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, const Fe* X, const void* d_z, const void* d_E,
                   Spartan* out) {
   const Side* pp = &sd;
@@ -502,7 +505,8 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
   {
     const vdf_fe* tabs[5] = {(const vdf_fe*)d_eq, (const vdf_fe*)d_az, (const vdf_fe*)d_bz, (const vdf_fe*)d_cz, (const vdf_fe*)d_e};
     vdf_fe* vecs[5] = {(vdf_fe*)d_eq, (vdf_fe*)d_az, (vdf_fe*)d_bz, (vdf_fe*)d_cz, (vdf_fe*)d_e};
-    for (size_t n = L.M; n > 1; n >>= 1) {
+    size_t n = L.M;
+    for (; n > SUMCHECK_HOST_TAIL; n >>= 1) {
       std::array<Fe, 3> ev;
       HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_R1CS_ROUND, tabs, (const vdf_fe*)&u, n, (vdf_fe*)ev.data()));
       tr.absorb_fe("outer", ev.data(), 3, F);
@@ -513,12 +517,36 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
       out->outer.push_back(ev);
       rx.push_back(r);
     }
+    // The last rounds on the HOST: a round over a table of a few hundred entries is two launches, a synchronisation and the
+    // transcript -- ~0.25 ms of latency for microseconds of arithmetic -- nine times per sum-check.  The tables come down once
+    // (5 x 512 elements) and the same sums, the same challenges and the same folds follow in host arithmetic (exact: the
+    // values are the kernels', snark.hip reduce_term<2> / k_fold_halves).
+    std::vector<Fe> hv[5];
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    for (int k = 0; k < 5; ++k) { hv[k].resize(n); HIPCALL(ctx, vdf_dev_memcpy(ctx, hv[k].data(), vecs[k], n * 32)); }
+    for (; n > 1; n >>= 1) {
+      const size_t h = n / 2;
+      std::array<Fe, 3> ev = {zero(), zero(), zero()};
+      for (size_t i = 0; i < h; ++i) {
+        Fe lo[5], d[5], v[5];
+        for (int k = 0; k < 5; ++k) { lo[k] = hv[k][i]; d[k] = sub(hv[k][h + i], lo[k], F); }
+        auto term = [&](const Fe* w) { return mul(w[0], sub(sub(mul(w[1], w[2], F), mul(u, w[3], F), F), w[4], F), F); };
+        ev[0] = add(ev[0], term(lo), F);
+        for (int k = 0; k < 5; ++k) v[k] = add(lo[k], add(d[k], d[k], F), F);
+        ev[1] = add(ev[1], term(v), F);
+        for (int k = 0; k < 5; ++k) v[k] = add(v[k], d[k], F);
+        ev[2] = add(ev[2], term(v), F);
+      }
+      tr.absorb_fe("outer", ev.data(), 3, F);
+      const Fe r = tr.challenge("outer", F, raw);
+      const Fe omr = sub(one(F), r, F);
+      for (int k = 0; k < 5; ++k)
+        for (size_t i = 0; i < h; ++i) hv[k][i] = add(mul(omr, hv[k][i], F), mul(r, hv[k][h + i], F), F);
+      out->outer.push_back(ev);
+      rx.push_back(r);
+    }
+    out->claims[0] = hv[1][0]; out->claims[1] = hv[2][0]; out->claims[2] = hv[3][0]; out->claims[3] = hv[4][0];
   }
-  HIPCALL(ctx, vdf_ctx_sync(ctx));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, &out->claims[0], d_az, 32));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, &out->claims[1], d_bz, 32));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, &out->claims[2], d_cz, 32));
-  HIPCALL(ctx, vdf_dev_memcpy(ctx, &out->claims[3], d_e, 32));
   tr.absorb_fe("claims", out->claims, 4, F);
   const Fe rho = tr.challenge("rho", F, raw);
   // ---- inner sum-check -----------------------------------------------------------------------------------
@@ -533,7 +561,8 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
   {
     const vdf_fe* tabs[2] = {(const vdf_fe*)d_mvec, (const vdf_fe*)d_zpad};
     vdf_fe* vecs[2] = {(vdf_fe*)d_mvec, (vdf_fe*)d_zpad};
-    for (size_t n = L.Z; n > 1; n >>= 1) {
+    size_t n = L.Z;
+    for (; n > SUMCHECK_HOST_TAIL; n >>= 1) {
       std::array<Fe, 2> ev;
       HIPCALL(ctx, vdf_reduce(ctx, sd.field, VDF_REDUCE_QUADRATIC_ROUND, tabs, nullptr, n, (vdf_fe*)ev.data()));
       tr.absorb_fe("inner", ev.data(), 2, F);
@@ -541,6 +570,25 @@ int spartan_prove(const Side& sd, const Aff& cW, const Aff& cE, const Fe& u, con
       const Fe omr = sub(one(F), r, F);
       const Fe c_lo[2] = {omr, omr}, c_hi[2] = {r, r};
       HIPCALL(ctx, vdf_fold_halves(ctx, sd.field, 2, vecs, (const vdf_fe*)c_lo, (const vdf_fe*)c_hi, n));
+      out->inner.push_back(ev);
+      ry.push_back(r);
+    }
+    std::vector<Fe> hv[2];                                      // the last rounds on the host (as in the outer sum-check)
+    HIPCALL(ctx, vdf_ctx_sync(ctx));
+    for (int k = 0; k < 2; ++k) { hv[k].resize(n); HIPCALL(ctx, vdf_dev_memcpy(ctx, hv[k].data(), vecs[k], n * 32)); }
+    for (; n > 1; n >>= 1) {
+      const size_t h = n / 2;
+      std::array<Fe, 2> ev = {zero(), zero()};
+      for (size_t i = 0; i < h; ++i) {
+        const Fe p0 = hv[0][i], p1 = hv[0][h + i], q0 = hv[1][i], q1 = hv[1][h + i];
+        ev[0] = add(ev[0], mul(p0, q0, F), F);
+        ev[1] = add(ev[1], mul(sub(add(p1, p1, F), p0, F), sub(add(q1, q1, F), q0, F), F), F);
+      }
+      tr.absorb_fe("inner", ev.data(), 2, F);
+      const Fe r = tr.challenge("inner", F, raw);
+      const Fe omr = sub(one(F), r, F);
+      for (int k = 0; k < 2; ++k)
+        for (size_t i = 0; i < h; ++i) hv[k][i] = add(mul(omr, hv[k][i], F), mul(r, hv[k][h + i], F), F);
       out->inner.push_back(ev);
       ry.push_back(r);
     }

@@ -45,8 +45,9 @@ namespace vdf { const vdf_hip_tuning& tuning(); }     // process-wide tuning (ab
 // order they were created, and a prover whose three queues are neighbours runs 10-14 % faster than one whose queues are not)
 struct vdf_queue_family {
   int device = 0;
-  hipStream_t s[3] = {nullptr, nullptr, nullptr};
-  bool used[3] = {false, false, false};
+  static constexpr int N = 6;
+  hipStream_t s[N] = {};
+  bool used[N] = {};
   ~vdf_queue_family();
 };
 
@@ -57,6 +58,7 @@ struct vdf_ctx {
   int pool_slot = -1;                // >= 0: the stream belongs to the device's pool of hardware queues (vdf_ctx_create_pooled)
   std::shared_ptr<vdf_queue_family> family;   // the stream is family->s[family_idx] (vdf_ctx_create: 0; vdf_ctx_create_pooled_near: 1, 2)
   int family_idx = -1;
+  bool foreign_stream = false;       // vdf_ctx_set_stream put a caller's stream in place of the context's own
   bool async = false;
   int msm_window = 0;          // 0 = automatic
   std::mutex mu;

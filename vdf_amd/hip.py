@@ -226,8 +226,9 @@ class Context:
         self._check(lib.vdf_ctx_queue_info(self.handle, C.byref(a), C.byref(b), C.byref(c)))
         return {"pooled": bool(a.value), "sharers": b.value, "device_streams": c.value}
 
-    def set_stream(self, stream_ptr: int) -> None:
-        self._check(lib.vdf_ctx_set_stream(self.handle, stream_ptr))
+    def set_stream(self, stream_ptr) -> None:
+        """A foreign hipStream_t (e.g. a torch stream's .cuda_stream); None / 0 = back to the context's own."""
+        self._check(lib.vdf_ctx_set_stream(self.handle, stream_ptr or None))
 
     @property
     def stream(self) -> int:
