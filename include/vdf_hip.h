@@ -455,6 +455,8 @@ typedef struct vdf_hip_tuning {
                                   without a Montgomery reduction (fe_mul_u128); 0: the general multiplication (1) */
   int32_t fixup_serial;        /* 1: the slice heads of a bucket are added by ONE lane (k_fixup_serial: 2.4 x fewer instructions per
                                   addition, a longer dependent chain; 1); 0: by a quad of lanes (k_fixup) */
+  int32_t sort_staged;         /* 1: the sort's second pass lays a tile of entries out bucket by bucket in LDS and writes whole
+                                  runs (k_fine_staged); 0: every entry written on its own (k_fine) */
 } vdf_hip_tuning;
 int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
 int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */

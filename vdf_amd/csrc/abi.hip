@@ -123,7 +123,7 @@ vdf_hip_tuning tuning_defaults() {
   t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
   t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
   t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0; t.nifs_fused = 1; t.fold_u128 = 1;
-  t.fixup_serial = 1;
+  t.fixup_serial = 1; t.sort_staged = 1;
   return t;
 }
 bool tuning_valid(const vdf_hip_tuning& t) {
@@ -133,7 +133,7 @@ bool tuning_valid(const vdf_hip_tuning& t) {
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
          (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) &&
-         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1) && in(t.fixup_serial, 0, 1);
+         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1) && in(t.fixup_serial, 0, 1) && in(t.sort_staged, 0, 1);
 }
 void tuning_publish(const vdf_hip_tuning& t) {           // caller holds g_tune_mu (or is the once-initialiser)
   g_tune_snapshots.push_back(t);
@@ -149,7 +149,7 @@ void tuning_from_env() {
       {"VDF_MSM_L", &t.slice_len}, {"VDF_MSM_PB", &t.part_bits}, {"VDF_MSM_RED", &t.reduction},
       {"VDF_MSM_RED_QUADS", &t.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &t.heavy_min}, {"VDF_MSM_GIANT_SPAN", &t.giant_span},
       {"VDF_NIFS_LANES", &t.nifs_lanes}, {"VDF_SHIM_CACHE", &t.shim_cache}, {"VDF_NIFS_FUSED", &t.nifs_fused}, {"VDF_FOLD_U128", &t.fold_u128},
-      {"VDF_MSM_FIXUP_SERIAL", &t.fixup_serial}};
+      {"VDF_MSM_FIXUP_SERIAL", &t.fixup_serial}, {"VDF_MSM_SORT_STAGED", &t.sort_staged}};
   for (const auto& v : vars) {
     const char* e = std::getenv(v.name);
     if (!e || !*e) continue;

@@ -212,11 +212,12 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.pb = 0;
   while (p.pb < c - 1 && ((uint32_t)p.gsets << p.pb) < (uint32_t)num_cus) ++p.pb;
   if (tuning().part_bits >= 0 && tuning().part_bits <= c - 1) p.pb = tuning().part_bits;      // tuning override
-  // windows of 18 bits and more: pass B with more than 2^8 fine buckets per partition collapses (k_fine at 2^22 points: 0.65 ms
-  // at 8 fine bits, 3.0 at 9, 6.0 at 10 with 256 partitions -- 2^9..2^10 four-byte write streams per workgroup defeat the
-  // L2's write combining; profiles/r05_window_sweep.txt), so the partitions take the surplus bits instead (up to 8192 of them:
-  // pass A's cursors are 32 KB of LDS) and its chunks grow so that a (workgroup, partition) run stays a few lines long
-  const int fine_max = c >= 18 && tuning().part_bits < 0 ? 8 : 10;
+  // windows of 18 bits and more WITHOUT the staged sort (sort_staged = 0): the partitions take the surplus bits (up to 8192 of
+  // them: pass A's cursors are 32 KB of LDS), pass B keeps 2^8 fine buckets, and pass A's chunks grow so that a (workgroup,
+  // partition) run stays a few lines long (window 20 at 2^22 points: sort 1.78 -> 1.16 ms; profiles/r05_window_sweep.txt)
+  // (with the STAGED sort, sort_staged = 1, both passes write whole pieces whatever the bucket count, and pass A's staging
+  // needs few partitions to have several records per partition and tile: 512 partitions, up to 2^10 fine buckets)
+  const int fine_max = c >= 18 && tuning().part_bits < 0 && !tuning().sort_staged ? 8 : 10;
   while (c - 1 - p.pb > fine_max) ++p.pb;
   while (p.pb > 0 && ((uint32_t)p.gsets << p.pb) > 8192u) --p.pb;
   p.fb = c - 1 - p.pb;
@@ -296,7 +297,7 @@ template <class SP, bool SCATTER>
 __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c, int windows, int sets, int pb, int fb,
                                               uint32_t bins, uint32_t chA, uint32_t tstride,
                                               uint32_t* __restrict__ countsA, const uint32_t* __restrict__ pstart,
-                                              uint64_t* __restrict__ recs, int wave_prio) {
+                                              uint32_t* __restrict__ recsP, uint16_t* __restrict__ recsK, int wave_prio) {
   raise_wave_priority(wave_prio);
   __shared__ uint32_t limbs[9 * 256];
   extern __shared__ uint32_t cur[];                   // bins counters (histogram) or cursors (scatter)
@@ -328,12 +329,99 @@ __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c,
       const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
       const uint32_t bin = ((set0 + s) << pb) | ((mag - 1) >> fb);
       const uint32_t pos = atomicAdd(&cur[bin], 1u);
-      if (SCATTER) recs[pos] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + pbase + i) | (d & SIGN_BIT));
+      if (SCATTER) { recsP[pos] = (j * tstride + pbase + i) | (d & SIGN_BIT); recsK[pos] = (uint16_t)((mag - 1) & fmask); }
     }
   }
   if (!SCATTER) {
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < bins; b += 256) mine[b] = cur[b];
+  }
+}
+
+// Pass A's scatter STAGED through LDS (vdf_hip_tuning.sort_staged; up to 512 partitions, up to 16 windows).  k_part<true>
+// writes every 8-byte record on its own, and a (workgroup, partition) run -- contiguous in memory -- fills over the whole
+// life of the workgroup: with 2048 partitions and 64 workgroups per XCD that is 16 MB of half-written lines against 4 MB of
+// L2, and the lines go to HBM several times (2^24 points, window 20: 2.3 ms for 1.75 GB).  Here a workgroup takes its chunk
+// in tiles of 256 scalars: the tile's records (up to 4096) are ranked by partition in LDS, laid out partition by partition,
+// and copied out by consecutive lanes, so a partition's share of a tile (8 records on average at 512 partitions) leaves as
+// one 64-byte piece.  Same cursors, same result layout as k_part<true>; the order inside a run differs, which nothing reads.
+static constexpr uint32_t PART_STAGE_BINS = 512;
+template <class SP>
+__global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont, int c, int windows, int sets, int pb, int fb,
+                                                     uint32_t bins, uint32_t chA, uint32_t tstride,
+                                                     const uint32_t* __restrict__ countsA, const uint32_t* __restrict__ pstart,
+                                                     uint32_t* __restrict__ recsP, uint16_t* __restrict__ recsK, int wave_prio) {
+  raise_wave_priority(wave_prio);
+  __shared__ uint32_t limbs[9 * 256];
+  __shared__ uint32_t cur[PART_STAGE_BINS];
+  __shared__ uint32_t tcnt[PART_STAGE_BINS];
+  __shared__ uint32_t toff[PART_STAGE_BINS + 1];
+  __shared__ uint64_t stage[256 * 16];
+  __shared__ uint16_t sbin[256 * 16];
+  const uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
+  for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] = pstart[b] + mine[b]; tcnt[b] = 0; }
+  int g = 0;
+  while (g < pg.groups - 1 && blockIdx.x >= pg.blk_end[g]) ++g;
+  const uint32_t blk0 = g ? pg.blk_end[g - 1] : 0u;
+  const uint32_t* __restrict__ scalars = pg.scalars[g];
+  const uint32_t n = pg.n[g];
+  const uint32_t lo = (blockIdx.x - blk0) * chA;
+  const uint32_t hi = (lo + chA < n) ? lo + chA : n;
+  const uint32_t fmask = (1u << fb) - 1u;
+  const uint32_t set0 = (uint32_t)g * (uint32_t)sets;
+  const uint32_t pbase = pg.off[g];
+  const uint32_t per_lane = (bins + 63) / 64;
+  __syncthreads();
+  for (uint32_t base = lo; base < hi; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    uint64_t rec[16];
+    uint32_t rb[16];                                               // partition | rank << 16 (a tile holds at most 4096 records)
+    int nrec = 0;
+    if (i < hi) {
+      stage_scalar<SP>(limbs, fe_load<SP>(scalars + (size_t)i * 8), is_mont);
+      DigitIter it{limbs + threadIdx.x, 0u};
+      for (int w = 0; w < windows; ++w) {
+        const uint32_t d = it.next(w, c);
+        const uint32_t mag = d & ~SIGN_BIT;
+        if (!mag) continue;
+        const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
+        const uint32_t bin = ((set0 + s) << pb) | ((mag - 1) >> fb);
+        const uint32_t rank = atomicAdd(&tcnt[bin], 1u);
+        rec[nrec] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + pbase + i) | (d & SIGN_BIT));
+        rb[nrec] = bin | (rank << 16);
+        ++nrec;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                        // exclusive scan of the tile's partition counts: wavefront 0
+      uint32_t run = 0;
+      const uint32_t b0 = threadIdx.x * per_lane;
+      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < bins) run += tcnt[b0 + k];
+      uint32_t incl = run;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += o; }
+      uint32_t off = incl - run;
+      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < bins) { toff[b0 + k] = off; off += tcnt[b0 + k]; }
+      if (threadIdx.x == 63) toff[bins] = incl;                    // the tile's record count
+    }
+    __syncthreads();
+    for (int k = 0; k < nrec; ++k) {
+      const uint32_t bin = rb[k] & 0xFFFFu, p = toff[bin] + (rb[k] >> 16);
+      stage[p] = rec[k];
+      sbin[p] = (uint16_t)bin;
+    }
+    __syncthreads();
+    const uint32_t tile_n = toff[bins];
+    for (uint32_t q = threadIdx.x; q < tile_n; q += 256) {
+      const uint32_t b = sbin[q];
+      const uint64_t r = stage[q];
+      const uint32_t pos = cur[b] + (q - toff[b]);
+      recsP[pos] = (uint32_t)r;
+      recsK[pos] = (uint16_t)(r >> 32);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] += tcnt[b]; tcnt[b] = 0; }
+    __syncthreads();
   }
 }
 
@@ -429,7 +517,7 @@ __device__ __forceinline__ uint32_t lds_take_slot(uint32_t* h, uint32_t key) {
   return atomicAdd(&h[key], 1u);
 }
 
-__global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ pstart,
+__global__ __launch_bounds__(1024) void k_fine(const uint32_t* __restrict__ recsP, const uint16_t* __restrict__ recsK, const uint32_t* __restrict__ pstart,
                                                uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
                                                uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc,
                                                uint32_t slots, uint32_t Lfixed, uint32_t* __restrict__ tstart, int wave_prio) {
@@ -445,11 +533,11 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
   for (; i + 3 * 1024 < hi; i += 4 * 1024) {              // four independent loads in flight per lane
     uint32_t k[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) k[u] = (uint32_t)(recs[i + u * 1024] >> 32);
+    for (int u = 0; u < 4; ++u) k[u] = recsK[i + u * 1024];
 #pragma unroll
     for (int u = 0; u < 4; ++u) lds_take_slot(h, k[u]);
   }
-  for (; i < hi; i += 1024) lds_take_slot(h, (uint32_t)(recs[i] >> 32));
+  for (; i < hi; i += 1024) lds_take_slot(h, (uint32_t)recsK[i]);
   __syncthreads();
   const uint32_t cnt = (f < nf) ? h[f] : 0u;
   sc[f] = cnt;
@@ -486,19 +574,128 @@ __global__ __launch_bounds__(1024) void k_fine(const uint64_t* __restrict__ recs
   __syncthreads();
   i = lo + f;
   for (; i + 3 * 1024 < hi; i += 4 * 1024) {
-    uint64_t r[4];
+    uint32_t r[4], kk[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = recs[i + u * 1024];
+    for (int u = 0; u < 4; ++u) { r[u] = recsP[i + u * 1024]; kk[u] = recsK[i + u * 1024]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t pos = lds_take_slot(h, (uint32_t)(r[u] >> 32));
-      sorted[pos] = (uint32_t)r[u];
+      const uint32_t pos = lds_take_slot(h, kk[u]);
+      sorted[pos] = r[u];
     }
   }
   for (; i < hi; i += 1024) {
-    const uint64_t r = recs[i];
-    const uint32_t pos = lds_take_slot(h, (uint32_t)(r >> 32));
-    sorted[pos] = (uint32_t)r;
+    const uint32_t pos = lds_take_slot(h, (uint32_t)recsK[i]);
+    sorted[pos] = recsP[i];
+  }
+}
+
+// Pass B with its scatter STAGED through LDS (vdf_hip_tuning.sort_staged).  k_fine's second phase writes every entry on its
+// own -- 64 lanes, 64 four-byte writes to ~60 different lines per instruction, one L2 transaction each: at 2^24 points the
+// 2 x 10^8 entries are 0.8 ms of L2 transactions alone.  Here a workgroup takes its partition in tiles of 4096 records: a
+// tile's entries are ranked by fine bucket in LDS (a tile histogram, one wavefront's scan), laid out bucket by bucket in an
+// LDS buffer, and copied out by consecutive lanes -- a run of a tile's entries for one bucket (16 on average at 2^8 fine
+// buckets) leaves as one or two whole lines.  Phase 1 (histogram, bucket starts, empty buckets, slice starts) is k_fine's.
+template <int PER>                                      // records per thread and tile: 4 (4096 per tile) up to 2^8 fine buckets, 8 beyond
+__global__ __launch_bounds__(1024) void k_fine_staged(const uint32_t* __restrict__ recsP, const uint16_t* __restrict__ recsK, const uint32_t* __restrict__ pstart,
+                                                      uint32_t bins, uint32_t nf, uint32_t* __restrict__ bstart,
+                                                      uint32_t* __restrict__ sorted, char* __restrict__ bucket_acc,
+                                                      uint32_t slots, uint32_t Lfixed, uint32_t* __restrict__ tstart, int wave_prio) {
+  raise_wave_priority(wave_prio);
+  __shared__ uint32_t h[1024];
+  __shared__ uint32_t sc[1024];
+  __shared__ uint32_t tcnt[1024];
+  constexpr uint32_t FINE_TILE = 1024u * PER;
+  __shared__ uint32_t stage[FINE_TILE];
+  __shared__ uint16_t sbin[FINE_TILE];
+  const uint32_t bin = blockIdx.x, f = threadIdx.x;
+  const uint32_t lo = pstart[bin], hi = pstart[bin + 1];
+  const uint32_t L = slice_len(pstart[bins], slots, Lfixed);
+  h[f] = 0;
+  __syncthreads();
+  uint32_t i = lo + f;
+  for (; i + 3 * 1024 < hi; i += 4 * 1024) {
+    uint32_t k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[u] = recsK[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lds_take_slot(h, k[u]);
+  }
+  for (; i < hi; i += 1024) lds_take_slot(h, (uint32_t)recsK[i]);
+  __syncthreads();
+  const uint32_t cnt = (f < nf) ? h[f] : 0u;
+  sc[f] = cnt;
+  __syncthreads();
+  for (uint32_t d = 1; d < nf; d <<= 1) {
+    const uint32_t t = (f >= d) ? sc[f - d] : 0u;
+    __syncthreads();
+    sc[f] += t;
+    __syncthreads();
+  }
+  if (f < nf) {
+    const uint32_t start = lo + sc[f] - cnt;
+    bstart[(size_t)bin * nf + f] = start;
+    h[f] = start;                                          // cursor: the bucket's next free position
+    if (cnt == 0) {
+      uint4* z = reinterpret_cast<uint4*>(bucket_acc + ((size_t)bin * nf + f) * 128);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (bin == bins - 1 && f == nf - 1) bstart[(size_t)bins * nf] = pstart[bins];
+    if ((uint64_t)cnt <= 32ull * L)
+      for (uint32_t t = (start + L - 1) / L; (uint64_t)t * L < (uint64_t)start + cnt; ++t) tstart[t] = bin * nf + f;
+  }
+  __syncthreads();
+  for (uint32_t ff = 0; ff < nf; ++ff) {
+    const uint32_t c = sc[ff] - (ff ? sc[ff - 1] : 0u);
+    if ((uint64_t)c <= 32ull * L) continue;
+    const uint32_t st = h[ff];
+    for (uint32_t t = (st + L - 1) / L + f; (uint64_t)t * L < (uint64_t)st + c; t += 1024) tstart[t] = bin * nf + ff;
+  }
+  __syncthreads();
+  // ---- phase 2: tile by tile through LDS
+  const uint32_t per_lane = (nf + 63) / 64;                 // fine buckets each lane of wavefront 0 scans (nf <= 1024: at most 16)
+  for (uint32_t base = lo; base < hi; base += FINE_TILE) {
+    const uint32_t tile_n = hi - base < FINE_TILE ? hi - base : FINE_TILE;
+    tcnt[f] = 0;
+    __syncthreads();
+    uint32_t key[PER], pay[PER], rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const uint32_t s = (uint32_t)u * 1024 + f;
+      key[u] = 0xFFFFFFFFu;
+      if (s < tile_n) {
+        key[u] = recsK[base + s]; pay[u] = recsP[base + s];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (key[u] != 0xFFFFFFFFu) rank[u] = lds_take_slot(tcnt, key[u]);
+    __syncthreads();
+    // exclusive scan of the tile histogram by wavefront 0: a lane's run of per_lane buckets, then a shuffle scan over the lanes
+    if (f < 64) {
+      uint32_t run = 0;
+      const uint32_t b0 = f * per_lane;
+      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < nf) run += tcnt[b0 + k];
+      uint32_t incl = run;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)f >= d) incl += o; }
+      uint32_t off = incl - run;
+      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < nf) { sc[b0 + k] = off; off += tcnt[b0 + k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (key[u] != 0xFFFFFFFFu) {
+      const uint32_t p = sc[key[u]] + rank[u];
+      stage[p] = pay[u];
+      sbin[p] = (uint16_t)key[u];
+    }
+    __syncthreads();
+    for (uint32_t s = f; s < tile_n; s += 1024) {
+      const uint32_t b = sbin[s];
+      sorted[h[b] + (s - sc[b])] = stage[s];
+    }
+    __syncthreads();
+    if (f < nf) h[f] += tcnt[f];
+    __syncthreads();
   }
 }
 
@@ -1211,7 +1408,10 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   uint32_t* countsA = reinterpret_cast<uint32_t*>(base + w.countsA);
   uint32_t* pcount = reinterpret_cast<uint32_t*>(base + w.pcount);
   uint32_t* pstart = reinterpret_cast<uint32_t*>(base + w.pstart);
-  uint64_t* recs = reinterpret_cast<uint64_t*>(base + w.recs);
+  // records of pass A, split: 4-byte payloads (point | table | sign), then 2-byte fine keys -- 6 bytes per entry over the
+  // passes where the packed 8-byte record moved 8 (written once, read twice: 18 instead of 28 bytes per entry with the output)
+  uint32_t* recsP = reinterpret_cast<uint32_t*>(base + w.recs);
+  uint16_t* recsK = reinterpret_cast<uint16_t*>(base + w.recs + (size_t)p.windows * p.n * 4);
   uint32_t* bstart = reinterpret_cast<uint32_t*>(base + w.bstart);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + w.sorted);
   char* bucket_acc = ext_bucket_acc ? ext_bucket_acc : base + w.bucket_acc;
@@ -1234,14 +1434,25 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   {
   KTimer kt(st, "msm_sort(5 launches)", 0.0);
   hipLaunchKernelGGL((k_part<SP, false>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
-                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs, prio);
+                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recsP, recsK, prio);
   hipLaunchKernelGGL(k_part_scan, dim3(p.bins), dim3(256), 0, st, countsA, p.bins, p.nblkA, pcount, heavy, heavy + 1 + nkeys + 2, prio);
   hipLaunchKernelGGL(k_scan_keys, dim3(1), dim3(1024), 0, st, pcount, p.bins, pstart, prio);
-  hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
-                     p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recs, prio);
+  if (tuning().sort_staged && p.bins <= PART_STAGE_BINS && p.windows <= 16)
+    hipLaunchKernelGGL((k_part_staged<SP>), dim3(p.nblkA), dim3(256), 0, st, pg, is_mont ? 1 : 0, p.c, p.windows,
+                       p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recsP, recsK, prio);
+  else
+    hipLaunchKernelGGL((k_part<SP, true>), dim3(p.nblkA), dim3(256), lds_bins, st, pg, is_mont ? 1 : 0, p.c, p.windows,
+                       p.sets, p.pb, p.fb, p.bins, p.chA, p.tstride, countsA, pstart, recsP, recsK, prio);
   // pass B
-  hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recs, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
-                     reinterpret_cast<uint32_t*>(base + w.tstart), prio);
+  if (tuning().sort_staged && nf <= 256)
+    hipLaunchKernelGGL(k_fine_staged<4>, dim3(p.bins), dim3(1024), 0, st, recsP, recsK, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
+                       reinterpret_cast<uint32_t*>(base + w.tstart), prio);
+  else if (tuning().sort_staged)
+    hipLaunchKernelGGL(k_fine_staged<8>, dim3(p.bins), dim3(1024), 0, st, recsP, recsK, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
+                       reinterpret_cast<uint32_t*>(base + w.tstart), prio);
+  else
+    hipLaunchKernelGGL(k_fine, dim3(p.bins), dim3(1024), 0, st, recsP, recsK, pstart, p.bins, nf, bstart, sorted, bucket_acc, p.slots, p.Lfixed,
+                       reinterpret_cast<uint32_t*>(base + w.tstart), prio);
   }
   if (ev) VDF_TRY_HIP(hipEventRecord(ev[1], st));
   // the sort is light; the accumulation fills every SIMD: a caller that knows of latency-critical work on another queue
