@@ -7,13 +7,14 @@
 // A call handles a batch of 1..4 MSMs ("groups") over one generator table; to everything after pass A a group is
 // just more bucket sets.  Pipeline (all on the device, one stream, no host round trip, 10 launches):
 //   Two-level counting sort of the (window, point) entries by bucket, b = (p << fb) | f:
-//   k_part<hist> / k_part_scan / k_scan_keys / k_part<scatter>   pass A: every workgroup turns a chunk of one
+//   k_part<hist> / k_part_scan / k_scan_keys / k_part_staged (k_part<scatter>)   pass A: every workgroup turns a chunk of one
 //                 group's scalars into signed c-bit digits (Booth-style carry) on the fly and partitions the
 //                 entries by group, bucket set and the high bucket bits p (about one partition per CU, cursors
-//                 in LDS); each (workgroup, partition) run is contiguous, so the 8-byte records leave as whole
-//                 lines instead of one 64-byte sector per 4-byte write
-//   k_fine        pass B: one 1024-thread workgroup per partition: histogram of the low bits f in LDS, scan
-//                 (= the partition's bucket starts), scatter into the sorted list; it also zeroes the
+//                 in LDS); each (workgroup, partition) run is contiguous; a record is a 4-byte payload (point | table |
+//                 sign) and a 2-byte fine key in two arrays, and a tile of records is laid out partition by partition
+//                 in LDS first so that it leaves as whole pieces (k_part_staged; round 5)
+//   k_fine_staged (k_fine)   pass B: one 1024-thread workgroup per partition: histogram of the low bits f in LDS, scan
+//                 (= the partition's bucket starts), scatter into the sorted list tile by tile through LDS; it also zeroes the
 //                 accumulator of every empty bucket (no memset) and tells each k_accumulate thread its first bucket
 //   k_accumulate  every thread owns a fixed-length slice of the SORTED entry list and runs a
 //                 sequential segmented reduce over it with an XYZZ accumulator in registers
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
   __shared__ uint32_t cur[PART_STAGE_BINS];
   __shared__ uint32_t tcnt[PART_STAGE_BINS];
   __shared__ uint32_t toff[PART_STAGE_BINS + 1];
-  __shared__ uint64_t stage[256 * 16];
+  __shared__ uint32_t stage[256 * 16];                            // payloads; 8 bytes of LDS per record in all: three workgroups per CU
+  __shared__ uint16_t skey[256 * 16];
   __shared__ uint16_t sbin[256 * 16];
   const uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
   for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] = pstart[b] + mine[b]; tcnt[b] = 0; }
@@ -407,17 +409,17 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
     __syncthreads();
     for (int k = 0; k < nrec; ++k) {
       const uint32_t bin = rb[k] & 0xFFFFu, p = toff[bin] + (rb[k] >> 16);
-      stage[p] = rec[k];
+      stage[p] = (uint32_t)rec[k];
+      skey[p] = (uint16_t)(rec[k] >> 32);
       sbin[p] = (uint16_t)bin;
     }
     __syncthreads();
     const uint32_t tile_n = toff[bins];
     for (uint32_t q = threadIdx.x; q < tile_n; q += 256) {
       const uint32_t b = sbin[q];
-      const uint64_t r = stage[q];
       const uint32_t pos = cur[b] + (q - toff[b]);
-      recsP[pos] = (uint32_t)r;
-      recsK[pos] = (uint16_t)(r >> 32);
+      recsP[pos] = stage[q];
+      recsK[pos] = skey[q];
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] += tcnt[b]; tcnt[b] = 0; }
