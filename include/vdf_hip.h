@@ -457,6 +457,8 @@ typedef struct vdf_hip_tuning {
                                   addition, a longer dependent chain; 1); 0: by a quad of lanes (k_fixup) */
   int32_t sort_staged;         /* 1: the sort's second pass lays a tile of entries out bucket by bucket in LDS and writes whole
                                   runs (k_fine_staged); 0: every entry written on its own (k_fine) */
+  int32_t glv;                 /* 1: a table-less MSM over a whole generator set of 2^12 points or more uses the curve's endomorphism
+                                  (2n points, 129-bit half-scalars: half the Horner chain); 0: never */
 } vdf_hip_tuning;
 int  vdf_hip_tuning_get(vdf_hip_tuning* out);            /* the values in force (struct_size filled in) */
 int  vdf_hip_tuning_set(const vdf_hip_tuning* in);       /* VDF_ERR_BAD_ARG (nothing changed) if a field is out of range */

@@ -826,3 +826,36 @@ def test_lazy_addition_chains_stay_inside_their_bound():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "coordinates above 2m + 2^130: 0, mismatches 0" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_endomorphism_split_on_edge_scalars(ctx, cref, curve):
+    """The table-less path over a whole generator set of 2^12 points and more splits every scalar k = k1 + lambda k2 (msm.hip
+    k_glv_split; constants generated by tools/gen_constants.py) and runs 2n points [P | phi(P)] with 127-bit half-scalars:
+    scalars at the edges of the split's arithmetic -- 0, 1, 2, r - 1, r - 2, lambda, lambda +- 1, (r - 1) / 2, powers of two
+    around 2^127 / 2^128 / 2^254, all-ones words -- against the C restatement, and the same vector with the endomorphism off."""
+    from vdf_amd.hip import tuning_get, tuning_set
+    r = o.curve_scalar_modulus(curve)
+    n = 4096 + 37
+    lam = pow(5, (r - 1) // 3, r)                               # a primitive cube root of unity in the scalar field
+    edges = [0, 1, 2, r - 1, r - 2, lam, lam + 1, lam - 1, (lam * lam) % r, (r - 1) // 2, (r + 1) // 2, 1 << 126, 1 << 127, (1 << 127) - 1,
+             (1 << 127) + 1, 1 << 128, (1 << 128) - 1, 1 << 129, 1 << 253, (1 << 254) - 1, 1 << 254, (1 << 254) + 1, r // 3, 2 * r // 3,
+             (1 << 64) - 1, ((1 << 192) - 1) % r]
+    rng = np.random.default_rng(7 + curve)
+    sc = rand_limbs(rng, n)
+    sc[:len(edges)] = limbs([e % r for e in edges])
+    sc[n - len(edges):] = limbs([(r - e) % r for e in edges])
+    bases = ctx.bases_generate(curve, 45, n)
+    pts = bases.download()
+    want = cpu_msm(cref, curve, pts, sc)
+    assert tuning_get().glv == 1
+    assert jac_to_affine(ctx.msm(bases, sc), curve) == want
+    assert jac_to_affine(ctx.msm(bases, mont(ints(sc), r), is_mont=True), curve) == want         # Montgomery-form scalars
+    tuning_set(glv=0)
+    try:
+        assert jac_to_affine(ctx.msm(bases, sc), curve) == want
+    finally:
+        tuning_set(glv=1)
+    # a prefix of the set does not take the endomorphism (its point array is the whole set's): same answer
+    assert jac_to_affine(ctx.msm(bases, sc[:4100], n=4100), curve) == cpu_msm(cref, curve, pts[:4100], sc[:4100])
+    bases.free()

@@ -123,7 +123,7 @@ vdf_hip_tuning tuning_defaults() {
   t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
   t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
   t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0; t.nifs_fused = 1; t.fold_u128 = 1;
-  t.fixup_serial = 1; t.sort_staged = 1;
+  t.fixup_serial = 1; t.sort_staged = 1; t.glv = 1;
   return t;
 }
 bool tuning_valid(const vdf_hip_tuning& t) {
@@ -133,7 +133,7 @@ bool tuning_valid(const vdf_hip_tuning& t) {
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
          (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) &&
-         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1) && in(t.fixup_serial, 0, 1) && in(t.sort_staged, 0, 1);
+         in(t.nifs_fused, 0, 1) && in(t.fold_u128, 0, 1) && in(t.fixup_serial, 0, 1) && in(t.sort_staged, 0, 1) && in(t.glv, 0, 1);
 }
 void tuning_publish(const vdf_hip_tuning& t) {           // caller holds g_tune_mu (or is the once-initialiser)
   g_tune_snapshots.push_back(t);
@@ -149,7 +149,7 @@ void tuning_from_env() {
       {"VDF_MSM_L", &t.slice_len}, {"VDF_MSM_PB", &t.part_bits}, {"VDF_MSM_RED", &t.reduction},
       {"VDF_MSM_RED_QUADS", &t.reduction_quads}, {"VDF_MSM_HEAVY_MIN", &t.heavy_min}, {"VDF_MSM_GIANT_SPAN", &t.giant_span},
       {"VDF_NIFS_LANES", &t.nifs_lanes}, {"VDF_SHIM_CACHE", &t.shim_cache}, {"VDF_NIFS_FUSED", &t.nifs_fused}, {"VDF_FOLD_U128", &t.fold_u128},
-      {"VDF_MSM_FIXUP_SERIAL", &t.fixup_serial}, {"VDF_MSM_SORT_STAGED", &t.sort_staged}};
+      {"VDF_MSM_FIXUP_SERIAL", &t.fixup_serial}, {"VDF_MSM_SORT_STAGED", &t.sort_staged}, {"VDF_MSM_GLV", &t.glv}};
   for (const auto& v : vars) {
     const char* e = std::getenv(v.name);
     if (!e || !*e) continue;
@@ -225,6 +225,9 @@ bool direct_enabled() { return vdf::tuning().msm_direct != 0; }       // (tuning
 
 size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 
+constexpr size_t GLV_MIN_POINTS = 1u << 12;      // below this the split's launches cost what the shorter chain saves
+constexpr size_t GLV_MAX_POINTS = 1u << 21;      // measured (profiles/r05_glv_tableless.txt): 2^14 1.25 -> 0.75 ms, 2^18 1.81 -> 1.29, 2^20 2.86 -> 2.61;
+                                                 // at 2^22 the doubled point array slows the gathers by what the chain saves (7.11 -> 7.22)
 Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* offset, const vdf_fe* const* scalars,
                 const size_t* n, int is_mont, vdf_jac* out) {
   if (!bases || !out || !offset || !scalars || !n) return Status{VDF_ERR_BAD_ARG, "null bases/out/arrays"};
@@ -298,6 +301,45 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
     plan = vdf::msm_make_plan(groups, n, offset, bases->tbl_c, bases->tbl_sets, bases->tbl_tables, ctx->num_cus, ctx->acc_fill);
     plan.tstride = (uint32_t)bases->n;
     pts = reinterpret_cast<const char*>(bases->d_table);
+  } else if (groups == 1 && offset[0] == 0 && n[0] == bases->n && n[0] >= GLV_MIN_POINTS && n[0] <= GLV_MAX_POINTS && ctx->msm_window == 0 &&
+             vdf::tuning().glv) {
+    // No table, the whole generator set: the endomorphism (msm.hip k_glv_*).  2n points [P | phi(P)] kept with the generators
+    // (made on first use), 2n half-scalars of 129 bits + sign in this context's scratch: 9 bucket sets instead of 16 and a
+    // Horner chain of 128 doublings instead of 240 behind the same number of bucket additions.
+    vdf_bases* mb = const_cast<vdf_bases*>(bases);
+    {
+      std::lock_guard<std::mutex> lock(mb->glv_mu);
+      if (!mb->d_pts2) {
+        void* p2 = nullptr;
+        VDF_TRY_HIP(hipMalloc(&p2, 2 * bases->n * sizeof(vdf_affine)));
+        Status sg = vdf::glv_points(bases->curve, bases->d_pts, bases->n, p2, ctx->stream);
+        if (sg.code == VDF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) sg = Status{VDF_ERR_DEVICE, "glv points"};
+        if (sg.code != VDF_OK) { (void)hipFree(p2); return sg; }
+        mb->d_pts2 = p2;
+      }
+    }
+    const size_t need = 2 * n[0] * sizeof(vdf_fe);
+    if (ctx->glv_bytes < need) {
+      VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->glv_scalars) (void)hipFree(ctx->glv_scalars);
+      ctx->glv_scalars = nullptr; ctx->glv_bytes = 0;
+      VDF_TRY_HIP(hipMalloc(&ctx->glv_scalars, need));
+      ctx->glv_bytes = need;
+    }
+    VDF_TRY(vdf::glv_split(bases->curve, d_scalars[0], n[0], is_mont != 0, ctx->glv_scalars, ctx->stream));
+    d_scalars[0] = ctx->glv_scalars;
+    is_mont = 0;
+    const size_t n2[1] = {2 * n[0]}, off2[1] = {0};
+    // the window: with the rounded split the half-scalars are below 2^127, so 16-bit windows use eight FULL windows (the top
+    // digit has 15 significant bits and never carries); a ninth bucket set exists for scalars that hit the rounding's last unit
+    // and is empty otherwise.  Windows that leave the top digit a few bits wide (17: 10 of 17; 15: 9 of 15) put an eighth of all
+    // entries into one sort partition (measured: the sort 0.4 -> 2.2 ms at 2^20).  Smaller sets: 13 (ten windows, 10 of 13 on top).
+    const int ca = vdf::msm_auto_window(n2[0]);
+    const int c = ca >= 15 ? 16 : 13;
+    plan = vdf::msm_make_plan(1, n2, off2, c, 0, 0, ctx->num_cus, ctx->acc_fill, 132);
+    plan.tstride = 0;
+    pts = reinterpret_cast<const char*>(bases->d_pts2);
+    ntot = n2[0];
   } else {
     int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(nmax);
     while (c > 4 && !vdf::msm_plan_feasible(groups, c, 0)) --c;     // a table-less window is a tuning knob: lowered to what fits
@@ -615,6 +657,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->h_out) (void)hipHostFree(ctx->h_out);
   if (ctx->reduce_scratch) (void)hipFree(ctx->reduce_scratch);
   if (ctx->direct_arrived) (void)hipFree(ctx->direct_arrived);
+  if (ctx->glv_scalars) (void)hipFree(ctx->glv_scalars);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
@@ -875,6 +918,7 @@ void vdf_bases_free(vdf_bases* bases) {
     if (bases->d_pts) (void)hipFree(bases->d_pts);
     if (bases->d_table) (void)hipFree(bases->d_table);
     if (bases->d_digits) (void)hipFree(bases->d_digits);
+    if (bases->d_pts2) (void)hipFree(bases->d_pts2);
   }
   delete bases;
 }

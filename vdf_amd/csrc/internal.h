@@ -90,6 +90,8 @@ struct vdf_ctx {
   int acc_fill = 0;                  // accumulate workgroups per CU this context's MSMs fill (vdf_ctx_set_accumulate_fill; 0 = process-wide)
   int light_prio = 3;                // wave priority of this context's sort / bucket-reduction kernels (vdf_ctx_set_light_priority)
   hipEvent_t acc_gate = nullptr;     // one-shot: the next bucket-method MSM's accumulation waits for this event (vdf_ctx_gate_accumulate)
+  void* glv_scalars = nullptr;       // 2n half-scalars of the endomorphism's split (table-less MSMs over a whole generator set)
+  size_t glv_bytes = 0;
   uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
 };
 
@@ -98,6 +100,8 @@ struct vdf_bases {
   int curve = 0;
   size_t n = 0;
   void* d_pts = nullptr;       // n affine points, 64 B each
+  void* d_pts2 = nullptr;      // [P | phi(P)], 2n points: made by the first table-less MSM over the whole set (abi.hip msm_core)
+  std::mutex glv_mu;
   // fixed-base table: tables x n affine points; table j holds 2^(c*sets*j) * P_i
   int tbl_c = 0, tbl_sets = 0, tbl_tables = 0;
   void* d_table = nullptr;
@@ -180,7 +184,8 @@ struct MsmPlan {
   uint32_t gblk_end[MSM_MAX_GROUPS] = {0, 0, 0, 0}; // pass-A workgroups: group g owns [gblk_end[g-1], gblk_end[g])
   uint32_t n = 0;        // points, all groups
   int c = 0;             // window bits
-  int windows = 0;       // ceil(256 / c)
+  int windows = 0;       // ceil(256 / c)  (ceil(132 / c) for the endomorphism's half-scalars)
+  bool signed_scalars = false;   // the scalars are sign-and-magnitude words (k_glv_split)
   int sets = 0;          // bucket sets per group (Horner length); windows = sets * tables
   int gsets = 0;         // groups * sets
   int tables = 0;
@@ -197,7 +202,10 @@ struct MsmPlan {
   uint32_t tstride = 0;  // points per fixed-base table (tables > 1)
   size_t ws_bytes = 0;
 };
-MsmPlan msm_make_plan(int groups, const size_t* n, const size_t* offsets, int c, int sets, int tables, int num_cus, int acc_fill = 0);
+MsmPlan msm_make_plan(int groups, const size_t* n, const size_t* offsets, int c, int sets, int tables, int num_cus, int acc_fill = 0,
+                      int scalar_bits = 256);
+Status glv_points(int curve, const void* d_pts, size_t n, void* d_out, hipStream_t stream);      // [P | phi(P)]: 2n points
+Status glv_split(int curve, const void* d_scalars, size_t n, bool is_mont, void* d_out, hipStream_t stream);   // [k1 | k2]: 2n sign-and-magnitude words
 inline MsmPlan msm_make_plan(size_t n, int c, int sets, int tables, int num_cus) {
   const size_t zero = 0;
   return msm_make_plan(1, &n, &zero, c, sets, tables, num_cus);

@@ -188,7 +188,7 @@ bool msm_plan_feasible(int groups, int c, int sets) {
   return ((uint64_t)groups * sets << (over > 0 ? over : 0)) <= 8192u;
 }
 
-MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus, int acc_fill) {
+MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, int sets, int tables, int num_cus, int acc_fill, int scalar_bits) {
   MsmPlan p;
   p.groups = groups;
   size_t n = 0, nmax = 0;
@@ -200,7 +200,8 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   }
   p.n = (uint32_t)n;
   p.c = c;
-  p.windows = (256 + c - 1) / c;
+  p.windows = (scalar_bits + c - 1) / c;       // 256: field elements; 132: the half-scalars of the endomorphism (129 bits + the digits' carry)
+  p.signed_scalars = scalar_bits != 256;
   if (sets <= 0 || tables <= 0) { sets = p.windows; tables = 1; }
   p.sets = sets;
   p.gsets = groups * sets;
@@ -292,6 +293,7 @@ struct PartGroups {
   const uint32_t* scalars[MSM_MAX_GROUPS];
   uint32_t n[MSM_MAX_GROUPS], off[MSM_MAX_GROUPS], blk_end[MSM_MAX_GROUPS];
   int groups;
+  int signed_scalars;      // the scalars are sign-and-magnitude words (bit 255 = sign; k_glv_split): the sign flips every digit
 };
 
 template <class SP, bool SCATTER>
@@ -321,10 +323,13 @@ __global__ __launch_bounds__(256) void k_part(PartGroups pg, int is_mont, int c,
   for (; i < hi; i += 256) {
     const Fe<SP> curs = nxt;
     if (i + 256 < hi) nxt = fe_load<SP>(scalars + (size_t)(i + 256) * 8);   // next scalar in flight
-    stage_scalar<SP>(limbs, curs, is_mont);
+    Fe<SP> mags = curs;
+    uint32_t ssign = 0;
+    if (pg.signed_scalars) { ssign = mags.v[7] & SIGN_BIT; mags.v[7] &= ~SIGN_BIT; }
+    stage_scalar<SP>(limbs, mags, is_mont);
     DigitIter it{limbs + threadIdx.x, 0u};
     for (int w = 0; w < windows; ++w) {
-      const uint32_t d = it.next(w, c);
+      const uint32_t d = it.next(w, c) ^ ssign;
       const uint32_t mag = d & ~SIGN_BIT;
       if (!mag) continue;
       const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
@@ -380,10 +385,13 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
     uint32_t rb[16];                                               // partition | rank << 16 (a tile holds at most 4096 records)
     int nrec = 0;
     if (i < hi) {
-      stage_scalar<SP>(limbs, fe_load<SP>(scalars + (size_t)i * 8), is_mont);
+      Fe<SP> mags = fe_load<SP>(scalars + (size_t)i * 8);
+      uint32_t ssign = 0;
+      if (pg.signed_scalars) { ssign = mags.v[7] & SIGN_BIT; mags.v[7] &= ~SIGN_BIT; }
+      stage_scalar<SP>(limbs, mags, is_mont);
       DigitIter it{limbs + threadIdx.x, 0u};
       for (int w = 0; w < windows; ++w) {
-        const uint32_t d = it.next(w, c);
+        const uint32_t d = it.next(w, c) ^ ssign;
         const uint32_t mag = d & ~SIGN_BIT;
         if (!mag) continue;
         const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
@@ -1353,6 +1361,132 @@ __global__ __launch_bounds__(256) void k_validate_points(const char* __restrict_
   if (bad) { atomicOr(&flags[0], bad); atomicMin(&flags[1], i); }
 }
 
+// ---- the curves' endomorphism for the table-less path (vdf_hip_tuning.glv) --------------------------------------------
+// y^2 = x^3 + 5 has phi(x, y) = (zeta x, y) = [lambda] (x, y) with zeta, lambda primitive cube roots of unity in the base and
+// scalar field.  k = k1 + lambda k2 with |k1|, |k2| < 2^129 (pasta_constants.h: the lattice and its rounding constants), so
+// sum k_i P_i = sum k1_i P_i + k2_i phi(P_i): twice the points, HALF the scalar length -- the same number of bucket additions,
+// 9 bucket sets instead of 16 and a Horner chain of 128 doublings instead of 240 (the table-less path's tail was 42 % of
+// its time, all of it that chain).
+// out[i] = P_i, out[n + i] = phi(P_i)
+template <class P>
+__global__ __launch_bounds__(256) void k_glv_points(const char* __restrict__ pts, uint32_t n, char* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Affine<P> a = affine_load<P>(pts + (size_t)i * 64);
+  affine_store<P>(out + (size_t)i * 64, a);
+  Affine<P> b = a;
+  Fe<P> zeta;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) zeta.v[l] = P::GLV_ZETA[l];
+  b.x = fe_mul(a.x, zeta);                                  // (0, 0), the identity, stays (0, 0)
+  affine_store<P>(out + ((size_t)n + i) * 64, b);
+}
+// round(a * b / 2^382) for two 256-bit integers, as five limbs
+__device__ __forceinline__ void mul_shift_382(const uint32_t a[8], const uint32_t b[8], uint32_t c[5]) {
+  uint32_t p[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) p[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t t = (uint64_t)a[i] * b[j] + p[i + j] + carry;
+      p[i + j] = (uint32_t)t;
+      carry = (uint32_t)(t >> 32);
+    }
+    p[i + 8] = carry;
+  }
+  // + 2^381: the quotient is ROUNDED, not truncated -- the half-scalars then stay below (|a1| + |a2|) / 2 < 2^127, so that the
+  // eighth 16-bit window's digit never carries (a carry would put half of all scalars into one bucket of a ninth window)
+  uint64_t cy = (uint64_t)p[11] + (1u << 29);
+  p[11] = (uint32_t)cy; cy >>= 32;
+#pragma unroll
+  for (int i = 12; i < 16; ++i) { cy += p[i]; p[i] = (uint32_t)cy; cy >>= 32; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = (p[11 + j] >> 30) | (p[12 + j] << 2);
+  c[4] = p[15] >> 30;
+}
+// acc (8 limbs, mod 2^256) += or -= c (5 limbs) * m (5 limbs)
+template <bool SUB>
+__device__ __forceinline__ void muladd_5x5(uint32_t acc[8], const uint32_t c[5], const uint32_t m[5]) {
+  uint32_t p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (i + j < 8) {
+        const uint64_t t = (uint64_t)c[i] * m[j] + p[i + j] + carry;
+        p[i + j] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+      }
+    }
+    if (i + 5 < 8) p[i + 5] = carry;
+  }
+  uint64_t cy = 0;                                            // carry / borrow
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (SUB) { const uint64_t d = (uint64_t)acc[i] - p[i] - cy; acc[i] = (uint32_t)d; cy = (d >> 63) & 1u; }
+    else { const uint64_t d = (uint64_t)acc[i] + p[i] + cy; acc[i] = (uint32_t)d; cy = d >> 32; }
+  }
+}
+// a two's-complement 256-bit integer of magnitude below 2^130 -> magnitude | sign << 255
+__device__ __forceinline__ void to_sign_magnitude(uint32_t v[8]) {
+  const uint32_t neg = v[7] >> 31;
+  if (neg) {
+    uint64_t cy = 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint64_t d = (uint64_t)(~v[i]) + cy; v[i] = (uint32_t)d; cy = d >> 32; }
+  }
+  v[7] = (v[7] & 0x7FFFFFFFu) | (neg << 31);
+}
+// SP = the scalar field.  out[i] = k1_i, out[n + i] = k2_i as sign-and-magnitude words
+template <class SP>
+__global__ __launch_bounds__(256) void k_glv_split(const uint32_t* __restrict__ scalars, uint32_t n, int is_mont, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Fe<SP> k = fe_load<SP>(scalars + (size_t)i * 8);
+  if (is_mont) k = fe_from_mont(k);
+  uint32_t g1[8], g2[8], a1[5], a2[5], nb1[5], b2[5], c1[5], c2[5];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { g1[l] = SP::GLV_G1[l]; g2[l] = SP::GLV_G2[l]; }
+#pragma unroll
+  for (int l = 0; l < 5; ++l) { a1[l] = SP::GLV_A1[l]; a2[l] = SP::GLV_A2[l]; nb1[l] = SP::GLV_NB1[l]; b2[l] = SP::GLV_B2[l]; }
+  mul_shift_382(k.v, g1, c1);
+  mul_shift_382(k.v, g2, c2);
+  uint32_t k1[8], k2[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { k1[l] = k.v[l]; k2[l] = 0; }
+  muladd_5x5<true>(k1, c1, a1);
+  muladd_5x5<true>(k1, c2, a2);
+  muladd_5x5<false>(k2, c1, nb1);
+  muladd_5x5<true>(k2, c2, b2);
+  to_sign_magnitude(k1);
+  to_sign_magnitude(k2);
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { out[(size_t)i * 8 + l] = k1[l]; out[((size_t)n + i) * 8 + l] = k2[l]; }
+}
+Status glv_points(int curve, const void* d_pts, size_t n, void* d_out, hipStream_t stream) {
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (curve == VDF_CURVE_PALLAS) hipLaunchKernelGGL((k_glv_points<FpParams>), grid, dim3(256), 0, stream, reinterpret_cast<const char*>(d_pts), (uint32_t)n, reinterpret_cast<char*>(d_out));
+  else if (curve == VDF_CURVE_VESTA) hipLaunchKernelGGL((k_glv_points<FqParams>), grid, dim3(256), 0, stream, reinterpret_cast<const char*>(d_pts), (uint32_t)n, reinterpret_cast<char*>(d_out));
+  else return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+Status glv_split(int curve, const void* d_scalars, size_t n, bool is_mont, void* d_out, hipStream_t stream) {
+  const dim3 grid((unsigned)((n + 255) / 256));
+  KTimer kt(stream, "k_glv_split", 96.0 * n);
+  if (curve == VDF_CURVE_PALLAS) hipLaunchKernelGGL((k_glv_split<FqParams>), grid, dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_scalars), (uint32_t)n, is_mont ? 1 : 0, reinterpret_cast<uint32_t*>(d_out));
+  else if (curve == VDF_CURVE_VESTA) hipLaunchKernelGGL((k_glv_split<FpParams>), grid, dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(d_scalars), (uint32_t)n, is_mont ? 1 : 0, reinterpret_cast<uint32_t*>(d_out));
+  else return Status{VDF_ERR_BAD_ARG, "unknown curve"};
+  VDF_TRY_HIP(hipGetLastError());
+  return Status{};
+}
+
 // table[j][i] = 2^(shift*j) * P_i
 template <class P>
 __global__ __launch_bounds__(256) void k_precompute(const char* __restrict__ pts, uint32_t n, int shift, int tables,
@@ -1425,6 +1559,7 @@ static Status msm_run_t(const MsmPlan& p, const void* d_points, const void* cons
   const uint32_t nf = 1u << p.fb;
   PartGroups pg{};
   pg.groups = p.groups;
+  pg.signed_scalars = p.signed_scalars ? 1 : 0;
   for (int g = 0; g < p.groups; ++g) {
     pg.scalars[g] = reinterpret_cast<const uint32_t*>(d_scalars[g]);
     pg.n[g] = p.gn[g]; pg.off[g] = p.goff[g]; pg.blk_end[g] = p.gblk_end[g];

@@ -17,7 +17,7 @@ class HipTuning(C.Structure):
     """vdf_hip_tuning (include/vdf_hip.h): process-wide tuning of the kernels."""
     _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_int32) for k in (
         "msm_direct", "direct_priority", "direct_fused", "light_priority", "accumulate_fill", "accumulate_lds", "slice_len", "part_bits",
-        "reduction", "reduction_quads", "heavy_min", "giant_span", "nifs_lanes", "shim_cache", "nifs_fused", "fold_u128", "fixup_serial", "sort_staged")]
+        "reduction", "reduction_quads", "heavy_min", "giant_span", "nifs_lanes", "shim_cache", "nifs_fused", "fold_u128", "fixup_serial", "sort_staged", "glv")]
 
 
 def tuning_get() -> HipTuning:
