@@ -537,9 +537,6 @@ void pool_count_owned(int device, int delta) {
   g_pool[device].owned += delta;
 }
 }  // namespace
-// (experiment knobs, read once: which of the family's streams a role takes, and how many it opens)
-static int family_slot(const char* name, int dflt) { const char* e = std::getenv(name); const int v = e ? std::atoi(e) : dflt; return v >= 1 && v < vdf_queue_family::N ? v : dflt; }
-static int family_size() { const int a = family_slot("VDF_Q_SIDE", 1), b = family_slot("VDF_Q_CRITICAL", 2); return 1 + (a > b ? a : b); }
 vdf_queue_family::~vdf_queue_family() {
   int n = 0;
   for (hipStream_t& q : s) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); q = nullptr; ++n; }
@@ -567,7 +564,8 @@ int vdf_ctx_create_pooled_near(vdf_ctx* parent, int role, vdf_ctx** out) {
   int idx = -1;
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    const int want = role == VDF_QUEUE_SIDE ? family_slot("VDF_Q_SIDE", 1) : family_slot("VDF_Q_CRITICAL", 2);   // the neighbour right behind the parent's stream, and the one after it
+    const int want = role == VDF_QUEUE_SIDE ? 1 : 2;   // the neighbour right behind the parent's stream, and the one after it (other
+                                                       // assignments and larger families measured no better: profiles/r05_family_slots.txt)
     if (parent->family && !parent->foreign_stream && parent->family->s[want] && !parent->family->used[want]) { fam = parent->family; idx = want; fam->used[idx] = true; }
   }
   if (idx < 0) return vdf_ctx_create_pooled(&dev, 1, role, out);    // taken (a second prover on this context) or no family: the pool
@@ -617,7 +615,7 @@ static int ctx_create_impl(const int* device_ids, int n_devices, int role, vdf_c
       auto fam = std::make_shared<vdf_queue_family>();
       fam->device = c->device;
       int made = 0;
-      for (int k = 0; k < family_size() && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&fam->s[k], hipStreamNonBlocking); if (e == hipSuccess) ++made; }
+      for (int k = 0; k < vdf_queue_family::N && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&fam->s[k], hipStreamNonBlocking); if (e == hipSuccess) ++made; }
       pool_count_owned(c->device, made);
       if (e == hipSuccess) { fam->used[0] = true; c->family = fam; c->family_idx = 0; c->stream = fam->s[0]; }
     } else if (role > 0) e = pool_take(c->device, role, &c->stream, &c->pool_slot);

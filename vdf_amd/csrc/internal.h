@@ -45,7 +45,7 @@ namespace vdf { const vdf_hip_tuning& tuning(); }     // process-wide tuning (ab
 // order they were created, and a prover whose three queues are neighbours runs 10-14 % faster than one whose queues are not)
 struct vdf_queue_family {
   int device = 0;
-  static constexpr int N = 6;
+  static constexpr int N = 3;
   hipStream_t s[N] = {};
   bool used[N] = {};
   ~vdf_queue_family();
