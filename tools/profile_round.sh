@@ -3,7 +3,7 @@
 # VALU count (separate --pmc passes, kernel trace only, as MI355X_MICROARCH.md prescribes), and the raw micro-benchmark
 # logs the issue-rate model rests on.  Every bench.py under rocprofv3 runs with --no-cpu: nothing is spawned under the
 # profiler (the cpu_baseline leg may rebuild the C restatement) and no CPU MSM sits inside a profiled run.
-TAG=${1:-r04}
+TAG=${1:-r05}
 COMMIT=${2:-unknown}      # the commit of the code being profiled (the GPU box has no .git): stamped into the JSON files
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -29,5 +29,6 @@ python tools/make_valu_model.py $OUT/op_rates.txt $OUT/clock_probe.txt $OUT/valu
 python tools/timeline.py $(ls $OUT/prove/*.db | head -1) k_nifs_cross 7 3 > $OUT/prove_step_timeline.txt 2>&1
 python tools/gpu_step_events.py 16 ref > $OUT/prove_step_events.txt 2>&1
 python tools/pmc_sum.py $OUT/prove_valu > $OUT/prove_step_valu_per_kernel.txt 2>&1
-timeout -k 10 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err || exit 1
+timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err || exit 1
+cp $R/bench_detail.json $OUT/bench_detail.json
 tail -c 800 $OUT/bench_line.json
