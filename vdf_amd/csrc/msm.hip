@@ -359,12 +359,12 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
                                                      uint32_t* __restrict__ recsP, uint16_t* __restrict__ recsK, int wave_prio) {
   raise_wave_priority(wave_prio);
   __shared__ uint32_t limbs[9 * 256];
-  __shared__ uint32_t cur[PART_STAGE_BINS];
-  __shared__ uint32_t tcnt[PART_STAGE_BINS];
-  __shared__ uint32_t toff[PART_STAGE_BINS + 1];
-  __shared__ uint32_t stage[256 * 16];                            // payloads; 8 bytes of LDS per record in all: three workgroups per CU
-  __shared__ uint16_t skey[256 * 16];
-  __shared__ uint16_t sbin[256 * 16];
+  __shared__ uint32_t cur[PART_STAGE_BINS];                        // global cursors: where each partition's next record goes
+  __shared__ uint32_t tcnt[PART_STAGE_BINS];                       // the tile's records per partition
+  __shared__ uint32_t toff[PART_STAGE_BINS + 1];                   // ... their exclusive scan (the tile's layout in `stage`)
+  __shared__ uint32_t tpos[PART_STAGE_BINS];                       // ... and the cursors of the placement pass
+  __shared__ uint32_t stage[256 * 16];                             // payloads; 8 bytes of LDS per record: three workgroups per CU
+  __shared__ uint32_t skb[256 * 16];                               // fine key | partition << 16
   const uint32_t* mine = countsA + (size_t)blockIdx.x * bins;
   for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] = pstart[b] + mine[b]; tcnt[b] = 0; }
   int g = 0;
@@ -378,28 +378,24 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
   const uint32_t set0 = (uint32_t)g * (uint32_t)sets;
   const uint32_t pbase = pg.off[g];
   const uint32_t per_lane = (bins + 63) / 64;
+  Fe<SP> nxt = fe_zero<SP>();
+  if (lo + threadIdx.x < hi) nxt = fe_load<SP>(scalars + (size_t)(lo + threadIdx.x) * 8);
   __syncthreads();
   for (uint32_t base = lo; base < hi; base += 256) {
     const uint32_t i = base + threadIdx.x;
-    uint64_t rec[16];
-    uint32_t rb[16];                                               // partition | rank << 16 (a tile holds at most 4096 records)
-    int nrec = 0;
+    Fe<SP> mags = nxt;
+    if (i + 256 < hi) nxt = fe_load<SP>(scalars + (size_t)(i + 256) * 8);    // the next tile's scalar in flight across this tile's barriers
+    uint32_t ssign = 0;
+    // pass 1: count the tile's records per partition (the digits are extracted twice -- two LDS reads and a few instructions
+    // each -- rather than kept: sixteen records per lane in registers would be indexed dynamically, i.e. live in scratch)
     if (i < hi) {
-      Fe<SP> mags = fe_load<SP>(scalars + (size_t)i * 8);
-      uint32_t ssign = 0;
       if (pg.signed_scalars) { ssign = mags.v[7] & SIGN_BIT; mags.v[7] &= ~SIGN_BIT; }
       stage_scalar<SP>(limbs, mags, is_mont);
       DigitIter it{limbs + threadIdx.x, 0u};
       for (int w = 0; w < windows; ++w) {
-        const uint32_t d = it.next(w, c) ^ ssign;
-        const uint32_t mag = d & ~SIGN_BIT;
+        const uint32_t mag = it.next(w, c) & ~SIGN_BIT;
         if (!mag) continue;
-        const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
-        const uint32_t bin = ((set0 + s) << pb) | ((mag - 1) >> fb);
-        const uint32_t rank = atomicAdd(&tcnt[bin], 1u);
-        rec[nrec] = ((uint64_t)((mag - 1) & fmask) << 32) | (uint64_t)((j * tstride + pbase + i) | (d & SIGN_BIT));
-        rb[nrec] = bin | (rank << 16);
-        ++nrec;
+        atomicAdd(&tcnt[((set0 + (uint32_t)w % (uint32_t)sets) << pb) | ((mag - 1) >> fb)], 1u);
       }
     }
     __syncthreads();
@@ -411,23 +407,30 @@ __global__ __launch_bounds__(256) void k_part_staged(PartGroups pg, int is_mont,
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += o; }
       uint32_t off = incl - run;
-      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < bins) { toff[b0 + k] = off; off += tcnt[b0 + k]; }
+      for (uint32_t k = 0; k < per_lane; ++k) if (b0 + k < bins) { toff[b0 + k] = off; tpos[b0 + k] = off; off += tcnt[b0 + k]; }
       if (threadIdx.x == 63) toff[bins] = incl;                    // the tile's record count
     }
     __syncthreads();
-    for (int k = 0; k < nrec; ++k) {
-      const uint32_t bin = rb[k] & 0xFFFFu, p = toff[bin] + (rb[k] >> 16);
-      stage[p] = (uint32_t)rec[k];
-      skey[p] = (uint16_t)(rec[k] >> 32);
-      sbin[p] = (uint16_t)bin;
+    if (i < hi) {                                                  // pass 2: place the records, partition by partition
+      DigitIter it{limbs + threadIdx.x, 0u};
+      for (int w = 0; w < windows; ++w) {
+        const uint32_t d = it.next(w, c) ^ ssign;
+        const uint32_t mag = d & ~SIGN_BIT;
+        if (!mag) continue;
+        const uint32_t s = (uint32_t)w % (uint32_t)sets, j = (uint32_t)w / (uint32_t)sets;
+        const uint32_t bin = ((set0 + s) << pb) | ((mag - 1) >> fb);
+        const uint32_t p = atomicAdd(&tpos[bin], 1u);
+        stage[p] = (j * tstride + pbase + i) | (d & SIGN_BIT);
+        skb[p] = ((mag - 1) & fmask) | (bin << 16);
+      }
     }
     __syncthreads();
     const uint32_t tile_n = toff[bins];
     for (uint32_t q = threadIdx.x; q < tile_n; q += 256) {
-      const uint32_t b = sbin[q];
+      const uint32_t kb = skb[q], b = kb >> 16;
       const uint32_t pos = cur[b] + (q - toff[b]);
       recsP[pos] = stage[q];
-      recsK[pos] = skey[q];
+      recsK[pos] = (uint16_t)kb;
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < bins; b += 256) { cur[b] += tcnt[b]; tcnt[b] = 0; }
