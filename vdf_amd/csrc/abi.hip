@@ -307,7 +307,22 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
     // (made on first use), 2n half-scalars of 129 bits + sign in this context's scratch: 9 bucket sets instead of 16 and a
     // Horner chain of 128 doublings instead of 240 behind the same number of bucket additions.
     vdf_bases* mb = const_cast<vdf_bases*>(bases);
-    {
+    const void* pts2 = nullptr;
+    if (bases->ephemeral) {
+      // a generator set made for ONE call (the uncached shims: upload, MSM, free): [P | phi(P)] goes into this context's scratch,
+      // made on the call's own stream -- no allocation, no synchronisation, nothing to free with the set (an allocation and a
+      // hipFree more per shim call showed as occasional 25 ms stalls of later calls: the driver's deferred unmapping)
+      const size_t pbytes = 2 * bases->n * sizeof(vdf_affine);
+      if (ctx->glv_pts_bytes < pbytes) {
+        VDF_TRY_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->glv_pts) (void)hipFree(ctx->glv_pts);
+        ctx->glv_pts = nullptr; ctx->glv_pts_bytes = 0;
+        VDF_TRY_HIP(hipMalloc(&ctx->glv_pts, pbytes));
+        ctx->glv_pts_bytes = pbytes;
+      }
+      VDF_TRY(vdf::glv_points(bases->curve, bases->d_pts, bases->n, ctx->glv_pts, ctx->stream));
+      pts2 = ctx->glv_pts;
+    } else {
       std::lock_guard<std::mutex> lock(mb->glv_mu);
       if (!mb->d_pts2) {
         void* p2 = nullptr;
@@ -317,6 +332,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
         if (sg.code != VDF_OK) { (void)hipFree(p2); return sg; }
         mb->d_pts2 = p2;
       }
+      pts2 = mb->d_pts2;
     }
     const size_t need = 2 * n[0] * sizeof(vdf_fe);
     if (ctx->glv_bytes < need) {
@@ -338,7 +354,7 @@ Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* 
     const int c = ca >= 15 ? 16 : 13;
     plan = vdf::msm_make_plan(1, n2, off2, c, 0, 0, ctx->num_cus, ctx->acc_fill, 132);
     plan.tstride = 0;
-    pts = reinterpret_cast<const char*>(bases->d_pts2);
+    pts = reinterpret_cast<const char*>(pts2);
     ntot = n2[0];
   } else {
     int c = ctx->msm_window ? ctx->msm_window : vdf::msm_auto_window(nmax);
@@ -434,6 +450,7 @@ void shim(int curve, vdf_jac* out, const vdf_affine* points, size_t n, const vdf
     lock.unlock();
     vdf_bases* b = nullptr;
     if (vdf_bases_upload(ctx, curve, points, n, &b) != VDF_OK) shim_die("generator upload", ctx->err);
+    b->ephemeral = true;                               // one call's generators: scratch, not a second allocation, for [P | phi(P)]
     if (vdf_msm(ctx, b, 0, scalars, n, is_mont ? 1 : 0, out) != VDF_OK) shim_die("MSM", ctx->err);
     vdf_bases_free(b);
     return;
@@ -656,6 +673,7 @@ void vdf_ctx_destroy(vdf_ctx* ctx) {
   if (ctx->reduce_scratch) (void)hipFree(ctx->reduce_scratch);
   if (ctx->direct_arrived) (void)hipFree(ctx->direct_arrived);
   if (ctx->glv_scalars) (void)hipFree(ctx->glv_scalars);
+  if (ctx->glv_pts) (void)hipFree(ctx->glv_pts);
   for (auto& tc : ctx->timed) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(tc.ev[i]);
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);

@@ -92,6 +92,8 @@ struct vdf_ctx {
   hipEvent_t acc_gate = nullptr;     // one-shot: the next bucket-method MSM's accumulation waits for this event (vdf_ctx_gate_accumulate)
   void* glv_scalars = nullptr;       // 2n half-scalars of the endomorphism's split (table-less MSMs over a whole generator set)
   size_t glv_bytes = 0;
+  void* glv_pts = nullptr;           // [P | phi(P)] of an EPHEMERAL generator set (the uncached shims): scratch, reused call after call
+  size_t glv_pts_bytes = 0;
   uint32_t* direct_arrived = nullptr;  // MSM_MAX_GROUPS counters of the direct sum's last-arriver step (zero between calls)
 };
 
@@ -102,6 +104,7 @@ struct vdf_bases {
   void* d_pts = nullptr;       // n affine points, 64 B each
   void* d_pts2 = nullptr;      // [P | phi(P)], 2n points: made by the first table-less MSM over the whole set (abi.hip msm_core)
   std::mutex glv_mu;
+  bool ephemeral = false;      // made for one call (abi.hip shim): nothing derived from it is worth keeping
   // fixed-base table: tables x n affine points; table j holds 2^(c*sets*j) * P_i
   int tbl_c = 0, tbl_sets = 0, tbl_tables = 0;
   void* d_table = nullptr;
