@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1], weak scaling for N > 1 as configs[3]): one Pippenger MSM over
 2^20 Pallas points PER GPU.  A "step" = one pass of the hot path over one batch of synthetic input
-already resident in HBM: scalars -> signed digits -> LDS counting sort -> bucket accumulation ->
+already resident in HBM: scalars -> signed digits -> LDS-staged counting sort -> bucket accumulation ->
 bucket reduction -> one Jacobian point; with N GPUs the global MSM has N * 2^20 points, sharded by
 point-chunk, and each step ends with the all-gather of N 96-byte partials (RCCL over xGMI) and a
 local point-sum.  value = points processed by all ranks / max-over-ranks wall time.
@@ -173,7 +173,9 @@ def parse():
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
     ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
                     help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
-    ap.add_argument("--depth", type=int, default=2, help="independent MSM steps in flight (contexts / streams)")
+    ap.add_argument("--depth", type=int, default=3, help="independent MSM steps in flight (contexts / streams); round 5, one box, interleaved: "
+                    "2 -> 0.906-0.911, 3 -> 0.930-0.933, 4 -> 0.849-0.852 GPoints/s (rounds 2-4: three gave what two did -- the sort and the "
+                    "fix-up were dearer then)")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="take the N > 1 code path (process group, all-gather on the step's stream) with a world of one")
     ap.add_argument("--strong-log2n", type=int, default=24,
@@ -374,7 +376,7 @@ def msm_sizes_leg(ctx, curve, sizes=(20, 22, 24), reps=5):
     ctx2.close()
     out["what"] = ("one MSM at a time on one stream (ms = median latency of %d stream-synchronised calls; GPoints_per_s from the "
                    "same calls back to back), [k_i]G generators, exact = the result equals [sum s_i k_i mod q] G; `value` of this "
-                   "line is the 2^20 case with two independent MSMs in flight (pipelined)" % reps)
+                   "line is the 2^20 case with the independent MSMs of --depth in flight (pipelined)" % reps)
     return out
 
 
