@@ -826,6 +826,7 @@ def test_lazy_addition_chains_stay_inside_their_bound():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "coordinates above 2m + 2^130: 0, mismatches 0" in r.stdout, r.stdout
+    assert "bit for bit (524288 values): mismatches 0" in r.stdout, r.stdout           # fe_sqr_lazy (the additions' two squarings)
 
 
 @pytest.mark.parametrize("curve", CURVES)

@@ -25,6 +25,31 @@ __device__ Affine<P> rnd_pt(uint32_t& s) {
   return xyzz_to_affine(xyzz_mul_u64(g, ((uint64_t)s << 20) | 12345u));
 }
 
+// (0) fe_sqr_lazy against fe_mul_lazy(a, a), BIT FOR BIT (before any canonicalisation: both compute (a^2 + q m) / 2^256), over
+// all of [0, 2^256): random words, values around 2^255 and 2^256 - 1 (the doubled number's ninth limb), words of all ones / top
+// bits only (every a_j >> 31 carry into the next limb of 2a), small values.
+__global__ void k_sqr(uint32_t* bad) {
+  uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 71u;
+  for (int it = 0; it < 512; ++it) {
+    Fe<P> a;
+    for (int i = 0; i < 8; ++i) { s = s * 1664525u + 1013904223u; a.v[i] = s ^ (s >> 13); }
+    const int kind = it & 15;
+    if (kind == 1) for (int i = 0; i < 8; ++i) a.v[i] = 0xFFFFFFFFu;
+    if (kind == 2) for (int i = 0; i < 8; ++i) a.v[i] = 0x80000000u;
+    if (kind == 3) for (int i = 0; i < 8; ++i) a.v[i] = (a.v[i] & 1u) ? 0xFFFFFFFFu : 0u;
+    if (kind == 4) { for (int i = 0; i < 7; ++i) a.v[i] = 0; a.v[7] = 0x80000000u; }
+    if (kind == 5) { for (int i = 0; i < 7; ++i) a.v[i] = 0xFFFFFFFFu; a.v[7] = 0x7FFFFFFFu; }
+    if (kind == 6) for (int i = 1; i < 8; ++i) a.v[i] = 0;
+    if (kind == 7) for (int i = 0; i < 8; ++i) a.v[i] |= 0x80000000u;
+    if (kind == 8) for (int i = 0; i < 8; ++i) a.v[i] &= 0x7FFFFFFFu;
+    if (kind == 9) for (int i = 0; i < 8; ++i) a.v[i] = (it >> 4) == i ? 0xFFFFFFFFu : 0u;
+    const Fe<P> want = fe_mul_lazy(a, a), got = fe_sqr_lazy(a);
+    bool same = true;
+    for (int i = 0; i < 8; ++i) same = same && want.v[i] == got.v[i];
+    if (!same) atomicAdd(&bad[15], 1u);
+  }
+}
+
 __global__ void k_check(uint32_t* bad, int steps) {
   uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 17u;
   // (1) fe_mul2_lazy vs two products and an addition
@@ -118,9 +143,11 @@ __global__ void k_long(uint32_t* bad, int steps, int cancel_every) {
 int main(int argc, char** argv) {
   const int long_steps = argc > 1 ? atoi(argv[1]) : 10240;
   uint32_t* d; CK(hipMalloc(&d, 64)); CK(hipMemset(d, 0, 64));
+  hipLaunchKernelGGL(k_sqr, dim3(16), dim3(64), 0, 0, d);
   hipLaunchKernelGGL(k_check, dim3(8), dim3(64), 0, 0, d, 24);
   CK(hipDeviceSynchronize());
   uint32_t h[16]; CK(hipMemcpy(h, d, 64, hipMemcpyDeviceToHost));
+  printf("fe_sqr_lazy vs fe_mul_lazy(a, a), bit for bit (524288 values): mismatches %u\n", h[15]);
   printf("fe_mul2_lazy mismatches %u, fe_neg_lazy mismatches %u, chain mismatches %u (first steps:", h[0], h[1], h[2]);
   for (int k = 0; k < 8; ++k) printf(" %u", h[3 + k]);
   printf(")\n");
@@ -130,5 +157,5 @@ int main(int argc, char** argv) {
   printf("long chains (%d additions x 256 lanes, cancel every 997): coordinates above 2m + 2^130: %u, mismatches %u, cancellations %u\n",
          long_steps, h[12], h[13], h[14]);
   if (h[14] == 0) { printf("no cancellation was exercised\n"); return 1; }
-  return (h[0] | h[1] | h[2] | h[12] | h[13]) ? 1 : 0;
+  return (h[0] | h[1] | h[2] | h[12] | h[13] | h[15]) ? 1 : 0;
 }

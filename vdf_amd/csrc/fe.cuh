@@ -322,6 +322,27 @@ template <class P> __device__ __forceinline__ Fe<P> fe_mul_lazy(const Fe<P>& a, 
   return o;
 }
 
+// a*a in the lazy domain: the integer (a^2 + q m) / 2^256 of fe_mul_lazy(a, a), bit for bit, from 43 limb products instead of 64.
+// a^2 = sum_i a_i E_i B^(2i) with E_i = a_i + 2 (a div B^(i+1)) B: its limbs are a_i, then (a_(i+1) << 1) mod 2^32, then limbs
+// i+2 .. 8 of the doubled number 2a (whose limb i+2 carries a_(i+1)'s top bit in) -- eight diagonal products, seven with a
+// shifted neighbour, 28 with limbs of 2a; 15 shifts build those.  Needs a < 2^256 (every lazy value is).
+template <class P> __device__ __forceinline__ Fe<P> fe_sqr_lazy(const Fe<P>& a) {
+  constexpr uint32_t M1 = P::MOD[1], M2 = P::MOD[2], M3 = P::MOD[3], M7 = P::MOD[7];
+  const uint32_t* A = a.v;
+  uint32_t S[8], D[9];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) S[j] = a.v[j] << 1;
+#pragma unroll
+  for (int j = 2; j < 8; ++j) D[j] = __builtin_amdgcn_alignbit(a.v[j], a.v[j - 1], 31);
+  D[8] = a.v[7] >> 31;
+  uint32_t r[8];
+#include "fe_sqr_gfx950.inc"
+  Fe<P> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = r[i];
+  return o;
+}
+
 // a - b (+ 2m on borrow) for a, b in [0, 2m + eps).  Three-operand form: the difference goes to registers of its own
 // (early-clobber outputs), so an operand that stays live afterwards -- X1, Y1, Q in the bucket addition -- is not copied first
 // (the in-place form cost eight v_mov per live operand: 42 moves per addition in round 4's first version of the loop).
@@ -449,6 +470,7 @@ template <class P> __device__ __forceinline__ Fe<P> fe_canon(Fe<P> a) {
 template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
 // host pass: canonical arithmetic is a valid instance of the lazy interface
 template <class P> VDF_HD Fe<P> fe_mul_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
+template <class P> VDF_HD Fe<P> fe_sqr_lazy(const Fe<P>& a) { return fe_mul_generic(a, a); }
 template <class P> VDF_HD Fe<P> fe_canon(Fe<P> a) { return a; }
 template <class P> VDF_HD Fe<P> fe_sub_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_sub(a, b); }
 template <class P> VDF_HD Fe<P> fe_mul2_lazy(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
