@@ -173,9 +173,11 @@ def parse():
     ap.add_argument("--sets", type=int, default=1, help="bucket sets of the fixed-base table (1 = no Horner tail)")
     ap.add_argument("--bases", choices=["tai", "dlog"], default="tai",
                     help="generator family: seeded try-and-increment (SURVEY.md 8d config 2) or [k_i]G with known k_i")
-    ap.add_argument("--depth", type=int, default=3, help="independent MSM steps in flight (contexts / streams); round 5, one box, interleaved: "
-                    "2 -> 0.906-0.911, 3 -> 0.930-0.933, 4 -> 0.849-0.852 GPoints/s (rounds 2-4: three gave what two did -- the sort and the "
-                    "fix-up were dearer then)")
+    ap.add_argument("--depth", type=int, default=0, help="independent MSM steps in flight (contexts / streams); 0 = two for timed regions of fewer than "
+                    "40 steps, three for longer ones.  Steps started together sort, accumulate and reduce together for a few rounds before they drift "
+                    "into overlap, and a region ends with as many tails as are in flight: a region's two ends cost ~1.7 ms at three in flight and "
+                    "~0.6 ms at two, a steady step 1.08 ms at three and 1.11 at two (profiles/r05_chained_accumulations_not_adopted.txt, one box, "
+                    "interleaved: 20 steps 0.908-0.919 at three against 0.919-0.934 at two; 100 steps 0.962-0.971 against 0.938-0.947; four: 0.83-0.87)")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="take the N > 1 code path (process group, all-gather on the step's stream) with a world of one")
     ap.add_argument("--strong-log2n", type=int, default=24,
@@ -1162,7 +1164,7 @@ def main():
     # `depth` contexts (stream + MSM workspace each) share one generator table; step i runs on context i % depth.
     # Steps are independent MSMs, so two in flight let one pipeline's sort and latency-bound tail run under the
     # other's ALU-bound bucket accumulation (light kernels carry a raised wave priority for exactly this).
-    depth = max(1, args.depth)
+    depth = args.depth if args.depth > 0 else (2 if args.steps < 40 else 3)
     ctxs = [vdf_amd.Context(local_rank) for _ in range(depth)]
     ctx = ctxs[0]
     family = vdf_amd.GENS_TRY_AND_INCREMENT if args.bases == "tai" else vdf_amd.GENS_KNOWN_DLOG
