@@ -120,7 +120,7 @@ std::atomic<const vdf_hip_tuning*> g_tune{nullptr};
 vdf_hip_tuning tuning_defaults() {
   vdf_hip_tuning t{};
   t.struct_size = (uint32_t)sizeof(vdf_hip_tuning);
-  t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 2;
+  t.msm_direct = 1; t.direct_priority = 2; t.direct_fused = 1; t.light_priority = 3; t.accumulate_fill = 0;
   t.accumulate_lds = 0; t.slice_len = 0; t.part_bits = -1; t.reduction = 1; t.reduction_quads = 0; t.heavy_min = 0;
   t.giant_span = 0; t.nifs_lanes = 0; t.shim_cache = 0; t.nifs_fused = 1; t.fold_u128 = 1;
   t.fixup_serial = 1; t.sort_staged = 1; t.glv = 1;
@@ -129,7 +129,7 @@ vdf_hip_tuning tuning_defaults() {
 bool tuning_valid(const vdf_hip_tuning& t) {
   auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
   return in(t.msm_direct, 0, 1) && in(t.direct_priority, 0, 3) && in(t.direct_fused, 0, 1) && in(t.light_priority, 0, 3) &&
-         in(t.accumulate_fill, 1, 3) && in(t.accumulate_lds, 0, 65536) && in(t.slice_len, 0, 65536) && in(t.part_bits, -1, 19) &&
+         in(t.accumulate_fill, 0, 3) && in(t.accumulate_lds, 0, 65536) && in(t.slice_len, 0, 65536) && in(t.part_bits, -1, 19) &&
          in(t.reduction, 0, 1) && (t.reduction_quads == 0 || in(t.reduction_quads, 64, 65536)) &&
          (t.heavy_min == 0 || in(t.heavy_min, 1, 4096)) && (t.giant_span == 0 || in(t.giant_span, 16, 1 << 20)) &&
          (t.nifs_lanes == 0 || t.nifs_lanes == 1 || t.nifs_lanes == 4 || t.nifs_lanes == 8) && in(t.shim_cache, 0, 64) &&

@@ -6,7 +6,7 @@
 // alone (~1500 cycles each at one wave per SIMD).  Here FOUR adjacent lanes (a quad) own one point,
 // lane q holding coordinate q (0 = X, 1 = Y, 2 = ZZ, 3 = ZZZ).  The add-2008-s / dbl-2008-s-1
 // formulas have at most four independent multiplications per dependency level, so a quad evaluates
-// an addition in 4 multiplication stages (a doubling in 4), exchanging operands with DPP
+// an addition in 4 multiplication stages (a doubling in 3), exchanging operands with DPP
 // quad_perm moves (one VALU instruction per 32-bit register, no LDS).  Same instruction stream in
 // all four lanes; per-lane operand choice is v_cndmask on the lane's quad position.
 //
@@ -76,27 +76,29 @@ template <class P> __device__ __forceinline__ QPoint<P> qpoint_neg(QPoint<P> a) 
   return a;
 }
 
-// 2 * a  (dbl-2008-s-1, a = 0) in four multiplication stages
+// 2 * a  (dbl-2008-s-1, a = 0) in THREE stages -- a squaring and two multiplications: M^2 needs only X^2, so it rides in the spare
+// lane of the second stage (S, W, ZZ3 take three) instead of opening a stage of its own; the first stage is squarings in every
+// lane (43 limb products instead of 64, fe_sqr_inl).  The Horner chain of the table-less path is 128 of these in a row.
 template <class P> __device__ __attribute__((noinline)) QPoint<P> qpoint_dbl(QPoint<P> a) {
   if (a.inf) return a;
   const int q = quad_pos();
   const Fe<P> c2 = fe_dbl(a.c);                                   // lane 1: U = 2Y
-  const Fe<P> A1 = fe_select(q == 1, c2, a.c);
-  const Fe<P> t1 = fe_mul_inl(A1, A1);                            // lane 0: X^2, lane 1: V = U^2
+  const Fe<P> A1 = fe_select(q == 1, c2, a.c);                    // lane 0: X, 1: U, 2: ZZ, 3: ZZZ
+  const Fe<P> t1 = fe_sqr_inl(A1);                                // lane 0: X^2, lane 1: V = U^2
   const Fe<P> V = quad_bcast<1>(t1);
-  const Fe<P> t2 = fe_mul_inl(A1, V);                             // lane 0: S = X*V, lane 1: W = U*V, lane 2: ZZ3 = ZZ*V
-  const Fe<P> W = quad_bcast<1>(t2);
   const Fe<P> xx = quad_bcast<0>(t1);
   const Fe<P> M = fe_add(fe_dbl(xx), xx);                         // 3 X^2 (all lanes)
-  const Fe<P> A3 = fe_select(q == 0, M, W);
-  const Fe<P> B3 = fe_select(q == 0, M, a.c);
-  const Fe<P> t3 = fe_mul_inl(A3, B3);                            // lane 0: M^2, lane 1: W*Y, lane 3: ZZZ3 = W*ZZZ
+  const Fe<P> A2 = fe_select(q == 3, M, A1);
+  const Fe<P> B2 = fe_select(q == 3, M, V);
+  const Fe<P> t2 = fe_mul_inl(A2, B2);                            // lane 0: S = X*V, 1: W = U*V, 2: ZZ3 = ZZ*V, 3: M^2
   const Fe<P> S = quad_bcast<0>(t2);
-  const Fe<P> mm = quad_bcast<0>(t3);
+  const Fe<P> W = quad_bcast<1>(t2);
+  const Fe<P> mm = quad_bcast<3>(t2);
   const Fe<P> x3 = fe_sub(fe_sub(mm, S), S);                      // all lanes
-  const Fe<P> t4 = fe_mul_inl(M, fe_sub(S, x3));                  // M*(S - X3) (all lanes)
-  const Fe<P> wy = quad_bcast<1>(t3);
-  const Fe<P> y3 = fe_sub(t4, wy);
+  const Fe<P> A3 = fe_select(q == 0, M, W);
+  const Fe<P> B3 = fe_select(q == 0, fe_sub(S, x3), a.c);
+  const Fe<P> t3 = fe_mul_inl(A3, B3);                            // lane 0: M*(S - X3), 1: W*Y, 3: ZZZ3 = W*ZZZ
+  const Fe<P> y3 = fe_sub(quad_bcast<0>(t3), quad_bcast<1>(t3));
   QPoint<P> r;
   r.c = fe_select(q == 0, x3, fe_select(q == 1, y3, fe_select(q == 2, t2, t3)));
   r.inf = false;

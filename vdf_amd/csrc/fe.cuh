@@ -466,7 +466,14 @@ template <class P> __device__ __forceinline__ Fe<P> fe_canon(Fe<P> a) {
   fe_cond_sub<P>(a.v);
   return a;
 }
+// canonical a^2 for canonical a: the lazy squaring's result is below 2m (as fe_mul_inl's before its subtraction)
+template <class P> __device__ __forceinline__ Fe<P> fe_sqr_inl(const Fe<P>& a) {
+  Fe<P> r = fe_sqr_lazy(a);
+  fe_cond_sub<P>(r.v);
+  return r;
+}
 #else
+template <class P> VDF_HD Fe<P> fe_sqr_inl(const Fe<P>& a) { return fe_mul_generic(a, a); }
 template <class P> VDF_HD Fe<P> fe_mul_inl(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
 // host pass: canonical arithmetic is a valid instance of the lazy interface
 template <class P> VDF_HD Fe<P> fe_mul_lazy(const Fe<P>& a, const Fe<P>& b) { return fe_mul_generic(a, b); }
@@ -488,7 +495,6 @@ template <class P> VDF_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) { return 
 template <class P> VDF_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul_inl(a, b); }
 #endif
 template <class P> VDF_HD Fe<P> fe_sqr(const Fe<P>& a) { return fe_mul(a, a); }
-template <class P> VDF_HD Fe<P> fe_sqr_inl(const Fe<P>& a) { return fe_mul_inl(a, a); }
 // compile-time choice between the two
 template <bool INL, class P> VDF_HD Fe<P> fe_mul_sel(const Fe<P>& a, const Fe<P>& b) {
   if constexpr (INL) return fe_mul_inl(a, b); else return fe_mul(a, b);

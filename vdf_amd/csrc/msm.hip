@@ -202,7 +202,8 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.c = c;
   p.windows = (scalar_bits + c - 1) / c;       // 256: field elements; 132: the half-scalars of the endomorphism (129 bits + the digits' carry)
   p.signed_scalars = scalar_bits != 256;
-  if (sets <= 0 || tables <= 0) { sets = p.windows; tables = 1; }
+  const bool tableless = sets <= 0 || tables <= 0;
+  if (tableless) { sets = p.windows; tables = 1; }
   p.sets = sets;
   p.gsets = groups * sets;
   p.tables = tables;
@@ -242,6 +243,10 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
   int acc_wg = acc_fill ? acc_fill : tuning().accumulate_fill;         // the context's choice, else the process-wide one
+  // automatic: two; three without a table from 2^22 entries on (2n points [P | phi(P)], nine bucket sets: 2.47 -> 2.33 ms at 2^20 points,
+  // 1.26 -> 1.22 at 2^18, but 0.79 -> 0.84 at 2^16, where the extra slice heads cost more than the occupancy gives:
+  // profiles/r05_fill_tableless.txt; over a table three are no faster for MSMs in flight and slower in a prover)
+  if (acc_wg == 0) acc_wg = (tableless && ne >= ((size_t)1 << 22)) ? ACC_WG_PER_CU : ACC_WG_FILL;
   if (acc_wg < 1 || acc_wg > ACC_WG_PER_CU) acc_wg = ACC_WG_FILL;
   const size_t slots = (size_t)num_cus * acc_wg * 256;
   size_t L = (ne + slots - 1) / slots;           // upper bound: the kernels shorten it to the actual entry count
