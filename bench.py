@@ -724,15 +724,22 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
     # Settle (untimed): one whole pass over the chain -- base case + every fold -- before the first timed repeat: the device
     # reaches the clock it then holds, every workspace has its final size, the helper threads are awake (the
     # first repeat of a cold leg ran 10 % slow and the mean carried it)
+    # The stage times (vdf_nova_last_step_ms: host wall-clock per stage of a step) are read in THIS pass, after every step: inside
+    # a timed repeat the harness does nothing between two steps -- whatever it does there is on the chain's critical path (the
+    # next step's first launches wait for it; reading the stages after every step cost 3 %, after every fourth 1 %).
     settle_steps = 0
+    trace = bool(os.environ.get("VDF_BENCH_TRACE"))
     if nsteps > 2:
         for k in range(nsteps):
             proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
+            if k >= first_timed:
+                stages.append(proof.last_step_ms())
+                if trace:
+                    print("step %d" % k, {a_: round(b_, 3) for a_, b_ in stages[-1].items()}, file=sys.stderr)
         proof.instance(INST_FRESH_SECONDARY)
         ctx.sync()
         settle_steps = nsteps
     import gc
-    trace = bool(os.environ.get("VDF_BENCH_TRACE"))
     for rep in range(max(1, repeats)):
         if proof is not None:
             proof.free()
@@ -754,18 +761,14 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
                 first_fold = time.perf_counter() - a
         a = time.perf_counter()
         prev, worst = a, (0.0, -1)
-        # (the harness's own work between two steps is on the chain's critical path -- the next step's first launches wait for
-        # it: the stage times are sampled every fourth step, not read after every one)
         for k in range(first_timed, nsteps):
             proof = NovaVDFProof.prove_step(pp, proof, circuits, k, z0)
             now = time.perf_counter()
             if now - prev > worst[0]:
                 worst = (now - prev, k)
             prev = now
-            if (k & 3) == 0 or trace:
+            if nsteps <= 2:
                 stages.append(proof.last_step_ms())
-                if trace:
-                    print("step %d" % k, {a_: round(b_, 3) for a_, b_ in stages[-1].items()}, file=sys.stderr)
         proof.instance(INST_FRESH_SECONDARY)     # the last secondary commitment (it rides in the NEXT step's batch otherwise)
         ctx.sync()
         end = time.perf_counter()
@@ -798,7 +801,7 @@ def prove_step_leg(ctx, log2t, nsteps, kind=1, repeats=5, chains=2, with_compres
            "stage": "Nova IVC step on the Pallas/Vesta cycle: NIFS of the previous secondary instance, synthesis + commitment + NIFS "
                     "of the primary augmented circuit (MinRoot step circuit inside), synthesis of the secondary augmented circuit "
                     "(TrivialTestCircuit); constant-size proof, hash-checking verifier",
-           "stage_ms_meaning": "host wall-clock per stage (vdf_nova_last_step_ms): *_synthesis = host field arithmetic of an augmented "
+           "stage_ms_meaning": "read in the untimed settle pass over the same chain; host wall-clock per stage (vdf_nova_last_step_ms): *_synthesis = host field arithmetic of an augmented "
                                "circuit (hashes, in-circuit curve arithmetic); secondary_nifs / primary_wait = GPU cross term + commitments"}
     if with_roofline and nsteps > 3:
         # a pass of its own with HIP events around every launch of the prover's three queues (two event records per launch:
