@@ -189,7 +189,8 @@ def parse():
     ap.add_argument("--prove-log2t", type=int, default=16, help="MinRoot iterations per prove_step (2^k)")
     ap.add_argument("--prove-chains", type=int, default=2,
                     help="also report the aggregate rate of this many independent chains proven concurrently (1 = skip)")
-    ap.add_argument("--prove-steps", type=int, default=26, help="1 base case + 1 warm-up fold + timed steady-state folds")
+    ap.add_argument("--prove-steps", type=int, default=52, help="1 base case + 1 warm-up fold + timed steady-state folds (50: a timed repeat opens with an empty "
+                    "lookahead and closes with a drain -- about 0.5 ms whatever its length, 2.4 % of 24 steps, 1.2 % of 50; tools/gpu_prove_modes.py: 100 steps)")
     ap.add_argument("--prove-repeats", type=int, default=7, help="the steady state is timed this many times (a fresh proof each): 7 x 24 = 168 timed steps; the median repeat is reported (a host stall of a few ms -- other tenants of the node -- lands in one or two)")
     ap.add_argument("--digit-budget-gib", type=int, default=20,
                     help="HBM the prove_step leg lets the digit tables of a parameter set take (vdf_nova_tuning.digit_budget_bytes).  The "
