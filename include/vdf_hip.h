@@ -439,7 +439,7 @@ typedef struct vdf_hip_tuning {
   int32_t light_priority;      /* ceiling of the wave priority of sort / fix-up / bucket-reduction kernels, 0..3 (3);
                                   a context lowers its own with vdf_ctx_set_light_priority */
   int32_t accumulate_fill;     /* resident bucket-accumulation workgroups per CU one launch is sized for, 1..3; 0 (the default) =
-                                  automatic: two; three for a table-less MSM of 2^22 (scalar, window) entries or more; a context overrides it with
+                                  automatic: three for a single MSM of 2^22 (scalar, window) entries or more, two below and for batches; a context overrides it with
                                   vdf_ctx_set_accumulate_fill */
   int32_t accumulate_lds;      /* bytes of unused LDS per accumulation workgroup: caps its occupancy per CU (0) */
   int32_t slice_len;           /* fixed slice length of the bucket accumulation, 1..65536; 0 = from the entry count */

@@ -243,10 +243,13 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // (any L: entries are read one dword at a time), at least 8 so that slice heads stay few.
   size_t ne = (size_t)n * p.windows;
   int acc_wg = acc_fill ? acc_fill : tuning().accumulate_fill;         // the context's choice, else the process-wide one
-  // automatic: two; three without a table from 2^22 entries on (2n points [P | phi(P)], nine bucket sets: 2.47 -> 2.33 ms at 2^20 points,
-  // 1.26 -> 1.22 at 2^18, but 0.79 -> 0.84 at 2^16, where the extra slice heads cost more than the occupancy gives:
-  // profiles/r05_fill_tableless.txt; over a table three are no faster for MSMs in flight and slower in a prover)
-  if (acc_wg == 0) acc_wg = (tableless && ne >= ((size_t)1 << 22)) ? ACC_WG_PER_CU : ACC_WG_FILL;
+  // automatic: three for a single MSM of 2^22 (scalar, window) entries or more, two below and for batches.  Three wavefronts per SIMD hide the gathers and the
+  // dependent issue better than two (k_accumulate alone at 2^20 points over a table: 1.043-1.056 against 1.076-1.079 ms; without a
+  // table, 2n points [P | phi(P)] and nine bucket sets: 2.47 -> 2.33 ms per call); below that the extra slice heads cost more than
+  // the occupancy gives (table-less 2^16: 0.79 -> 0.84 ms).  MSMs in flight measure the same either way; a prover's side queues
+  // set three themselves (profiles/r05_fill_tableless.txt).
+  (void)tableless;
+  if (acc_wg == 0) acc_wg = (groups == 1 && ne >= ((size_t)1 << 22)) ? ACC_WG_PER_CU : ACC_WG_FILL;   // (batches: two, as measured in a prover)
   if (acc_wg < 1 || acc_wg > ACC_WG_PER_CU) acc_wg = ACC_WG_FILL;
   const size_t slots = (size_t)num_cus * acc_wg * 256;
   size_t L = (ne + slots - 1) / slots;           // upper bound: the kernels shorten it to the actual entry count
