@@ -57,8 +57,8 @@ __device__ __forceinline__ void raise_wave_priority(int wave_prio = 3) {
   else if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
 }
 static constexpr int ACC_WG_PER_CU = 3;     // resident k_accumulate workgroups per CU (VGPR budget)
-static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many: two waves per SIMD already issue at ~99 % of three,
-                                            // and a third fewer slices means a third fewer slice heads for k_fixup to add
+static constexpr int ACC_WG_FILL = 2;       // ... of which one round fills this many below 2^22 entries and in batches: a third fewer slices means a
+                                            // third fewer slice heads for k_fixup to add (large single MSMs fill all three: msm_make_plan)
 // The fix-up is a chain of dependent additions per bucket, so its duration is the LONGEST chain of the launch (a quad
 // addition is ~3 us): a bucket spanning more than heavy_span slices goes to a wavefront (chain span/16 + 5), one
 // spanning more than GIANT_SPAN to several wavefronts, GIANT_CHUNK heads each.  heavy_span adapts to the launch
