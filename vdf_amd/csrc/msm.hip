@@ -202,8 +202,7 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   p.c = c;
   p.windows = (scalar_bits + c - 1) / c;       // 256: field elements; 132: the half-scalars of the endomorphism (129 bits + the digits' carry)
   p.signed_scalars = scalar_bits != 256;
-  const bool tableless = sets <= 0 || tables <= 0;
-  if (tableless) { sets = p.windows; tables = 1; }
+  if (sets <= 0 || tables <= 0) { sets = p.windows; tables = 1; }
   p.sets = sets;
   p.gsets = groups * sets;
   p.tables = tables;
@@ -248,7 +247,6 @@ MsmPlan msm_make_plan(int groups, const size_t* gn, const size_t* goff, int c, i
   // table, 2n points [P | phi(P)] and nine bucket sets: 2.47 -> 2.33 ms per call); below that the extra slice heads cost more than
   // the occupancy gives (table-less 2^16: 0.79 -> 0.84 ms).  MSMs in flight measure the same either way; a prover's side queues
   // set three themselves (profiles/r05_fill_tableless.txt).
-  (void)tableless;
   if (acc_wg == 0) acc_wg = (groups == 1 && ne >= ((size_t)1 << 22)) ? ACC_WG_PER_CU : ACC_WG_FILL;   // (batches: two, as measured in a prover)
   if (acc_wg < 1 || acc_wg > ACC_WG_PER_CU) acc_wg = ACC_WG_FILL;
   const size_t slots = (size_t)num_cus * acc_wg * 256;
