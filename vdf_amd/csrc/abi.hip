@@ -226,7 +226,10 @@ bool direct_enabled() { return vdf::tuning().msm_direct != 0; }       // (tuning
 size_t field_of_curve_scalar(int curve) { return curve == VDF_CURVE_PALLAS ? VDF_FIELD_FQ : VDF_FIELD_FP; }
 
 constexpr size_t GLV_MIN_POINTS = 1u << 12;      // below this the split's launches cost what the shorter chain saves
-constexpr size_t GLV_MAX_POINTS = 1u << 21;      // measured (profiles/r05_glv_tableless.txt): 2^14 1.25 -> 0.75 ms, 2^18 1.81 -> 1.29, 2^20 2.86 -> 2.61;
+#ifndef VDF_GLV_MAX_LOG2
+#define VDF_GLV_MAX_LOG2 21          /* (an A/B build may move it: make ab AB_FLAGS=-DVDF_GLV_MAX_LOG2=23) */
+#endif
+constexpr size_t GLV_MAX_POINTS = (size_t)1 << VDF_GLV_MAX_LOG2;      // measured (profiles/r05_glv_tableless.txt): 2^14 1.25 -> 0.75 ms, 2^18 1.81 -> 1.29, 2^20 2.86 -> 2.61;
                                                  // at 2^22 the doubled point array slows the gathers by what the chain saves (7.11 -> 7.22)
 Status msm_core(vdf_ctx* ctx, const vdf_bases* bases, int groups, const size_t* offset, const vdf_fe* const* scalars,
                 const size_t* n, int is_mont, vdf_jac* out) {
