@@ -104,7 +104,7 @@ def test_out_of_range_tuning_is_refused(ctx):
 
 
 HIP_VARIANTS = [dict(msm_direct=0), dict(direct_fused=0), dict(direct_priority=0), dict(light_priority=1), dict(accumulate_fill=3),
-                dict(accumulate_fill=1), dict(accumulate_lds=55296), dict(slice_len=16), dict(reduction=0), dict(nifs_lanes=1),
+                dict(accumulate_fill=1), dict(accumulate_fill=2), dict(accumulate_lds=55296), dict(slice_len=16), dict(reduction=0), dict(nifs_lanes=1),
                 dict(nifs_lanes=4), dict(nifs_fused=0), dict(fold_u128=0), dict(heavy_min=2, giant_span=16), dict(fixup_serial=0), dict(sort_staged=0), dict(glv=0),
                 dict(fixup_serial=0, heavy_min=2, giant_span=16)]
 
